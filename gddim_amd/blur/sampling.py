@@ -1,0 +1,68 @@
+"""Blur gDDIM sampler -- drop-in for blur_jax/sampling.py:11-89 on the native MI355X engine.
+
+  get_sampling_fn(config, sde, model, shape, inverse_scaler, is_p=True)     :11-40 (only 'order0' exists)
+  get_rev_ts(sde, ts_order, num_step)                                       :42-51
+  get_order0_sampler(sde, model, data_shape, ts_order, nfe, inverse_scaler, is_p=False)   :53-89
+
+`sampling_fn(rng, state, batch_size, u=None) -> (x, nfe)` (2-tuple, unlike CLD).  The NFE loop
+[IDCT -> U-Net -> DCT -> per-frequency DDIM update] runs entirely in `gd_sample_blur`."""
+import itertools
+
+import numpy as np
+
+from ..cld.sampling import _seed_of, _unreplicate_rng
+from . import utils
+
+_LOCAL_DEVICE_COUNT = 1
+_TOKENS = itertools.count(1)
+
+
+def get_rev_ts(sde, ts_order, num_step):
+    return np.power(np.linspace(np.power(sde.sampling_T, 1.0 / ts_order), np.power(sde.sampling_eps, 1.0 / ts_order),
+                                num_step + 1), ts_order)
+
+
+def get_order0_sampler(sde, model, data_shape, ts_order, nfe, inverse_scaler, is_p=False):
+    rev_ts = get_rev_ts(sde, ts_order=ts_order, num_step=nfe)
+    mean_coef = sde.y_mean_coef(rev_ts)[..., 0]  # (nfe+1, 32, 32): identical for every image (t is batch-uniform)
+    std_coef = sde.y_std_coef(rev_ts)
+    probe = np.array([-1.0, 0.0, 1.0])
+    scaled = np.asarray(inverse_scaler(probe), dtype=np.float64)
+    fuse_scale = bool(np.allclose(scaled, (probe + 1.0) / 2.0))
+    post_scale = None if fuse_scale or np.allclose(scaled, probe) else inverse_scaler
+    token = ("blur_order0", next(_TOKENS))
+
+    def sampler(rng, state, batch_size, u=None, use_graph=True):
+        import torch
+        if u is None:
+            u = sde.prior_sampling(_seed_of(rng), (batch_size,) + tuple(data_shape))
+        if not hasattr(u, 'is_cuda'):
+            u = torch.as_tensor(np.asarray(u), dtype=torch.float32)
+        if not u.is_cuda:
+            u = u.to(torch.device('cuda', torch.cuda.current_device()))
+        eng = model.engine_for(state.params_ema, data_shape[-1], batch_size, u.device.index)
+        eng.set_schedule_blur(rev_ts[:nfe], mean_coef, std_coef, token=token)
+        x = eng.sample_blur(u.to(torch.float32), inverse_scale=fuse_scale, use_graph=use_graph)
+        if post_scale is not None:
+            x = post_scale(x)
+        return x, nfe
+
+    def psampler(prng, pstate, batch_size, u=None, use_graph=True):
+        rng = _unreplicate_rng(prng)
+        if u is None:
+            u = sde.prior_sampling(_seed_of(rng), (_LOCAL_DEVICE_COUNT, batch_size,) + tuple(data_shape))
+        assert u.shape[0] == _LOCAL_DEVICE_COUNT, "one process drives one GPU: leading device axis must be 1"
+        x, n = sampler(rng, pstate, batch_size, u[0], use_graph)
+        return x[None], n
+
+    return psampler if is_p else sampler
+
+
+def get_sampling_fn(config, sde, model, shape, inverse_scaler, is_p=True):
+    del shape
+    sampler_name = config.sampling.method
+    data_shape = utils.get_data_shape(config)
+    if sampler_name.lower() == 'order0':
+        return get_order0_sampler(sde=sde, model=model, data_shape=data_shape, ts_order=config.sampling.ts_order,
+                                  nfe=config.sampling.nfe, inverse_scaler=inverse_scaler, is_p=is_p)
+    raise RuntimeError

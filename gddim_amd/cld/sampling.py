@@ -1,0 +1,194 @@
+"""CLD gDDIM samplers -- drop-in for cld_jax/sampling.py on the native MI355X engine.
+
+Same factory names, argument names and return tuples as the reference:
+
+  get_sampling_fn(config, sde, model, shape, inverse_scaler)           cld_jax/sampling.py:41-154
+  get_deis_sampler(sde, model, data_shape, nfe, inverse_scaler, deis_order, ts_order=2,
+                   denoising=False, is_p=False)                        :251-253
+  get_order0_sampler(sde, model, data_shape, nfe, inverse_scaler, is_em=False,
+                     denoising=False, is_p=False)                      :156-202
+  get_hyd_deis_sampler(...)                                            :255-269 (different rev_ts only)
+  get_rev_ts / get_denoising_step / get_cld_denoising_step             :241-249, :30-39, :23-27
+
+The returned callable is `sampling_fn(rng, state, batch_size, u=None)`:
+  is_p=False: u (B,H,W,C,2) -> (x (B,H,W,C), v (B,H,W,C), nfe)
+  is_p=True : the reference pmaps over jax.local_device_count(); here one process drives one GPU, so the
+              leading device axis has length 1: u (1,B,H,W,C,2) -> (xs (1,B,H,W,C), vs, nfe).  Multi-GPU runs
+              launch one process per GPU (gddim_amd.distributed).
+`u` is the parity hook: with it the deterministic samplers never touch the RNG.
+
+Inside the callable nothing but the native engine runs: the whole NFE loop (U-Net forward + fused
+2x2 exponential-integrator update per step, denoising step, inverse scaling) is `gd_sample_cld`, replayed
+from a hipGraph.  The other samplers of the reference's factory (sdeis, ldeis, mldeis, ode, sscs, em) are
+outside this round's scope and raise NotImplementedError.
+"""
+import itertools
+
+import numpy as np
+
+from .._abi import GddimError
+from ..models import utils as mutils
+from . import utils
+
+_LOCAL_DEVICE_COUNT = 1  # one process per GPU
+_TOKENS = itertools.count(1)
+
+
+def get_cld_denoising_step(sde, t, denoising_eps):
+    cur_F = sde.s_F(t)
+
+    def step_fn(u):
+        return u + utils.sbmm(cur_F, u) * (-denoising_eps)
+
+    return step_fn
+
+
+def get_denoising_step(sde, model, t, denoising_eps):
+    """u + F u dt - G G score dt at time t with dt = -denoising_eps (cld_jax/sampling.py:30-39).
+    Stand-alone (unfused) version built from the operator API; the fused samplers below do this in-kernel."""
+    cur_F, cur_G = sde.s_F(t), sde.s_G(t)
+
+    def step_fn(state, u):
+        import torch
+        eps_fn = mutils.get_eps_fn(sde, model, state.params_ema, state.model_state, train=False, continuous=True)
+        _ones = torch.ones(u.shape[0], device=u.device, dtype=torch.float32)
+        dt = denoising_eps * (-1)
+        cur_eps = eps_fn(u, _ones * t)
+        cur_score = sde.eps2score(cur_eps, _ones * t)
+        return u + utils.sbmm(cur_F, u) * dt - utils.sbmm(cur_G @ cur_G, cur_score) * dt
+
+    return step_fn
+
+
+def get_rev_ts(sde, ts_order, num_step):
+    return np.power(np.linspace(np.power(sde.T, 1.0 / ts_order), np.power(sde.sampling_eps, 1.0 / ts_order), num_step + 1),
+                    ts_order)
+
+
+def _denoise_mats(sde, t):
+    F = sde.s_F(t)
+    G = sde.s_G(t)
+    RinvT = sde.s_invR(t).T
+    return F, G @ G, RinvT
+
+
+def _unreplicate_rng(prng):
+    try:
+        return prng[0]
+    except (TypeError, IndexError):
+        return prng
+
+
+def _seed_of(rng):
+    if rng is None:
+        return 0
+    if isinstance(rng, (int, np.integer)):
+        return int(rng)
+    if hasattr(rng, 'integers'):
+        return int(rng.integers(0, 2 ** 62))
+    a = np.asarray(rng.detach().cpu() if hasattr(rng, 'detach') else rng).astype(np.uint64).ravel()
+    return int(np.bitwise_xor.reduce(a * np.uint64(0x9E3779B97F4A7C15) + np.arange(a.size, dtype=np.uint64)) >> np.uint64(2))
+
+
+def _make_sampler(sde, model, data_shape, nfe, inverse_scaler, rev_ts, coef, denoising, is_p, tag):
+    """Shared closure builder: `coef` is (num_step, n_slots, 2, 2) = [Psi_i, C_i0, ...]."""
+    num_step = coef.shape[0]
+    dn = _denoise_mats(sde, sde.sampling_eps) if denoising else (None, None, None)
+    # the reference applies `inverse_scaler` after the loop; the engine fuses the centered one, (x+1)/2
+    probe = np.array([-1.0, 0.0, 1.0])
+    scaled = np.asarray(inverse_scaler(probe), dtype=np.float64)
+    if np.allclose(scaled, (probe + 1.0) / 2.0):
+        fuse_scale, post_scale = True, None
+    elif np.allclose(scaled, probe):
+        fuse_scale, post_scale = False, None
+    else:
+        fuse_scale, post_scale = False, inverse_scaler
+    token = (tag, next(_TOKENS))
+    ts32 = np.asarray(rev_ts[:num_step], dtype=np.float32)
+    coef32 = np.ascontiguousarray(coef, dtype=np.float32)
+
+    def sampler(rng, state, batch_size, u=None, use_graph=True):
+        import torch
+        if u is None:
+            u = sde.prior_sampling(_seed_of(rng), (batch_size,) + tuple(data_shape))
+        if not hasattr(u, 'is_cuda'):
+            u = torch.as_tensor(np.asarray(u), dtype=torch.float32)
+        if not u.is_cuda:
+            u = u.to(torch.device('cuda', torch.cuda.current_device()))
+        u = u.to(torch.float32)
+        assert tuple(u.shape) == (batch_size,) + tuple(data_shape) + (2,), "u must be (B, *data_shape, 2)"
+        eng = model.engine_for(state.params_ema, 2 * data_shape[-1], batch_size, u.device.index)
+        eng.set_schedule_cld(ts32, coef32, denoising, sde.sampling_eps, dn[0], dn[1], dn[2], token=token)
+        x, v = eng.sample_cld(u, inverse_scale=fuse_scale, use_graph=use_graph)
+        if post_scale is not None:
+            x = post_scale(x)
+        return x, v, nfe
+
+    def psampler(prng, pstate, batch_size, u=None, use_graph=True):
+        rng = _unreplicate_rng(prng)
+        if u is None:
+            u = sde.prior_sampling(_seed_of(rng), (_LOCAL_DEVICE_COUNT, batch_size,) + tuple(data_shape))
+        assert u.shape[0] == _LOCAL_DEVICE_COUNT, "one process drives one GPU: leading device axis must be 1"
+        x, v, n = sampler(rng, pstate, batch_size, u[0], use_graph)
+        return x[None], v[None], n
+
+    return psampler if is_p else sampler
+
+
+def get_order0_sampler(sde, model, data_shape, nfe, inverse_scaler, is_em=False, denoising=False, is_p=False):
+    if is_em:
+        raise NotImplementedError("is_em=True (prepare_naive_coef) is outside this round's scope")
+    num_step = nfe - 1 if denoising else nfe
+    rev_ts = get_rev_ts(sde, 2, num_step)  # ts_order is hard-coded to 2 here (cld_jax/sampling.py:162)
+    mean_matrix, eps_matrix = sde.prepare_order0_coef(rev_ts)
+    coef = np.stack([mean_matrix, eps_matrix], axis=1)  # n_slots = 2: no epsilon history
+    return _make_sampler(sde, model, data_shape, nfe, inverse_scaler, rev_ts, coef, denoising, is_p, "order0")
+
+
+def _impl_deis_sampler(sde, model, data_shape, nfe, inverse_scaler, deis_order, rev_ts, denoising=False, is_p=False):
+    deis_coef = sde.get_deis_coef(deis_order, rev_ts)  # (num_step, deis_order + 3, 2, 2)
+    return _make_sampler(sde, model, data_shape, nfe, inverse_scaler, rev_ts, deis_coef, denoising, is_p, "deis")
+
+
+def get_deis_sampler(sde, model, data_shape, nfe, inverse_scaler, deis_order, ts_order=2, denoising=False, is_p=False):
+    rev_ts = get_rev_ts(sde, ts_order, nfe - 1 if denoising else nfe)
+    return _impl_deis_sampler(sde, model, data_shape, nfe, inverse_scaler, deis_order, rev_ts, denoising, is_p)
+
+
+def get_hyd_deis_sampler(sde, model, data_shape, nfe, inverse_scaler, deis_order, noise_nfe_ratio=0.3, img_t_ratio=0.3,
+                         ts_order=2.0, denoising=False, is_p=False):
+    num_step = nfe - 1 if denoising else nfe
+    mid_t = sde.T * img_t_ratio
+    noise_nfe = int(num_step * noise_nfe_ratio)
+    img_nfe = num_step - noise_nfe
+    noise_ts = np.linspace(sde.T, mid_t, noise_nfe, endpoint=False)
+    # reference: get_rev_ts(sde, ts_order, img_nfe) restarts at sde.T (cld_jax/sampling.py:264) -- kept as is
+    img_ts = get_rev_ts(sde, ts_order, img_nfe)
+    rev_ts = np.concatenate([noise_ts, img_ts])
+    assert rev_ts.shape[0] == num_step + 1
+    return _impl_deis_sampler(sde, model, data_shape, nfe, inverse_scaler, deis_order, rev_ts, denoising, is_p)
+
+
+def get_sampling_fn(config, sde, model, shape, inverse_scaler):
+    """Create a sampling function (cld_jax/sampling.py:41-154)."""
+    del shape
+    sampler_name = config.sampling.method
+    data_shape = utils.get_data_shape(config)
+    name = sampler_name.lower()
+    if name == 'order0':
+        return get_order0_sampler(sde=sde, model=model, data_shape=data_shape, nfe=config.sampling.nfe,
+                                  inverse_scaler=inverse_scaler, is_em=config.sampling.is_em,
+                                  denoising=config.sampling.noise_removal, is_p=True)
+    if name == 'deis':
+        return get_deis_sampler(sde=sde, model=model, data_shape=data_shape, nfe=config.sampling.nfe,
+                                inverse_scaler=inverse_scaler, deis_order=config.sampling.deis_order,
+                                ts_order=config.sampling.ts_order, denoising=config.sampling.noise_removal, is_p=True)
+    if name == 'hybdeis':
+        return get_hyd_deis_sampler(sde=sde, model=model, data_shape=data_shape, nfe=config.sampling.nfe,
+                                    inverse_scaler=inverse_scaler, deis_order=config.sampling.deis_order,
+                                    noise_nfe_ratio=config.sampling.noise_nfe_ratio,
+                                    img_t_ratio=config.sampling.img_t_ratio, ts_order=config.sampling.ts_order,
+                                    denoising=config.sampling.noise_removal, is_p=True)
+    if name in ('sdeis', 'ldeis', 'mldeis', 'ode', 'sscs', 'em'):
+        raise NotImplementedError("sampling.method=%r is not built yet (SURVEY.md section 8f, N3)" % sampler_name)
+    raise RuntimeError

@@ -1,0 +1,167 @@
+"""Critically-damped Langevin diffusion: SDE algebra for the sampler (host side, float64 numpy).
+
+Replaces the sampling members of cld_jax/sde_lib.py:45-331 (class CLD, from_config).  Closed forms are
+evaluated directly; R(t) comes from the native float64 scan `gd_cld_r_table` (the reference's 1e6-step
+lax.scan + pickle cache, :93-118) and is interpolated exactly as get_interp_fn does (:32-43: 100 000 knots,
+searchsorted side='right', linear).  The reference computes all of this in float32; float64 here differs
+from it by <= 6e-5 absolute on the DEIS table (tests/test_oracle_cld.py), far inside the 1e-3 parity bar.
+"""
+import ctypes
+
+import numpy as np
+
+from .. import _abi
+from . import deis
+
+
+def inv_2x2(m):
+    a, b, c, d = m[..., 0, 0], m[..., 0, 1], m[..., 1, 0], m[..., 1, 1]
+    coef = 1.0 / (a * d - b * c)
+    out = np.empty_like(m)
+    out[..., 0, 0], out[..., 0, 1], out[..., 1, 0], out[..., 1, 1] = d * coef, -b * coef, -c * coef, a * coef
+    return out
+
+
+_R_CACHE = {}
+
+
+class CLD(object):
+    def __init__(self, m_inv=4.0, beta_0=4.0, beta_1=0.0, vv_gamma=0.04, numerical_eps=1e-6, mixed_score=False,
+                 used_cache=True, x64=False, is_R_rk=False, R_dt=1e-5):
+        self.mixed_score = mixed_score
+        self.used_cache = used_cache
+        self.x64 = x64
+        self.m_inv = float(m_inv)
+        self.Gamma = 2.0 / np.sqrt(m_inv)
+        self.beta_0 = float(beta_0)
+        self.beta_1 = float(beta_1)
+        self.vv_gamma = float(vv_gamma)
+        self.numerical_eps = float(numerical_eps)
+        self.R_0 = np.array([[np.sqrt(numerical_eps), 0.0], [0.0, np.sqrt(vv_gamma / m_inv + numerical_eps)]])
+        self.is_R_rk = bool(is_R_rk)
+        self.R_dt = float(R_dt)
+        self._xp, self._fp = self._r_knots()
+        self.sampling_eps = 1e-3
+        self.T = 1.0
+
+    # ---- R(t) ----
+    def _r_knots(self):
+        key = (self.m_inv, self.beta_0, self.beta_1, self.vv_gamma, self.numerical_eps, self.is_R_rk, self.R_dt)
+        if self.used_cache and key in _R_CACHE:
+            return _R_CACHE[key]
+        n = int(1.0 / self.R_dt) + 1  # sde_lib.py:114 (note int(1/1e-5) == 99999)
+        table = np.empty((n, 2, 2))
+        _abi.check(_abi.lib().gd_cld_r_table(self.m_inv, self.beta_0, self.beta_1, self.vv_gamma, self.numerical_eps,
+                                             int(self.is_R_rk), self.R_dt, n, table.ctypes.data_as(ctypes.c_void_p)))
+        ts = np.linspace(0, 1.0 + self.R_dt, n, endpoint=False)
+        idx = np.linspace(0, n - 1, 100_000).astype(int)
+        _R_CACHE[key] = (ts[idx], table[idx])
+        return _R_CACHE[key]
+
+    def v_R(self, t):
+        """R at a vector of times, (n, 2, 2)."""
+        t = np.atleast_1d(np.asarray(t, dtype=np.float64))
+        xp, fp = self._xp, self._fp
+        i = np.clip(np.searchsorted(xp, t, side='right'), 1, len(xp) - 1)
+        dx = xp[i] - xp[i - 1]
+        w = np.where(dx == 0, 1.0, (t - xp[i - 1]) / np.where(dx == 0, 1.0, dx))
+        return fp[i - 1] + w[:, None, None] * (fp[i] - fp[i - 1])
+
+    def s_R(self, t):
+        return self.v_R(t)[0]
+
+    def s_invR(self, t):
+        return inv_2x2(self.s_R(t))
+
+    def v_invR(self, t):
+        return inv_2x2(self.v_R(t))
+
+    def s_cov(self, t):
+        R = self.s_R(t)
+        return R @ R.T
+
+    # ---- schedule / drift / diffusion ----
+    def beta(self, t):
+        return self.beta_0 + self.beta_1 * np.asarray(t, dtype=np.float64)
+
+    def beta_int(self, t):
+        t = np.asarray(t, dtype=np.float64)
+        return self.beta_0 * t + 0.5 * self.beta_1 * t ** 2
+
+    def s_F(self, t):
+        b = float(self.beta(t))
+        return np.array([[0.0, b * self.m_inv], [-b, -self.Gamma * b * self.m_inv]])
+
+    def s_G(self, t):
+        b = float(self.beta(t))
+        return np.array([[0.0, 0.0], [0.0, np.sqrt(2 * self.Gamma * b)]])
+
+    def vs_psi(self, s_vec, t):
+        """Psi(s_n, t) = expm(int_s^t F): e^{-ab/2} [[1+ab/2, a^2 b/4], [-b, 1-ab/2]], a = 2 sqrt(m_inv)."""
+        b = self.beta_int(t) - self.beta_int(s_vec)
+        a = 2 * np.sqrt(self.m_inv)
+        e = np.exp(-a * b / 2)
+        out = np.empty(np.shape(b) + (2, 2))
+        out[..., 0, 0] = (1 + a * b / 2) * e
+        out[..., 0, 1] = 0.25 * a * a * b * e
+        out[..., 1, 0] = -b * e
+        out[..., 1, 1] = (1 - a * b / 2) * e
+        return out
+
+    def s_psi(self, s, t):
+        return self.vs_psi(np.float64(s), t)
+
+    def vv_psi(self, s_vec, t_vec):
+        return self.vs_psi(np.asarray(s_vec, dtype=np.float64), np.asarray(t_vec, dtype=np.float64))
+
+    def v_eps_integrand(self, t_vec):
+        """1/2 G G R^-T at a vector of times (G G^T has the single entry 2 Gamma beta at [1,1])."""
+        t_vec = np.atleast_1d(np.asarray(t_vec, dtype=np.float64))
+        invT = np.swapaxes(inv_2x2(self.v_R(t_vec)), -1, -2)
+        out = np.zeros_like(invT)
+        out[:, 1, :] = (self.Gamma * self.beta(t_vec))[:, None] * invT[:, 1, :]
+        return out
+
+    def s_eps_integrand(self, t):
+        return self.v_eps_integrand(t)[0]
+
+    # ---- device-side helpers ----
+    def eps2score(self, eps, ts):
+        """score = -R(t)^-T eps, per-sample t (sde_lib.py:246-253); eps is a device tensor (B,...,d,2)."""
+        from .. import ops
+        t = ts.detach().cpu().numpy() if hasattr(ts, 'detach') else np.asarray(ts)
+        m = -np.swapaxes(self.v_invR(t), -1, -2)
+        return ops.bmm(m.astype(np.float32), eps)
+
+    def prior_sampling(self, rng, shape, device=None):
+        """x ~ N(0, I), v ~ N(0, I)/sqrt(m_inv), stacked on the last axis (sde_lib.py:270-274).
+        Drawn with torch's generator on the device; jax's threefry stream cannot be reproduced, so parity
+        runs pass `u` explicitly."""
+        import torch
+        device = torch.device('cuda', torch.cuda.current_device()) if device is None else device
+        g = torch.Generator(device=device)
+        g.manual_seed(int(rng) if not hasattr(rng, 'integers') else int(rng.integers(0, 2 ** 62)))
+        xs = torch.randn(tuple(shape), generator=g, device=device, dtype=torch.float32)
+        vs = torch.randn(tuple(shape), generator=g, device=device, dtype=torch.float32) / float(np.sqrt(self.m_inv))
+        return torch.stack([xs, vs], dim=-1)
+
+    # ---- sampler coefficient tables ----
+    def prepare_order0_coef(self, rev_ts, num_item=1000):
+        """sde_lib.py:289-306: Psi_i and a 1000-point left Riemann epsilon matrix per step."""
+        ts = np.asarray(rev_ts, dtype=np.float64)
+        mean = self.vv_psi(ts[:-1], ts[1:])
+        eps = deis.get_ab_eps_coef(self, 0, ts, 0, num_item=num_item)[:, 0]
+        return mean, eps
+
+    def get_deis_coef(self, order, rev_timesteps, used_cache=True):
+        """(N, order+3, 2, 2) = [Psi_i, C_i0 .. C_i(order+1)] (sde_lib.py:308-319; highest_order = order+1)."""
+        ts = np.asarray(rev_timesteps, dtype=np.float64)
+        x_coef = self.vv_psi(ts[:-1], ts[1:])
+        eps_coef = deis.get_ab_eps_coef(self, order + 1, ts, order)
+        return np.concatenate([x_coef[:, None], eps_coef], axis=1)
+
+
+def from_config(config):
+    return CLD(m_inv=config.model.m_inv, beta_0=config.model.beta_0, beta_1=config.model.beta_1,
+               vv_gamma=config.model.vv_gamma, mixed_score=config.model.mixed_score, is_R_rk=config.model.is_R_rk,
+               used_cache=config.model.used_cache, R_dt=config.model.R_dt, x64=config.model.x64)

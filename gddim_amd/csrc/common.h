@@ -1,0 +1,116 @@
+// Shared declarations of the gddim_amd native library (host side).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+
+namespace gd {
+
+void set_error(const char *fmt, ...);
+
+#define GD_HIP(expr)                                                                             \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess) {                                                                  \
+            gd::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return 1;                                                                            \
+        }                                                                                        \
+    } while (0)
+
+#define GD_CHECK(cond, ...)            \
+    do {                               \
+        if (!(cond)) {                 \
+            gd::set_error(__VA_ARGS__); \
+            return 1;                  \
+        }                              \
+    } while (0)
+
+#define GD_TRY(expr)          \
+    do {                      \
+        int _r = (expr);      \
+        if (_r) return _r;    \
+    } while (0)
+
+// ---- implicit-GEMM parameters (kernels/igemm.hip) ---------------------------------------------
+// C[m][n] = (alpha * sum_k A[m][k] * B[n][k] + bias[n] + rowbias[img(m)][n] + res[m][n]) * out_scale
+//   A: implicit im2col of up to two NHWC sources (channel concat), k = (dy*KW + dx)*Cin + c
+//   B: [N][K] row-major (weights, or a K-matrix), or k-major [K][N] (b_kmajor)
+struct GemmParams {
+    const float *a0;
+    const float *a1;
+    int C0, C1;      // channels taken from a0 / a1 (Cin = C0 + C1), both multiples of 4
+    int lda0, lda1;  // pixel stride (floats) of each source
+    int H, W;        // input spatial size
+    int OH, OW;      // output spatial size
+    int KH, KW, stride, pad;
+    int M;           // rows (per z-slice): images*OH*OW
+    int N, K;        // K = KH*KW*(C0+C1)
+    long long sA;    // z-stride of a0 (floats)
+    const float *b;
+    int ldb;
+    int b_kmajor;
+    long long sB;
+    float *out;
+    int ldc;
+    long long sC;
+    const float *bias;     // [N] or null
+    const float *rowbias;  // [(m / rows_per_image) * ld_rowbias + n] or null
+    int ld_rowbias;
+    int rows_per_image;
+    const float *res;  // [m * ldres + n] or null
+    int ldres;
+    float alpha;
+    float out_scale;
+    int in_act;  // 1: swish applied to A elements on load
+    int m_tiles, n_tiles;
+};
+
+int launch_igemm(const GemmParams &p, int batch_z, hipStream_t s);
+const char *igemm_variant_name(const GemmParams &p, int batch_z);
+
+// ---- normalisation / activation / resampling (kernels/norm_act.hip) -----------------------------
+constexpr int GN_MAX_SLICES = 16;
+int gn_slices(int batch, int HW);
+// partial sums: part[b][slice][g][2] = (sum, sumsq); sources as in GemmParams (channel concat)
+int launch_gn_stats(const float *x0, int C0, const float *x1, int C1, float *part, int batch, int HW, int groups,
+                    int slices, hipStream_t s);
+int launch_gn_apply(const float *x0, int C0, const float *x1, int C1, const float *part, const float *gamma,
+                    const float *beta, float *out, int batch, int HW, int groups, int slices, int act, float eps,
+                    hipStream_t s);
+int launch_fir_up2(const float *x, float *out, int batch, int H, int W, int C, hipStream_t s);
+int launch_fir_down2(const float *x, float *out, int batch, int H, int W, int C, hipStream_t s);
+int launch_softmax_rows(float *x, long long rows, int cols, hipStream_t s);
+int launch_swish(const float *x, float *out, long long n, hipStream_t s);
+// temb0[b][0:E] = sin(2 pi W log(label_b)), [E:2E] = cos(...); label_b = labels[b] or 999*ts[*step]
+int launch_fourier(const float *labels, const float *ts_table, const int *step, const float *W, float *out, int batch,
+                   int E, hipStream_t s);
+int launch_pad_channels(const float *x, int ld_in, float *out, long long pixels, int Cin, int Cpad, float mul,
+                        float add, hipStream_t s);
+int launch_scale_rows(float *x, const float *labels, int batch, long long per_image, hipStream_t s);
+
+// ---- sampler update rules (kernels/update.hip) ---------------------------------------------------
+int launch_ab_step(const float *u, const float *coef, const float *new_eps, const float *hist_in, float *u_out,
+                   float *hist_out, int n_hist, long long n_pairs, hipStream_t s);
+int launch_ab_step_scalar(const float *x, const float *coef, const float *new_eps, const float *hist_in, float *x_out,
+                          float *hist_out, int n_hist, long long n, hipStream_t s);
+int launch_bmm2x2(const float *m, const float *in, float *out, long long n_pairs, int per_sample,
+                  long long pairs_per_sample, hipStream_t s);
+int launch_dct2d_32(const float *in, float *out, int batch, int channels, int inverse, hipStream_t s);
+// CLD fused-sampler kernels on the channel-planar state (B*HW, 8) = [x_0..x_{C-1}, v_0..v_{C-1}, 0..]
+int launch_cld_pack(const float *u, float *u8, float *ring, int ring_slots, long long pixels, int C, hipStream_t s);
+int launch_cld_unpack_pairs(const float *planar, int ld, float *pairs, long long pixels, int C, hipStream_t s);
+int launch_cld_ab_step(float *u8, const float *eps, float *ring, int ring_slots, const float *coef_table, int n_slots,
+                       const int *step, long long pixels, int C, hipStream_t s);
+int launch_cld_finish(const float *u8, const float *eps, const float *dn /*12 floats: F, GG, RinvT*/, float dt,
+                      int denoise, int inverse_scale, float *x_out, float *v_out, long long pixels, int C,
+                      hipStream_t s);
+int launch_advance_step(int *step, hipStream_t s);
+// blur fused-sampler kernels
+int launch_blur_idct_pad(const float *y, float *x8, int batch, int C, hipStream_t s);
+int launch_blur_step(float *y, const float *eps_x, const float *mean_coef, const float *std_coef, const int *step,
+                     int batch, int C, hipStream_t s);
+int launch_blur_finish(const float *y, float *x_out, int batch, int C, int inverse_scale, hipStream_t s);
+
+}  // namespace gd

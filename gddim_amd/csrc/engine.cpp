@@ -1,0 +1,637 @@
+// gddim_amd engine: owns the plan, the packed weights, the activation arena and the sampler state of one GPU,
+// and implements the C ABI of include/gddim_amd.h.  No CPU compute fallback exists: every compute entry point
+// launches HIP kernels or fails.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "plan.h"
+
+namespace gd {
+
+static thread_local std::string g_err;
+
+void set_error(const char *fmt, ...) {
+    char buf[2048];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+
+}  // namespace gd
+
+using namespace gd;
+
+struct ProfAcc {
+    double ms = 0, flops = 0, bytes = 0;
+    long long launches = 0;
+};
+
+struct PendingEvent {
+    hipEvent_t a, b;
+    std::string name;
+    double flops, bytes;
+};
+
+struct gd_engine {
+    Plan plan;
+    int device = -1;
+    bool plan_only = true;
+    bool params_uploaded = false;
+    // device memory
+    float *arena = nullptr;
+    float *wbuf = nullptr;
+    std::vector<long long> slot_off;  // floats into wbuf
+    long long wbuf_floats = 0;
+    float *xin = nullptr, *epsb = nullptr, *labels = nullptr, *eps_planar = nullptr;
+    // sampler state
+    float *u8 = nullptr, *ring = nullptr, *ystate = nullptr;
+    long long ring_cap = 0;
+    float *ts_dev = nullptr, *coef_dev = nullptr, *dn_dev = nullptr, *mean_dev = nullptr, *std_dev = nullptr;
+    int *step_dev = nullptr;
+    int sched_kind = 0;  // 1 cld, 2 blur
+    int num_step = 0, n_slots = 0, denoise = 0;
+    float t_denoise = 0;
+    // graphs keyed by batch
+    struct Graphs { hipGraphExec_t step = nullptr, fin = nullptr; };
+    std::map<int, Graphs> graphs;
+    // profiling
+    bool prof = false;
+    std::map<std::string, ProfAcc> prof_acc;
+    std::vector<PendingEvent> pending;
+};
+
+static const float *slot_ptr(gd_engine *e, int slot) { return slot < 0 ? nullptr : e->wbuf + e->slot_off[slot]; }
+
+static void drop_graphs(gd_engine *e) {
+    for (auto &kv : e->graphs) {
+        if (kv.second.step) (void)hipGraphExecDestroy(kv.second.step);
+        if (kv.second.fin) (void)hipGraphExecDestroy(kv.second.fin);
+    }
+    e->graphs.clear();
+}
+
+struct Bind {
+    const float *x_in;
+    const float *labels;  // nullptr: labels = 999 * ts_dev[*step_dev]
+    float *eps_out;
+};
+
+static float *tptr(gd_engine *e, const Bind &b, const TRef &r, int batch) {
+    if (r.t < 0) return nullptr;
+    const Tensor &t = e->plan.tensors[r.t];
+    float *base;
+    switch (t.ext) {
+        case EXT_X_IN: base = const_cast<float *>(b.x_in); break;
+        case EXT_LABELS: base = const_cast<float *>(b.labels); break;
+        case EXT_EPS_OUT: base = b.eps_out; break;
+        default: base = e->arena + (size_t)t.offset * batch; break;
+    }
+    return base ? base + r.col : nullptr;
+}
+
+struct ProfScope {
+    gd_engine *e;
+    hipStream_t s;
+    PendingEvent ev;
+    bool on;
+    ProfScope(gd_engine *e_, hipStream_t s_, const std::string &name, double flops, double bytes) : e(e_), s(s_), on(e_->prof) {
+        if (!on) return;
+        ev.name = name; ev.flops = flops; ev.bytes = bytes;
+        (void)hipEventCreate(&ev.a);
+        (void)hipEventCreate(&ev.b);
+        (void)hipEventRecord(ev.a, s);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        (void)hipEventRecord(ev.b, s);
+        e->pending.push_back(ev);
+    }
+};
+
+static int run_op(gd_engine *e, const Op &op, const Bind &b, int batch, hipStream_t s) {
+    const Plan &P = e->plan;
+    switch (op.kind) {
+        case OP_FOURIER: {
+            ProfScope ps(e, s, "fourier", 0, 0);
+            return launch_fourier(b.labels, e->ts_dev, e->step_dev, slot_ptr(e, op.w_slot), tptr(e, b, op.out, batch), batch,
+                                  op.N, s);
+        }
+        case OP_GEMM: {
+            GemmParams g{};
+            g.a0 = tptr(e, b, op.a0, batch);
+            g.a1 = tptr(e, b, op.a1, batch);
+            g.C0 = op.C0; g.C1 = op.C1; g.lda0 = op.lda0; g.lda1 = op.lda1 ? op.lda1 : 4;
+            g.H = op.H; g.W = op.W; g.OH = op.OH; g.OW = op.OW; g.KH = op.KH; g.KW = op.KW; g.stride = op.stride; g.pad = op.pad;
+            g.N = op.N; g.K = op.K;
+            int z = 1;
+            if (op.z_per_image) { g.M = op.m_per_image; z = batch; g.sA = op.sA; g.sB = op.sB; g.sC = op.sC; }
+            else g.M = op.m_per_image * batch;
+            if (op.w_slot >= 0) g.b = slot_ptr(e, op.w_slot);
+            else g.b = tptr(e, b, op.bten, batch);
+            g.ldb = op.ldb; g.b_kmajor = op.b_kmajor;
+            g.out = tptr(e, b, op.out, batch); g.ldc = op.ldc;
+            g.bias = op.bias_slot >= 0 ? slot_ptr(e, op.bias_slot) + op.bias_off : nullptr;
+            g.rowbias = tptr(e, b, op.rowbias, batch); g.ld_rowbias = op.ld_rowbias; g.rows_per_image = op.m_per_image;
+            g.res = tptr(e, b, op.res, batch); g.ldres = op.ldres;
+            g.alpha = op.alpha; g.out_scale = op.out_scale; g.in_act = op.in_act;
+            ProfScope ps(e, s, e->prof ? igemm_variant_name(g, z) : "", op.flops_per_image * batch, 0);
+            return launch_igemm(g, z, s);
+        }
+        case OP_GN_STATS: {
+            const int HW = op.H * op.W;
+            const int sl = gn_slices(batch, HW);
+            ProfScope ps(e, s, "gn_stats", 0, 4.0 * batch * HW * (op.C0 + op.C1));
+            return launch_gn_stats(tptr(e, b, op.a0, batch), op.C0, tptr(e, b, op.a1, batch), op.C1, tptr(e, b, op.stats, batch),
+                                   batch, HW, op.groups, sl, s);
+        }
+        case OP_GN_APPLY: {
+            const int HW = op.H * op.W;
+            const int sl = gn_slices(batch, HW);
+            ProfScope ps(e, s, "gn_apply", 0, 8.0 * batch * HW * (op.C0 + op.C1));
+            return launch_gn_apply(tptr(e, b, op.a0, batch), op.C0, tptr(e, b, op.a1, batch), op.C1, tptr(e, b, op.stats, batch),
+                                   slot_ptr(e, op.gamma_slot), slot_ptr(e, op.beta_slot), tptr(e, b, op.out, batch), batch, HW,
+                                   op.groups, sl, op.act, 1e-6f, s);
+        }
+        case OP_FIR_UP: {
+            ProfScope ps(e, s, "fir_up2", 0, 4.0 * batch * op.H * op.W * op.C0 * 5);
+            return launch_fir_up2(tptr(e, b, op.a0, batch), tptr(e, b, op.out, batch), batch, op.H, op.W, op.C0, s);
+        }
+        case OP_FIR_DOWN: {
+            ProfScope ps(e, s, "fir_down2", 0, 4.0 * batch * op.H * op.W * op.C0 * 1.25);
+            return launch_fir_down2(tptr(e, b, op.a0, batch), tptr(e, b, op.out, batch), batch, op.H, op.W, op.C0, s);
+        }
+        case OP_SOFTMAX: {
+            ProfScope ps(e, s, "softmax", 0, 8.0 * batch * op.rows_per_image * op.cols);
+            return launch_softmax_rows(tptr(e, b, op.out, batch), (long long)batch * op.rows_per_image, op.cols, s);
+        }
+        case OP_AFFINE_PAD: {
+            ProfScope ps(e, s, "affine_pad", 0, 0);
+            return launch_pad_channels(tptr(e, b, op.a0, batch), op.lda0, tptr(e, b, op.out, batch),
+                                       (long long)batch * op.H * op.W, op.cin, op.cpad, op.mul, op.add, s);
+        }
+        case OP_SCALE_ROWS: {
+            GD_CHECK(b.labels != nullptr, "scale_by_sigma needs explicit labels (not supported inside the fused sampler)");
+            return launch_scale_rows(tptr(e, b, op.out, batch), b.labels, batch, op.m_per_image, s);
+        }
+    }
+    GD_CHECK(false, "unknown op kind %d", op.kind);
+    (void)P;
+}
+
+static int run_unet(gd_engine *e, const Bind &b, int batch, hipStream_t s) {
+    for (const Op &op : e->plan.ops) GD_TRY(run_op(e, op, b, batch, s));
+    return 0;
+}
+
+static int check_compute(gd_engine *e, int batch) {
+    GD_CHECK(e != nullptr, "null engine");
+    GD_CHECK(!e->plan_only, "engine was created in plan-only mode (device < 0): no GPU compute available");
+    GD_CHECK(e->params_uploaded, "parameters not loaded: call gd_engine_params_ready first");
+    GD_CHECK(batch >= 1 && batch <= e->plan.desc.max_batch, "batch %d outside [1, max_batch=%d]", batch, e->plan.desc.max_batch);
+    GD_HIP(hipSetDevice(e->device));
+    return 0;
+}
+
+extern "C" {
+
+const char *gd_last_error(void) { return g_err.c_str(); }
+int gd_version(void) { return 100; }
+
+int gd_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// ---- engine ----
+int gd_engine_create(const gd_model_desc *desc, int device, gd_engine **out) {
+    GD_CHECK(desc && out, "null argument");
+    gd_engine *e = new gd_engine();
+    if (e->plan.build(*desc)) { delete e; return 1; }
+    e->device = device;
+    e->plan_only = device < 0;
+    e->slot_off.resize(e->plan.slots.size());
+    long long off = 0;
+    for (size_t i = 0; i < e->plan.slots.size(); ++i) {
+        e->slot_off[i] = off;
+        off += (e->plan.slots[i].rows * e->plan.slots[i].cols + 63) / 64 * 64;
+    }
+    e->wbuf_floats = off;
+    if (!e->plan_only) {
+        auto fail = [&](const char *what, hipError_t err) {
+            set_error("%s: %s", what, hipGetErrorString(err));
+            gd_engine_destroy(e);
+            return 1;
+        };
+        hipError_t err;
+        if ((err = hipSetDevice(device)) != hipSuccess) return fail("hipSetDevice", err);
+        const size_t B = desc->max_batch;
+        const size_t pix = B * desc->image_size * desc->image_size;
+        const int CP = e->plan.CP;
+#define GD_ALLOC(ptr, n)                                                                \
+    if ((err = hipMalloc((void **)&(ptr), (size_t)(n) * sizeof(float))) != hipSuccess) \
+        return fail("hipMalloc " #ptr, err);
+        GD_ALLOC(e->arena, (size_t)e->plan.arena_per_image * B);
+        GD_ALLOC(e->wbuf, (size_t)e->wbuf_floats);
+        GD_ALLOC(e->xin, pix * CP);
+        GD_ALLOC(e->epsb, pix * desc->in_channels);
+        GD_ALLOC(e->eps_planar, pix * desc->in_channels);
+        GD_ALLOC(e->labels, B);
+        GD_ALLOC(e->u8, pix * CP);
+        GD_ALLOC(e->ystate, pix * desc->in_channels);
+        GD_ALLOC(e->dn_dev, 12);
+        GD_ALLOC(e->step_dev, 1);
+#undef GD_ALLOC
+        (void)hipMemset(e->step_dev, 0, sizeof(int));
+    }
+    *out = e;
+    return 0;
+}
+
+int gd_engine_destroy(gd_engine *e) {
+    if (!e) return 0;
+    if (!e->plan_only) {
+        (void)hipSetDevice(e->device);
+        (void)hipDeviceSynchronize();
+        drop_graphs(e);
+        for (auto &p : e->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+        float *bufs[] = {e->arena, e->wbuf, e->xin, e->epsb, e->eps_planar, e->labels, e->u8, e->ring, e->ystate,
+                         e->ts_dev, e->coef_dev, e->dn_dev, e->mean_dev, e->std_dev, (float *)e->step_dev};
+        for (float *b : bufs)
+            if (b) (void)hipFree(b);
+    }
+    delete e;
+    return 0;
+}
+
+int gd_engine_plan_json(gd_engine *e, char *buf, size_t cap, size_t *needed) {
+    GD_CHECK(e, "null engine");
+    const std::string j = e->plan.json();
+    if (needed) *needed = j.size() + 1;
+    if (buf && cap >= j.size() + 1) memcpy(buf, j.c_str(), j.size() + 1);
+    return 0;
+}
+
+double gd_engine_flops_per_image(gd_engine *e, int conv3x3_only) {
+    if (!e) return 0;
+    return conv3x3_only ? e->plan.conv3x3_flops_per_image : e->plan.flops_per_image;
+}
+
+// ---- weights ----
+int gd_engine_num_params(gd_engine *e) { return e ? (int)e->plan.params.size() : 0; }
+
+int gd_engine_param_info(gd_engine *e, int index, char *name_buf, size_t name_cap, int64_t *shape4, int *ndim) {
+    GD_CHECK(e && index >= 0 && index < (int)e->plan.params.size(), "bad param index");
+    const Param &p = e->plan.params[index];
+    if (name_buf && name_cap) { strncpy(name_buf, p.name.c_str(), name_cap - 1); name_buf[name_cap - 1] = 0; }
+    if (ndim) *ndim = (int)p.shape.size();
+    if (shape4)
+        for (size_t i = 0; i < 4; ++i) shape4[i] = i < p.shape.size() ? p.shape[i] : 1;
+    return 0;
+}
+
+int gd_engine_load_param(gd_engine *e, const char *name, const float *host_data, const int64_t *shape, int ndim) {
+    GD_CHECK(e && name && host_data && shape, "null argument");
+    e->params_uploaded = false;
+    return e->plan.load_param(name, host_data, shape, ndim);
+}
+
+int gd_engine_params_ready(gd_engine *e) {
+    GD_CHECK(e, "null engine");
+    std::string missing;
+    int nmiss = 0;
+    for (const Param &p : e->plan.params)
+        if (!p.loaded) {
+            if (nmiss < 8) missing += (nmiss ? ", " : "") + p.name;
+            ++nmiss;
+        }
+    GD_CHECK(nmiss == 0, "%d parameters not loaded: %s%s", nmiss, missing.c_str(), nmiss > 8 ? ", ..." : "");
+    if (!e->plan_only) {
+        GD_HIP(hipSetDevice(e->device));
+        for (size_t i = 0; i < e->plan.slots.size(); ++i) {
+            const WSlot &s = e->plan.slots[i];
+            GD_HIP(hipMemcpy(e->wbuf + e->slot_off[i], s.host.data(), s.host.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
+        e->params_uploaded = true;
+    }
+    return 0;
+}
+
+int gd_engine_packed_weight(gd_engine *e, const char *slot, float *host_out, size_t cap_floats, size_t *n_floats) {
+    GD_CHECK(e && slot, "null argument");
+    for (const WSlot &s : e->plan.slots)
+        if (s.name == slot) {
+            if (n_floats) *n_floats = s.host.size();
+            if (host_out) {
+                GD_CHECK(cap_floats >= s.host.size(), "buffer too small for slot '%s'", slot);
+                memcpy(host_out, s.host.data(), s.host.size() * sizeof(float));
+            }
+            return 0;
+        }
+    GD_CHECK(false, "unknown weight slot '%s'", slot);
+}
+
+// ---- score network ----
+int gd_unet_forward(gd_engine *e, const float *x_dev, const float *labels_dev, float *out_dev, int batch, void *stream) {
+    GD_TRY(check_compute(e, batch));
+    GD_CHECK(x_dev && labels_dev && out_dev, "null device pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const gd_model_desc &d = e->plan.desc;
+    const long long pix = (long long)batch * d.image_size * d.image_size;
+    GD_TRY(launch_pad_channels(x_dev, d.in_channels, e->xin, pix, d.in_channels, e->plan.CP, 1.f, 0.f, s));
+    Bind b{e->xin, labels_dev, out_dev};
+    return run_unet(e, b, batch, s);
+}
+
+int gd_cld_eps(gd_engine *e, const float *u_dev, const float *t_dev, float *eps_dev, int batch, void *stream) {
+    GD_TRY(check_compute(e, batch));
+    GD_CHECK(u_dev && t_dev && eps_dev, "null device pointer");
+    const gd_model_desc &d = e->plan.desc;
+    GD_CHECK(d.in_channels % 2 == 0, "CLD needs an even number of U-Net channels");
+    hipStream_t s = (hipStream_t)stream;
+    const int C = d.in_channels / 2;
+    const long long pix = (long long)batch * d.image_size * d.image_size;
+    GD_TRY(launch_pad_channels(t_dev, 1, e->labels, batch, 1, 1, 999.f, 0.f, s));  // labels = t * 999 (models/utils.py:172)
+    GD_TRY(launch_cld_pack(u_dev, e->xin, nullptr, 0, pix, C, s));
+    Bind b{e->xin, e->labels, e->eps_planar};
+    GD_TRY(run_unet(e, b, batch, s));
+    return launch_cld_unpack_pairs(e->eps_planar, d.in_channels, eps_dev, pix, C, s);
+}
+
+// ---- schedules ----
+static int upload(float **dst, const float *src, size_t n) {
+    if (*dst) { (void)hipFree(*dst); *dst = nullptr; }
+    GD_HIP(hipMalloc((void **)dst, n * sizeof(float)));
+    GD_HIP(hipMemcpy(*dst, src, n * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int gd_engine_set_schedule_cld(gd_engine *e, int num_step, int n_slots, const float *ts_host, const float *coef_host,
+                               int denoise, float t_denoise, const float *dn_F, const float *dn_GG, const float *dn_RinvT) {
+    GD_CHECK(e && !e->plan_only, "engine has no GPU");
+    GD_CHECK(num_step >= 0 && n_slots >= 2 && ts_host && coef_host, "bad schedule");
+    GD_CHECK(e->plan.desc.in_channels % 2 == 0, "CLD needs an even number of U-Net channels");
+    GD_HIP(hipSetDevice(e->device));
+    GD_HIP(hipDeviceSynchronize());
+    drop_graphs(e);
+    std::vector<float> ts(ts_host, ts_host + num_step);
+    ts.push_back(t_denoise);  // ts[num_step]: the time of the denoising evaluation
+    GD_TRY(upload(&e->ts_dev, ts.data(), ts.size()));
+    GD_TRY(upload(&e->coef_dev, coef_host, (size_t)std::max(1, num_step) * n_slots * 4));
+    if (denoise) {
+        GD_CHECK(dn_F && dn_GG && dn_RinvT, "denoise matrices missing");
+        float dn[12];
+        memcpy(dn, dn_F, 16); memcpy(dn + 4, dn_GG, 16); memcpy(dn + 8, dn_RinvT, 16);
+        GD_HIP(hipMemcpy(e->dn_dev, dn, sizeof dn, hipMemcpyHostToDevice));
+    }
+    const int ring_slots = n_slots - 2;
+    const gd_model_desc &d = e->plan.desc;
+    const long long need = (long long)ring_slots * d.max_batch * d.image_size * d.image_size * d.in_channels;
+    if (need > e->ring_cap) {
+        if (e->ring) (void)hipFree(e->ring);
+        e->ring = nullptr;
+        GD_HIP(hipMalloc((void **)&e->ring, (size_t)need * sizeof(float)));
+        e->ring_cap = need;
+    }
+    e->sched_kind = 1; e->num_step = num_step; e->n_slots = n_slots; e->denoise = denoise; e->t_denoise = t_denoise;
+    return 0;
+}
+
+static int capture_begin(hipStream_t s) {
+    GD_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
+    return 0;
+}
+
+static int capture_end(hipStream_t s, hipGraphExec_t *exec) {
+    hipGraph_t g = nullptr;
+    GD_HIP(hipStreamEndCapture(s, &g));
+    hipError_t err = hipGraphInstantiate(exec, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    GD_CHECK(err == hipSuccess, "hipGraphInstantiate: %s", hipGetErrorString(err));
+    return 0;
+}
+
+int gd_sample_cld(gd_engine *e, int batch, const float *u_in_dev, float *x_out_dev, float *v_out_dev, int inverse_scale,
+                  int use_graph, void *stream) {
+    GD_TRY(check_compute(e, batch));
+    GD_CHECK(e->sched_kind == 1, "no CLD schedule installed (gd_engine_set_schedule_cld)");
+    GD_CHECK(u_in_dev && x_out_dev && v_out_dev, "null device pointer");
+    GD_CHECK(!e->plan.desc.scale_by_sigma, "scale_by_sigma is not supported inside the fused sampler");
+    hipStream_t s = (hipStream_t)stream;
+    const gd_model_desc &d = e->plan.desc;
+    const int C = d.in_channels / 2;
+    const long long pix = (long long)batch * d.image_size * d.image_size;
+    const int ring_slots = e->n_slots - 2;
+    GD_TRY(launch_cld_pack(u_in_dev, e->u8, e->ring, ring_slots, pix, C, s));
+    GD_HIP(hipMemsetAsync(e->step_dev, 0, sizeof(int), s));
+    Bind b{e->u8, nullptr, e->epsb};
+    auto step_body = [&]() -> int {
+        GD_TRY(run_unet(e, b, batch, s));
+        GD_TRY(launch_cld_ab_step(e->u8, e->epsb, e->ring, ring_slots, e->coef_dev, e->n_slots, e->step_dev, pix, C, s));
+        return launch_advance_step(e->step_dev, s);
+    };
+    const bool graph = use_graph && !e->prof;
+    if (graph) {
+        gd_engine::Graphs &g = e->graphs[batch];
+        if (!g.step) {
+            GD_TRY(capture_begin(s));
+            int r = step_body();
+            int r2 = capture_end(s, &g.step);
+            if (r || r2) return 1;
+        }
+        if (e->denoise && !g.fin) {
+            GD_TRY(capture_begin(s));
+            int r = run_unet(e, b, batch, s);
+            int r2 = capture_end(s, &g.fin);
+            if (r || r2) return 1;
+        }
+        for (int i = 0; i < e->num_step; ++i) GD_HIP(hipGraphLaunch(g.step, s));
+        if (e->denoise) GD_HIP(hipGraphLaunch(g.fin, s));
+    } else {
+        for (int i = 0; i < e->num_step; ++i) GD_TRY(step_body());
+        if (e->denoise) GD_TRY(run_unet(e, b, batch, s));  // step == num_step -> t = t_denoise
+    }
+    return launch_cld_finish(e->u8, e->epsb, e->dn_dev, -e->t_denoise, e->denoise, inverse_scale, x_out_dev, v_out_dev, pix, C,
+                             s);
+}
+
+int gd_engine_set_schedule_blur(gd_engine *e, int nfe, const float *ts_host, const float *mean_coef_host,
+                                const float *std_coef_host) {
+    GD_CHECK(e && !e->plan_only, "engine has no GPU");
+    GD_CHECK(nfe >= 1 && ts_host && mean_coef_host && std_coef_host, "bad schedule");
+    GD_CHECK(e->plan.desc.image_size == 32, "the blur SDE is hard-wired to 32x32 (blur_jax/sde_lib.py:24)");
+    GD_HIP(hipSetDevice(e->device));
+    GD_HIP(hipDeviceSynchronize());
+    drop_graphs(e);
+    GD_TRY(upload(&e->ts_dev, ts_host, nfe));
+    GD_TRY(upload(&e->mean_dev, mean_coef_host, (size_t)(nfe + 1) * 1024));
+    GD_TRY(upload(&e->std_dev, std_coef_host, (size_t)(nfe + 1)));
+    e->sched_kind = 2; e->num_step = nfe;
+    return 0;
+}
+
+int gd_sample_blur(gd_engine *e, int batch, const float *y_in_dev, float *x_out_dev, int inverse_scale, int use_graph,
+                   void *stream) {
+    GD_TRY(check_compute(e, batch));
+    GD_CHECK(e->sched_kind == 2, "no blur schedule installed (gd_engine_set_schedule_blur)");
+    GD_CHECK(y_in_dev && x_out_dev, "null device pointer");
+    GD_CHECK(!e->plan.desc.scale_by_sigma, "scale_by_sigma is not supported inside the fused sampler");
+    hipStream_t s = (hipStream_t)stream;
+    const gd_model_desc &d = e->plan.desc;
+    const int C = d.in_channels;
+    const size_t n = (size_t)batch * 1024 * C;
+    GD_HIP(hipMemcpyAsync(e->ystate, y_in_dev, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    GD_HIP(hipMemsetAsync(e->step_dev, 0, sizeof(int), s));
+    Bind b{e->xin, nullptr, e->epsb};
+    auto step_body = [&]() -> int {
+        GD_TRY(launch_blur_idct_pad(e->ystate, e->xin, batch, C, s));
+        GD_TRY(run_unet(e, b, batch, s));
+        GD_TRY(launch_blur_step(e->ystate, e->epsb, e->mean_dev, e->std_dev, e->step_dev, batch, C, s));
+        return launch_advance_step(e->step_dev, s);
+    };
+    const bool graph = use_graph && !e->prof;
+    if (graph) {
+        gd_engine::Graphs &g = e->graphs[batch];
+        if (!g.step) {
+            GD_TRY(capture_begin(s));
+            int r = step_body();
+            int r2 = capture_end(s, &g.step);
+            if (r || r2) return 1;
+        }
+        for (int i = 0; i < e->num_step; ++i) GD_HIP(hipGraphLaunch(g.step, s));
+    } else {
+        for (int i = 0; i < e->num_step; ++i) GD_TRY(step_body());
+    }
+    return launch_blur_finish(e->ystate, x_out_dev, batch, C, inverse_scale, s);
+}
+
+// ---- profiling ----
+int gd_engine_profile(gd_engine *e, int enable) {
+    GD_CHECK(e, "null engine");
+    e->prof = enable != 0;
+    if (enable) {
+        e->prof_acc.clear();
+        for (auto &p : e->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+        e->pending.clear();
+    }
+    return 0;
+}
+
+int gd_engine_profile_read(gd_engine *e, gd_prof_entry *out, int cap, int *n) {
+    GD_CHECK(e && !e->plan_only, "engine has no GPU");
+    GD_HIP(hipSetDevice(e->device));
+    GD_HIP(hipDeviceSynchronize());
+    for (auto &p : e->pending) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            ProfAcc &a = e->prof_acc[p.name];
+            a.ms += ms; a.flops += p.flops; a.bytes += p.bytes; a.launches++;
+        }
+        (void)hipEventDestroy(p.a);
+        (void)hipEventDestroy(p.b);
+    }
+    e->pending.clear();
+    int i = 0;
+    for (auto &kv : e->prof_acc) {
+        if (out && i < cap) {
+            memset(&out[i], 0, sizeof out[i]);
+            strncpy(out[i].name, kv.first.c_str(), sizeof(out[i].name) - 1);
+            out[i].ms = kv.second.ms; out[i].flops = kv.second.flops; out[i].bytes = kv.second.bytes;
+            out[i].launches = kv.second.launches;
+        }
+        ++i;
+    }
+    if (n) *n = i;
+    return 0;
+}
+
+// ---- stand-alone operators ----
+int gd_ab_step(const float *u_dev, const float *coef_dev, const float *new_eps_dev, const float *hist_in_dev, float *u_out_dev,
+               float *hist_out_dev, int n_hist, long long n_pairs, void *stream) {
+    GD_CHECK(u_dev && coef_dev && new_eps_dev && u_out_dev && (n_hist == 0 || (hist_in_dev && hist_out_dev)), "null pointer");
+    return launch_ab_step(u_dev, coef_dev, new_eps_dev, hist_in_dev, u_out_dev, hist_out_dev, n_hist, n_pairs, (hipStream_t)stream);
+}
+
+int gd_ab_step_scalar(const float *x_dev, const float *coef_dev, const float *new_eps_dev, const float *hist_in_dev,
+                      float *x_out_dev, float *hist_out_dev, int n_hist, long long n, void *stream) {
+    GD_CHECK(x_dev && coef_dev && new_eps_dev && x_out_dev && (n_hist == 0 || (hist_in_dev && hist_out_dev)), "null pointer");
+    return launch_ab_step_scalar(x_dev, coef_dev, new_eps_dev, hist_in_dev, x_out_dev, hist_out_dev, n_hist, n, (hipStream_t)stream);
+}
+
+int gd_bmm2x2(const float *m_dev, const float *in_dev, float *out_dev, long long n_pairs, int per_sample,
+              long long pairs_per_sample, void *stream) {
+    GD_CHECK(m_dev && in_dev && out_dev, "null pointer");
+    return launch_bmm2x2(m_dev, in_dev, out_dev, n_pairs, per_sample, pairs_per_sample, (hipStream_t)stream);
+}
+
+int gd_dct2d_32(const float *in_dev, float *out_dev, int batch, int channels, int inverse, void *stream) {
+    GD_CHECK(in_dev && out_dev && batch >= 1 && channels >= 1, "bad argument");
+    return launch_dct2d_32(in_dev, out_dev, batch, channels, inverse, (hipStream_t)stream);
+}
+
+int gd_conv2d(const float *x_dev, const float *w_dev, const float *bias_dev, const float *res_dev, float *out_dev, int batch,
+              int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, float alpha, float out_scale, void *stream) {
+    GD_CHECK(x_dev && w_dev && out_dev, "null pointer");
+    GemmParams g{};
+    g.a0 = x_dev; g.C0 = Cin; g.lda0 = Cin; g.lda1 = 4;
+    g.H = H; g.W = W; g.KH = KH; g.KW = KW; g.stride = stride; g.pad = pad;
+    g.OH = (H + 2 * pad - KH) / stride + 1;
+    g.OW = (W + 2 * pad - KW) / stride + 1;
+    g.M = batch * g.OH * g.OW; g.N = Cout; g.K = KH * KW * Cin;
+    g.b = w_dev; g.ldb = g.K;
+    g.out = out_dev; g.ldc = Cout; g.bias = bias_dev; g.res = res_dev; g.ldres = Cout;
+    g.rows_per_image = g.OH * g.OW;
+    g.alpha = alpha; g.out_scale = out_scale;
+    return launch_igemm(g, 1, (hipStream_t)stream);
+}
+
+int gd_group_norm(const float *x_dev, const float *scale_dev, const float *bias_dev, float *out_dev, int batch, int HW, int C,
+                  int groups, int act, void *stream) {
+    GD_CHECK(x_dev && scale_dev && bias_dev && out_dev, "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const int sl = gn_slices(batch, HW);
+    float *part = nullptr;
+    GD_HIP(hipMalloc((void **)&part, (size_t)batch * sl * groups * 2 * sizeof(float)));
+    int r = launch_gn_stats(x_dev, C, nullptr, 0, part, batch, HW, groups, sl, s);
+    if (!r) r = launch_gn_apply(x_dev, C, nullptr, 0, part, scale_dev, bias_dev, out_dev, batch, HW, groups, sl, act, 1e-6f, s);
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(part);
+    return r;
+}
+
+int gd_fir_resample(const float *x_dev, float *out_dev, int batch, int H, int W, int C, int up, void *stream) {
+    GD_CHECK(x_dev && out_dev, "null pointer");
+    return up ? launch_fir_up2(x_dev, out_dev, batch, H, W, C, (hipStream_t)stream)
+              : launch_fir_down2(x_dev, out_dev, batch, H, W, C, (hipStream_t)stream);
+}
+
+int gd_attention(const float *qkv_dev, float *scratch_dev, float *out_dev, int batch, int N, int C, void *stream) {
+    GD_CHECK(qkv_dev && scratch_dev && out_dev, "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    GemmParams g{};
+    g.a0 = qkv_dev; g.C0 = C; g.lda0 = 3 * C; g.lda1 = 4; g.H = 1; g.W = N; g.OH = 1; g.OW = N; g.KH = g.KW = 1; g.stride = 1;
+    g.M = N; g.N = N; g.K = C; g.sA = (long long)N * 3 * C;
+    g.b = qkv_dev + C; g.ldb = 3 * C; g.sB = g.sA;
+    g.out = scratch_dev; g.ldc = N; g.sC = (long long)N * N;
+    g.alpha = (float)std::pow((double)C, -0.5); g.out_scale = 1.f; g.rows_per_image = N;
+    GD_TRY(launch_igemm(g, batch, s));
+    GD_TRY(launch_softmax_rows(scratch_dev, (long long)batch * N, N, s));
+    GemmParams h{};
+    h.a0 = scratch_dev; h.C0 = N; h.lda0 = N; h.lda1 = 4; h.H = 1; h.W = N; h.OH = 1; h.OW = N; h.KH = h.KW = 1; h.stride = 1;
+    h.M = N; h.N = C; h.K = N; h.sA = (long long)N * N;
+    h.b = qkv_dev + 2 * C; h.ldb = 3 * C; h.b_kmajor = 1; h.sB = (long long)N * 3 * C;
+    h.out = out_dev; h.ldc = C; h.sC = (long long)N * C;
+    h.alpha = 1.f; h.out_scale = 1.f; h.rows_per_image = N;
+    return launch_igemm(h, batch, s);
+}
+
+}  // extern "C"

@@ -1,0 +1,317 @@
+// Bandwidth-bound kernels of the NCSN++ forward: GroupNorm(+swish), FIR resampling, softmax,
+// Fourier time embedding, channel padding.  All tensors NHWC fp32, accessed as float4 along C
+// (every channel count in the network is a multiple of 4), one wave64 reading 1 KiB contiguous.
+//
+// Reference semantics:
+//   GroupNorm  flax nn.GroupNorm(num_groups=min(C//4,32)), epsilon 1e-6, var = E[x^2]-E[x]^2, stats over
+//              (H, W, C/G) per sample, contiguous channel groups  (call sites layerspp.py:69,196,218,
+//              ncsnpp.py:236)
+//   swish      x*sigmoid(x)                                   (layers.py:39-40)
+//   FIR        upsample_2d / downsample_2d with k=[1,3,3,1]   (up_or_down_sampling.py:333-411);
+//              closed forms in SURVEY.md App. E
+//   softmax    jax.nn.softmax over the key axis               (layerspp.py:76)
+//   Fourier    [sin, cos](2 pi W log(labels))                 (layerspp.py:33-43, ncsnpp.py:74-77)
+#include "../common.h"
+
+namespace gd {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float swish_e(float x) { return x * __frcp_rn(1.0f + __expf(-x)); }
+
+int gn_slices(int batch, int HW) {
+    // enough blocks to fill 256 CUs several times over, but at least 64 pixels per slice
+    int s = 1;
+    while (s < GN_MAX_SLICES && (long long)batch * s < 2048 && HW / (s * 2) >= 64) s *= 2;
+    return s;
+}
+
+// ---- GroupNorm statistics: part[b][slice][g] = (sum, sumsq) over the slice's pixels -------------
+// grid (slices, B), 256 threads; T = (256 / C4) * C4 threads active so that each thread keeps one
+// fixed float4 column (4 channels) and strides over pixel rows; groups are reduced through LDS.
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float *__restrict__ x0, int C0, const float *__restrict__ x1,
+                                                        int C1, float *__restrict__ part, int HW, int groups, int slices) {
+    __shared__ float s_sum[256], s_sq[256];
+    const int C = C0 + C1, C4 = C >> 2;
+    const int rows_pp = 256 / C4;
+    const int T = rows_pp * C4;
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y, sl = blockIdx.x;
+    const int per = (HW + slices - 1) / slices;
+    const int p_beg = sl * per, p_end = min(HW, p_beg + per);
+    float s = 0.f, q = 0.f;
+    if (tid < T) {
+        const int f = tid % C4, rp = tid / C4;
+        const int c = f * 4;
+        const float *src;
+        int ld, cc;
+        if (c < C0) { src = x0; ld = C0; cc = c; } else { src = x1; ld = C1; cc = c - C0; }
+        src += (size_t)b * HW * ld + cc;
+        for (int p = p_beg + rp; p < p_end; p += rows_pp) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(src + (size_t)p * ld);
+            s += (v[0] + v[1]) + (v[2] + v[3]);
+            q += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+        }
+    }
+    s_sum[tid] = s;
+    s_sq[tid] = q;
+    __syncthreads();
+    if (tid < groups) {
+        const int f4pg = C4 / groups;  // float4 columns per group
+        float ts = 0.f, tq = 0.f;
+        for (int rp = 0; rp < rows_pp; ++rp)
+            for (int k = 0; k < f4pg; ++k) {
+                const int i = rp * C4 + tid * f4pg + k;
+                ts += s_sum[i];
+                tq += s_sq[i];
+            }
+        float *o = part + (((size_t)b * slices + sl) * groups + tid) * 2;
+        o[0] = ts;
+        o[1] = tq;
+    }
+}
+
+// ---- GroupNorm apply (+ optional swish); reduces the slice partials in its prologue ---------------
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float *__restrict__ x0, int C0, const float *__restrict__ x1,
+                                                        int C1, const float *__restrict__ part,
+                                                        const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                        float *__restrict__ out, int HW, int groups, int slices,
+                                                        int act, float eps) {
+    const int C = C0 + C1, C4 = C >> 2;
+    const int rows_pp = 256 / C4;
+    const int T = rows_pp * C4;
+    const int tid = threadIdx.x;
+    if (tid >= T) return;
+    const int b = blockIdx.y;
+    const int nblk = gridDim.x;
+    const int per = (HW + nblk - 1) / nblk;
+    const int p_beg = blockIdx.x * per, p_end = min(HW, p_beg + per);
+    const int f = tid % C4, rp = tid / C4;
+    const int c = f * 4;
+    const int g = f / (C4 / groups);
+    float ts = 0.f, tq = 0.f;
+    for (int sl = 0; sl < slices; ++sl) {
+        const float *pp = part + (((size_t)b * slices + sl) * groups + g) * 2;
+        ts += pp[0];
+        tq += pp[1];
+    }
+    const float inv_n = 1.0f / ((float)HW * (float)(C / groups));
+    const float mean = ts * inv_n;
+    const float var = tq * inv_n - mean * mean;
+    const float rstd = rsqrtf(var + eps);
+    const f32x4 ga = *reinterpret_cast<const f32x4 *>(gamma + c);
+    const f32x4 be = *reinterpret_cast<const f32x4 *>(beta + c);
+    f32x4 sc, sh;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { sc[i] = rstd * ga[i]; sh[i] = be[i] - mean * rstd * ga[i]; }
+    const float *src;
+    int ld, cc;
+    if (c < C0) { src = x0; ld = C0; cc = c; } else { src = x1; ld = C1; cc = c - C0; }
+    src += (size_t)b * HW * ld + cc;
+    float *dst = out + (size_t)b * HW * C + c;
+    for (int p = p_beg + rp; p < p_end; p += rows_pp) {
+        f32x4 v = *reinterpret_cast<const f32x4 *>(src + (size_t)p * ld);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float y = v[i] * sc[i] + sh[i];
+            v[i] = act ? swish_e(y) : y;
+        }
+        *reinterpret_cast<f32x4 *>(dst + (size_t)p * C) = v;
+    }
+}
+
+int launch_gn_stats(const float *x0, int C0, const float *x1, int C1, float *part, int batch, int HW, int groups,
+                    int slices, hipStream_t s) {
+    const int C = C0 + C1;
+    GD_CHECK(C % 4 == 0 && C0 % 4 == 0 && C / 4 <= 256 && (C / 4) % groups == 0 && groups <= 256,
+             "group_norm: unsupported C=%d (C0=%d) groups=%d", C, C0, groups);
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(slices, batch), dim3(256), 0, s, x0, C0, x1, C1, part, HW, groups, slices);
+    GD_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_gn_apply(const float *x0, int C0, const float *x1, int C1, const float *part, const float *gamma,
+                    const float *beta, float *out, int batch, int HW, int groups, int slices, int act, float eps,
+                    hipStream_t s) {
+    int nblk = 1;
+    while (nblk < 64 && (long long)batch * nblk < 4096 && HW / (nblk * 2) >= 16) nblk *= 2;
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(nblk, batch), dim3(256), 0, s, x0, C0, x1, C1, part, gamma, beta, out, HW,
+                       groups, slices, act, eps);
+    GD_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---- FIR [1,3,3,1] 2x resampling, zero boundary -------------------------------
+// up:   y[2m] = (x[m-1] + 3 x[m]) / 4,  y[2m+1] = (3 x[m] + x[m+1]) / 4   per axis
+// down: y[i]  = (x[2i-1] + 3 x[2i] + 3 x[2i+1] + x[2i+2]) / 8             per axis
+__global__ __launch_bounds__(256) void fir_up2_kernel(const float *__restrict__ x, float *__restrict__ out, int H, int W,
+                                                       int C4, long long total) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int f = (int)(idx % C4);
+    long long r = idx / C4;
+    const int OW = 2 * W, OH = 2 * H;
+    const int ox = (int)(r % OW);
+    r /= OW;
+    const int oy = (int)(r % OH);
+    const int b = (int)(r / OH);
+    // per axis: even output 2m uses (m-1: 1/4, m: 3/4); odd output 2m+1 uses (m: 3/4, m+1: 1/4)
+    const int my = oy >> 1, mx = ox >> 1;
+    const int y0 = (oy & 1) ? my : my - 1, y1 = y0 + 1;
+    const int x0 = (ox & 1) ? mx : mx - 1, x1 = x0 + 1;
+    const float wy0 = (oy & 1) ? 0.75f : 0.25f, wy1 = 1.0f - wy0;
+    const float wx0 = (ox & 1) ? 0.75f : 0.25f, wx1 = 1.0f - wx0;
+    const f32x4 *xb = reinterpret_cast<const f32x4 *>(x) + (size_t)b * H * W * C4 + f;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    auto tap = [&](int yy, int xx, float w) {
+        if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
+            const f32x4 v = xb[((size_t)yy * W + xx) * C4];
+            acc += v * w;
+        }
+    };
+    tap(y0, x0, wy0 * wx0);
+    tap(y0, x1, wy0 * wx1);
+    tap(y1, x0, wy1 * wx0);
+    tap(y1, x1, wy1 * wx1);
+    reinterpret_cast<f32x4 *>(out)[idx] = acc;
+}
+
+__global__ __launch_bounds__(256) void fir_down2_kernel(const float *__restrict__ x, float *__restrict__ out, int H,
+                                                         int W, int C4, long long total) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int f = (int)(idx % C4);
+    long long r = idx / C4;
+    const int OW = W / 2, OH = H / 2;
+    const int ox = (int)(r % OW);
+    r /= OW;
+    const int oy = (int)(r % OH);
+    const int b = (int)(r / OH);
+    const f32x4 *xb = reinterpret_cast<const f32x4 *>(x) + (size_t)b * H * W * C4 + f;
+    const float wt[4] = {0.125f, 0.375f, 0.375f, 0.125f};
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int yy = 2 * oy - 1 + a;
+        if ((unsigned)yy >= (unsigned)H) continue;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int xx = 2 * ox - 1 + c;
+            if ((unsigned)xx >= (unsigned)W) continue;
+            acc += xb[((size_t)yy * W + xx) * C4] * (wt[a] * wt[c]);
+        }
+    }
+    reinterpret_cast<f32x4 *>(out)[idx] = acc;
+}
+
+int launch_fir_up2(const float *x, float *out, int batch, int H, int W, int C, hipStream_t s) {
+    GD_CHECK(C % 4 == 0, "fir_up2: C %% 4 != 0");
+    const long long total = (long long)batch * 4 * H * W * (C / 4);
+    hipLaunchKernelGGL(fir_up2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, out, H, W, C / 4, total);
+    GD_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_fir_down2(const float *x, float *out, int batch, int H, int W, int C, hipStream_t s) {
+    GD_CHECK(C % 4 == 0 && H % 2 == 0 && W % 2 == 0, "fir_down2: bad shape");
+    const long long total = (long long)batch * (H / 2) * (W / 2) * (C / 4);
+    hipLaunchKernelGGL(fir_down2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, out, H, W, C / 4, total);
+    GD_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---- row softmax, one wave64 per row ----------------------------------------------------------------
+__global__ __launch_bounds__(256) void softmax_rows_kernel(float *__restrict__ x, long long rows, int cols) {
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    float *r = x + (size_t)row * cols;
+    float mx = -INFINITY;
+    for (int c = lane; c < cols; c += 64) mx = fmaxf(mx, r[c]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sum = 0.f;
+    for (int c = lane; c < cols; c += 64) {
+        const float e = expf(r[c] - mx);
+        r[c] = e;
+        sum += e;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float inv = 1.0f / sum;
+    for (int c = lane; c < cols; c += 64) r[c] *= inv;
+}
+
+int launch_softmax_rows(float *x, long long rows, int cols, hipStream_t s) {
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, rows, cols);
+    GD_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---- small elementwise helpers ------------------------------------------------------------------------
+__global__ void swish_kernel(const float *__restrict__ x, float *__restrict__ out, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = swish_e(x[i]);
+}
+
+int launch_swish(const float *x, float *out, long long n, hipStream_t s) {
+    hipLaunchKernelGGL(swish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, out, n);
+    GD_HIP(hipGetLastError());
+    return 0;
+}
+
+__global__ void fourier_kernel(const float *__restrict__ labels, const float *__restrict__ ts_table,
+                               const int *__restrict__ step, const float *__restrict__ W, float *__restrict__ out,
+                               int batch, int E) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= batch * E) return;
+    const int b = i / E, j = i - b * E;
+    const float label = labels ? labels[b] : 999.0f * ts_table[*step];
+    const float xp = logf(label) * W[j] * 2.0f * 3.14159265358979323846f;
+    float sn, cs;
+    sincosf(xp, &sn, &cs);
+    out[(size_t)b * 2 * E + j] = sn;
+    out[(size_t)b * 2 * E + E + j] = cs;
+}
+
+int launch_fourier(const float *labels, const float *ts_table, const int *step, const float *W, float *out, int batch,
+                   int E, hipStream_t s) {
+    hipLaunchKernelGGL(fourier_kernel, dim3((batch * E + 255) / 256), dim3(256), 0, s, labels, ts_table, step, W, out,
+                       batch, E);
+    GD_HIP(hipGetLastError());
+    return 0;
+}
+
+// out[p][0:Cpad] = [x[p*ld_in + 0:Cin] * mul + add, 0...]
+__global__ void pad_channels_kernel(const float *__restrict__ x, int ld_in, float *__restrict__ out, long long pixels,
+                                    int Cin, int Cpad, float mul, float add) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= pixels * Cpad) return;
+    const long long p = i / Cpad;
+    const int c = (int)(i - p * Cpad);
+    out[i] = c < Cin ? x[p * ld_in + c] * mul + add : 0.f;
+}
+
+int launch_pad_channels(const float *x, int ld_in, float *out, long long pixels, int Cin, int Cpad, float mul, float add,
+                        hipStream_t s) {
+    const long long n = pixels * Cpad;
+    hipLaunchKernelGGL(pad_channels_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, ld_in, out, pixels, Cin,
+                       Cpad, mul, add);
+    GD_HIP(hipGetLastError());
+    return 0;
+}
+
+// x[b][...] /= labels[b]   (config.model.scale_by_sigma, ncsnpp.py:239-241)
+__global__ void scale_rows_kernel(float *__restrict__ x, const float *__restrict__ labels, long long per_image, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) x[i] = x[i] / labels[i / per_image];
+}
+
+int launch_scale_rows(float *x, const float *labels, int batch, long long per_image, hipStream_t s) {
+    const long long n = (long long)batch * per_image;
+    hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, labels, per_image, n);
+    GD_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace gd

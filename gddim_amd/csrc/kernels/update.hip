@@ -1,0 +1,371 @@
+// gDDIM update rules as fused per-pixel kernels (HBM-bound, <0.1 % of a sampler call).
+//
+// Reference semantics:
+//   multistep_ab_step   u' = Psi u + sum_o C_o eps_o, history shift        cld_jax/deis.py:141-151
+//   ab_step (scalar)    x' = c_0 x + sum_o c_{o+1} eps_o                    blur_jax/multistep.py:94-97
+//   sbmm / bmm          per-pixel 2x2 mat-vec                                cld_jax/utils.py:179-185
+//   denoising step      u + F u dt - G G score dt, score = -R^-T eps         cld_jax/sampling.py:30-39
+//   output              x = inverse_scaler(u[...,0]), v = u[...,1]           cld_jax/sampling.py:228-229
+//   pack / unpack       'b ... d g -> b ... (g d)'                           cld_jax/models/utils.py:153,158
+//   blur order-0 step   y' = m(t') (y - s(t) e_y)/m(t) + s(t') e_y           blur_jax/sampling.py:62-75
+//   2-D ortho DCT       batch_img_dct / batch_img_idct                       blur_jax/blur.py:99-106
+//
+// The fused CLD sampler keeps the state channel-planar, (pixels, CP) = [x_0..x_{C-1}, v_0..v_{C-1}, 0..],
+// which IS the U-Net input, so no pack/unpack runs inside the NFE loop.  The epsilon history is a
+// ring of n_hist slots in the U-Net output layout (pixels, 2C); the ring head and the coefficient
+// row are derived from a device-side step counter so one captured hipGraph serves every step.
+#include "../common.h"
+
+namespace gd {
+
+// ---- generic operators on (n, 2) pairs ---------------------------------------------------------------
+__global__ __launch_bounds__(256) void ab_step_kernel(const float2 *__restrict__ u, const float *__restrict__ coef,
+                                                       const float2 *__restrict__ new_eps,
+                                                       const float2 *__restrict__ hist_in, float2 *__restrict__ u_out,
+                                                       float2 *__restrict__ hist_out, int n_hist, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float2 uv = u[i];
+    const float2 e0 = new_eps[i];
+    float ox = coef[0] * uv.x + coef[1] * uv.y;
+    float oy = coef[2] * uv.x + coef[3] * uv.y;
+    ox += coef[4] * e0.x + coef[5] * e0.y;
+    oy += coef[6] * e0.x + coef[7] * e0.y;
+    float2 prev = e0;
+    for (int j = 0; j < n_hist; ++j) {
+        const float2 h = hist_in[(size_t)j * n + i];
+        const float *c = coef + 8 + 4 * j;
+        ox += c[0] * h.x + c[1] * h.y;
+        oy += c[2] * h.x + c[3] * h.y;
+        hist_out[(size_t)j * n + i] = prev;  // full_eps[:-1]
+        prev = h;
+    }
+    u_out[i] = make_float2(ox, oy);
+}
+
+int launch_ab_step(const float *u, const float *coef, const float *new_eps, const float *hist_in, float *u_out,
+                   float *hist_out, int n_hist, long long n_pairs, hipStream_t s) {
+    hipLaunchKernelGGL(ab_step_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, s, (const float2 *)u, coef,
+                       (const float2 *)new_eps, (const float2 *)hist_in, (float2 *)u_out, (float2 *)hist_out, n_hist,
+                       n_pairs);
+    GD_HIP(hipGetLastError());
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void ab_step_scalar_kernel(const float *__restrict__ x, const float *__restrict__ coef,
+                                                              const float *__restrict__ new_eps,
+                                                              const float *__restrict__ hist_in, float *__restrict__ x_out,
+                                                              float *__restrict__ hist_out, int n_hist, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float e0 = new_eps[i];
+    float o = coef[0] * x[i] + coef[1] * e0;
+    float prev = e0;
+    for (int j = 0; j < n_hist; ++j) {
+        const float h = hist_in[(size_t)j * n + i];
+        o += coef[2 + j] * h;
+        hist_out[(size_t)j * n + i] = prev;
+        prev = h;
+    }
+    x_out[i] = o;
+}
+
+int launch_ab_step_scalar(const float *x, const float *coef, const float *new_eps, const float *hist_in, float *x_out,
+                          float *hist_out, int n_hist, long long n, hipStream_t s) {
+    hipLaunchKernelGGL(ab_step_scalar_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, coef, new_eps,
+                       hist_in, x_out, hist_out, n_hist, n);
+    GD_HIP(hipGetLastError());
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void bmm2x2_kernel(const float *__restrict__ m, const float2 *__restrict__ in,
+                                                      float2 *__restrict__ out, long long n, int per_sample,
+                                                      long long pps) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float *mm = per_sample ? m + 4 * (i / pps) : m;
+    const float2 v = in[i];
+    out[i] = make_float2(mm[0] * v.x + mm[1] * v.y, mm[2] * v.x + mm[3] * v.y);
+}
+
+int launch_bmm2x2(const float *m, const float *in, float *out, long long n_pairs, int per_sample,
+                  long long pairs_per_sample, hipStream_t s) {
+    hipLaunchKernelGGL(bmm2x2_kernel, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, s, m, (const float2 *)in,
+                       (float2 *)out, n_pairs, per_sample, pairs_per_sample);
+    GD_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---- CLD fused sampler ---------------------------------------------------------------------------------
+// (pixels, C, 2) -> planar (pixels, CP) [+ every ring slot (pixels, 2C) initialised with the same values,
+// cld_jax/sampling.py:225: eps_pred = stack([u] * (deis_order + 1))]
+__global__ __launch_bounds__(256) void cld_pack_kernel(const float2 *__restrict__ u, float *__restrict__ u8,
+                                                        float *__restrict__ ring, int ring_slots, long long pixels, int C,
+                                                        int CP) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= pixels * C) return;
+    const long long p = i / C;
+    const int c = (int)(i - p * C);
+    const float2 v = u[i];
+    u8[p * CP + c] = v.x;
+    u8[p * CP + C + c] = v.y;
+    if (c == 0)
+        for (int k = 2 * C; k < CP; ++k) u8[p * CP + k] = 0.f;
+    const size_t slot = (size_t)pixels * 2 * C;
+    for (int sidx = 0; sidx < ring_slots; ++sidx) {
+        ring[sidx * slot + p * 2 * C + c] = v.x;
+        ring[sidx * slot + p * 2 * C + C + c] = v.y;
+    }
+}
+
+int launch_cld_pack(const float *u, float *u8, float *ring, int ring_slots, long long pixels, int C, hipStream_t s) {
+    const int CP = (2 * C + 3) / 4 * 4;
+    const long long n = pixels * C;
+    hipLaunchKernelGGL(cld_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float2 *)u, u8, ring,
+                       ring_slots, pixels, C, CP);
+    GD_HIP(hipGetLastError());
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void cld_unpack_kernel(const float *__restrict__ planar, int ld,
+                                                          float2 *__restrict__ pairs, long long pixels, int C) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= pixels * C) return;
+    const long long p = i / C;
+    const int c = (int)(i - p * C);
+    pairs[i] = make_float2(planar[p * ld + c], planar[p * ld + C + c]);
+}
+
+int launch_cld_unpack_pairs(const float *planar, int ld, float *pairs, long long pixels, int C, hipStream_t s) {
+    const long long n = pixels * C;
+    hipLaunchKernelGGL(cld_unpack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, planar, ld, (float2 *)pairs,
+                       pixels, C);
+    GD_HIP(hipGetLastError());
+    return 0;
+}
+
+// One AB step in place.  coef row = coef_table[*step][n_slots][4]; ring logical index j lives in physical
+// slot (head + j) % ring_slots with head = (-step) mod ring_slots; the new eps overwrites the oldest slot,
+// which becomes the next step's head.
+__global__ __launch_bounds__(256) void cld_ab_step_kernel(float *__restrict__ u8, const float *__restrict__ eps,
+                                                           float *__restrict__ ring, int ring_slots,
+                                                           const float *__restrict__ coef_table, int n_slots,
+                                                           const int *__restrict__ step_ptr, long long pixels, int C,
+                                                           int CP) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= pixels * C) return;
+    const long long p = i / C;
+    const int c = (int)(i - p * C);
+    const int step = *step_ptr;
+    const float *coef = coef_table + (size_t)step * n_slots * 4;
+    const float x = u8[p * CP + c], v = u8[p * CP + C + c];
+    const size_t eo = (size_t)p * 2 * C + c;
+    const float ex = eps[eo], ev = eps[eo + C];
+    float ox = coef[0] * x + coef[1] * v;
+    float ov = coef[2] * x + coef[3] * v;
+    ox += coef[4] * ex + coef[5] * ev;
+    ov += coef[6] * ex + coef[7] * ev;
+    if (ring_slots > 0) {
+        const size_t slot = (size_t)pixels * 2 * C;
+        const int head = (ring_slots - step % ring_slots) % ring_slots;
+        int phys = head;
+        for (int j = 0; j < ring_slots; ++j) {
+            const float hx = ring[phys * slot + eo], hv = ring[phys * slot + eo + C];
+            const float *cc = coef + 8 + 4 * j;
+            ox += cc[0] * hx + cc[1] * hv;
+            ov += cc[2] * hx + cc[3] * hv;
+            if (++phys == ring_slots) phys = 0;
+        }
+        const int nh = (head + ring_slots - 1) % ring_slots;
+        ring[nh * slot + eo] = ex;
+        ring[nh * slot + eo + C] = ev;
+    }
+    u8[p * CP + c] = ox;
+    u8[p * CP + C + c] = ov;
+}
+
+int launch_cld_ab_step(float *u8, const float *eps, float *ring, int ring_slots, const float *coef_table, int n_slots,
+                       const int *step, long long pixels, int C, hipStream_t s) {
+    const int CP = (2 * C + 3) / 4 * 4;
+    const long long n = pixels * C;
+    hipLaunchKernelGGL(cld_ab_step_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, u8, eps, ring, ring_slots,
+                       coef_table, n_slots, step, pixels, C, CP);
+    GD_HIP(hipGetLastError());
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void cld_finish_kernel(const float *__restrict__ u8, const float *__restrict__ eps,
+                                                          const float *__restrict__ dn, float dt, int denoise,
+                                                          int inverse_scale, float *__restrict__ x_out,
+                                                          float *__restrict__ v_out, long long pixels, int C, int CP) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= pixels * C) return;
+    const long long p = i / C;
+    const int c = (int)(i - p * C);
+    float x = u8[p * CP + c], v = u8[p * CP + C + c];
+    if (denoise) {
+        const float ex = eps[(size_t)p * 2 * C + c], ev = eps[(size_t)p * 2 * C + C + c];
+        const float *F = dn, *GG = dn + 4, *Rt = dn + 8;
+        // score = -R^-T eps
+        const float sx = -(Rt[0] * ex + Rt[1] * ev), sv = -(Rt[2] * ex + Rt[3] * ev);
+        const float fx = F[0] * x + F[1] * v, fv = F[2] * x + F[3] * v;
+        const float gx = GG[0] * sx + GG[1] * sv, gv = GG[2] * sx + GG[3] * sv;
+        x = x + fx * dt - gx * dt;
+        v = v + fv * dt - gv * dt;
+    }
+    x_out[i] = inverse_scale ? (x + 1.0f) / 2.0f : x;
+    v_out[i] = v;
+}
+
+int launch_cld_finish(const float *u8, const float *eps, const float *dn, float dt, int denoise, int inverse_scale,
+                      float *x_out, float *v_out, long long pixels, int C, hipStream_t s) {
+    const int CP = (2 * C + 3) / 4 * 4;
+    const long long n = pixels * C;
+    hipLaunchKernelGGL(cld_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, u8, eps, dn, dt, denoise,
+                       inverse_scale, x_out, v_out, pixels, C, CP);
+    GD_HIP(hipGetLastError());
+    return 0;
+}
+
+__global__ void advance_step_kernel(int *step) { *step += 1; }
+
+int launch_advance_step(int *step, hipStream_t s) {
+    hipLaunchKernelGGL(advance_step_kernel, dim3(1), dim3(1), 0, s, step);
+    GD_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---- 32x32 orthonormal DCT, LDS resident -------------------------------------------------------------
+// D[k][n] = s_k cos(pi (2n+1) k / 64), s_0 = 1/sqrt(32), s_k = sqrt(2/32).
+// forward  Y = D X D^T ; inverse X = D^T Y D.   One block of 256 threads per (b, c) plane.
+constexpr int DN = 32, DL = 33;
+
+__device__ __forceinline__ void dct_fill_basis(float *D) {
+    for (int i = threadIdx.x; i < DN * DN; i += 256) {
+        const int k = i / DN, n = i - k * DN;
+        const double sc = (k == 0) ? 0.17677669529663688 /* 1/sqrt(32) */ : 0.25 /* sqrt(2/32) */;
+        D[k * DL + n] = (float)(sc * cospi((double)((2 * n + 1) * k) / 64.0));
+    }
+}
+
+// X (in LDS, [32][33]) -> Y (in LDS); T scratch.  inverse: uses D^T.
+__device__ __forceinline__ void dct_plane(const float *D, float *X, float *T, int inverse) {
+    // stage 1: T = Dm X   (Dm = D forward, D^T inverse)
+    for (int i = threadIdx.x; i < DN * DN; i += 256) {
+        const int r = i / DN, cidx = i - r * DN;
+        float acc = 0.f;
+#pragma unroll 8
+        for (int n = 0; n < DN; ++n) acc += (inverse ? D[n * DL + r] : D[r * DL + n]) * X[n * DL + cidx];
+        T[r * DL + cidx] = acc;
+    }
+    __syncthreads();
+    // stage 2: X = T Dm^T
+    for (int i = threadIdx.x; i < DN * DN; i += 256) {
+        const int r = i / DN, cidx = i - r * DN;
+        float acc = 0.f;
+#pragma unroll 8
+        for (int m = 0; m < DN; ++m) acc += T[r * DL + m] * (inverse ? D[m * DL + cidx] : D[cidx * DL + m]);
+        X[r * DL + cidx] = acc;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void dct2d_32_kernel(const float *__restrict__ in, float *__restrict__ out, int C,
+                                                        int inverse) {
+    __shared__ float D[DN * DL], X[DN * DL], T[DN * DL];
+    const int b = blockIdx.x / C, c = blockIdx.x - b * C;
+    dct_fill_basis(D);
+    const float *src = in + (size_t)b * DN * DN * C + c;
+    for (int i = threadIdx.x; i < DN * DN; i += 256) X[(i / DN) * DL + (i % DN)] = src[(size_t)i * C];
+    __syncthreads();
+    dct_plane(D, X, T, inverse);
+    float *dst = out + (size_t)b * DN * DN * C + c;
+    for (int i = threadIdx.x; i < DN * DN; i += 256) dst[(size_t)i * C] = X[(i / DN) * DL + (i % DN)];
+}
+
+int launch_dct2d_32(const float *in, float *out, int batch, int channels, int inverse, hipStream_t s) {
+    hipLaunchKernelGGL(dct2d_32_kernel, dim3(batch * channels), dim3(256), 0, s, in, out, channels, inverse);
+    GD_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---- blur fused sampler ------------------------------------------------------------------------------
+// x8 (B,32,32,CP) = [IDCT(y) , 0...]: the U-Net input of blur_jax/models/utils.py:155-160 (y2x)
+__global__ __launch_bounds__(256) void blur_idct_pad_kernel(const float *__restrict__ y, float *__restrict__ x8, int C,
+                                                             int CP) {
+    __shared__ float D[DN * DL], X[DN * DL], T[DN * DL];
+    const int b = blockIdx.x / CP, c = blockIdx.x - b * CP;
+    float *dst = x8 + (size_t)b * DN * DN * CP + c;
+    if (c >= C) {
+        for (int i = threadIdx.x; i < DN * DN; i += 256) dst[(size_t)i * CP] = 0.f;
+        return;
+    }
+    dct_fill_basis(D);
+    const float *src = y + (size_t)b * DN * DN * C + c;
+    for (int i = threadIdx.x; i < DN * DN; i += 256) X[(i / DN) * DL + (i % DN)] = src[(size_t)i * C];
+    __syncthreads();
+    dct_plane(D, X, T, 1);
+    for (int i = threadIdx.x; i < DN * DN; i += 256) dst[(size_t)i * CP] = X[(i / DN) * DL + (i % DN)];
+}
+
+int launch_blur_idct_pad(const float *y, float *x8, int batch, int C, hipStream_t s) {
+    const int CP = (C + 3) / 4 * 4;
+    hipLaunchKernelGGL(blur_idct_pad_kernel, dim3(batch * CP), dim3(256), 0, s, y, x8, C, CP);
+    GD_HIP(hipGetLastError());
+    return 0;
+}
+
+// y <- m(t')/1 * [ (y - s(t) e_y) / m(t) ] + s(t') e_y with e_y = DCT(eps_x); coefficient rows indexed by *step
+__global__ __launch_bounds__(256) void blur_step_kernel(float *__restrict__ y, const float *__restrict__ eps_x,
+                                                         const float *__restrict__ mean_coef,
+                                                         const float *__restrict__ std_coef,
+                                                         const int *__restrict__ step_ptr, int C) {
+    __shared__ float D[DN * DL], X[DN * DL], T[DN * DL];
+    const int b = blockIdx.x / C, c = blockIdx.x - b * C;
+    const int step = *step_ptr;
+    dct_fill_basis(D);
+    const float *src = eps_x + (size_t)b * DN * DN * C + c;
+    for (int i = threadIdx.x; i < DN * DN; i += 256) X[(i / DN) * DL + (i % DN)] = src[(size_t)i * C];
+    __syncthreads();
+    dct_plane(D, X, T, 0);
+    const float *m0 = mean_coef + (size_t)step * DN * DN, *m1 = m0 + DN * DN;
+    const float s0 = std_coef[step], s1 = std_coef[step + 1];
+    float *yy = y + (size_t)b * DN * DN * C + c;
+    for (int i = threadIdx.x; i < DN * DN; i += 256) {
+        const float ey = X[(i / DN) * DL + (i % DN)];
+        const float ycur = yy[(size_t)i * C];
+        const float y0 = 1.0f / m0[i] * (ycur - s0 * ey);  // blur_jax/sampling.py:69
+        yy[(size_t)i * C] = m1[i] * y0 + s1 * ey;           // :71-74
+    }
+}
+
+int launch_blur_step(float *y, const float *eps_x, const float *mean_coef, const float *std_coef, const int *step,
+                     int batch, int C, hipStream_t s) {
+    hipLaunchKernelGGL(blur_step_kernel, dim3(batch * C), dim3(256), 0, s, y, eps_x, mean_coef, std_coef, step, C);
+    GD_HIP(hipGetLastError());
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void blur_finish_kernel(const float *__restrict__ y, float *__restrict__ x_out, int C,
+                                                           int inverse_scale) {
+    __shared__ float D[DN * DL], X[DN * DL], T[DN * DL];
+    const int b = blockIdx.x / C, c = blockIdx.x - b * C;
+    dct_fill_basis(D);
+    const float *src = y + (size_t)b * DN * DN * C + c;
+    for (int i = threadIdx.x; i < DN * DN; i += 256) X[(i / DN) * DL + (i % DN)] = src[(size_t)i * C];
+    __syncthreads();
+    dct_plane(D, X, T, 1);
+    float *dst = x_out + (size_t)b * DN * DN * C + c;
+    for (int i = threadIdx.x; i < DN * DN; i += 256) {
+        const float v = X[(i / DN) * DL + (i % DN)];
+        dst[(size_t)i * C] = inverse_scale ? (v + 1.0f) / 2.0f : v;
+    }
+}
+
+int launch_blur_finish(const float *y, float *x_out, int batch, int C, int inverse_scale, hipStream_t s) {
+    hipLaunchKernelGGL(blur_finish_kernel, dim3(batch * C), dim3(256), 0, s, y, x_out, C, inverse_scale);
+    GD_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace gd

@@ -1,0 +1,571 @@
+// Builds the NCSN++ execution plan.  Every block below follows the reference module it lowers:
+//   NCSNpp.__call__           cld_jax/models/ncsnpp.py:41-243
+//   ResnetBlockBigGANpp       cld_jax/models/layerspp.py:180-227
+//   AttnBlockpp               cld_jax/models/layerspp.py:61-83
+//   Downsample(fir,with_conv) cld_jax/models/layerspp.py:134-140 -> up_or_down_sampling.py:40-73,168-209
+// Parameter names are flax's auto-names (module class + per-parent call counter), SURVEY.md App. A.2.
+#include "plan.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <sstream>
+
+#include "common.h"
+
+namespace gd {
+
+// ---------------------------------------------------------------- arena (first fit, per-image floats)
+long long Plan::arena_alloc(long long size) {
+    size = (size + 63) / 64 * 64;
+    for (size_t i = 0; i < free_list_.size(); ++i) {
+        if (free_list_[i].size >= size) {
+            long long off = free_list_[i].off;
+            free_list_[i].off += size;
+            free_list_[i].size -= size;
+            if (free_list_[i].size == 0) free_list_.erase(free_list_.begin() + i);
+            return off;
+        }
+    }
+    long long off = arena_per_image;
+    // extend: if the last free block touches the end, grow from it
+    if (!free_list_.empty() && free_list_.back().off + free_list_.back().size == arena_per_image) {
+        off = free_list_.back().off;
+        free_list_.pop_back();
+    }
+    arena_per_image = off + size;
+    return off;
+}
+
+void Plan::arena_free(long long off, long long size) {
+    size = (size + 63) / 64 * 64;
+    Block b{off, size};
+    auto it = std::lower_bound(free_list_.begin(), free_list_.end(), b,
+                               [](const Block &x, const Block &y) { return x.off < y.off; });
+    it = free_list_.insert(it, b);
+    // coalesce with next / previous
+    size_t i = it - free_list_.begin();
+    if (i + 1 < free_list_.size() && free_list_[i].off + free_list_[i].size == free_list_[i + 1].off) {
+        free_list_[i].size += free_list_[i + 1].size;
+        free_list_.erase(free_list_.begin() + i + 1);
+    }
+    if (i > 0 && free_list_[i - 1].off + free_list_[i - 1].size == free_list_[i].off) {
+        free_list_[i - 1].size += free_list_[i].size;
+        free_list_.erase(free_list_.begin() + i);
+    }
+}
+
+int Plan::new_tensor(const std::string &name, int H, int W, int C, int ext, long long per_image) {
+    Tensor t;
+    t.name = name;
+    t.H = H; t.W = W; t.C = C;
+    t.per_image = per_image >= 0 ? per_image : (long long)H * W * C;
+    t.ext = ext;
+    t.refs = 1;
+    if (ext == EXT_NONE) t.offset = arena_alloc(t.per_image);
+    tensors.push_back(t);
+    return (int)tensors.size() - 1;
+}
+
+void Plan::release(int t) {
+    if (t < 0) return;
+    Tensor &T = tensors[t];
+    if (--T.refs == 0 && T.ext == EXT_NONE) arena_free(T.offset, T.per_image);
+}
+
+int Plan::new_slot(const std::string &name, long long rows, long long cols) {
+    WSlot s;
+    s.name = name;
+    s.rows = rows; s.cols = cols;
+    s.host.assign((size_t)(rows * cols), 0.f);
+    slots.push_back(std::move(s));
+    return (int)slots.size() - 1;
+}
+
+void Plan::add_param(const std::string &name, std::vector<int64_t> shape, int kind, int slot, long long row_off, int ipad) {
+    Param p;
+    p.name = name; p.shape = std::move(shape); p.kind = kind; p.slot = slot; p.row_off = row_off; p.ipad = ipad;
+    param_index[name] = (int)params.size();
+    params.push_back(std::move(p));
+}
+
+// ---------------------------------------------------------------- GroupNorm (+swish): stats + apply
+// returns the normalised tensor (H, W, Ca+Cb); inputs are not released
+int Plan::gn(const std::string &label, const std::string &pname, int xa, int Ca, int xb, int Cb, int H, int W, int act) {
+    const int C = Ca + Cb;
+    const int G = std::min(C / 4, 32);  // nn.GroupNorm(num_groups=min(C // 4, 32))
+    int st = new_tensor(label + ".stats", 1, 1, 1, EXT_NONE, (long long)GN_MAX_SLICES * G * 2);
+    int gs = new_slot(pname + "/scale", 1, C), bs = new_slot(pname + "/bias", 1, C);
+    add_param(pname + "/scale", {C}, P_VEC, gs, 0);
+    add_param(pname + "/bias", {C}, P_VEC, bs, 0);
+    Op s;
+    s.kind = OP_GN_STATS; s.label = label + ".stats";
+    s.a0 = {xa, 0}; s.C0 = Ca; s.a1 = {xb, 0}; s.C1 = Cb; s.H = H; s.W = W; s.groups = G; s.stats = {st, 0};
+    ops.push_back(s);
+    int out = new_tensor(label + ".out", H, W, C);
+    Op a = s;
+    a.kind = OP_GN_APPLY; a.label = label + ".apply"; a.act = act; a.gamma_slot = gs; a.beta_slot = bs; a.out = {out, 0};
+    ops.push_back(a);
+    release(st);
+    return out;
+}
+
+// ---------------------------------------------------------------- nn.Conv (SAME) as implicit GEMM
+// pname: flax module path holding {kernel, bias}.  out_t >= 0 writes into an existing (external) tensor.
+int Plan::conv(const std::string &label, const std::string &pname, int xa, int Ca, int xb, int Cb, int H, int W, int ksize,
+               int O, int res_t, float out_scale, int rowbias_t, int rowbias_col, int out_t) {
+    const int Cin = Ca + Cb;
+    int ws = new_slot(pname + "/kernel", O, (long long)ksize * ksize * Cin);
+    int bs = new_slot(pname + "/bias", 1, O);
+    add_param(pname + "/kernel", {ksize, ksize, Cin, O}, P_CONV, ws, 0, Cin);
+    add_param(pname + "/bias", {O}, P_VEC, bs, 0);
+    int out = out_t >= 0 ? out_t : new_tensor(label + ".out", H, W, O);
+    Op g;
+    g.kind = OP_GEMM; g.label = label;
+    g.a0 = {xa, 0}; g.C0 = Ca; g.lda0 = tensors[xa].C;
+    if (Cb) { g.a1 = {xb, 0}; g.C1 = Cb; g.lda1 = tensors[xb].C; }
+    g.H = H; g.W = W; g.OH = H; g.OW = W; g.KH = g.KW = ksize; g.stride = 1; g.pad = ksize / 2;
+    g.m_per_image = H * W; g.N = O; g.K = ksize * ksize * Cin;
+    g.w_slot = ws; g.ldb = g.K; g.bias_slot = bs;
+    if (rowbias_t >= 0) { g.rowbias = {rowbias_t, rowbias_col}; g.ld_rowbias = tensors[rowbias_t].C; }
+    if (res_t >= 0) { g.res = {res_t, 0}; g.ldres = tensors[res_t].C; }
+    g.out = {out, 0}; g.ldc = tensors[out].C; g.out_scale = out_scale;
+    g.flops_per_image = 2.0 * H * W * O * g.K;
+    g.is_conv3x3 = ksize == 3;
+    ops.push_back(g);
+    return out;
+}
+
+// ---------------------------------------------------------------- ResnetBlockBigGANpp (layerspp.py:180-227)
+int Plan::resblock(int idx, int xa, int Ca, int xb, int Cb, int H, int W, int O, bool up, bool down, int &outH) {
+    const std::string n = "ResnetBlockBigGANpp_" + std::to_string(idx);
+    const int C = Ca + Cb;
+    const float scale = desc.skip_rescale ? (float)(1.0 / std::sqrt(2.0)) : 1.f;
+    // h = act(GroupNorm_0(x))
+    int h0 = gn(n + ".gn0", n + "/GroupNorm_0", xa, Ca, xb, Cb, H, W, 1);
+    int xs_src = xa;  // shortcut source (single tensor unless concat)
+    int H2 = H, W2 = W;
+    int xr = -1;  // resampled x
+    if (up || down) {
+        // both h and x are FIR-resampled (layerspp.py:198-211); never combined with a concat input
+        H2 = up ? 2 * H : H / 2;
+        W2 = up ? 2 * W : W / 2;
+        int h0r = new_tensor(n + ".h_resampled", H2, W2, C);
+        Op f;
+        f.kind = up ? OP_FIR_UP : OP_FIR_DOWN; f.label = n + (up ? ".fir_up_h" : ".fir_down_h");
+        f.a0 = {h0, 0}; f.C0 = C; f.H = H; f.W = W; f.out = {h0r, 0};
+        ops.push_back(f);
+        release(h0);
+        h0 = h0r;
+        xr = new_tensor(n + ".x_resampled", H2, W2, C);
+        f.label = n + (up ? ".fir_up_x" : ".fir_down_x");
+        f.a0 = {xa, 0}; f.out = {xr, 0};
+        ops.push_back(f);
+        xs_src = xr;
+    }
+    // h = Conv_0(h) + Dense_0(act(temb))[:, None, None, :]
+    const int tcol = tproj_t_ >= 0 ? rb_tproj_off_[idx] : 0;
+    int h1 = conv(n + ".conv0", n + "/Conv_0", h0, C, -1, 0, H2, W2, 3, O, -1, 1.f, tproj_t_, tcol);
+    release(h0);
+    if (tproj_t_ >= 0) {
+        add_param(n + "/Dense_0/kernel", {desc.nf * 4, O}, P_DENSE, tproj_slot_w_, tcol);
+        add_param(n + "/Dense_0/bias", {O}, P_VEC, tproj_slot_b_, tcol);
+    }
+    // h = act(GroupNorm_1(h)); Dropout is the identity at inference
+    int h2 = gn(n + ".gn1", n + "/GroupNorm_1", h1, O, -1, 0, H2, W2, 1);
+    release(h1);
+    // shortcut: conv1x1 iff C != out_ch or up or down (layerspp.py:221-222)
+    int res_t;
+    int xs = -1;
+    if (C != O || up || down) {
+        if (up || down) xs = conv(n + ".conv2", n + "/Conv_2", xs_src, C, -1, 0, H2, W2, 1, O, -1, 1.f, -1, 0);
+        else xs = conv(n + ".conv2", n + "/Conv_2", xa, Ca, xb, Cb, H2, W2, 1, O, -1, 1.f, -1, 0);
+        res_t = xs;
+    } else {
+        res_t = xa;
+    }
+    // (x + Conv_1(h)) / sqrt(2)
+    int out = conv(n + ".conv1", n + "/Conv_1", h2, O, -1, 0, H2, W2, 3, O, res_t, scale, -1, 0);
+    release(h2);
+    release(xs);
+    release(xr);
+    outH = H2;
+    return out;
+}
+
+// ---------------------------------------------------------------- AttnBlockpp (layerspp.py:61-83)
+int Plan::attn(int idx, int x, int H, int W, int C) {
+    const std::string n = "AttnBlockpp_" + std::to_string(idx);
+    const int HW = H * W;
+    const float scale = desc.skip_rescale ? (float)(1.0 / std::sqrt(2.0)) : 1.f;
+    int hn = gn(n + ".gn", n + "/GroupNorm_0", x, C, -1, 0, H, W, 0);
+    // q, k, v = NIN_0..2(h) as one GEMM with N = 3C
+    int wq = new_slot(n + "/qkv_W", 3 * C, C), bq = new_slot(n + "/qkv_b", 1, 3 * C);
+    for (int i = 0; i < 3; ++i) {
+        add_param(n + "/NIN_" + std::to_string(i) + "/W", {C, C}, P_DENSE, wq, (long long)i * C);
+        add_param(n + "/NIN_" + std::to_string(i) + "/b", {C}, P_VEC, bq, (long long)i * C);
+    }
+    int qkv = new_tensor(n + ".qkv", H, W, 3 * C);
+    {
+        Op g;
+        g.kind = OP_GEMM; g.label = n + ".qkv";
+        g.a0 = {hn, 0}; g.C0 = C; g.lda0 = C; g.H = H; g.W = W; g.OH = H; g.OW = W;
+        g.m_per_image = HW; g.N = 3 * C; g.K = C; g.w_slot = wq; g.ldb = C; g.bias_slot = bq;
+        g.out = {qkv, 0}; g.ldc = 3 * C;
+        g.flops_per_image = 2.0 * HW * 3 * C * C;
+        ops.push_back(g);
+    }
+    release(hn);
+    // w = softmax(q k^T * C^-1/2)
+    int S = new_tensor(n + ".scores", 1, 1, 1, EXT_NONE, (long long)HW * HW);
+    {
+        Op g;
+        g.kind = OP_GEMM; g.label = n + ".qk";
+        g.a0 = {qkv, 0}; g.C0 = C; g.lda0 = 3 * C; g.H = 1; g.W = HW; g.OH = 1; g.OW = HW;
+        g.m_per_image = HW; g.z_per_image = 1; g.N = HW; g.K = C;
+        g.bten = {qkv, C}; g.ldb = 3 * C; g.b_kmajor = 0;
+        g.sA = (long long)HW * 3 * C; g.sB = g.sA; g.sC = (long long)HW * HW;
+        g.out = {S, 0}; g.ldc = HW; g.alpha = (float)std::pow((double)C, -0.5);
+        g.flops_per_image = 2.0 * HW * HW * C;
+        ops.push_back(g);
+        Op sm;
+        sm.kind = OP_SOFTMAX; sm.label = n + ".softmax"; sm.out = {S, 0}; sm.rows_per_image = HW; sm.cols = HW;
+        ops.push_back(sm);
+    }
+    // h = w v
+    int ho = new_tensor(n + ".av", H, W, C);
+    {
+        Op g;
+        g.kind = OP_GEMM; g.label = n + ".av";
+        g.a0 = {S, 0}; g.C0 = HW; g.lda0 = HW; g.H = 1; g.W = HW; g.OH = 1; g.OW = HW;
+        g.m_per_image = HW; g.z_per_image = 1; g.N = C; g.K = HW;
+        g.bten = {qkv, 2 * C}; g.ldb = 3 * C; g.b_kmajor = 1;
+        g.sA = (long long)HW * HW; g.sB = (long long)HW * 3 * C; g.sC = (long long)HW * C;
+        g.out = {ho, 0}; g.ldc = C;
+        g.flops_per_image = 2.0 * HW * HW * C;
+        ops.push_back(g);
+    }
+    release(S);
+    release(qkv);
+    // (x + NIN_3(h)) / sqrt(2)
+    int wo = new_slot(n + "/NIN_3/W", C, C), bo = new_slot(n + "/NIN_3/b", 1, C);
+    add_param(n + "/NIN_3/W", {C, C}, P_DENSE, wo, 0);
+    add_param(n + "/NIN_3/b", {C}, P_VEC, bo, 0);
+    int out = new_tensor(n + ".out", H, W, C);
+    {
+        Op g;
+        g.kind = OP_GEMM; g.label = n + ".proj";
+        g.a0 = {ho, 0}; g.C0 = C; g.lda0 = C; g.H = H; g.W = W; g.OH = H; g.OW = W;
+        g.m_per_image = HW; g.N = C; g.K = C; g.w_slot = wo; g.ldb = C; g.bias_slot = bo;
+        g.res = {x, 0}; g.ldres = C; g.out = {out, 0}; g.ldc = C; g.out_scale = scale;
+        g.flops_per_image = 2.0 * HW * C * C;
+        ops.push_back(g);
+    }
+    release(ho);
+    return out;
+}
+
+// ---------------------------------------------------------------- NCSNpp.__call__
+int Plan::build(const gd_model_desc &d) {
+    desc = d;
+    GD_CHECK(d.num_levels >= 1 && d.num_levels <= GD_MAX_LEVELS, "num_levels out of range");
+    GD_CHECK(d.nf >= 16 && d.nf % 16 == 0, "nf must be a multiple of 16 (GroupNorm groups of >= 4 channels), got %d", d.nf);
+    GD_CHECK(d.in_channels >= 1 && d.image_size >= (1 << (d.num_levels - 1)), "bad in_channels / image_size");
+    GD_CHECK(d.image_size % (1 << (d.num_levels - 1)) == 0, "image_size must be divisible by 2^(levels-1)");
+    GD_CHECK(d.max_batch >= 1, "max_batch must be >= 1");
+    const int nf = d.nf, nres = d.num_levels, nrb = d.num_res_blocks;
+    CP = (d.in_channels + 3) / 4 * 4;
+    auto is_attn = [&](int res) {
+        for (int i = 0; i < d.num_attn_resolutions; ++i)
+            if (d.attn_resolutions[i] == res) return true;
+        return false;
+    };
+
+    // pre-walk: out_ch of every ResnetBlock in call order -> column offsets of the fused temb projection
+    {
+        std::vector<int> outs;
+        int c = nf;
+        std::vector<int> hs{nf};
+        for (int l = 0; l < nres; ++l) {
+            for (int b = 0; b < nrb; ++b) { c = nf * d.ch_mult[l]; outs.push_back(c); hs.push_back(c); }
+            if (l != nres - 1) { outs.push_back(c); hs.push_back(c); }
+        }
+        outs.push_back(c); outs.push_back(c);
+        for (int l = nres - 1; l >= 0; --l) {
+            for (int b = 0; b < nrb + 1; ++b) { hs.pop_back(); c = nf * d.ch_mult[l]; outs.push_back(c); }
+            if (l != 0) outs.push_back(c);
+        }
+        sum_cout_ = 0;
+        for (int o : outs) { rb_tproj_off_.push_back(sum_cout_); sum_cout_ += o; }
+    }
+
+    t_x_in = new_tensor("x_in", d.image_size, d.image_size, CP, EXT_X_IN);
+    t_labels = new_tensor("labels", 1, 1, 1, EXT_LABELS);
+    t_eps_out = new_tensor("eps_out", d.image_size, d.image_size, d.in_channels, EXT_EPS_OUT);
+
+    // ---- time embedding (ncsnpp.py:71-91) ----
+    if (d.conditional) {
+        int wf = new_slot("GaussianFourierProjection_0/W", 1, nf);
+        add_param("GaussianFourierProjection_0/W", {nf}, P_VEC, wf, 0);
+        int t0 = new_tensor("temb.fourier", 1, 1, 2 * nf);
+        Op f;
+        f.kind = OP_FOURIER; f.label = "temb.fourier"; f.a0 = {t_labels, 0}; f.w_slot = wf; f.N = nf; f.out = {t0, 0};
+        ops.push_back(f);
+        auto dense = [&](const std::string &label, const std::string &pname, int in_t, int in_c, int out_c, int act_in) {
+            int ws = new_slot(pname + "/kernel", out_c, in_c), bs = new_slot(pname + "/bias", 1, out_c);
+            add_param(pname + "/kernel", {in_c, out_c}, P_DENSE, ws, 0);
+            add_param(pname + "/bias", {out_c}, P_VEC, bs, 0);
+            int o = new_tensor(label, 1, 1, out_c);
+            Op g;
+            g.kind = OP_GEMM; g.label = label; g.a0 = {in_t, 0}; g.C0 = in_c; g.lda0 = in_c; g.m_per_image = 1;
+            g.N = out_c; g.K = in_c; g.w_slot = ws; g.ldb = in_c; g.bias_slot = bs; g.out = {o, 0}; g.ldc = out_c;
+            g.in_act = act_in; g.flops_per_image = 2.0 * out_c * in_c;
+            ops.push_back(g);
+            return o;
+        };
+        int t1 = dense("temb.dense0", "Dense_0", t0, 2 * nf, 4 * nf, 0);
+        release(t0);
+        temb_t_ = dense("temb.dense1", "Dense_1", t1, 4 * nf, 4 * nf, 1);
+        release(t1);
+        // all per-block Dense_0(act(temb)) as one GEMM: (B, 4nf) x (4nf, sum Cout)
+        tproj_slot_w_ = new_slot("temb_proj/kernel", sum_cout_, 4 * nf);
+        tproj_slot_b_ = new_slot("temb_proj/bias", 1, sum_cout_);
+        tproj_t_ = new_tensor("temb.proj", 1, 1, sum_cout_);
+        Op g;
+        g.kind = OP_GEMM; g.label = "temb.proj"; g.a0 = {temb_t_, 0}; g.C0 = 4 * nf; g.lda0 = 4 * nf; g.m_per_image = 1;
+        g.N = sum_cout_; g.K = 4 * nf; g.w_slot = tproj_slot_w_; g.ldb = 4 * nf; g.bias_slot = tproj_slot_b_;
+        g.out = {tproj_t_, 0}; g.ldc = sum_cout_; g.in_act = 1; g.flops_per_image = 2.0 * sum_cout_ * 4 * nf;
+        ops.push_back(g);
+        release(temb_t_);
+    }
+
+    // ---- input (ncsnpp.py:136-146) ----
+    int x = t_x_in;
+    if (!d.centered) {
+        int xc = new_tensor("x_centered", d.image_size, d.image_size, CP);
+        Op a;
+        a.kind = OP_AFFINE_PAD; a.label = "x_2x_minus_1"; a.a0 = {x, 0}; a.lda0 = CP; a.cin = d.in_channels; a.cpad = CP;
+        a.mul = 2.f; a.add = -1.f; a.out = {xc, 0}; a.H = a.W = d.image_size;
+        ops.push_back(a);
+        x = xc;
+    } else {
+        retain(x);
+    }
+    int pyr = -1, pyrC = CP;
+    if (d.progressive_input_residual) { pyr = x; retain(pyr); }
+
+    int rb = 0, at = 0, dn = 0;
+    int res = d.image_size;
+    struct Skip { int t, C; };
+    std::vector<Skip> hs;
+    // stem conv: K uses the padded channel count; algorithmic FLOPs count the real ones
+    int h = conv("stem", "Conv_0", x, CP, -1, 0, res, res, 3, nf, -1, 1.f, -1, 0);
+    params[param_index["Conv_0/kernel"]].shape = {3, 3, d.in_channels, nf};
+    ops.back().flops_per_image = 2.0 * res * res * nf * 9 * d.in_channels;
+    release(x);
+    int C = nf;
+    hs.push_back({h, C});  // hs owns the reference
+    // ---- down path (ncsnpp.py:147-173) ----
+    for (int l = 0; l < nres; ++l) {
+        for (int b = 0; b < nrb; ++b) {
+            int oh;
+            int o = resblock(rb++, hs.back().t, hs.back().C, -1, 0, res, res, nf * d.ch_mult[l], false, false, oh);
+            C = nf * d.ch_mult[l];
+            if (is_attn(res)) {
+                int o2 = attn(at++, o, res, res, C);
+                release(o);
+                o = o2;
+            }
+            hs.push_back({o, C});
+        }
+        if (l != nres - 1) {
+            int oh;
+            int o = resblock(rb++, hs.back().t, hs.back().C, -1, 0, res, res, C, false, true, oh);
+            res = oh;
+            if (d.progressive_input_residual) {
+                // Downsample_k/Conv2d_0: FIR pad + 3x3 stride-2 VALID conv == one 6x6 stride-2 pad-2 conv
+                const std::string pn = "Downsample_" + std::to_string(dn++) + "/Conv2d_0";
+                int ws = new_slot(pn + "/weight", C, 36LL * pyrC), bs = new_slot(pn + "/bias", 1, C);
+                const int real_in = (pyr == t_x_in || tensors[pyr].name == "x_centered") ? d.in_channels : pyrC;
+                add_param(pn + "/weight", {3, 3, real_in, C}, P_CONV_FIR6, ws, 0, pyrC);
+                add_param(pn + "/bias", {C}, P_VEC, bs, 0);
+                int np = new_tensor(pn + ".out", res, res, C);
+                Op g;
+                g.kind = OP_GEMM; g.label = "pyramid_down_" + std::to_string(dn - 1);
+                g.a0 = {pyr, 0}; g.C0 = pyrC; g.lda0 = pyrC; g.H = 2 * res; g.W = 2 * res; g.OH = res; g.OW = res;
+                g.KH = g.KW = 6; g.stride = 2; g.pad = 2; g.m_per_image = res * res; g.N = C; g.K = 36 * pyrC;
+                g.w_slot = ws; g.ldb = g.K; g.bias_slot = bs; g.res = {o, 0}; g.ldres = C; g.out = {np, 0}; g.ldc = C;
+                g.out_scale = d.skip_rescale ? (float)(1.0 / std::sqrt(2.0)) : 1.f;
+                g.flops_per_image = 2.0 * res * res * C * 9 * real_in;
+                g.is_conv3x3 = 1;
+                ops.push_back(g);
+                release(pyr);
+                release(o);
+                pyr = np; pyrC = C;
+                retain(pyr);  // one ref for `pyr`, one for hs below
+                o = np;
+            }
+            hs.push_back({o, C});
+        }
+    }
+    release(pyr);
+    // ---- middle (ncsnpp.py:175-178) ----
+    h = hs.back().t;
+    retain(h);
+    {
+        int oh;
+        int o = resblock(rb++, h, C, -1, 0, res, res, C, false, false, oh);
+        release(h);
+        int o2 = attn(at++, o, res, res, C);
+        release(o);
+        h = resblock(rb++, o2, C, -1, 0, res, res, C, false, false, oh);
+        release(o2);
+    }
+    // ---- up path (ncsnpp.py:183-229) ----
+    for (int l = nres - 1; l >= 0; --l) {
+        for (int b = 0; b < nrb + 1; ++b) {
+            Skip s = hs.back();
+            hs.pop_back();
+            int oh;
+            int o = resblock(rb++, h, C, s.t, s.C, res, res, nf * d.ch_mult[l], false, false, oh);
+            release(h);
+            release(s.t);
+            h = o;
+            C = nf * d.ch_mult[l];
+        }
+        if (is_attn(res)) {
+            int o = attn(at++, h, res, res, C);
+            release(h);
+            h = o;
+        }
+        if (l != 0) {
+            int oh;
+            int o = resblock(rb++, h, C, -1, 0, res, res, C, true, false, oh);
+            release(h);
+            h = o;
+            res = oh;
+        }
+    }
+    GD_CHECK(hs.empty(), "internal: skip stack not empty");
+    // ---- head (ncsnpp.py:236-241) ----
+    {
+        int hh = gn("head.gn", "GroupNorm_0", h, C, -1, 0, res, res, 1);
+        release(h);
+        conv("head.conv", "Conv_1", hh, C, -1, 0, res, res, 3, d.in_channels, -1, 1.f, -1, 0, t_eps_out);
+        release(hh);
+        if (d.scale_by_sigma) {
+            Op sgm;
+            sgm.kind = OP_SCALE_ROWS; sgm.label = "scale_by_sigma"; sgm.out = {t_eps_out, 0}; sgm.a0 = {t_labels, 0};
+            sgm.m_per_image = res * res * d.in_channels;
+            ops.push_back(sgm);
+        }
+    }
+    if (tproj_t_ >= 0) release(tproj_t_);
+    GD_CHECK((int)rb_tproj_off_.size() == rb, "internal: resblock count mismatch (%d vs %d)", (int)rb_tproj_off_.size(), rb);
+
+    flops_per_image = conv3x3_flops_per_image = 0;
+    for (const Op &o : ops) {
+        flops_per_image += o.flops_per_image;
+        if (o.is_conv3x3) conv3x3_flops_per_image += o.flops_per_image;
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------- parameter packing
+int Plan::load_param(const std::string &name, const float *data, const int64_t *shape, int ndim) {
+    auto it = param_index.find(name);
+    GD_CHECK(it != param_index.end(), "unknown parameter '%s'", name.c_str());
+    Param &p = params[it->second];
+    GD_CHECK((int)p.shape.size() == ndim, "parameter '%s': expected %d dims, got %d", name.c_str(), (int)p.shape.size(), ndim);
+    for (int i = 0; i < ndim; ++i)
+        GD_CHECK(p.shape[i] == shape[i], "parameter '%s': dim %d is %lld, expected %lld", name.c_str(), i,
+                 (long long)shape[i], (long long)p.shape[i]);
+    WSlot &s = slots[p.slot];
+    switch (p.kind) {
+        case P_VEC: {
+            for (int64_t i = 0; i < shape[0]; ++i) s.host[(size_t)(p.row_off + i)] = data[i];
+            break;
+        }
+        case P_DENSE: {  // (in, out) -> rows row_off.., cols = in
+            const int64_t in = shape[0], out = shape[1];
+            GD_CHECK(in == s.cols, "parameter '%s': inner dim %lld != slot cols %lld", name.c_str(), (long long)in, s.cols);
+            for (int64_t o = 0; o < out; ++o)
+                for (int64_t i = 0; i < in; ++i) s.host[(size_t)((p.row_off + o) * s.cols + i)] = data[i * out + o];
+            break;
+        }
+        case P_CONV: {  // HWIO -> [O][(dy*KW+dx)*Ipad + i]
+            const int64_t kh = shape[0], kw = shape[1], I = shape[2], O = shape[3];
+            const int64_t ip = p.ipad;
+            for (int64_t o = 0; o < O; ++o)
+                for (int64_t t = 0; t < kh * kw; ++t)
+                    for (int64_t i = 0; i < I; ++i)
+                        s.host[(size_t)(o * s.cols + t * ip + i)] = data[(t * I + i) * O + o];
+            break;
+        }
+        case P_CONV_FIR6: {
+            // conv_downsample_2d (up_or_down_sampling.py:168-209): upfirdn with k = outer([1,3,3,1])/64, pads (2,2),
+            // then 3x3 stride-2 VALID conv.  Both are correlations (the FIR is symmetric), so the composition is a
+            // 6x6 stride-2 pad-2 correlation with W6[u][v] = sum_{a+s=u, b+t=v} w[a][b] k[s][t].
+            const int64_t I = shape[2], O = shape[3];
+            const int64_t ip = p.ipad;
+            const double k1[4] = {1.0 / 8, 3.0 / 8, 3.0 / 8, 1.0 / 8};
+            std::vector<double> w6((size_t)36);
+            for (int64_t o = 0; o < O; ++o)
+                for (int64_t i = 0; i < I; ++i) {
+                    std::fill(w6.begin(), w6.end(), 0.0);
+                    for (int a = 0; a < 3; ++a)
+                        for (int b = 0; b < 3; ++b) {
+                            const double w = data[((a * 3 + b) * I + i) * O + o];
+                            for (int ss = 0; ss < 4; ++ss)
+                                for (int tt = 0; tt < 4; ++tt) w6[(a + ss) * 6 + (b + tt)] += w * k1[ss] * k1[tt];
+                        }
+                    for (int t = 0; t < 36; ++t) s.host[(size_t)(o * s.cols + t * ip + i)] = (float)w6[t];
+                }
+            break;
+        }
+    }
+    p.loaded = true;
+    return 0;
+}
+
+// ---------------------------------------------------------------- JSON dump
+static void jref(std::ostringstream &o, const char *k, const TRef &r) { o << "\"" << k << "\":[" << r.t << "," << r.col << "],"; }
+
+std::string Plan::json() const {
+    std::ostringstream o;
+    o.precision(9);
+    o << "{\"CP\":" << CP << ",\"arena_per_image\":" << arena_per_image << ",\"flops_per_image\":" << flops_per_image
+      << ",\"conv3x3_flops_per_image\":" << conv3x3_flops_per_image << ",\"gn_max_slices\":" << GN_MAX_SLICES
+      << ",\"tensors\":[";
+    for (size_t i = 0; i < tensors.size(); ++i) {
+        const Tensor &t = tensors[i];
+        o << (i ? "," : "") << "{\"name\":\"" << t.name << "\",\"H\":" << t.H << ",\"W\":" << t.W << ",\"C\":" << t.C
+          << ",\"per_image\":" << t.per_image << ",\"offset\":" << t.offset << ",\"ext\":" << t.ext << "}";
+    }
+    o << "],\"slots\":[";
+    for (size_t i = 0; i < slots.size(); ++i)
+        o << (i ? "," : "") << "{\"name\":\"" << slots[i].name << "\",\"rows\":" << slots[i].rows << ",\"cols\":" << slots[i].cols << "}";
+    o << "],\"ops\":[";
+    for (size_t i = 0; i < ops.size(); ++i) {
+        const Op &p = ops[i];
+        o << (i ? "," : "") << "{\"kind\":" << p.kind << ",\"label\":\"" << p.label << "\",";
+        jref(o, "a0", p.a0); jref(o, "a1", p.a1); jref(o, "bten", p.bten); jref(o, "rowbias", p.rowbias);
+        jref(o, "res", p.res); jref(o, "out", p.out); jref(o, "stats", p.stats);
+        o << "\"C0\":" << p.C0 << ",\"C1\":" << p.C1 << ",\"lda0\":" << p.lda0 << ",\"lda1\":" << p.lda1 << ",\"H\":" << p.H
+          << ",\"W\":" << p.W << ",\"OH\":" << p.OH << ",\"OW\":" << p.OW << ",\"KH\":" << p.KH << ",\"KW\":" << p.KW
+          << ",\"stride\":" << p.stride << ",\"pad\":" << p.pad << ",\"m_per_image\":" << p.m_per_image
+          << ",\"z_per_image\":" << p.z_per_image << ",\"N\":" << p.N << ",\"K\":" << p.K << ",\"w_slot\":" << p.w_slot
+          << ",\"ldb\":" << p.ldb << ",\"b_kmajor\":" << p.b_kmajor << ",\"sA\":" << p.sA << ",\"sB\":" << p.sB
+          << ",\"sC\":" << p.sC << ",\"bias_slot\":" << p.bias_slot << ",\"bias_off\":" << p.bias_off
+          << ",\"ld_rowbias\":" << p.ld_rowbias << ",\"ldres\":" << p.ldres << ",\"ldc\":" << p.ldc << ",\"alpha\":" << p.alpha
+          << ",\"out_scale\":" << p.out_scale << ",\"in_act\":" << p.in_act << ",\"groups\":" << p.groups
+          << ",\"act\":" << p.act << ",\"gamma_slot\":" << p.gamma_slot << ",\"beta_slot\":" << p.beta_slot
+          << ",\"rows_per_image\":" << p.rows_per_image << ",\"cols\":" << p.cols << ",\"cin\":" << p.cin
+          << ",\"cpad\":" << p.cpad << ",\"mul\":" << p.mul << ",\"add\":" << p.add << ",\"flops_per_image\":" << p.flops_per_image
+          << ",\"is_conv3x3\":" << p.is_conv3x3 << "}";
+    }
+    o << "]}";
+    return o.str();
+}
+
+}  // namespace gd

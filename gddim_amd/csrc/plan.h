@@ -1,0 +1,141 @@
+// U-Net execution plan: the NCSN++ forward (cld_jax/models/ncsnpp.py:41-243) lowered to a flat list of
+// kernel-level ops over an activation arena, plus the weight slots the flax parameter tree is packed into.
+// Pure host code (no HIP): the plan can be built and inspected on a machine without a GPU.
+#pragma once
+#include <cstdint>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/gddim_amd.h"
+
+namespace gd {
+
+enum OpKind {
+    OP_FOURIER = 0,
+    OP_GEMM,
+    OP_GN_STATS,
+    OP_GN_APPLY,
+    OP_FIR_UP,
+    OP_FIR_DOWN,
+    OP_SOFTMAX,
+    OP_AFFINE_PAD,
+    OP_SCALE_ROWS,
+};
+
+// external tensors are bound to caller pointers at run time
+enum ExtKind { EXT_NONE = 0, EXT_X_IN, EXT_LABELS, EXT_EPS_OUT };
+
+struct Tensor {
+    std::string name;
+    int H = 1, W = 1, C = 1;
+    long long per_image = 0;  // floats per image
+    long long offset = -1;    // arena offset (floats per image); address = arena + offset * batch
+    int ext = EXT_NONE;
+    int refs = 0;
+};
+
+struct TRef {
+    int t = -1;
+    int col = 0;  // channel offset inside the tensor
+};
+
+struct Op {
+    int kind = OP_GEMM;
+    std::string label;
+    // ---- GEMM / conv ----
+    TRef a0, a1;
+    int C0 = 0, C1 = 0, lda0 = 0, lda1 = 0;
+    int H = 1, W = 1, OH = 1, OW = 1, KH = 1, KW = 1, stride = 1, pad = 0;
+    int m_per_image = 1;  // rows contributed by one image
+    int z_per_image = 0;  // 1: blockIdx.z = image, M = m_per_image (attention matmuls)
+    int N = 0, K = 0;
+    int w_slot = -1;      // B from a weight slot ([N][K] row-major) ...
+    TRef bten;            // ... or from a tensor
+    int ldb = 0, b_kmajor = 0;
+    long long sA = 0, sB = 0, sC = 0;  // per-image strides when z_per_image
+    int bias_slot = -1;
+    int bias_off = 0;
+    TRef rowbias;
+    int ld_rowbias = 0;
+    TRef res;
+    int ldres = 0;
+    TRef out;
+    int ldc = 0;
+    float alpha = 1.f, out_scale = 1.f;
+    int in_act = 0;
+    // ---- GroupNorm ----
+    int groups = 0, act = 0, gamma_slot = -1, beta_slot = -1;
+    TRef stats;
+    // ---- softmax ----
+    int rows_per_image = 0, cols = 0;
+    // ---- affine pad ----
+    int cin = 0, cpad = 0;
+    float mul = 1.f, add = 0.f;
+    // ---- accounting ----
+    double flops_per_image = 0;  // algorithmic 2*MAC
+    int is_conv3x3 = 0;
+};
+
+struct WSlot {
+    std::string name;
+    long long rows = 0, cols = 0;
+    std::vector<float> host;  // packed [rows][cols]
+};
+
+enum ParamKind {
+    P_VEC = 0,     // (n,) -> slot[row_off ... row_off+n)   (slot viewed as flat)
+    P_DENSE,       // (in, out) -> rows [row_off, row_off+out), cols = in   (transposed)
+    P_CONV,        // (kh, kw, I, O) -> [O][kh*kw*Ipad], input channels zero-padded to ipad
+    P_CONV_FIR6,   // (3, 3, I, O) composed with the [1,3,3,1]^2/64 FIR -> [O][36*Ipad] (6x6, stride 2, pad 2)
+};
+
+struct Param {
+    std::string name;  // flax path joined by '/'
+    std::vector<int64_t> shape;
+    int kind = P_VEC;
+    int slot = -1;
+    long long row_off = 0;
+    int ipad = 0;
+    bool loaded = false;
+};
+
+struct Plan {
+    gd_model_desc desc{};
+    int CP = 0;  // U-Net input channels padded to a multiple of 4
+    std::vector<Tensor> tensors;
+    std::vector<Op> ops;
+    std::vector<WSlot> slots;
+    std::vector<Param> params;
+    std::map<std::string, int> param_index;
+    long long arena_per_image = 0;  // floats
+    int t_x_in = -1, t_labels = -1, t_eps_out = -1;
+    double flops_per_image = 0, conv3x3_flops_per_image = 0;
+
+    int build(const gd_model_desc &d);  // 0 ok
+    int load_param(const std::string &name, const float *data, const int64_t *shape, int ndim);
+    std::string json() const;
+
+   private:
+    // arena
+    struct Block { long long off, size; };
+    std::vector<Block> free_list_;
+    long long arena_alloc(long long size);
+    void arena_free(long long off, long long size);
+    // builders
+    int new_tensor(const std::string &name, int H, int W, int C, int ext = EXT_NONE, long long per_image = -1);
+    void retain(int t) { tensors[t].refs++; }
+    void release(int t);
+    int new_slot(const std::string &name, long long rows, long long cols);
+    void add_param(const std::string &name, std::vector<int64_t> shape, int kind, int slot, long long row_off, int ipad = 0);
+    int gn(const std::string &prefix, const std::string &pname, int xa, int Ca, int xb, int Cb, int H, int W, int act);
+    int conv(const std::string &label, const std::string &pname, int xa, int Ca, int xb, int Cb, int H, int W, int ksize,
+             int O, int res_t, float out_scale, int rowbias_t, int rowbias_col, int out_t = -1);
+    int resblock(int idx, int xa, int Ca, int xb, int Cb, int H, int W, int O, bool up, bool down, int &outH);
+    int attn(int idx, int x, int H, int W, int C);
+    int temb_t_ = -1, tproj_t_ = -1, tproj_slot_w_ = -1, tproj_slot_b_ = -1;
+    std::vector<int> rb_tproj_off_;
+    int sum_cout_ = 0;
+};
+
+}  // namespace gd

@@ -1,0 +1,200 @@
+/*
+ * gddim_amd -- C ABI of the MI355X-native gDDIM sampling engine.
+ *
+ * This is the drop-in boundary for the reference's sampler hot path.  The
+ * reference (qsh-zh/gDDIM) is pure Python/JAX and has no FFI of its own; every entry point
+ * below cites the reference Python interface it stands in for, and the gddim_amd Python package binds it
+ * with ctypes under the reference's own function names (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on error; gd_last_error() gives the text
+ *     (thread-local).  Nothing falls back to a CPU path: a call that needs the GPU fails.
+ *   - "dev" pointers are device (HBM) pointers, "host" pointers are host memory.  No torch
+ *     or other framework types cross this boundary.
+ *   - tensors are dense fp32, NHWC; a CLD state u is (B,H,W,C,2) as in the reference
+ *     (last axis = (x, v)); the U-Net sees it channel-planar as (B,H,W,2C) =
+ *     [x_0..x_{C-1}, v_0..v_{C-1}]  (cld_jax/models/utils.py:153,158).
+ *   - `stream` is a hipStream_t passed as void*; NULL = the null stream.
+ *   - an engine belongs to one GPU and is not thread-safe; gd_sample_* performs no device
+ *     allocation (everything is sized at gd_engine_create for max_batch) so it can be captured
+ *     into / replayed from a hipGraph.
+ */
+#ifndef GDDIM_AMD_H
+#define GDDIM_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gd_engine gd_engine;
+
+#define GD_MAX_LEVELS 8
+
+/* NCSN++ architecture switches = the fields NCSNpp.__call__ reads from `config`
+ * (cld_jax/models/ncsnpp.py:41-69; values in cld_jax/configs/accr_dcifar10_config.py:24-47,
+ * blur_jax/configs/ddpm_deep_cifar10_config.py:24-47).  Only the live branches are built:
+ * resblock_type='biggan', fir=True with fir_kernel=[1,3,3,1], embedding_type='fourier',
+ * progressive='none', nonlinearity='swish'; gd_engine_create rejects anything else. */
+typedef struct gd_model_desc {
+    int image_size;                       /* config.data.image_size (H = W)                      */
+    int in_channels;                      /* U-Net in/out channels: 2*num_channels (CLD) or num_channels (blur) */
+    int nf;                               /* config.model.nf                                      */
+    int num_res_blocks;                   /* config.model.num_res_blocks                          */
+    int num_levels;                       /* len(config.model.ch_mult)                            */
+    int ch_mult[GD_MAX_LEVELS];           /* config.model.ch_mult                                 */
+    int num_attn_resolutions;             /* len(config.model.attn_resolutions)                   */
+    int attn_resolutions[GD_MAX_LEVELS];  /* config.model.attn_resolutions                        */
+    int conditional;                      /* config.model.conditional                             */
+    int skip_rescale;                     /* config.model.skip_rescale                            */
+    int progressive_input_residual;       /* config.model.progressive_input == 'residual' (else 'none') */
+    int scale_by_sigma;                   /* config.model.scale_by_sigma                          */
+    int centered;                         /* config.data.centered (False: x <- 2x-1, ncsnpp.py:136-138) */
+    int max_batch;                        /* largest per-GPU batch this engine will be asked for  */
+} gd_model_desc;
+
+/* ---- diagnostics ---------------------------------------------------------------------- */
+const char *gd_last_error(void);
+int gd_version(void);
+/* Number of visible HIP devices (0 when there is no GPU / driver). */
+int gd_device_count(void);
+
+/* ---- host-side SDE math (no GPU) -------------------------------------------------------- */
+/* R(t) table of the CLD SDE: fixed-step integration of dR/dt = F R + 1/2 G G^T R^-T from
+ * R_0 = diag(sqrt(numerical_eps), sqrt(vv_gamma/m_inv + numerical_eps)), emitting the state
+ * before each of n steps (out: n x 4 doubles, row-major 2x2).
+ * Replaces: cld_jax/sde_lib.py:93-118 (_get_s_R_fn: lax.scan over scan_body_fn) and
+ * cld_jax/deis.py:5-17 (runge_kutta).  Computed in float64 (the reference runs float32,
+ * DESIGN.md "precision" explains why float64 is within parity). */
+int gd_cld_r_table(double m_inv, double beta_0, double beta_1, double vv_gamma, double numerical_eps,
+                   int is_rk, double R_dt, size_t n, double *out_host);
+
+/* ---- engine life cycle ------------------------------------------------------------------ */
+/* device >= 0: build the plan, allocate weights + activation arena on that GPU.
+ * device <  0: plan-only (host) mode -- no GPU touched; used to inspect the plan / packed
+ *              weights on machines without a GPU.  Compute calls fail in this mode.
+ * Replaces: mutils.init_model / model.init (cld_jax/models/utils.py:109-125) as far as
+ * shapes go, and the jit/pmap compilation of `sampler` (cld_jax/sampling.py:212-237). */
+int gd_engine_create(const gd_model_desc *desc, int device, gd_engine **out);
+int gd_engine_destroy(gd_engine *e);
+
+/* Plan introspection: a JSON document listing every op, tensor and weight slot. */
+int gd_engine_plan_json(gd_engine *e, char *buf, size_t cap, size_t *needed);
+/* Algorithmic FLOPs (2*MAC of every conv/dense/attention contraction) of one U-Net
+ * evaluation of one image; conv3x3_only != 0 counts only 3x3 convolutions. */
+double gd_engine_flops_per_image(gd_engine *e, int conv3x3_only);
+
+/* ---- weights ------------------------------------------------------------------------------
+ * One call per leaf of the flax parameter tree `state.params_ema`
+ * (cld_jax/sampling.py:216, cld_jax/models/utils.py:32-40), named by its path joined with '/',
+ * e.g. "ResnetBlockBigGANpp_3/Conv_0/kernel"; data is host fp32 in flax layout (conv HWIO,
+ * Dense (in,out), NIN W (in,out), vectors).  The engine re-packs into its GEMM layout.
+ * Replaces: flax_utils.replicate(state) host->device copy (cld_jax/run_lib.py:711). */
+int gd_engine_num_params(gd_engine *e);
+int gd_engine_param_info(gd_engine *e, int index, char *name_buf, size_t name_cap, int64_t *shape4, int *ndim);
+int gd_engine_load_param(gd_engine *e, const char *name, const float *host_data, const int64_t *shape, int ndim);
+/* Fails (listing what is missing) unless every parameter has been loaded. */
+int gd_engine_params_ready(gd_engine *e);
+/* Export a packed weight slot to host memory (plan-only and GPU mode). */
+int gd_engine_packed_weight(gd_engine *e, const char *slot, float *host_out, size_t cap_floats, size_t *n_floats);
+
+/* ---- score network ------------------------------------------------------------------------
+ * eps = NCSNpp(x, labels): x_dev (B,H,W,in_channels), labels_dev (B,) = 999*t, out_dev like x.
+ * Replaces: model.apply(variables, x, labels, train=False, mutable=False)
+ * (cld_jax/models/utils.py:156; NCSNpp.__call__, cld_jax/models/ncsnpp.py:41-243). */
+int gd_unet_forward(gd_engine *e, const float *x_dev, const float *labels_dev, float *out_dev, int batch, void *stream);
+/* CLD wrapper: u_dev / eps_dev are (B,H,W,C,2); labels = 999*t_dev (t per sample).
+ * Replaces: get_eps_fn(...)(u, t) with mixed_score=False (cld_jax/models/utils.py:168-182). */
+int gd_cld_eps(gd_engine *e, const float *u_dev, const float *t_dev, float *eps_dev, int batch, void *stream);
+
+/* ---- CLD gDDIM sampler ---------------------------------------------------------------------
+ * Install the schedule of one sampler instance:
+ *   ts_host[num_step]                 rev_ts[i], the time fed to the network at step i
+ *   coef_host[num_step][n_slots][4]   deis_coef[i] = [Psi_i, C_i0 .. C_i(n_slots-2)], 2x2 row-major,
+ *                                     n_slots = deis_order + 3 (order0 sampler: n_slots = 2)
+ *   denoise != 0: after the loop apply u + F u dt - GG score dt at t_denoise with dt = -t_denoise
+ *   dn_F/dn_GG/dn_RinvT: F(t), G(t)@G(t), inv(R(t))^T at t = t_denoise (host, 4 floats each)
+ * Replaces: the closure state of _impl_deis_sampler / get_order0_sampler
+ * (cld_jax/sampling.py:204-211,156-177): deis_coef = sde.get_deis_coef(order, rev_ts),
+ * step_fn = get_denoising_step(...) (cld_jax/sampling.py:30-39). */
+int gd_engine_set_schedule_cld(gd_engine *e, int num_step, int n_slots, const float *ts_host, const float *coef_host,
+                               int denoise, float t_denoise, const float *dn_F, const float *dn_GG,
+                               const float *dn_RinvT);
+/* One sampler call: u_in_dev (B,H,W,C,2) initial noise -> x_out_dev (B,H,W,C) = (u_x+1)/2 when
+ * inverse_scale != 0 else u_x, v_out_dev (B,H,W,C).  use_graph: 0 eager launches, 1 replay a
+ * captured hipGraph per step (captured on first use for this batch size).
+ * Replaces: sampler(rng, state, batch_size, u) (cld_jax/sampling.py:212-230 / :178-193):
+ * fori_loop(body_fn) = eps_fn + multistep_ab_step, then step_fn, inverse_scaler. */
+int gd_sample_cld(gd_engine *e, int batch, const float *u_in_dev, float *x_out_dev, float *v_out_dev,
+                  int inverse_scale, int use_graph, void *stream);
+
+/* ---- blur gDDIM sampler --------------------------------------------------------------------
+ *   ts_host[nfe]                     rev_ts[i]
+ *   mean_coef_host[nfe+1][32*32]     y_mean_coef(rev_ts[i]) = sqrt(alpha) * D_t per frequency (h,w)
+ *   std_coef_host[nfe+1]             y_std_coef(rev_ts[i]) = sqrt(1 - alpha)
+ * Replaces: get_order0_sampler closure (blur_jax/sampling.py:53-61) + sde.y_mean_coef /
+ * y_std_coef (blur_jax/sde_lib.py:90-97). */
+int gd_engine_set_schedule_blur(gd_engine *e, int nfe, const float *ts_host, const float *mean_coef_host,
+                                const float *std_coef_host);
+/* y_in_dev (B,32,32,C) -> x_out_dev (B,32,32,C) = inverse_scaler(IDCT(y_nfe)).
+ * Replaces: sampler(rng, state, batch_size, u) (blur_jax/sampling.py:55-80). */
+int gd_sample_blur(gd_engine *e, int batch, const float *y_in_dev, float *x_out_dev, int inverse_scale,
+                   int use_graph, void *stream);
+
+/* ---- profiling -----------------------------------------------------------------------------
+ * When enabled, eager launches are bracketed by hipEvents on the launch stream and the
+ * accumulated per-kernel-class durations / algorithmic FLOPs / bytes can be read back. */
+typedef struct gd_prof_entry {
+    char name[48];
+    double ms;        /* accumulated device time                   */
+    double flops;     /* accumulated algorithmic FLOPs (2*MAC)     */
+    double bytes;     /* accumulated algorithmic HBM bytes         */
+    long long launches;
+} gd_prof_entry;
+int gd_engine_profile(gd_engine *e, int enable);
+int gd_engine_profile_read(gd_engine *e, gd_prof_entry *out, int cap, int *n);
+
+/* ---- stand-alone operators (no engine; tests + the Python mirror of the reference helpers) ----
+ * All pointers are device pointers. */
+/* u' = Psi u + sum_o C_o eps_o with full_eps = [new_eps, eps_pred[0..n_hist-1]];
+ * coef_dev: (n_hist + 2) x 4 floats [Psi, C_0..C_{n_hist}]; tensors (n, 2) pairs, n = B*H*W*C.
+ * hist_out_dev (n_hist, n, 2) receives full_eps[:-1] (may not alias hist_in).
+ * Replaces: multistep_ab_step (cld_jax/deis.py:141-151). */
+int gd_ab_step(const float *u_dev, const float *coef_dev, const float *new_eps_dev, const float *hist_in_dev,
+               float *u_out_dev, float *hist_out_dev, int n_hist, long long n_pairs, void *stream);
+/* x' = c_0 x + sum_o c_{o+1} eps_o, scalar coefficients; same history convention.
+ * Replaces: ab_step (blur_jax/multistep.py:94-97). */
+int gd_ab_step_scalar(const float *x_dev, const float *coef_dev, const float *new_eps_dev, const float *hist_in_dev,
+                      float *x_out_dev, float *hist_out_dev, int n_hist, long long n, void *stream);
+/* out[..., i] = sum_j m[i][j] in[..., j] on (n,2) pairs; per_sample != 0: m_dev is (B,2,2) and
+ * pairs_per_sample gives the grouping.  Replaces: sbmm / bmm (cld_jax/utils.py:179-185). */
+int gd_bmm2x2(const float *m_dev, const float *in_dev, float *out_dev, long long n_pairs, int per_sample,
+              long long pairs_per_sample, void *stream);
+/* Orthonormal 2-D DCT-II (inverse == 0) or its inverse (DCT-III) over the 32x32 plane of every
+ * (b, c) of an NHWC tensor (B,32,32,C).
+ * Replaces: batch_img_dct / batch_img_idct (blur_jax/blur.py:99-106). */
+int gd_dct2d_32(const float *in_dev, float *out_dev, int batch, int channels, int inverse, void *stream);
+/* Generic implicit-GEMM convolution (the MFMA kernel), NHWC x [Cout][KH*KW*Cin] -> NHWC:
+ * out = (alpha * conv(x) + bias + res) * out_scale.  w_dev is the packed [Cout][KH][KW][Cin] form.
+ * Replaces: nn.Conv / lax.conv_general_dilated call sites (cld_jax/models/layers.py:66-107). */
+int gd_conv2d(const float *x_dev, const float *w_dev, const float *bias_dev, const float *res_dev, float *out_dev,
+              int batch, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, float alpha,
+              float out_scale, void *stream);
+/* flax GroupNorm(num_groups, eps=1e-6) (+ swish when act != 0) on NHWC (B,H,W,C).
+ * Replaces: nn.GroupNorm + nn.swish call sites (cld_jax/models/layerspp.py:69,196,218). */
+int gd_group_norm(const float *x_dev, const float *scale_dev, const float *bias_dev, float *out_dev, int batch,
+                  int HW, int C, int groups, int act, void *stream);
+/* FIR [1,3,3,1] 2x resampling of NHWC tensors.  Replaces: upsample_2d / downsample_2d
+ * (cld_jax/models/up_or_down_sampling.py:333-411). */
+int gd_fir_resample(const float *x_dev, float *out_dev, int batch, int H, int W, int C, int up, void *stream);
+/* Single-head self-attention core on projected q,k,v packed as qkv_dev (B,N,3C):
+ * out (B,N,C) = softmax(q k^T C^-1/2) v; scratch_dev must hold B*N*N floats.
+ * Replaces: the two einsums + softmax of AttnBlockpp (cld_jax/models/layerspp.py:74-78). */
+int gd_attention(const float *qkv_dev, float *scratch_dev, float *out_dev, int batch, int N, int C, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GDDIM_AMD_H */

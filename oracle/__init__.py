@@ -1,0 +1,20 @@
+"""ORACLE -- CPU restatement of the reference's gDDIM sampling hot path.
+
+TEST INFRASTRUCTURE ONLY.  Only ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` may import this package, and only as the checker.
+The product (``gddim_amd``) never imports it and fails loudly when its HIP library is
+missing.
+
+PARITY UNPINNED: the reference (qsh-zh/gDDIM) is pure Python on jax==0.2.8 / flax==0.3.1 /
+ml_collections / jammy (``/root/reference/Dockerfile:1-15``); none is installed here, there
+is no network, and the reference's own tests (``cld_jax/tests/*``) contain no assertion,
+fixture or golden vector.  So this oracle cannot be checked against reference outputs.
+It is instead written line-by-line from the cited reference sources and pinned by analytic
+known-answer tests (``tests/test_oracle_*.py``): matrix exponential vs scipy ``expm``,
+``R R^T`` vs the Lyapunov ODE, DEIS coefficients vs adaptive quadrature and the Lagrange
+row-sum identity, DCT vs ``scipy.fft.dctn``, FIR resampling vs ``scipy.signal.upfirdn``,
+conv/GroupNorm/softmax vs independent numpy loops, and the Dirac-data closed-form sampler
+trajectory.  Third-party arithmetic the reference delegates to (flax ``nn.Conv`` /
+``nn.GroupNorm(epsilon=1e-6)`` / ``nn.Dense``, ``jax.nn.softmax``, ``lax.conv_general_dilated``)
+is restated from its published semantics.
+"""

@@ -1,0 +1,39 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def native_lib():
+    """Build (if stale) and load the native library; the build is a cross-compile and needs no GPU."""
+    from gddim_amd import build, _abi
+    build.build()
+    return _abi.lib()
+
+
+def tiny_config(kind="cld", nf=16, num_res_blocks=1, image_size=16, ch_mult=(1, 2, 2), attn=(8,), centered=True,
+                progressive_input='residual'):
+    """A small NCSN++ of the benchmarked family (biggan blocks, fir, fourier, skip_rescale)."""
+    if kind == "cld":
+        from gddim_amd.configs import cld_accr_dcifar10 as c
+    else:
+        from gddim_amd.configs import blur_ddpm_deep_cifar10 as c
+    cfg = c.get_config()
+    cfg.model.nf = nf
+    cfg.model.num_res_blocks = num_res_blocks
+    cfg.model.ch_mult = tuple(ch_mult)
+    cfg.model.attn_resolutions = tuple(attn)
+    cfg.model.progressive_input = progressive_input
+    cfg.data.image_size = image_size
+    cfg.data.centered = centered
+    return cfg

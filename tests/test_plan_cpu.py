@@ -1,0 +1,80 @@
+"""CPU checks of the native planner + weight packing: the engine's plan, executed op by op by the torch
+emulation in plan_interp.py on the engine's own packed weights, must reproduce the oracle U-Net."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import tiny_config
+from oracle import ncsnpp as oracle_net
+from plan_interp import PlanInterp
+
+
+def _run(cfg, in_ch, B=2, seed=0):
+    from gddim_amd.engine import Engine
+    eng = Engine(cfg, in_ch, max_batch=B, plan_only=True)
+    params = oracle_net.random_params(cfg, in_ch, seed=seed, dtype=np.float32)
+    assert set(oracle_net.flatten(params)) == set(eng.param_specs()), "parameter names differ from the oracle's flax tree"
+    for k, shp in eng.param_specs().items():
+        assert tuple(oracle_net.flatten(params)[k].shape) == shp, k
+    eng.load_params(params)
+    rng = np.random.default_rng(seed + 1)
+    H = cfg.data.image_size
+    x = torch.as_tensor(rng.standard_normal((B, H, H, in_ch)), dtype=torch.float64)
+    if not cfg.data.centered:
+        x = x * 0.25 + 0.5
+    labels = torch.as_tensor(rng.uniform(1.0, 999.0, size=(B,)), dtype=torch.float64)
+    CP = eng.plan()["CP"]
+    xin = torch.zeros(B, H, H, CP, dtype=torch.float64)
+    xin[..., :in_ch] = x
+    got = PlanInterp(eng).run(xin, labels)
+    with torch.no_grad():
+        want = oracle_net.ncsnpp_forward(params, x, labels, cfg)
+    eng.close()
+    return got, want
+
+
+@pytest.mark.parametrize("kind,in_ch", [("cld", 6), ("blur", 3)])
+def test_plan_matches_oracle_tiny(native_lib, kind, in_ch):
+    got, want = _run(tiny_config(kind), in_ch)
+    assert torch.isfinite(got).all()
+    err = (got - want).abs().max().item()
+    # float32-packed weights (incl. the precomposed 6x6 FIR conv) vs float64 oracle on float32 weights
+    assert err < 2e-5 * max(1.0, want.abs().max().item()), err
+
+
+def test_plan_matches_oracle_variants(native_lib):
+    # not centered (x <- 2x-1), no input pyramid, attention at two resolutions, 2 res blocks, wider ch_mult
+    cfg = tiny_config("cld", nf=16, num_res_blocks=2, image_size=16, ch_mult=(1, 2, 3), attn=(8, 4), centered=False,
+                      progressive_input='none')
+    got, want = _run(cfg, 6, B=3, seed=3)
+    err = (got - want).abs().max().item()
+    assert err < 2e-5 * max(1.0, want.abs().max().item()), err
+
+
+def test_scale_by_sigma_and_unconditional(native_lib):
+    cfg = tiny_config("cld")
+    cfg.model.scale_by_sigma = True
+    got, want = _run(cfg, 6, B=2, seed=5)
+    assert (got - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item())
+
+
+def test_flops_match_survey(native_lib):
+    """SURVEY.md App. A.3 / BASELINE.md section 2: 37.179 GFLOP per image-eval (incl. 0.011 FIR, which the engine's
+    contraction count leaves out) and 33.704 GFLOP in 3x3 convolutions for the accr architecture at 32x32x6."""
+    from gddim_amd.configs import cld_accr_dcifar10, blur_ddpm_deep_cifar10
+    from gddim_amd.engine import Engine
+    e = Engine(cld_accr_dcifar10.get_config(), 6, 1, plan_only=True)
+    assert abs(e.flops_per_image() / 1e9 - (37.179 - 0.011)) < 2e-3
+    assert abs(e.flops_per_image(True) / 1e9 - 33.704) < 1e-3
+    assert len(e.param_specs()) == 963
+    n_params = sum(int(np.prod(s)) for s in e.param_specs().values())
+    assert abs(n_params / 1e6 - 107.60) < 0.01
+    e.close()
+    cfg = cld_accr_dcifar10.get_config()
+    cfg.data.image_size = 64
+    e = Engine(cfg, 6, 1, plan_only=True)
+    assert abs(e.flops_per_image(True) / 1e9 - 134.815) < 1e-3
+    e.close()
+    e = Engine(blur_ddpm_deep_cifar10.get_config(), 3, 1, plan_only=True)
+    assert abs(e.flops_per_image(True) / 1e9 - 33.688) < 1e-3
+    e.close()
