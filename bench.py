@@ -1,0 +1,175 @@
+#!/usr/bin/env python
+"""Headline benchmark: images/sec of the CLD gDDIM sampler (deis_order=2, NFE=50) on CIFAR-10-shaped
+synthetic batches -- BASELINE.json `metric`, config[1] at N=1 and config[3] (batch sharded, one process per
+GPU, RCCL all-gather of the uint8 images at the end of each round) at N>1.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+      bench.py --gpus N --steps K --warmup W
+
+A "step" is one full sampler call on this rank's batch: 49 x (NCSN++ forward + fused AB update) + the
+denoising evaluation + inverse scaling (prior sampling excluded, inputs resident in HBM), then uint8
+conversion and, for N>1, the all-gather.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+METRIC = "images/sec at NFE=50 CIFAR-10 32×32 (CLD gDDIM order-2), 1/2/4/8 GPU + FID@50k"
+FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+HBM_PEAK_GBS = 8000.0
+
+
+def cpu_baseline(cfg, params, nfe_full, cpu_batch, cpu_nfe):
+    """The reference JAX-CPU path cannot run here (no jax); timed instead: the torch-CPU fp32 ORACLE (a
+    restatement of the same algorithm, kind='port') on a bounded sample, all host cores."""
+    import torch
+    from oracle import cld as ocld
+    from oracle import ncsnpp as onet
+    # torch's CPU convolutions collapse when a 256-thread host pool is thrown at batch-4 problems (measured:
+    # 658 s for this sample with 256 threads), so the pool is capped; `cores` reports the threads actually used
+    cores = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(cores)
+    osde = ocld.CLD(is_R_rk=cfg.model.is_R_rk, R_dt=cfg.model.R_dt, dtype=np.float64)
+    rng = np.random.default_rng(0)
+    H, C = cfg.data.image_size, cfg.data.num_channels
+    u = np.stack([rng.standard_normal((cpu_batch, H, H, C)), rng.standard_normal((cpu_batch, H, H, C)) / 2], -1).astype(np.float32)
+    eps_fn = onet.cld_eps_fn(params, cfg, dtype=torch.float32)
+    rev_ts = ocld.get_rev_ts(osde, 2, cpu_nfe - 1)
+    coef = osde.get_deis_coef(2, rev_ts)
+    eps_fn(u[:1], np.full(1, 0.5, np.float32))  # warm the thread pool / allocator
+    t0 = time.perf_counter()
+    ocld.deis_sampler(osde, eps_fn, u, cpu_nfe, 2, ts_order=2, denoising=True, inverse_scaler=ocld.inverse_scaler_centered,
+                      deis_coef=coef, rev_ts=rev_ts)
+    dt = time.perf_counter() - t0
+    per_img_eval = dt / (cpu_batch * cpu_nfe)
+    return {"value": 1.0 / (per_img_eval * nfe_full), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": "torch-CPU fp32 oracle, batch=%d x NFE=%d network evaluations of the same architecture in %.1f s, "
+                      "scaled linearly to NFE=%d" % (cpu_batch, cpu_nfe, dt, nfe_full)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--nfe", type=int, default=50)
+    ap.add_argument("--order", type=int, default=2)
+    ap.add_argument("--image-size", type=int, default=32)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=2)
+    ap.add_argument("--cpu-nfe", type=int, default=2)
+    args = ap.parse_args()
+
+    import torch
+    from gddim_amd import build, distributed
+    from gddim_amd.cld import sampling, sde_lib
+    from gddim_amd.configs import cld_accr_dcifar10
+    from gddim_amd.datasets import get_data_inverse_scaler
+    from gddim_amd.models import utils as mutils
+
+    rank, world, local_rank = distributed.init_from_env()
+    assert world == args.gpus, "launch with --nproc-per-node equal to --gpus (WORLD_SIZE=%d, --gpus=%d)" % (world, args.gpus)
+    if not os.path.exists(os.path.join(ROOT, "gddim_amd", "libgddim_amd.so")):
+        if local_rank == 0:
+            build.build()
+        if world > 1:
+            torch.distributed.barrier()
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    cfg = cld_accr_dcifar10.get_config()
+    cfg.data.image_size = args.image_size
+    cfg.sampling.nfe = args.nfe
+    cfg.sampling.deis_order = args.order
+    cfg.sampling.method = "deis"
+    model, _, params = mutils.init_model(42, cfg, init_scale_override=1.0)  # identical weights on every rank
+    state = mutils.State(params_ema=params, model_state={})
+    sde = sde_lib.from_config(cfg)
+    sampling_fn = sampling.get_sampling_fn(cfg, sde, model, None, get_data_inverse_scaler(cfg))  # is_p=True
+    B = args.batch
+    shape = (1, B, args.image_size, args.image_size, cfg.data.num_channels)
+    g = torch.Generator(device=dev)
+    g.manual_seed(distributed.rank_seed(cfg.seed, 0, rank))
+    u = torch.stack([torch.randn(shape, generator=g, device=dev), torch.randn(shape, generator=g, device=dev) / 2.0], dim=-1)
+
+    def step():
+        xs, vs, nfe = sampling_fn([rank], state, B, u, use_graph=not args.no_graph)
+        u8 = distributed.to_uint8(xs[0])
+        return distributed.all_gather_samples(u8)
+
+    def fence():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+    dt = float(tt.item())
+    assert out.shape[0] == B * world and out.dtype == torch.uint8
+
+    eng = model.engine_for(params, 2 * cfg.data.num_channels, B, local_rank)
+    flops_img = eng.flops_per_image() * args.nfe
+    result = {
+        "metric": METRIC, "value": world * B * args.steps / dt, "unit": "images/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * dt / max(1, args.steps), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "CLD gDDIM deis_order=%d NFE=%d, batch=%d per GPU, %dx%dx3 synthetic noise, random-init NCSN++ "
+                               "(accr_dcifar10: nf=128, ch_mult=(1,2,2,2), 8 res blocks, attn@16)" %
+                               (args.order, args.nfe, B, args.image_size, args.image_size),
+                   "global_batch": B * world, "parallelism": "dp%d (one process per GPU, uint8 all-gather per round)" % world,
+                   "hipgraph": not args.no_graph, "tflop_per_image": flops_img / 1e12},
+        "e2e_tflops_per_gpu": B * args.steps * flops_img / dt / 1e12,
+    }
+
+    # ---- roofline of the dominant kernel: live hipEvent timing of every launch of one more sampler call ----
+    if not args.no_profile:
+        eng.profile(True)
+        sampling_fn([rank], state, B, u, use_graph=False)
+        torch.cuda.synchronize()
+        prof = eng.profile_read()
+        eng.profile(False)
+        tot_ms = sum(p["ms"] for p in prof)
+        dom = max(prof, key=lambda p: p["ms"])
+        achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
+        result["roofline"] = {"kernel": dom["name"], "bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
+                              "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                              "launches": dom["launches"], "avg_launch_ms": dom["ms"] / max(1, dom["launches"]),
+                              "flops_per_launch": dom["flops"] / max(1, dom["launches"]),
+                              "share_of_gpu_time": dom["ms"] / tot_ms if tot_ms else None}
+        result["kernel_breakdown"] = [
+            {"name": p["name"], "ms": round(p["ms"], 3), "launches": p["launches"],
+             "tflops": (p["flops"] / (p["ms"] * 1e-3) / 1e12) if p["flops"] and p["ms"] else None,
+             "gbs": (p["bytes"] / (p["ms"] * 1e-3) / 1e9) if p["bytes"] and p["ms"] else None}
+            for p in sorted(prof, key=lambda p: -p["ms"])]
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(cfg, params, args.nfe, args.cpu_batch, args.cpu_nfe)
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

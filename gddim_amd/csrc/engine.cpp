@@ -60,6 +60,10 @@ struct gd_engine {
     int sched_kind = 0;  // 1 cld, 2 blur
     int num_step = 0, n_slots = 0, denoise = 0;
     float t_denoise = 0;
+    // the sampler loop runs on the engine's own stream (graph capture is illegal on the null stream); it is
+    // ordered after / before the caller's stream with two events
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;
     // graphs keyed by batch
     struct Graphs { hipGraphExec_t step = nullptr, fin = nullptr; };
     std::map<int, Graphs> graphs;
@@ -252,6 +256,9 @@ int gd_engine_create(const gd_model_desc *desc, int device, gd_engine **out) {
         GD_ALLOC(e->step_dev, 1);
 #undef GD_ALLOC
         (void)hipMemset(e->step_dev, 0, sizeof(int));
+        if ((err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", err);
+        if ((err = hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming)) != hipSuccess) return fail("hipEventCreate", err);
+        if ((err = hipEventCreateWithFlags(&e->ev_out, hipEventDisableTiming)) != hipSuccess) return fail("hipEventCreate", err);
     }
     *out = e;
     return 0;
@@ -268,6 +275,9 @@ int gd_engine_destroy(gd_engine *e) {
                          e->ts_dev, e->coef_dev, e->dn_dev, e->mean_dev, e->std_dev, (float *)e->step_dev};
         for (float *b : bufs)
             if (b) (void)hipFree(b);
+        if (e->ev_in) (void)hipEventDestroy(e->ev_in);
+        if (e->ev_out) (void)hipEventDestroy(e->ev_out);
+        if (e->stream) (void)hipStreamDestroy(e->stream);
     }
     delete e;
     return 0;
@@ -407,7 +417,7 @@ int gd_engine_set_schedule_cld(gd_engine *e, int num_step, int n_slots, const fl
 }
 
 static int capture_begin(hipStream_t s) {
-    GD_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
+    GD_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     return 0;
 }
 
@@ -426,7 +436,10 @@ int gd_sample_cld(gd_engine *e, int batch, const float *u_in_dev, float *x_out_d
     GD_CHECK(e->sched_kind == 1, "no CLD schedule installed (gd_engine_set_schedule_cld)");
     GD_CHECK(u_in_dev && x_out_dev && v_out_dev, "null device pointer");
     GD_CHECK(!e->plan.desc.scale_by_sigma, "scale_by_sigma is not supported inside the fused sampler");
-    hipStream_t s = (hipStream_t)stream;
+    hipStream_t caller = (hipStream_t)stream;
+    hipStream_t s = e->stream;
+    GD_HIP(hipEventRecord(e->ev_in, caller));
+    GD_HIP(hipStreamWaitEvent(s, e->ev_in, 0));
     const gd_model_desc &d = e->plan.desc;
     const int C = d.in_channels / 2;
     const long long pix = (long long)batch * d.image_size * d.image_size;
@@ -460,8 +473,11 @@ int gd_sample_cld(gd_engine *e, int batch, const float *u_in_dev, float *x_out_d
         for (int i = 0; i < e->num_step; ++i) GD_TRY(step_body());
         if (e->denoise) GD_TRY(run_unet(e, b, batch, s));  // step == num_step -> t = t_denoise
     }
-    return launch_cld_finish(e->u8, e->epsb, e->dn_dev, -e->t_denoise, e->denoise, inverse_scale, x_out_dev, v_out_dev, pix, C,
-                             s);
+    GD_TRY(launch_cld_finish(e->u8, e->epsb, e->dn_dev, -e->t_denoise, e->denoise, inverse_scale, x_out_dev, v_out_dev, pix, C,
+                             s));
+    GD_HIP(hipEventRecord(e->ev_out, s));
+    GD_HIP(hipStreamWaitEvent(caller, e->ev_out, 0));
+    return 0;
 }
 
 int gd_engine_set_schedule_blur(gd_engine *e, int nfe, const float *ts_host, const float *mean_coef_host,
@@ -485,7 +501,10 @@ int gd_sample_blur(gd_engine *e, int batch, const float *y_in_dev, float *x_out_
     GD_CHECK(e->sched_kind == 2, "no blur schedule installed (gd_engine_set_schedule_blur)");
     GD_CHECK(y_in_dev && x_out_dev, "null device pointer");
     GD_CHECK(!e->plan.desc.scale_by_sigma, "scale_by_sigma is not supported inside the fused sampler");
-    hipStream_t s = (hipStream_t)stream;
+    hipStream_t caller = (hipStream_t)stream;
+    hipStream_t s = e->stream;
+    GD_HIP(hipEventRecord(e->ev_in, caller));
+    GD_HIP(hipStreamWaitEvent(s, e->ev_in, 0));
     const gd_model_desc &d = e->plan.desc;
     const int C = d.in_channels;
     const size_t n = (size_t)batch * 1024 * C;
@@ -511,7 +530,10 @@ int gd_sample_blur(gd_engine *e, int batch, const float *y_in_dev, float *x_out_
     } else {
         for (int i = 0; i < e->num_step; ++i) GD_TRY(step_body());
     }
-    return launch_blur_finish(e->ystate, x_out_dev, batch, C, inverse_scale, s);
+    GD_TRY(launch_blur_finish(e->ystate, x_out_dev, batch, C, inverse_scale, s));
+    GD_HIP(hipEventRecord(e->ev_out, s));
+    GD_HIP(hipStreamWaitEvent(caller, e->ev_out, 0));
+    return 0;
 }
 
 // ---- profiling ----

@@ -87,10 +87,10 @@ def init_params(config, in_channels, rng, init_scale_override=None):
             rf = int(np.prod(shp[:-2])) if len(shp) > 2 else 1
             fan_in, fan_out = shp[-2] * rf, shp[-1] * rf
             lim = math.sqrt(3.0 * scale / ((fan_in + fan_out) / 2.0))
-            a = rng.uniform(-lim, lim, size=shp)
+            a = (rng.random(shp, dtype=np.float32) * 2.0 - 1.0) * np.float32(lim)
         elif leaf == 'scale':
-            a = np.ones(shp)
+            a = np.ones(shp, dtype=np.float32)
         else:
-            a = np.zeros(shp)
-        flat[name] = a.astype(np.float32)
+            a = np.zeros(shp, dtype=np.float32)
+        flat[name] = np.asarray(a, dtype=np.float32)
     return mutils.unflatten(flat)

@@ -1,0 +1,184 @@
+"""GPU parity tests of the stand-alone HIP operators (through the C ABI) against the CPU oracle /
+plain torch-CPU float64 references on the same seeded inputs.  Tolerances are fp32-roundoff class and
+are stated per test."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev(native_lib):
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    assert native_lib.gd_device_count() >= 1
+    return torch.device("cuda", 0)
+
+
+def _rel_err(got, want):
+    got = np.asarray(got, dtype=np.float64)
+    want = np.asarray(want, dtype=np.float64)
+    return np.abs(got - want).max() / max(1e-30, np.abs(want).max())
+
+
+# ---- update rules -------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n_hist", [0, 1, 3])
+def test_ab_step_matches_oracle(dev, n_hist):
+    from gddim_amd import ops
+    from oracle import cld as ocld
+    rng = np.random.default_rng(n_hist)
+    shape = (5, 8, 8, 3, 2)
+    x = rng.standard_normal(shape).astype(np.float32)
+    new_eps = rng.standard_normal(shape).astype(np.float32)
+    hist = rng.standard_normal((n_hist,) + shape).astype(np.float32)
+    coef = (rng.standard_normal((n_hist + 2, 2, 2)) * 3).astype(np.float32)
+    want_x, want_h = ocld.multistep_ab_step(x.astype(np.float64), coef.astype(np.float64), new_eps.astype(np.float64),
+                                            hist.astype(np.float64))
+    got_x, got_h = ops.ab_step(torch.as_tensor(x, device=dev), coef, torch.as_tensor(new_eps, device=dev),
+                               torch.as_tensor(hist, device=dev))
+    assert _rel_err(got_x.cpu().numpy(), want_x) < 2e-6
+    assert np.array_equal(got_h.cpu().numpy(), want_h.astype(np.float32))  # pure data movement: bit exact
+
+
+def test_ab_step_scalar_and_bmm(dev):
+    from gddim_amd import ops
+    from oracle import blur as oblur, cld as ocld
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal((4, 32, 32, 3)).astype(np.float32)
+    ne = rng.standard_normal(x.shape).astype(np.float32)
+    hist = rng.standard_normal((2,) + x.shape).astype(np.float32)
+    coef = rng.standard_normal(4).astype(np.float32)
+    wx, wh = oblur.ms_ab_step(x.astype(np.float64), coef.astype(np.float64), ne.astype(np.float64), hist.astype(np.float64))
+    gx, gh = ops.ab_step_scalar(torch.as_tensor(x, device=dev), coef, torch.as_tensor(ne, device=dev), torch.as_tensor(hist, device=dev))
+    assert _rel_err(gx.cpu().numpy(), wx) < 2e-6
+    assert np.array_equal(gh.cpu().numpy(), wh.astype(np.float32))
+    u = rng.standard_normal((3, 4, 4, 3, 2)).astype(np.float32)
+    m = rng.standard_normal((2, 2)).astype(np.float32)
+    mb = rng.standard_normal((3, 2, 2)).astype(np.float32)
+    assert _rel_err(ops.sbmm(m, torch.as_tensor(u, device=dev)).cpu().numpy(), ocld.sbmm(m.astype(np.float64), u.astype(np.float64))) < 1e-6
+    assert _rel_err(ops.bmm(mb, torch.as_tensor(u, device=dev)).cpu().numpy(), ocld.bmm(mb.astype(np.float64), u.astype(np.float64))) < 1e-6
+
+
+def test_dct_matches_oracle_and_scipy(dev):
+    import scipy.fft
+    from gddim_amd import ops
+    from oracle import blur as oblur
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((3, 32, 32, 3)).astype(np.float32)
+    y = ops.dct2d_32(torch.as_tensor(x, device=dev)).cpu().numpy()
+    want = oblur.batch_img_dct(x.astype(np.float64))
+    assert np.abs(y - want).max() < 2e-5
+    assert np.abs(want - scipy.fft.dctn(x.astype(np.float64), axes=(1, 2), norm="ortho")).max() < 1e-12
+    back = ops.dct2d_32(torch.as_tensor(y, device=dev), inverse=True).cpu().numpy()
+    assert np.abs(back - x).max() < 2e-5  # round trip
+    assert np.abs(back - oblur.batch_img_idct(y.astype(np.float64))).max() < 2e-5
+
+
+# ---- implicit-GEMM convolution ----------------------------------------------------------------------------
+def _conv_case(dev, B, H, W, Cin, Cout, k, stride, pad, bias, res, seed, alpha=1.0, out_scale=1.0):
+    from gddim_amd import ops
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((k, k, Cin, Cout)) / math.sqrt(k * k * Cin)).astype(np.float32)  # HWIO
+    b = rng.standard_normal(Cout).astype(np.float32) if bias else None
+    want = F.conv2d(torch.as_tensor(x, dtype=torch.float64).permute(0, 3, 1, 2),
+                    torch.as_tensor(w, dtype=torch.float64).permute(3, 2, 0, 1), stride=stride, padding=pad).permute(0, 2, 3, 1)
+    want = alpha * want
+    if bias:
+        want = want + torch.as_tensor(b, dtype=torch.float64)
+    r = None
+    if res:
+        r = rng.standard_normal(tuple(want.shape)).astype(np.float32)
+        want = want + torch.as_tensor(r, dtype=torch.float64)
+    want = (want * out_scale).numpy()
+    wp = np.ascontiguousarray(np.transpose(w, (3, 0, 1, 2))).reshape(Cout, k * k * Cin)  # [O][kh][kw][I]
+    got = ops.conv2d(torch.as_tensor(x, device=dev), torch.as_tensor(wp, device=dev),
+                     None if b is None else torch.as_tensor(b, device=dev), None if r is None else torch.as_tensor(r, device=dev),
+                     KH=k, KW=k, stride=stride, pad=pad, alpha=alpha, out_scale=out_scale).cpu().numpy()
+    assert got.shape == want.shape
+    return np.abs(got - want).max() / max(1.0, np.abs(want).max())
+
+
+@pytest.mark.parametrize("case", [
+    # B, H, W, Cin, Cout, k, stride, pad, bias, res   -- the U-Net's layer shapes at small batch
+    (2, 8, 8, 128, 128, 3, 1, 1, True, False),       # 64x64 tiles
+    (3, 16, 16, 256, 256, 3, 1, 1, True, True),      # residual epilogue
+    (2, 32, 32, 8, 128, 3, 1, 1, True, False),       # stem: K = 72 (not a multiple of 32)
+    (2, 32, 32, 128, 6, 3, 1, 1, True, False),       # head: N = 6 (masked columns)
+    (2, 16, 16, 384, 256, 1, 1, 0, True, False),     # 1x1 shortcut
+    (2, 32, 32, 8, 128, 6, 2, 2, True, True),        # pyramid 6x6 stride 2 pad 2
+    (5, 4, 4, 512, 256, 3, 1, 1, False, False),      # rows of several images in one tile, M = 80 (ragged)
+    (1, 1, 1, 256, 512, 1, 1, 0, True, False),       # dense layer, M = 1
+    (48, 32, 32, 128, 128, 3, 1, 1, True, True),     # 49152 rows -> 128x128 tiles
+    (96, 16, 16, 64, 64, 3, 1, 1, True, False),      # 24576 rows, N = 64 -> 128x64 tiles
+])
+def test_conv2d_matches_torch_fp64(dev, case):
+    err = _conv_case(dev, *case, seed=hash(case) % 1000, alpha=1.0, out_scale=1.0 / math.sqrt(2.0) if case[-1] else 1.0)
+    assert err < 2e-5, (case, err)  # fp32 MFMA accumulate over K <= 4608
+
+
+def test_conv2d_transpose_detecting(dev):
+    """A = identity-like input with an asymmetric kernel: catches swapped row/col or tap order."""
+    from gddim_amd import ops
+    B, H, W, Cin, Cout = 1, 8, 8, 4, 36
+    x = torch.zeros(B, H, W, Cin)
+    x[0, 3, 5, 2] = 1.0  # a single impulse
+    w = torch.arange(3 * 3 * Cin * Cout, dtype=torch.float32).reshape(3, 3, Cin, Cout) / 100.0
+    wp = w.permute(3, 0, 1, 2).reshape(Cout, 9 * Cin).contiguous()
+    got = ops.conv2d(x.to(dev), wp.to(dev), KH=3, KW=3, stride=1, pad=1).cpu()
+    want = F.conv2d(x.permute(0, 3, 1, 2).double(), w.permute(3, 2, 0, 1).double(), padding=1).permute(0, 2, 3, 1)
+    assert (got.double() - want).abs().max() < 1e-5
+
+
+# ---- GroupNorm / FIR / attention -----------------------------------------------------------------------------
+@pytest.mark.parametrize("B,HW,C,act", [(3, 1024, 128, 1), (2, 256, 256, 1), (2, 64, 384, 1), (5, 16, 512, 0), (2, 256, 16, 1)])
+def test_group_norm_matches_oracle(dev, B, HW, C, act):
+    from gddim_amd import ops
+    from oracle import ncsnpp as onet
+    rng = np.random.default_rng(C + HW)
+    side = int(math.isqrt(HW))
+    x = (rng.standard_normal((B, side, side, C)) * 2 + 0.5).astype(np.float32)
+    p = {"scale": (1 + 0.2 * rng.standard_normal(C)).astype(np.float32), "bias": (0.3 * rng.standard_normal(C)).astype(np.float32)}
+    want = onet.group_norm(torch.as_tensor(x, dtype=torch.float64), p)
+    if act:
+        want = onet.swish(want)
+    G = min(C // 4, 32)
+    got = ops.group_norm(torch.as_tensor(x, device=dev), torch.as_tensor(p["scale"], device=dev), torch.as_tensor(p["bias"], device=dev),
+                         G, act=bool(act)).cpu().numpy()
+    assert np.abs(got - want.numpy()).max() < 3e-5
+
+
+@pytest.mark.parametrize("up", [True, False])
+def test_fir_resample_matches_oracle(dev, up):
+    from gddim_amd import ops
+    from oracle import ncsnpp as onet
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((2, 8, 8, 16)).astype(np.float32)
+    xt = torch.as_tensor(x, dtype=torch.float64)
+    want = onet.upsample_2d(xt, [1, 3, 3, 1]) if up else onet.downsample_2d(xt, [1, 3, 3, 1])
+    got = ops.fir_resample(torch.as_tensor(x, device=dev), up).cpu().numpy()
+    assert got.shape == tuple(want.shape)
+    assert np.abs(got - want.numpy()).max() < 2e-6
+
+
+@pytest.mark.parametrize("B,N,C", [(3, 256, 256), (4, 16, 256), (2, 64, 32)])
+def test_attention_matches_torch(dev, B, N, C):
+    from gddim_amd import ops
+    rng = np.random.default_rng(N)
+    qkv = rng.standard_normal((B, N, 3 * C)).astype(np.float32)
+    q, k, v = (torch.as_tensor(qkv[..., i * C:(i + 1) * C], dtype=torch.float64) for i in range(3))
+    w = torch.softmax(torch.einsum("bnc,bmc->bnm", q, k) * (C ** -0.5), dim=-1)
+    want = torch.einsum("bnm,bmc->bnc", w, v).numpy()
+    got = ops.attention(torch.as_tensor(qkv, device=dev)).cpu().numpy()
+    assert np.abs(got - want).max() < 2e-5
+
+
+def test_ops_refuse_cpu_tensors(native_lib):
+    """No CPU fallback: the operator API fails loudly on host tensors."""
+    from gddim_amd import ops
+    from gddim_amd._abi import GddimError
+    with pytest.raises(GddimError):
+        ops.sbmm(np.eye(2, dtype=np.float32), torch.zeros(1, 2, 2))
