@@ -67,8 +67,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=2)
-    ap.add_argument("--cpu-nfe", type=int, default=2)
+    ap.add_argument("--cpu-batch", type=int, default=16)
+    ap.add_argument("--cpu-nfe", type=int, default=10)
     args = ap.parse_args()
 
     import torch

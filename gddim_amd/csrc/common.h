@@ -65,6 +65,7 @@ struct GemmParams {
     float out_scale;
     int in_act;  // 1: swish applied to A elements on load
     int m_tiles, n_tiles;
+    const float *zeros;  // >= 16 B of device zeros (filled in by launch_igemm when null)
 };
 
 int launch_igemm(const GemmParams &p, int batch_z, hipStream_t s);

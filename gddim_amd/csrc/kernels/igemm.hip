@@ -20,13 +20,15 @@
 // [kb*8 + 4h, kb*8 + 4h + 4) of row i; MFMA number jj of that group therefore contracts
 // k = kb*8 + jj (lanes 0-31) and k = kb*8 + 4 + jj (lanes 32-63) -- A and B use the same
 // assignment, so the (k0,k1) pairing is consistent and the result is the plain k-sum.
-// The next chunk's global loads are issued before the current chunk's MFMAs (register staging) and are
-// branch-free (masked lanes read the tensor base; zeros are substituted when the registers go to LDS), so
-// HBM/L2 latency hides under ~64 MFMAs.  LDS is double buffered: one barrier per K chunk.
+// Staging is register based and branch-free: masked lanes (image border, ragged M/N/K) read a device zero buffer, so no
+// select follows the load.  Global loads run two chunks ahead of the MFMAs and, together with the LDS writes, are
+// interleaved by hand into the gaps of the MFMA stream (see the kernel comment).  LDS is double buffered.
 //
 // Block -> tile mapping is XCD-aware: consecutive block ids round-robin over the 8 XCDs, so ids
 // are grouped in runs of 8*n_tiles with the M tile varying fastest inside a run; the n_tiles
 // blocks that share one A tile then carry ids congruent mod 8 and run on the same XCD (shared L2).
+#include <cstdlib>
+
 #include "../common.h"
 
 namespace gd {
@@ -39,17 +41,31 @@ constexpr int LDT = 36;  // LDS row stride (floats): 32 + 4 pad -> 144 B, odd mu
 
 __device__ __forceinline__ float swish_f(float x) { return x * __frcp_rn(1.0f + __expf(-x)); }
 
-template <int BM, int BN, bool B_KMAJOR, bool IN_ACT>
-__global__ __launch_bounds__(256, 2) void igemm_f32_kernel(const GemmParams p) {
-    constexpr int RM = BM / 64, RN = BN / 64;  // 32x32 MFMA tiles per wave
-    constexpr int AJ = BM / 32, BJ = BN / 32;  // float4 staged per thread (A / B)
-    constexpr int BUF = (BM + BN) * LDT;       // floats per LDS stage
-    __shared__ __attribute__((aligned(16))) float smem[2 * BUF];  // double buffered: one barrier per K chunk
+// BM x BN block tile, WM x WN wave grid (64*WM*WN threads), DB: double-buffered LDS (one barrier per K chunk)
+// BM x BN block tile, WM x WN wave grid (64*WM*WN threads).
+//
+// K loop, software pipelined by hand.  At the top of iteration kc the staging registers hold chunk kc+1 (its global
+// loads were issued during iteration kc-1, i.e. a full chunk of latency budget) and LDS stage kc&1 holds chunk kc.
+// The iteration issues its 64/(WM*WN/4..) MFMAs in 16 groups (4 k-groups x 4 k-pairs); each gap between groups is
+// given one "piece" of staging work for the SAME wave -- write one staged float4 of chunk kc+1 to the other LDS stage,
+// then compute the address of and issue the global load of the same register for chunk kc+2 -- because a wave issues
+// in order and only instructions placed between two MFMAs execute in the 64-cycle shadow of the first one.
+// __builtin_amdgcn_sched_barrier(0) pins that order.  One barrier per chunk.
+template <int BM, int BN, int WM, int WN, bool B_KMAJOR, bool IN_ACT>
+__global__ __launch_bounds__(64 * WM * WN) void igemm_f32_kernel(const GemmParams p) {
+    constexpr int NT = 64 * WM * WN;
+    constexpr int RM = BM / (32 * WM), RN = BN / (32 * WN);  // 32x32 MFMA tiles per wave
+    constexpr int RPP = NT / 8;                              // tile rows staged per pass (8 threads x 16 B per row)
+    constexpr int AJ = BM / RPP, BJ = BN / RPP;              // float4 staged per thread (A / B)
+    constexpr int NP = AJ + BJ;                              // staging pieces per chunk
+    constexpr int BUF = (BM + BN) * LDT;                     // floats per LDS stage
+    static_assert(BM % RPP == 0 && BN % RPP == 0 && RM >= 1 && RN >= 1 && NP <= 14, "bad tile geometry");
+    __shared__ __attribute__((aligned(16))) float smem[2 * BUF];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
 
     // ---- XCD-aware block -> (mtile, ntile) ----
     const int nt = p.n_tiles;
@@ -65,16 +81,17 @@ __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(const GemmParams p) {
     const float *a0 = p.a0 + (size_t)z * p.sA;
     const float *a1 = p.a1;
     const float *bptr = p.b + (size_t)z * p.sB;
+    const float *zeros = p.zeros;  // >= 16 B of zeros: masked lanes load from here, so no select after the load
 
-    // ---- per-thread A row bookkeeping (fixed over the K loop) ----
-    const int arow = tid >> 3;        // 0..31, +32 per j
+    // ---- per-thread row bookkeeping (fixed over the K loop); offsets are 32-bit element counts ----
+    const int arow = tid >> 3;        // 0..RPP-1, +RPP per j
     const int kcol = (tid & 7) * 4;   // float offset inside the chunk
     int a_pix[AJ], a_iy0[AJ], a_ix0[AJ];
     {
         const int OHW = p.OH * p.OW;
 #pragma unroll
         for (int j = 0; j < AJ; ++j) {
-            const int m = m0 + arow + 32 * j;
+            const int m = m0 + arow + RPP * j;
             if (m < p.M) {
                 const int img = m / OHW;
                 const int r = m - img * OHW;
@@ -85,94 +102,85 @@ __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(const GemmParams p) {
                 a_ix0[j] = ox * p.stride - p.pad;
             } else {
                 a_pix[j] = 0;
-                a_iy0[j] = -(1 << 28);  // always out of the image: masked
+                a_iy0[j] = -(1 << 28);  // always outside the image: masked
                 a_ix0[j] = 0;
             }
         }
     }
+    int b_off[BJ];   // n-major: n * ldb (or -1 when n >= N); k-major: n (or -1)
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) {
+        if (!B_KMAJOR) {
+            const int n = n0 + arow + RPP * j;
+            b_off[j] = n < p.N ? n * p.ldb : -1;
+        } else {
+            const int n = n0 + ((tid >> 5) + (NT / 32) * j) * 4;
+            b_off[j] = n < p.N ? n : -1;
+        }
+    }
     const int Cin = p.C0 + p.C1;
-    // running decomposition of this thread's k = kc*32 + kcol into (dy, dx, c)
-    int c_run = kcol, dy = 0, dx = 0;
+    // decomposition of this thread's k = kc*32 + kcol into (dy, dx, c) for the chunk whose loads are issued next
+    int c_run = kcol, dy = 0, dx = 0, k_next = kcol;
     while (c_run >= Cin) {
         c_run -= Cin;
         if (++dx == p.KW) { dx = 0; ++dy; }
     }
-
-    // Staging registers.  Loads are unconditional (masked lanes read the tensor base) so the K loop has no
-    // divergent branches and no wait sits between the global loads and the MFMAs; the zero fill (image border,
-    // ragged M / N / K) is applied from the mask bits when the registers are written to LDS.
-    f32x4 ra[AJ], rb[BJ];
-    unsigned amask = 0, bmask = 0;
-
-    auto load_tiles = [&](int kc) {
-        const int kabs = kc * KC + kcol;
-        {
-            const bool kvalid = kabs < p.K;
-            const bool first = c_run < p.C0;
-            const float *src = first ? a0 : a1;
-            const int ld = first ? p.lda0 : p.lda1;
-            const int cc = first ? c_run : c_run - p.C0;
-            amask = 0;
-#pragma unroll
-            for (int j = 0; j < AJ; ++j) {
-                const int iy = a_iy0[j] + dy, ix = a_ix0[j] + dx;
-                const bool ok = kvalid && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-                const float *ptr = ok ? src + (size_t)(a_pix[j] + iy * p.W + ix) * ld + cc : a0;
-                ra[j] = *reinterpret_cast<const f32x4 *>(ptr);
-                amask |= (ok ? 1u : 0u) << j;
-            }
-        }
-        bmask = 0;
-        if (!B_KMAJOR) {
-#pragma unroll
-            for (int j = 0; j < BJ; ++j) {
-                const int n = n0 + arow + 32 * j;
-                const bool ok = n < p.N && kabs < p.K;
-                const float *ptr = ok ? bptr + (size_t)n * p.ldb + kabs : bptr;
-                rb[j] = *reinterpret_cast<const f32x4 *>(ptr);
-                bmask |= (ok ? 1u : 0u) << j;
-            }
-        } else {
-            const int kk = kc * KC + (tid & 31);
-#pragma unroll
-            for (int j = 0; j < BJ; ++j) {
-                const int n = n0 + ((tid >> 5) + 8 * j) * 4;
-                const bool ok = n < p.N && kk < p.K;
-                const float *ptr = ok ? bptr + (size_t)kk * p.ldb + n : bptr;
-                rb[j] = *reinterpret_cast<const f32x4 *>(ptr);
-                bmask |= (ok ? 1u : 0u) << j;
-            }
-        }
-        // advance (dy, dx, c) to the next chunk
+    auto advance_k = [&]() {
         c_run += KC;
+        k_next += KC;
         while (c_run >= Cin) {
             c_run -= Cin;
             if (++dx == p.KW) { dx = 0; ++dy; }
         }
     };
 
-    auto store_tiles = [&](float *As, float *Bs) {
-        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int j = 0; j < AJ; ++j) {
-            f32x4 v = ((amask >> j) & 1u) ? ra[j] : zero;
-            if (IN_ACT) { v[0] = swish_f(v[0]); v[1] = swish_f(v[1]); v[2] = swish_f(v[2]); v[3] = swish_f(v[3]); }
-            *reinterpret_cast<f32x4 *>(&As[(arow + 32 * j) * LDT + kcol]) = v;
-        }
-        if (!B_KMAJOR) {
-#pragma unroll
-            for (int j = 0; j < BJ; ++j)
-                *reinterpret_cast<f32x4 *>(&Bs[(arow + 32 * j) * LDT + kcol]) = ((bmask >> j) & 1u) ? rb[j] : zero;
+    f32x4 ra[AJ], rb[BJ];
+
+    // issue the global load of staged register `pc` (0..AJ-1: A rows, AJ..NP-1: B rows) for the chunk at k_next
+    auto load_piece = [&](int pc) {
+        if (pc < AJ) {
+            const int j = pc;
+            const bool first = c_run < p.C0;
+            const float *src = first ? a0 : a1;
+            const int ld = first ? p.lda0 : p.lda1;
+            const int cc = first ? c_run : c_run - p.C0;
+            const int iy = a_iy0[j] + dy, ix = a_ix0[j] + dx;
+            const bool ok = k_next < p.K && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const int off = (a_pix[j] + iy * p.W + ix) * ld + cc;
+            const float *ptr = ok ? src + off : zeros;
+            ra[j] = *reinterpret_cast<const f32x4 *>(ptr);
         } else {
-            const int kk = tid & 31;
-#pragma unroll
-            for (int j = 0; j < BJ; ++j) {
-                const f32x4 v = ((bmask >> j) & 1u) ? rb[j] : zero;
-                const int nl = ((tid >> 5) + 8 * j) * 4;
-                Bs[(nl + 0) * LDT + kk] = v[0];
-                Bs[(nl + 1) * LDT + kk] = v[1];
-                Bs[(nl + 2) * LDT + kk] = v[2];
-                Bs[(nl + 3) * LDT + kk] = v[3];
+            const int j = pc - AJ;
+            if (!B_KMAJOR) {
+                const bool ok = b_off[j] >= 0 && k_next < p.K;
+                const float *ptr = ok ? bptr + (b_off[j] + k_next) : zeros;
+                rb[j] = *reinterpret_cast<const f32x4 *>(ptr);
+            } else {
+                const int kk = k_next - kcol + (tid & 31);
+                const bool ok = b_off[j] >= 0 && kk < p.K;
+                const float *ptr = ok ? bptr + (kk * p.ldb + b_off[j]) : zeros;
+                rb[j] = *reinterpret_cast<const f32x4 *>(ptr);
+            }
+        }
+    };
+    // write staged register `pc` into LDS stage `st`
+    auto store_piece = [&](int pc, float *st) {
+        if (pc < AJ) {
+            f32x4 v = ra[pc];
+            if (IN_ACT) { v[0] = swish_f(v[0]); v[1] = swish_f(v[1]); v[2] = swish_f(v[2]); v[3] = swish_f(v[3]); }
+            *reinterpret_cast<f32x4 *>(&st[(arow + RPP * pc) * LDT + kcol]) = v;
+        } else {
+            const int j = pc - AJ;
+            float *Bs = st + BM * LDT;
+            if (!B_KMAJOR) {
+                *reinterpret_cast<f32x4 *>(&Bs[(arow + RPP * j) * LDT + kcol]) = rb[j];
+            } else {
+                const int kk = tid & 31;
+                const int nl = ((tid >> 5) + (NT / 32) * j) * 4;
+                Bs[(nl + 0) * LDT + kk] = rb[j][0];
+                Bs[(nl + 1) * LDT + kk] = rb[j][1];
+                Bs[(nl + 2) * LDT + kk] = rb[j][2];
+                Bs[(nl + 3) * LDT + kk] = rb[j][3];
             }
         }
     };
@@ -187,34 +195,63 @@ __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(const GemmParams p) {
 
     const int nk = (p.K + KC - 1) / KC;
     const int li = lane & 31, lh = lane >> 5;
-    const int a_off = (wm * (BM / 2) + li) * LDT + lh * 4;
-    const int b_off = BM * LDT + (wn * (BN / 2) + li) * LDT + lh * 4;
+    const int a_off = (wm * (BM / WM) + li) * LDT + lh * 4;
+    const int b_offl = BM * LDT + (wn * (BN / WN) + li) * LDT + lh * 4;
 
-    load_tiles(0);
-    store_tiles(smem, smem + BM * LDT);
+    // ---- prologue: chunk 0 -> LDS stage 0, chunk 1 -> registers (in flight) ----
+#pragma unroll
+    for (int pc = 0; pc < NP; ++pc) load_piece(pc);
+    advance_k();
+#pragma unroll
+    for (int pc = 0; pc < NP; ++pc) store_piece(pc, smem);
+#pragma unroll
+    for (int pc = 0; pc < NP; ++pc) load_piece(pc);  // k_next >= K loads zeros when nk == 1
+    advance_k();
     __syncthreads();
+
     for (int kc = 0; kc < nk; ++kc) {
         const float *cur = smem + (kc & 1) * BUF;
         float *nxt = smem + ((kc + 1) & 1) * BUF;
-        const bool more = kc + 1 < nk;
-        if (more) load_tiles(kc + 1);  // global loads stay in flight under the MFMAs below
+        f32x4 af[RM], bf[RN];
+#pragma unroll
+        for (int r = 0; r < RM; ++r) af[r] = *reinterpret_cast<const f32x4 *>(cur + a_off + r * 32 * LDT);
+#pragma unroll
+        for (int c = 0; c < RN; ++c) bf[c] = *reinterpret_cast<const f32x4 *>(cur + b_offl + c * 32 * LDT);
 #pragma unroll
         for (int kb = 0; kb < KC / 8; ++kb) {
-            f32x4 af[RM], bf[RN];
+            f32x4 afn[RM], bfn[RN];
 #pragma unroll
-            for (int r = 0; r < RM; ++r) af[r] = *reinterpret_cast<const f32x4 *>(cur + a_off + r * 32 * LDT + kb * 8);
-#pragma unroll
-            for (int c = 0; c < RN; ++c) bf[c] = *reinterpret_cast<const f32x4 *>(cur + b_off + c * 32 * LDT + kb * 8);
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj)
+            for (int jj = 0; jj < 4; ++jj) {
 #pragma unroll
                 for (int r = 0; r < RM; ++r)
 #pragma unroll
                     for (int c = 0; c < RN; ++c)
                         acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[r][jj], bf[c][jj], acc[r][c], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- work placed in the shadow of the MFMA group above ----
+                const int gap = kb * 4 + jj;
+                if (gap < NP) {
+                    // staged register `gap`: chunk kc+1 -> LDS, then reload it with chunk kc+2
+                    store_piece(gap, nxt);
+                    load_piece(gap);
+                } else if (gap == NP) {
+                    advance_k();
+                }
+                if (jj == 2 && kb + 1 < KC / 8) {  // fragments of the next k-group, one gap ahead of their use
+#pragma unroll
+                    for (int r = 0; r < RM; ++r) afn[r] = *reinterpret_cast<const f32x4 *>(cur + a_off + r * 32 * LDT + (kb + 1) * 8);
+#pragma unroll
+                    for (int c = 0; c < RN; ++c) bfn[c] = *reinterpret_cast<const f32x4 *>(cur + b_offl + c * 32 * LDT + (kb + 1) * 8);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (kb + 1 < KC / 8) {
+#pragma unroll
+                for (int r = 0; r < RM; ++r) af[r] = afn[r];
+#pragma unroll
+                for (int c = 0; c < RN; ++c) bf[c] = bfn[c];
+            }
         }
-        // the other stage was last read in iteration kc-1, and every wave has passed that iteration's barrier
-        if (more) store_tiles(nxt, nxt + BM * LDT);
         __syncthreads();
     }
 
@@ -225,12 +262,12 @@ __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(const GemmParams p) {
     const int rpi = p.rows_per_image;
 #pragma unroll
     for (int c = 0; c < RN; ++c) {
-        const int n = n0 + wn * (BN / 2) + c * 32 + li;
+        const int n = n0 + wn * (BN / WN) + c * 32 + li;
         const bool nok = n < p.N;
         const float bias = (p.bias && nok) ? p.bias[n] : 0.f;
 #pragma unroll
         for (int r = 0; r < RM; ++r) {
-            const int mb = m0 + wm * (BM / 2) + r * 32 + 4 * lh;
+            const int mb = m0 + wm * (BM / WM) + r * 32 + 4 * lh;
             float addv[16];
 #pragma unroll
             for (int v = 0; v < 16; ++v) addv[v] = bias;
@@ -269,6 +306,291 @@ __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(const GemmParams p) {
     }
 }
 
+// =====================================================================================================================
+// Fast path.  Counter evidence (profiles/): on gfx950 the fp32 MFMA never co-executes with VALU work
+// (SQ_VALU_MFMA_COEXEC_CYCLES = 0, MFMA-busy + VALU-busy ~ 100 %): every VALU instruction in the K loop costs matrix
+// throughput, whichever wave issues it.  This kernel therefore keeps the K loop (almost) VALU-free:
+//   * chunk bookkeeping (tap, channel base, source) is wave-uniform and lives in SGPRs (needs Cin % 32 == 0);
+//   * each staged row has a precomputed byte offset and a precomputed bit mask of the taps that fall outside the
+//     image; the per-chunk address is  voffset = rowbase | sext(invalid bit)  (2 VALU), the tap/channel displacement
+//     rides in the scalar soffset of a raw buffer load, and the buffer's bounds check returns the zero padding;
+//   * B (weights / K matrix) rows need no VALU at all: voffset is constant, soffset = chunk offset.
+// Same tiling, LDS layout, software pipeline and epilogue as the generic kernel above.
+// Requirements (checked by launch_igemm): (C0+C1) % 32 == 0, C0 % 32 == 0 when C1 > 0, KH*KW <= 32, every operand
+// smaller than 2 GiB, no input activation.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 buf_load16(__amdgpu_buffer_rsrc_t rsrc, int voffset, int soffset) {
+    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voffset, soffset, 0);
+    return __builtin_bit_cast(f32x4, v);
+}
+
+template <int BM, int BN, int WM, int WN, bool B_KMAJOR>
+__global__ __launch_bounds__(64 * WM * WN) void igemm_f32_fast_kernel(const GemmParams p) {
+    constexpr int NT = 64 * WM * WN;
+    constexpr int RM = BM / (32 * WM), RN = BN / (32 * WN);
+    constexpr int RPP = NT / 8;
+    constexpr int AJ = BM / RPP, BJ = BN / RPP;
+    constexpr int NP = AJ + BJ;
+    constexpr int BUF = (BM + BN) * LDT;
+    constexpr int OOB = (int)0x80000000u;  // voffset that fails the bounds check of every (< 2 GiB) buffer
+    static_assert(BM % RPP == 0 && BN % RPP == 0 && RM >= 1 && RN >= 1 && NP <= 14, "bad tile geometry");
+    __shared__ __attribute__((aligned(16))) float smem[2 * BUF];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+
+    const int nt = p.n_tiles;
+    const int id = blockIdx.x;
+    const int grp = id / (8 * nt);
+    const int rem = id - grp * 8 * nt;
+    const int ntile = rem >> 3;
+    const int mtile = grp * 8 + (rem & 7);
+    if (mtile >= p.m_tiles) return;
+    const int m0 = mtile * BM, n0 = ntile * BN;
+    const int z = blockIdx.z;
+
+    // ---- buffer descriptors (wave-uniform).  The A descriptors start `bias` bytes BEFORE the tensor so that the
+    // precomputed row offsets (which address tap (0,0), up to `pad` rows/columns outside the image) are non-negative.
+    const int Cin = p.C0 + p.C1;
+    const int taps = p.KH * p.KW;
+    const int a_imgs = (p.M + p.OH * p.OW - 1) / (p.OH * p.OW);
+    const int bias0 = (p.pad * p.W + p.pad) * p.lda0 * 4;
+    const int bias1 = (p.pad * p.W + p.pad) * p.lda1 * 4;
+    const char *a0c = reinterpret_cast<const char *>(p.a0 + (size_t)z * p.sA);
+    const __amdgpu_buffer_rsrc_t srd_a0 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(a0c - bias0), 0, a_imgs * p.H * p.W * p.lda0 * 4 + bias0, 0x00020000);
+    const char *a1c = reinterpret_cast<const char *>(p.C1 ? p.a1 : p.a0);
+    const __amdgpu_buffer_rsrc_t srd_a1 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(a1c - bias1), 0, a_imgs * p.H * p.W * p.lda1 * 4 + bias1, 0x00020000);
+    const char *bc = reinterpret_cast<const char *>(p.b + (size_t)z * p.sB);
+    const __amdgpu_buffer_rsrc_t srd_b =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(bc), 0, (B_KMAJOR ? p.K : p.N) * p.ldb * 4, 0x00020000);
+
+    // ---- per-thread, loop-invariant row data ----
+    const int arow = tid >> 3;
+    const int kcol = (tid & 7) * 4;
+    int rb0[AJ], rb1[AJ];      // byte offset of (row's tap (0,0) pixel, channel kcol) in source 0 / 1, + bias
+    unsigned inv[AJ];          // bit t set: tap t of this row lies outside the image (or the row is >= M)
+    {
+        const int OHW = p.OH * p.OW;
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) {
+            const int m = m0 + arow + RPP * j;
+            rb0[j] = 0; rb1[j] = 0; inv[j] = 0xFFFFFFFFu;
+            if (m < p.M) {
+                const int img = m / OHW;
+                const int r = m - img * OHW;
+                const int oy = r / p.OW;
+                const int ox = r - oy * p.OW;
+                const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+                const int pix = (img * p.H + iy0) * p.W + ix0;  // may be "negative" by at most pad*W + pad: the bias covers it
+                rb0[j] = pix * p.lda0 * 4 + bias0 + kcol * 4;
+                rb1[j] = pix * p.lda1 * 4 + bias1 + kcol * 4;
+                unsigned mk = 0;
+                for (int t = 0; t < taps; ++t) {
+                    const int ty = t / p.KW, tx = t - ty * p.KW;
+                    const bool okt = (unsigned)(iy0 + ty) < (unsigned)p.H && (unsigned)(ix0 + tx) < (unsigned)p.W;
+                    mk |= (okt ? 0u : 1u) << t;
+                }
+                inv[j] = mk;
+            }
+        }
+    }
+    int bvo[BJ];  // B voffset (bytes), OOB when the row / column group is outside N
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) {
+        if (!B_KMAJOR) {
+            const int n = n0 + arow + RPP * j;
+            bvo[j] = n < p.N ? (n * p.ldb + kcol) * 4 : OOB;
+        } else {
+            const int n = n0 + ((tid >> 5) + (NT / 32) * j) * 4;
+            bvo[j] = n < p.N ? ((tid & 31) * p.ldb + n) * 4 : OOB;
+        }
+    }
+
+    // ---- wave-uniform state of the chunk whose loads are issued next: tap (ty, tx), channel base c0 ----
+    int s_tap = 0, s_ty = 0, s_tx = 0, s_c0 = 0, s_kc = 0;
+    const int nk = p.K / KC;
+    auto advance_k = [&]() {
+        s_c0 += KC;
+        ++s_kc;
+        if (s_c0 >= Cin) {
+            s_c0 = 0;
+            ++s_tap;
+            if (++s_tx == p.KW) { s_tx = 0; ++s_ty; }
+        }
+    };
+
+    f32x4 ra[AJ], rb[BJ];
+
+    auto load_piece = [&](int pc) {
+        if (pc < AJ) {
+            const int j = pc;
+            // sign-extended "invalid" bit of the current tap: -1 pushes the offset out of bounds -> hardware returns 0
+            const int bad = __builtin_amdgcn_sbfe(inv[j], s_tap < 32 ? s_tap : 31, 1) | (s_kc < nk ? 0 : -1);
+            if (s_c0 < p.C0) {
+                const int soff = ((s_ty * p.W + s_tx) * p.lda0 + s_c0) * 4;
+                ra[j] = buf_load16(srd_a0, rb0[j] | (bad & OOB), soff);
+            } else {
+                const int soff = ((s_ty * p.W + s_tx) * p.lda1 + (s_c0 - p.C0)) * 4;
+                ra[j] = buf_load16(srd_a1, rb1[j] | (bad & OOB), soff);
+            }
+        } else {
+            const int j = pc - AJ;
+            const int soff = (B_KMAJOR ? s_kc * KC * p.ldb : s_kc * KC) * 4;
+            rb[j] = buf_load16(srd_b, s_kc < nk ? bvo[j] : OOB, soff);
+        }
+    };
+    auto store_piece = [&](int pc, float *st) {
+        if (pc < AJ) {
+            *reinterpret_cast<f32x4 *>(&st[(arow + RPP * pc) * LDT + kcol]) = ra[pc];
+        } else {
+            const int j = pc - AJ;
+            float *Bs = st + BM * LDT;
+            if (!B_KMAJOR) {
+                *reinterpret_cast<f32x4 *>(&Bs[(arow + RPP * j) * LDT + kcol]) = rb[j];
+            } else {
+                const int kk = tid & 31;
+                const int nl = ((tid >> 5) + (NT / 32) * j) * 4;
+                Bs[(nl + 0) * LDT + kk] = rb[j][0];
+                Bs[(nl + 1) * LDT + kk] = rb[j][1];
+                Bs[(nl + 2) * LDT + kk] = rb[j][2];
+                Bs[(nl + 3) * LDT + kk] = rb[j][3];
+            }
+        }
+    };
+
+    f32x16 acc[RM][RN];
+#pragma unroll
+    for (int r = 0; r < RM; ++r)
+#pragma unroll
+        for (int c = 0; c < RN; ++c)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[r][c][v] = 0.f;
+
+    const int li = lane & 31, lh = lane >> 5;
+    const int a_off = (wm * (BM / WM) + li) * LDT + lh * 4;
+    const int b_offl = BM * LDT + (wn * (BN / WN) + li) * LDT + lh * 4;
+
+#pragma unroll
+    for (int pc = 0; pc < NP; ++pc) load_piece(pc);
+    advance_k();
+#pragma unroll
+    for (int pc = 0; pc < NP; ++pc) store_piece(pc, smem);
+#pragma unroll
+    for (int pc = 0; pc < NP; ++pc) load_piece(pc);
+    advance_k();
+    __syncthreads();
+
+    for (int kc = 0; kc < nk; ++kc) {
+        const float *cur = smem + (kc & 1) * BUF;
+        float *nxt = smem + ((kc + 1) & 1) * BUF;
+        f32x4 af[RM], bf[RN];
+#pragma unroll
+        for (int r = 0; r < RM; ++r) af[r] = *reinterpret_cast<const f32x4 *>(cur + a_off + r * 32 * LDT);
+#pragma unroll
+        for (int c = 0; c < RN; ++c) bf[c] = *reinterpret_cast<const f32x4 *>(cur + b_offl + c * 32 * LDT);
+#pragma unroll
+        for (int kb = 0; kb < KC / 8; ++kb) {
+            f32x4 afn[RM], bfn[RN];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+#pragma unroll
+                for (int r = 0; r < RM; ++r)
+#pragma unroll
+                    for (int c = 0; c < RN; ++c)
+                        acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[r][jj], bf[c][jj], acc[r][c], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                const int gap = kb * 4 + jj;
+                if (gap < NP) {
+                    store_piece(gap, nxt);
+                    load_piece(gap);
+                } else if (gap == NP) {
+                    advance_k();
+                }
+                if (jj == 2 && kb + 1 < KC / 8) {
+#pragma unroll
+                    for (int r = 0; r < RM; ++r) afn[r] = *reinterpret_cast<const f32x4 *>(cur + a_off + r * 32 * LDT + (kb + 1) * 8);
+#pragma unroll
+                    for (int c = 0; c < RN; ++c) bfn[c] = *reinterpret_cast<const f32x4 *>(cur + b_offl + c * 32 * LDT + (kb + 1) * 8);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (kb + 1 < KC / 8) {
+#pragma unroll
+                for (int r = 0; r < RM; ++r) af[r] = afn[r];
+#pragma unroll
+                for (int c = 0; c < RN; ++c) bf[c] = bfn[c];
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue (identical to the generic kernel) ----
+    float *outp = p.out + (size_t)z * p.sC;
+    const int rpi = p.rows_per_image;
+#pragma unroll
+    for (int c = 0; c < RN; ++c) {
+        const int n = n0 + wn * (BN / WN) + c * 32 + li;
+        const bool nok = n < p.N;
+        const float bias = (p.bias && nok) ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < RM; ++r) {
+            const int mb = m0 + wm * (BM / WM) + r * 32 + 4 * lh;
+            float addv[16];
+#pragma unroll
+            for (int v = 0; v < 16; ++v) addv[v] = bias;
+            if (p.res) {
+                float t[16];
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int m = mb + (v & 3) + 8 * (v >> 2);
+                    const float *ptr = (nok && m < p.M) ? p.res + (size_t)m * p.ldres + n : p.res;
+                    t[v] = *ptr;
+                }
+#pragma unroll
+                for (int v = 0; v < 16; ++v) addv[v] += t[v];
+            }
+            if (p.rowbias) {
+                const int img_b = mb / rpi;
+                const int rem_b = mb - img_b * rpi;
+                float t[16];
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    int q = rem_b + (v & 3) + 8 * (v >> 2), img = img_b;
+                    while (q >= rpi) { q -= rpi; ++img; }
+                    const int m = mb + (v & 3) + 8 * (v >> 2);
+                    const float *ptr = (nok && m < p.M) ? p.rowbias + (size_t)img * p.ld_rowbias + n : p.rowbias;
+                    t[v] = *ptr;
+                }
+#pragma unroll
+                for (int v = 0; v < 16; ++v) addv[v] += t[v];
+            }
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int m = mb + (v & 3) + 8 * (v >> 2);
+                if (nok && m < p.M) outp[(size_t)m * p.ldc + n] = (p.alpha * acc[r][c][v] + addv[v]) * p.out_scale;
+            }
+        }
+    }
+}
+
+// ---- variant selection ------------------------------------------------------------------------------------------
+// GDDIM_IGEMM_VARIANT (env, read once) overrides the large-tile kernel for A/B measurements:
+//   0: 128x128, 8 waves (2x4)  [default]     1: 128x128, 4 waves (2x2)     2: 256x128, 8 waves (4x2) when M is large
+static int big_variant() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("GDDIM_IGEMM_VARIANT");
+        v = e ? atoi(e) : 0;
+        if (v < 0 || v > 2) v = 0;
+    }
+    return v;
+}
+
 static void pick_tiles(const GemmParams &p, int batch_z, int &bm, int &bn) {
     auto blocks = [&](int BM_, int BN_) {
         return (long long)((p.M + BM_ - 1) / BM_) * ((p.N + BN_ - 1) / BN_) * batch_z;
@@ -288,6 +610,46 @@ const char *igemm_variant_name(const GemmParams &p, int batch_z) {
     return "igemm_f32<64,64>";
 }
 
+static bool fast_ok(const GemmParams &p) {
+    static const int off = getenv("GDDIM_IGEMM_NOFAST") ? atoi(getenv("GDDIM_IGEMM_NOFAST")) : 0;
+    if (off || p.in_act) return false;
+    const int Cin = p.C0 + p.C1;
+    if (Cin % 32 != 0 || (p.C1 > 0 && p.C0 % 32 != 0) || p.KH * p.KW > 32 || p.K % 32 != 0) return false;
+    const long long imgs = (p.M + (long long)p.OH * p.OW - 1) / ((long long)p.OH * p.OW);
+    const long long bias = ((long long)p.pad * p.W + p.pad) * (p.lda0 > p.lda1 ? p.lda0 : p.lda1) * 4 + 64;
+    const long long a_bytes = imgs * p.H * p.W * (long long)(p.lda0 > p.lda1 ? p.lda0 : p.lda1) * 4 + bias;
+    const long long b_bytes = (long long)(p.b_kmajor ? p.K : p.N) * p.ldb * 4;
+    const long long soff_max = ((long long)(p.KH * p.W + p.KW) * (p.lda0 > p.lda1 ? p.lda0 : p.lda1) + (p.C0 + p.C1)) * 4;
+    return a_bytes + soff_max < (1LL << 31) && b_bytes + (long long)p.K * (p.b_kmajor ? p.ldb : 1) * 4 < (1LL << 31);
+}
+
+template <int BM, int BN, int WM, int WN>
+static void launch_variant(const GemmParams &p, dim3 grid, hipStream_t s) {
+    dim3 block(64 * WM * WN);
+    if (fast_ok(p)) {
+        if (p.b_kmajor) hipLaunchKernelGGL((igemm_f32_fast_kernel<BM, BN, WM, WN, true>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((igemm_f32_fast_kernel<BM, BN, WM, WN, false>), grid, block, 0, s, p);
+        return;
+    }
+    if (p.b_kmajor) hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, true, false>), grid, block, 0, s, p);
+    else if (p.in_act) hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, false, true>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WM, WN, false, false>), grid, block, 0, s, p);
+}
+
+// 64 B of device zeros per GPU (masked lanes of the staging loads read it); allocated once, never freed
+static const float *zero_buffer() {
+    static const float *buf[64] = {nullptr};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (!buf[dev]) {
+        float *p = nullptr;
+        if (hipMalloc((void **)&p, 256) != hipSuccess) return nullptr;
+        if (hipMemset(p, 0, 256) != hipSuccess) return nullptr;
+        buf[dev] = p;
+    }
+    return buf[dev];
+}
+
 int launch_igemm(const GemmParams &p_in, int batch_z, hipStream_t s) {
     GemmParams p = p_in;
     GD_CHECK(p.C0 > 0 && p.M > 0 && p.N > 0, "igemm: empty problem (C0=%d M=%d N=%d)", p.C0, p.M, p.N);
@@ -296,23 +658,33 @@ int launch_igemm(const GemmParams &p_in, int batch_z, hipStream_t s) {
     GD_CHECK(p.K == p.KH * p.KW * (p.C0 + p.C1), "igemm: K=%d != KH*KW*Cin=%d", p.K, p.KH * p.KW * (p.C0 + p.C1));
     GD_CHECK(!p.b_kmajor || p.N % 4 == 0, "igemm: k-major B needs N %% 4 == 0");
     GD_CHECK(p.ldb % 4 == 0 && p.lda0 % 4 == 0 && (p.C1 == 0 || p.lda1 % 4 == 0), "igemm: leading dims must be multiples of 4");
+    GD_CHECK(!(p.b_kmajor && p.in_act), "igemm: in_act with k-major B is not instantiated");
+    // staging offsets are 32-bit element counts
+    {
+        const long long imgs = (p.M + (long long)p.OH * p.OW - 1) / ((long long)p.OH * p.OW);
+        const long long a_elems = imgs * p.H * p.W * (long long)(p.lda0 > p.lda1 ? p.lda0 : p.lda1);
+        const long long b_elems = (long long)(p.b_kmajor ? p.K : p.N) * p.ldb;
+        GD_CHECK(a_elems < (1LL << 31) && b_elems < (1LL << 31), "igemm: operand larger than 2^31 elements per z-slice");
+    }
+    if (!p.zeros) p.zeros = zero_buffer();
+    GD_CHECK(p.zeros != nullptr, "igemm: cannot allocate the zero buffer");
     int bm, bn;
     pick_tiles(p, batch_z, bm, bn);
     p.m_tiles = (p.M + bm - 1) / bm;
     p.n_tiles = (p.N + bn - 1) / bn;
-    const int gx = ((p.m_tiles + 7) / 8) * 8 * p.n_tiles;
-    dim3 grid(gx, 1, batch_z), block(256);
-#define GD_LAUNCH(BM_, BN_)                                                                                         \
-    do {                                                                                                            \
-        if (p.b_kmajor) hipLaunchKernelGGL((igemm_f32_kernel<BM_, BN_, true, false>), grid, block, 0, s, p);        \
-        else if (p.in_act) hipLaunchKernelGGL((igemm_f32_kernel<BM_, BN_, false, true>), grid, block, 0, s, p);     \
-        else hipLaunchKernelGGL((igemm_f32_kernel<BM_, BN_, false, false>), grid, block, 0, s, p);                  \
-    } while (0)
-    GD_CHECK(!(p.b_kmajor && p.in_act), "igemm: in_act with k-major B is not instantiated");
-    if (bm == 128 && bn == 128) GD_LAUNCH(128, 128);
-    else if (bm == 128) GD_LAUNCH(128, 64);
-    else GD_LAUNCH(64, 64);
-#undef GD_LAUNCH
+    int gx = ((p.m_tiles + 7) / 8) * 8 * p.n_tiles;
+    if (bm == 128 && bn == 128 && big_variant() == 2 && (long long)((p.M + 255) / 256) * p.n_tiles * batch_z >= 512) {
+        p.m_tiles = (p.M + 255) / 256;
+        gx = ((p.m_tiles + 7) / 8) * 8 * p.n_tiles;
+        launch_variant<256, 128, 4, 2>(p, dim3(gx, 1, batch_z), s);
+    } else if (bm == 128 && bn == 128) {
+        if (big_variant() == 1) launch_variant<128, 128, 2, 2>(p, dim3(gx, 1, batch_z), s);
+        else launch_variant<128, 128, 2, 4>(p, dim3(gx, 1, batch_z), s);
+    } else if (bm == 128) {
+        launch_variant<128, 64, 2, 2>(p, dim3(gx, 1, batch_z), s);
+    } else {
+        launch_variant<64, 64, 2, 2>(p, dim3(gx, 1, batch_z), s);
+    }
     GD_HIP(hipGetLastError());
     return 0;
 }

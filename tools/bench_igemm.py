@@ -19,12 +19,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--only", type=int, default=-1, help="index into SHAPES")
     args = ap.parse_args()
     import torch
     from gddim_amd import ops
     dev = torch.device("cuda", 0)
     tot_ms, tot_fl = 0.0, 0.0
-    for H, Cin, Cout, k, cnt in SHAPES:
+    for H, Cin, Cout, k, cnt in (SHAPES if args.only < 0 else [SHAPES[args.only]]):
         x = torch.randn(args.batch, H, H, Cin, device=dev)
         w = torch.randn(Cout, k * k * Cin, device=dev) / (k * k * Cin) ** 0.5
         b = torch.randn(Cout, device=dev)
