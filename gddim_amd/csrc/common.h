@@ -70,6 +70,8 @@ struct GemmParams {
 
 int launch_igemm(const GemmParams &p, int batch_z, hipStream_t s);
 const char *igemm_variant_name(const GemmParams &p, int batch_z);
+// per-device zero buffer used by the staging loads; allocates on first use (call once outside graph capture)
+const float *igemm_zero_buffer();
 
 // ---- normalisation / activation / resampling (kernels/norm_act.hip) -----------------------------
 constexpr int GN_MAX_SLICES = 16;

@@ -256,6 +256,7 @@ int gd_engine_create(const gd_model_desc *desc, int device, gd_engine **out) {
         GD_ALLOC(e->step_dev, 1);
 #undef GD_ALLOC
         (void)hipMemset(e->step_dev, 0, sizeof(int));
+        if (!igemm_zero_buffer()) return fail("zero buffer", hipErrorOutOfMemory);  // never allocate inside a graph capture
         if ((err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", err);
         if ((err = hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming)) != hipSuccess) return fail("hipEventCreate", err);
         if ((err = hipEventCreateWithFlags(&e->ev_out, hipEventDisableTiming)) != hipSuccess) return fail("hipEventCreate", err);

@@ -637,7 +637,7 @@ static void launch_variant(const GemmParams &p, dim3 grid, hipStream_t s) {
 }
 
 // 64 B of device zeros per GPU (masked lanes of the staging loads read it); allocated once, never freed
-static const float *zero_buffer() {
+const float *igemm_zero_buffer() {
     static const float *buf[64] = {nullptr};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
@@ -666,7 +666,7 @@ int launch_igemm(const GemmParams &p_in, int batch_z, hipStream_t s) {
         const long long b_elems = (long long)(p.b_kmajor ? p.K : p.N) * p.ldb;
         GD_CHECK(a_elems < (1LL << 31) && b_elems < (1LL << 31), "igemm: operand larger than 2^31 elements per z-slice");
     }
-    if (!p.zeros) p.zeros = zero_buffer();
+    if (!p.zeros) p.zeros = igemm_zero_buffer();
     GD_CHECK(p.zeros != nullptr, "igemm: cannot allocate the zero buffer");
     int bm, bn;
     pick_tiles(p, batch_z, bm, bn);
