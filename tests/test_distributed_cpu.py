@@ -1,0 +1,56 @@
+"""N > 1 host logic on CPU: world_size-2 gloo processes exercise batch sharding, per-rank seeds and the end-of-round
+all-gather of uint8 samples (the only exchange on the path)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, global_batch, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from gddim_amd import distributed
+    r, w, lr = distributed.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    start, size = distributed.shard_batch(global_batch, w, r)
+    # stand-in for this rank's sampler output: image i of the round holds the value i/255 everywhere
+    x = (torch.arange(start, start + size, dtype=torch.float32) / 255.0).reshape(-1, 1, 1, 1).expand(size, 4, 4, 3)
+    u8 = distributed.to_uint8(x + 0.9 / 255.0)  # truncation, not rounding
+    full = distributed.all_gather_samples(u8.contiguous())
+    np.save(os.path.join(out_dir, "rank%d.npy" % r), full.numpy())
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_shard_and_all_gather_gloo(tmp_path):
+    world, global_batch = 2, 7  # uneven: shards of 4 and 3
+    mp.spawn(_worker, args=(world, _free_port(), global_batch, str(tmp_path)), nprocs=world, join=True)
+    outs = [np.load(os.path.join(str(tmp_path), "rank%d.npy" % r)) for r in range(world)]
+    assert outs[0].shape == (global_batch, 4, 4, 3) and outs[0].dtype == np.uint8
+    assert np.array_equal(outs[0], outs[1])                                   # every rank holds the whole round
+    assert np.array_equal(outs[0][:, 0, 0, 0], np.arange(global_batch))       # order = rank order, values truncated
+
+
+def test_shard_batch_and_seeds():
+    from gddim_amd import distributed
+    for gb, w in ((2048, 8), (1024, 8), (7, 2), (5, 8)):
+        parts = [distributed.shard_batch(gb, w, r) for r in range(w)]
+        assert sum(s for _, s in parts) == gb
+        assert all(parts[i][0] + parts[i][1] == parts[i + 1][0] for i in range(w - 1))
+        assert max(s for _, s in parts) - min(s for _, s in parts) <= 1
+    seeds = {distributed.rank_seed(42, rnd, r) for rnd in range(50) for r in range(8)}
+    assert len(seeds) == 400
+    assert np.array_equal(distributed.to_uint8(np.array([-0.1, 0.0, 0.999, 0.5, 1.2])), np.array([0, 0, 254, 127, 255], np.uint8))
