@@ -27,6 +27,21 @@ FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_
 HBM_PEAK_GBS = 8000.0
 
 
+def hbm_traffic(kernel_name):
+    """HBM bytes per launch of `kernel_name` from the committed PMC passes (profiles/r01_hbm_traffic.json:
+    (2*FETCH_SIZE + WRITE_SIZE)*1024 with the gfx950 FETCH_SIZE correction), or None when not profiled."""
+    path = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+    try:
+        table = json.load(open(path))["kernels"]
+    except (OSError, ValueError, KeyError):
+        return None
+    key = kernel_name.replace(" ", "")
+    for k, v in table.items():
+        if k.replace(" ", "") == key:
+            return v["hbm_bytes_per_launch"]
+    return None
+
+
 def cpu_baseline(cfg, params, nfe_full, cpu_batch, cpu_nfe):
     """The reference JAX-CPU path cannot run here (no jax); timed instead: the torch-CPU fp32 ORACLE (a
     restatement of the same algorithm, kind='port') on a bounded sample, all host cores."""
@@ -152,7 +167,7 @@ def main():
         dom = max(prof, key=lambda p: p["ms"])
         achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
         result["roofline"] = {"kernel": dom["name"], "bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
-                              "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                              "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": hbm_traffic(dom["name"]),
                               "launches": dom["launches"], "avg_launch_ms": dom["ms"] / max(1, dom["launches"]),
                               "flops_per_launch": dom["flops"] / max(1, dom["launches"]),
                               "share_of_gpu_time": dom["ms"] / tot_ms if tot_ms else None}

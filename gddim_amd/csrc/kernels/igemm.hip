@@ -27,6 +27,7 @@
 // Block -> tile mapping is XCD-aware: consecutive block ids round-robin over the 8 XCDs, so ids
 // are grouped in runs of 8*n_tiles with the M tile varying fastest inside a run; the n_tiles
 // blocks that share one A tile then carry ids congruent mod 8 and run on the same XCD (shared L2).
+#include <cstdio>
 #include <cstdlib>
 
 #include "../common.h"
@@ -602,25 +603,21 @@ static void pick_tiles(const GemmParams &p, int batch_z, int &bm, int &bn) {
     bm = 64; bn = 64;
 }
 
+static bool fast_ok(const GemmParams &p);
+
+// The kernel symbol (as rocprofv3 prints it) that launch_igemm would pick for this problem.
 const char *igemm_variant_name(const GemmParams &p, int batch_z) {
     int bm, bn;
     pick_tiles(p, batch_z, bm, bn);
-    if (bm == 128 && bn == 128) return "igemm_f32<128,128>";
-    if (bm == 128) return "igemm_f32<128,64>";
-    return "igemm_f32<64,64>";
-}
-
-static bool fast_ok(const GemmParams &p) {
-    static const int off = getenv("GDDIM_IGEMM_NOFAST") ? atoi(getenv("GDDIM_IGEMM_NOFAST")) : 0;
-    if (off || p.in_act) return false;
-    const int Cin = p.C0 + p.C1;
-    if (Cin % 32 != 0 || (p.C1 > 0 && p.C0 % 32 != 0) || p.KH * p.KW > 32 || p.K % 32 != 0) return false;
-    const long long imgs = (p.M + (long long)p.OH * p.OW - 1) / ((long long)p.OH * p.OW);
-    const long long bias = ((long long)p.pad * p.W + p.pad) * (p.lda0 > p.lda1 ? p.lda0 : p.lda1) * 4 + 64;
-    const long long a_bytes = imgs * p.H * p.W * (long long)(p.lda0 > p.lda1 ? p.lda0 : p.lda1) * 4 + bias;
-    const long long b_bytes = (long long)(p.b_kmajor ? p.K : p.N) * p.ldb * 4;
-    const long long soff_max = ((long long)(p.KH * p.W + p.KW) * (p.lda0 > p.lda1 ? p.lda0 : p.lda1) + (p.C0 + p.C1)) * 4;
-    return a_bytes + soff_max < (1LL << 31) && b_bytes + (long long)p.K * (p.b_kmajor ? p.ldb : 1) * 4 < (1LL << 31);
+    static thread_local char buf[96];
+    int wmm = 2, wnn = 2;
+    if (bm == 128 && bn == 128) {
+        if (big_variant() == 2 && (long long)((p.M + 255) / 256) * ((p.N + bn - 1) / bn) * batch_z >= 512) { bm = 256; wmm = 4; wnn = 2; }
+        else if (big_variant() != 1) { wmm = 2; wnn = 4; }
+    }
+    if (fast_ok(p)) snprintf(buf, sizeof buf, "igemm_f32_fast_kernel<%d,%d,%d,%d,%s>", bm, bn, wmm, wnn, p.b_kmajor ? "true" : "false");
+    else snprintf(buf, sizeof buf, "igemm_f32_kernel<%d,%d,%d,%d,%s,%s>", bm, bn, wmm, wnn, p.b_kmajor ? "true" : "false", p.in_act ? "true" : "false");
+    return buf;
 }
 
 template <int BM, int BN, int WM, int WN>
