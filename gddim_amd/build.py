@@ -48,7 +48,7 @@ def build(force=False, verbose=False):
         if verbose and out:
             print(out.decode())
     if rebuilt or not os.path.exists(LIB):
-        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-Wl,-z,defs", "-o", LIB] + objs  # undefined symbols fail the link
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -620,6 +620,21 @@ const char *igemm_variant_name(const GemmParams &p, int batch_z) {
     return buf;
 }
 
+// Eligibility of the VALU-free fast path (see igemm_f32_fast_kernel).  GDDIM_IGEMM_NOFAST=1 forces the generic kernel.
+static bool fast_ok(const GemmParams &p) {
+    static const int off = getenv("GDDIM_IGEMM_NOFAST") ? atoi(getenv("GDDIM_IGEMM_NOFAST")) : 0;
+    if (off || p.in_act) return false;
+    const int Cin = p.C0 + p.C1;
+    if (Cin % 32 != 0 || (p.C1 > 0 && p.C0 % 32 != 0) || p.KH * p.KW > 32 || p.K % 32 != 0) return false;
+    const long long ldmax = p.lda0 > p.lda1 ? p.lda0 : p.lda1;
+    const long long imgs = (p.M + (long long)p.OH * p.OW - 1) / ((long long)p.OH * p.OW);
+    const long long bias = ((long long)p.pad * p.W + p.pad) * ldmax * 4 + 64;
+    const long long a_bytes = imgs * p.H * p.W * ldmax * 4 + bias;
+    const long long b_bytes = (long long)(p.b_kmajor ? p.K : p.N) * p.ldb * 4;
+    const long long soff_max = ((long long)(p.KH * p.W + p.KW) * ldmax + (p.C0 + p.C1)) * 4;
+    return a_bytes + soff_max < (1LL << 31) && b_bytes + (long long)p.K * (p.b_kmajor ? p.ldb : 1) * 4 < (1LL << 31);
+}
+
 template <int BM, int BN, int WM, int WN>
 static void launch_variant(const GemmParams &p, dim3 grid, hipStream_t s) {
     dim3 block(64 * WM * WN);
