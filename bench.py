@@ -79,6 +79,7 @@ def main():
     ap.add_argument("--nfe", type=int, default=50)
     ap.add_argument("--order", type=int, default=2)
     ap.add_argument("--image-size", type=int, default=32)
+    ap.add_argument("--workload", choices=["cld", "blur"], default="cld", help="cld = BASELINE configs 2/4/5, blur = config 3")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
@@ -103,20 +104,41 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    cfg = cld_accr_dcifar10.get_config()
-    cfg.data.image_size = args.image_size
-    cfg.sampling.nfe = args.nfe
-    cfg.sampling.deis_order = args.order
-    cfg.sampling.method = "deis"
-    model, _, params = mutils.init_model(42, cfg, init_scale_override=1.0)  # identical weights on every rank
-    state = mutils.State(params_ema=params, model_state={})
-    sde = sde_lib.from_config(cfg)
-    sampling_fn = sampling.get_sampling_fn(cfg, sde, model, None, get_data_inverse_scaler(cfg))  # is_p=True
     B = args.batch
-    shape = (1, B, args.image_size, args.image_size, cfg.data.num_channels)
-    g = torch.Generator(device=dev)
-    g.manual_seed(distributed.rank_seed(cfg.seed, 0, rank))
-    u = torch.stack([torch.randn(shape, generator=g, device=dev), torch.randn(shape, generator=g, device=dev) / 2.0], dim=-1)
+    if args.workload == "cld":
+        cfg = cld_accr_dcifar10.get_config()
+        cfg.data.image_size = args.image_size
+        cfg.sampling.nfe = args.nfe
+        cfg.sampling.deis_order = args.order
+        cfg.sampling.method = "deis"
+        model, _, params = mutils.init_model(42, cfg, init_scale_override=1.0)  # identical weights on every rank
+        state = mutils.State(params_ema=params, model_state={})
+        sde = sde_lib.from_config(cfg)
+        sampling_fn = sampling.get_sampling_fn(cfg, sde, model, None, get_data_inverse_scaler(cfg))  # is_p=True
+        shape = (1, B, args.image_size, args.image_size, cfg.data.num_channels)
+        g = torch.Generator(device=dev)
+        g.manual_seed(distributed.rank_seed(cfg.seed, 0, rank))
+        u = torch.stack([torch.randn(shape, generator=g, device=dev), torch.randn(shape, generator=g, device=dev) / 2.0], dim=-1)
+        in_ch = 2 * cfg.data.num_channels
+        desc = "CLD gDDIM deis_order=%d NFE=%d" % (args.order, args.nfe)
+    else:
+        from gddim_amd.blur import sampling as bsampling, sde_lib as bsde_lib
+        from gddim_amd.configs import blur_ddpm_deep_cifar10
+        cfg = blur_ddpm_deep_cifar10.get_config()
+        cfg.sampling.nfe = args.nfe
+        model, _, params = mutils.init_model(42, cfg, init_scale_override=1.0)
+        state = mutils.State(params_ema=params, model_state={})
+        sde = bsde_lib.from_config(cfg)
+        blur_fn = bsampling.get_sampling_fn(cfg, sde, model, None, get_data_inverse_scaler(cfg))
+        g = torch.Generator(device=dev)
+        g.manual_seed(distributed.rank_seed(cfg.seed, 0, rank))
+        u = torch.randn((1, B, 32, 32, 3), generator=g, device=dev)
+        in_ch = cfg.data.num_channels
+        desc = "blur gDDIM order0 NFE=%d (ts_order=2, t0=1e-5, sigma_blur_max=10)" % args.nfe
+
+        def sampling_fn(rng, st, bs, uu, use_graph=True):
+            xs, n = blur_fn(rng, st, bs, uu, use_graph=use_graph)
+            return xs, None, n
 
     def step():
         xs, vs, nfe = sampling_fn([rank], state, B, u, use_graph=not args.no_graph)
@@ -142,15 +164,14 @@ def main():
     dt = float(tt.item())
     assert out.shape[0] == B * world and out.dtype == torch.uint8
 
-    eng = model.engine_for(params, 2 * cfg.data.num_channels, B, local_rank)
+    eng = model.engine_for(params, in_ch, B, local_rank)
     flops_img = eng.flops_per_image() * args.nfe
     result = {
-        "metric": METRIC, "value": world * B * args.steps / dt, "unit": "images/s", "n_gpus": world, "steps": args.steps,
+        "metric": METRIC if (args.workload == "cld" and args.nfe == 50 and args.image_size == 32) else "images/sec, " + desc, "value": world * B * args.steps / dt, "unit": "images/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * dt / max(1, args.steps), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "CLD gDDIM deis_order=%d NFE=%d, batch=%d per GPU, %dx%dx3 synthetic noise, random-init NCSN++ "
-                               "(accr_dcifar10: nf=128, ch_mult=(1,2,2,2), 8 res blocks, attn@16)" %
-                               (args.order, args.nfe, B, args.image_size, args.image_size),
+        "config": {"workload": "%s, batch=%d per GPU, %dx%dx3 synthetic noise, random-init NCSN++ "
+                               "(nf=128, ch_mult=(1,2,2,2), 8 res blocks, attn@16)" % (desc, B, cfg.data.image_size, cfg.data.image_size),
                    "global_batch": B * world, "parallelism": "dp%d (one process per GPU, uint8 all-gather per round)" % world,
                    "hipgraph": not args.no_graph, "tflop_per_image": flops_img / 1e12},
         "e2e_tflops_per_gpu": B * args.steps * flops_img / dt / 1e12,
@@ -177,7 +198,7 @@ def main():
              "gbs": (p["bytes"] / (p["ms"] * 1e-3) / 1e9) if p["bytes"] and p["ms"] else None}
             for p in sorted(prof, key=lambda p: -p["ms"])]
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "cld":
         result["cpu_baseline"] = cpu_baseline(cfg, params, args.nfe, args.cpu_batch, args.cpu_nfe)
     if rank == 0:
         print(json.dumps(result))

@@ -66,6 +66,9 @@ struct GemmParams {
     int in_act;  // 1: swish applied to A elements on load
     int m_tiles, n_tiles;
     const float *zeros;  // >= 16 B of device zeros (filled in by launch_igemm when null)
+    // magic numbers for division by OH*OW, OW and rows_per_image (filled in by launch_igemm)
+    unsigned mg_ohw, sh_ohw, mg_ow, sh_ow, mg_rpi, sh_rpi;
+    int diag;  // diagnostic ablations of the fast kernel (never set by the product path)
 };
 
 int launch_igemm(const GemmParams &p, int batch_z, hipStream_t s);

@@ -3,8 +3,10 @@
 // launches HIP kernels or fails.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -56,17 +58,22 @@ struct gd_engine {
     float *u8 = nullptr, *ring = nullptr, *ystate = nullptr;
     long long ring_cap = 0;
     float *ts_dev = nullptr, *coef_dev = nullptr, *dn_dev = nullptr, *mean_dev = nullptr, *std_dev = nullptr;
-    int *step_dev = nullptr;
+    int *step_dev = nullptr;  // GD_MAX_LANES counters (one per concurrent sub-batch)
     int sched_kind = 0;  // 1 cld, 2 blur
     int num_step = 0, n_slots = 0, denoise = 0;
     float t_denoise = 0;
     // the sampler loop runs on the engine's own stream (graph capture is illegal on the null stream); it is
     // ordered after / before the caller's stream with two events
-    hipStream_t stream = nullptr;
-    hipEvent_t ev_in = nullptr, ev_out = nullptr;
-    // graphs keyed by batch
+    // A sampler call is split into `lanes` independent sub-batches, each on its own stream: while one sub-batch is in a
+    // phase that leaves the matrix pipe idle (GroupNorm and other HBM-bound kernels, the prologue/epilogue round of a GEMM
+    // launch) the other one computes.  GD_LANES=1 disables the split.
+    static constexpr int MAX_LANES = 4;
+    hipStream_t stream[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_in = nullptr, ev_out[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
+    int lanes = 1;  // measured on MI355X (B=256): 2 lanes overlap in the trace but change throughput by < 1 %
+    // graphs keyed by (sub-batch size, first image, lane)
     struct Graphs { hipGraphExec_t step = nullptr, fin = nullptr; };
-    std::map<int, Graphs> graphs;
+    std::map<long long, Graphs> graphs;
     // profiling
     bool prof = false;
     std::map<std::string, ProfAcc> prof_acc;
@@ -85,8 +92,10 @@ static void drop_graphs(gd_engine *e) {
 
 struct Bind {
     const float *x_in;
-    const float *labels;  // nullptr: labels = 999 * ts_dev[*step_dev]
+    const float *labels;  // nullptr: labels = 999 * ts_dev[*step]
     float *eps_out;
+    float *arena;         // activation arena of this sub-batch
+    const int *step;      // device step counter of this sub-batch
 };
 
 static float *tptr(gd_engine *e, const Bind &b, const TRef &r, int batch) {
@@ -97,7 +106,7 @@ static float *tptr(gd_engine *e, const Bind &b, const TRef &r, int batch) {
         case EXT_X_IN: base = const_cast<float *>(b.x_in); break;
         case EXT_LABELS: base = const_cast<float *>(b.labels); break;
         case EXT_EPS_OUT: base = b.eps_out; break;
-        default: base = e->arena + (size_t)t.offset * batch; break;
+        default: base = b.arena + (size_t)t.offset * batch; break;
     }
     return base ? base + r.col : nullptr;
 }
@@ -126,12 +135,12 @@ static int run_op(gd_engine *e, const Op &op, const Bind &b, int batch, hipStrea
     switch (op.kind) {
         case OP_FOURIER: {
             ProfScope ps(e, s, "fourier", 0, 0);
-            return launch_fourier(b.labels, e->ts_dev, e->step_dev, slot_ptr(e, op.w_slot), tptr(e, b, op.out, batch), batch,
+            return launch_fourier(b.labels, e->ts_dev, b.step, slot_ptr(e, op.w_slot), tptr(e, b, op.out, batch), batch,
                                   op.N, s);
         }
         case OP_GEMM: {
             GemmParams g{};
-            g.a0 = tptr(e, b, op.a0, batch);
+            g.a0 = op.a_slot >= 0 ? slot_ptr(e, op.a_slot) + op.a_off : tptr(e, b, op.a0, batch);
             g.a1 = tptr(e, b, op.a1, batch);
             g.C0 = op.C0; g.C1 = op.C1; g.lda0 = op.lda0; g.lda1 = op.lda1 ? op.lda1 : 4;
             g.H = op.H; g.W = op.W; g.OH = op.OH; g.OW = op.OW; g.KH = op.KH; g.KW = op.KW; g.stride = op.stride; g.pad = op.pad;
@@ -253,13 +262,16 @@ int gd_engine_create(const gd_model_desc *desc, int device, gd_engine **out) {
         GD_ALLOC(e->u8, pix * CP);
         GD_ALLOC(e->ystate, pix * desc->in_channels);
         GD_ALLOC(e->dn_dev, 12);
-        GD_ALLOC(e->step_dev, 1);
+        GD_ALLOC(e->step_dev, gd_engine::MAX_LANES);
 #undef GD_ALLOC
-        (void)hipMemset(e->step_dev, 0, sizeof(int));
+        (void)hipMemset(e->step_dev, 0, sizeof(int) * gd_engine::MAX_LANES);
+        if (const char *ln = getenv("GD_LANES")) e->lanes = std::max(1, std::min((int)gd_engine::MAX_LANES, atoi(ln)));
         if (!igemm_zero_buffer()) return fail("zero buffer", hipErrorOutOfMemory);  // never allocate inside a graph capture
-        if ((err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", err);
         if ((err = hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming)) != hipSuccess) return fail("hipEventCreate", err);
-        if ((err = hipEventCreateWithFlags(&e->ev_out, hipEventDisableTiming)) != hipSuccess) return fail("hipEventCreate", err);
+        for (int i = 0; i < gd_engine::MAX_LANES; ++i) {
+            if ((err = hipStreamCreateWithFlags(&e->stream[i], hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", err);
+            if ((err = hipEventCreateWithFlags(&e->ev_out[i], hipEventDisableTiming)) != hipSuccess) return fail("hipEventCreate", err);
+        }
     }
     *out = e;
     return 0;
@@ -277,8 +289,10 @@ int gd_engine_destroy(gd_engine *e) {
         for (float *b : bufs)
             if (b) (void)hipFree(b);
         if (e->ev_in) (void)hipEventDestroy(e->ev_in);
-        if (e->ev_out) (void)hipEventDestroy(e->ev_out);
-        if (e->stream) (void)hipStreamDestroy(e->stream);
+        for (int i = 0; i < gd_engine::MAX_LANES; ++i) {
+            if (e->ev_out[i]) (void)hipEventDestroy(e->ev_out[i]);
+            if (e->stream[i]) (void)hipStreamDestroy(e->stream[i]);
+        }
     }
     delete e;
     return 0;
@@ -359,7 +373,7 @@ int gd_unet_forward(gd_engine *e, const float *x_dev, const float *labels_dev, f
     const gd_model_desc &d = e->plan.desc;
     const long long pix = (long long)batch * d.image_size * d.image_size;
     GD_TRY(launch_pad_channels(x_dev, d.in_channels, e->xin, pix, d.in_channels, e->plan.CP, 1.f, 0.f, s));
-    Bind b{e->xin, labels_dev, out_dev};
+    Bind b{e->xin, labels_dev, out_dev, e->arena, e->step_dev};
     return run_unet(e, b, batch, s);
 }
 
@@ -373,7 +387,7 @@ int gd_cld_eps(gd_engine *e, const float *u_dev, const float *t_dev, float *eps_
     const long long pix = (long long)batch * d.image_size * d.image_size;
     GD_TRY(launch_pad_channels(t_dev, 1, e->labels, batch, 1, 1, 999.f, 0.f, s));  // labels = t * 999 (models/utils.py:172)
     GD_TRY(launch_cld_pack(u_dev, e->xin, nullptr, 0, pix, C, s));
-    Bind b{e->xin, e->labels, e->eps_planar};
+    Bind b{e->xin, e->labels, e->eps_planar, e->arena, e->step_dev};
     GD_TRY(run_unet(e, b, batch, s));
     return launch_cld_unpack_pairs(e->eps_planar, d.in_channels, eps_dev, pix, C, s);
 }
@@ -431,6 +445,18 @@ static int capture_end(hipStream_t s, hipGraphExec_t *exec) {
     return 0;
 }
 
+// split `batch` images over the engine's lanes: sub-batch i = images [start[i], start[i] + size[i])
+static int split_lanes(gd_engine *e, int batch, bool allow, int *start, int *size) {
+    int n = allow ? e->lanes : 1;
+    if (batch < 2 * n) n = 1;
+    for (int i = 0, at = 0; i < n; ++i) {
+        size[i] = batch / n + (i < batch % n ? 1 : 0);
+        start[i] = at;
+        at += size[i];
+    }
+    return n;
+}
+
 int gd_sample_cld(gd_engine *e, int batch, const float *u_in_dev, float *x_out_dev, float *v_out_dev, int inverse_scale,
                   int use_graph, void *stream) {
     GD_TRY(check_compute(e, batch));
@@ -438,46 +464,79 @@ int gd_sample_cld(gd_engine *e, int batch, const float *u_in_dev, float *x_out_d
     GD_CHECK(u_in_dev && x_out_dev && v_out_dev, "null device pointer");
     GD_CHECK(!e->plan.desc.scale_by_sigma, "scale_by_sigma is not supported inside the fused sampler");
     hipStream_t caller = (hipStream_t)stream;
-    hipStream_t s = e->stream;
-    GD_HIP(hipEventRecord(e->ev_in, caller));
-    GD_HIP(hipStreamWaitEvent(s, e->ev_in, 0));
     const gd_model_desc &d = e->plan.desc;
     const int C = d.in_channels / 2;
-    const long long pix = (long long)batch * d.image_size * d.image_size;
+    const size_t HW = (size_t)d.image_size * d.image_size;
     const int ring_slots = e->n_slots - 2;
-    GD_TRY(launch_cld_pack(u_in_dev, e->u8, e->ring, ring_slots, pix, C, s));
-    GD_HIP(hipMemsetAsync(e->step_dev, 0, sizeof(int), s));
-    Bind b{e->u8, nullptr, e->epsb};
-    auto step_body = [&]() -> int {
-        GD_TRY(run_unet(e, b, batch, s));
-        GD_TRY(launch_cld_ab_step(e->u8, e->epsb, e->ring, ring_slots, e->coef_dev, e->n_slots, e->step_dev, pix, C, s));
-        return launch_advance_step(e->step_dev, s);
-    };
     const bool graph = use_graph && !e->prof;
-    if (graph) {
-        gd_engine::Graphs &g = e->graphs[batch];
-        if (!g.step) {
-            GD_TRY(capture_begin(s));
-            int r = step_body();
-            int r2 = capture_end(s, &g.step);
-            if (r || r2) return 1;
-        }
-        if (e->denoise && !g.fin) {
-            GD_TRY(capture_begin(s));
-            int r = run_unet(e, b, batch, s);
-            int r2 = capture_end(s, &g.fin);
-            if (r || r2) return 1;
-        }
-        for (int i = 0; i < e->num_step; ++i) GD_HIP(hipGraphLaunch(g.step, s));
-        if (e->denoise) GD_HIP(hipGraphLaunch(g.fin, s));
-    } else {
-        for (int i = 0; i < e->num_step; ++i) GD_TRY(step_body());
-        if (e->denoise) GD_TRY(run_unet(e, b, batch, s));  // step == num_step -> t = t_denoise
+    int start[gd_engine::MAX_LANES], size[gd_engine::MAX_LANES];
+    const int nl = split_lanes(e, batch, !e->prof, start, size);
+    GD_HIP(hipEventRecord(e->ev_in, caller));
+
+    struct Lane {
+        hipStream_t s;
+        int b;
+        long long pix;
+        float *u8, *eps, *ring;
+        int *step;
+        Bind bind;
+        gd_engine::Graphs *g;
+    } L[gd_engine::MAX_LANES];
+    for (int i = 0; i < nl; ++i) {
+        Lane &l = L[i];
+        l.s = e->stream[i];
+        l.b = size[i];
+        l.pix = (long long)size[i] * HW;
+        const size_t p0 = (size_t)start[i] * HW;
+        l.u8 = e->u8 + p0 * e->plan.CP;
+        l.eps = e->epsb + p0 * d.in_channels;
+        l.ring = e->ring ? e->ring + p0 * d.in_channels * ring_slots : nullptr;
+        l.step = e->step_dev + i;
+        l.bind = Bind{l.u8, nullptr, l.eps, e->arena + (size_t)e->plan.arena_per_image * start[i], l.step};
+        l.g = graph ? &e->graphs[((long long)size[i] << 40) | ((long long)start[i] << 8) | i] : nullptr;
+        GD_HIP(hipStreamWaitEvent(l.s, e->ev_in, 0));
+        GD_TRY(launch_cld_pack(u_in_dev + p0 * C * 2, l.u8, l.ring, ring_slots, l.pix, C, l.s));
+        GD_HIP(hipMemsetAsync(l.step, 0, sizeof(int), l.s));
     }
-    GD_TRY(launch_cld_finish(e->u8, e->epsb, e->dn_dev, -e->t_denoise, e->denoise, inverse_scale, x_out_dev, v_out_dev, pix, C,
-                             s));
-    GD_HIP(hipEventRecord(e->ev_out, s));
-    GD_HIP(hipStreamWaitEvent(caller, e->ev_out, 0));
+    auto step_body = [&](Lane &l) -> int {
+        GD_TRY(run_unet(e, l.bind, l.b, l.s));
+        GD_TRY(launch_cld_ab_step(l.u8, l.eps, l.ring, ring_slots, e->coef_dev, e->n_slots, l.step, l.pix, C, l.s));
+        return launch_advance_step(l.step, l.s);
+    };
+    if (graph) {
+        for (int i = 0; i < nl; ++i) {
+            Lane &l = L[i];
+            if (!l.g->step) {
+                GD_TRY(capture_begin(l.s));
+                int r = step_body(l);
+                int r2 = capture_end(l.s, &l.g->step);
+                if (r || r2) return 1;
+            }
+            if (e->denoise && !l.g->fin) {
+                GD_TRY(capture_begin(l.s));
+                int r = run_unet(e, l.bind, l.b, l.s);
+                int r2 = capture_end(l.s, &l.g->fin);
+                if (r || r2) return 1;
+            }
+        }
+        for (int k = 0; k < e->num_step; ++k)
+            for (int i = 0; i < nl; ++i) GD_HIP(hipGraphLaunch(L[i].g->step, L[i].s));
+        if (e->denoise)
+            for (int i = 0; i < nl; ++i) GD_HIP(hipGraphLaunch(L[i].g->fin, L[i].s));
+    } else {
+        for (int k = 0; k < e->num_step; ++k)
+            for (int i = 0; i < nl; ++i) GD_TRY(step_body(L[i]));
+        if (e->denoise)
+            for (int i = 0; i < nl; ++i) GD_TRY(run_unet(e, L[i].bind, L[i].b, L[i].s));  // step == num_step -> t = t_denoise
+    }
+    for (int i = 0; i < nl; ++i) {
+        Lane &l = L[i];
+        const size_t o0 = (size_t)start[i] * HW * C;
+        GD_TRY(launch_cld_finish(l.u8, l.eps, e->dn_dev, -e->t_denoise, e->denoise, inverse_scale, x_out_dev + o0, v_out_dev + o0,
+                                 l.pix, C, l.s));
+        GD_HIP(hipEventRecord(e->ev_out[i], l.s));
+        GD_HIP(hipStreamWaitEvent(caller, e->ev_out[i], 0));
+    }
     return 0;
 }
 
@@ -503,37 +562,63 @@ int gd_sample_blur(gd_engine *e, int batch, const float *y_in_dev, float *x_out_
     GD_CHECK(y_in_dev && x_out_dev, "null device pointer");
     GD_CHECK(!e->plan.desc.scale_by_sigma, "scale_by_sigma is not supported inside the fused sampler");
     hipStream_t caller = (hipStream_t)stream;
-    hipStream_t s = e->stream;
-    GD_HIP(hipEventRecord(e->ev_in, caller));
-    GD_HIP(hipStreamWaitEvent(s, e->ev_in, 0));
     const gd_model_desc &d = e->plan.desc;
     const int C = d.in_channels;
-    const size_t n = (size_t)batch * 1024 * C;
-    GD_HIP(hipMemcpyAsync(e->ystate, y_in_dev, n * sizeof(float), hipMemcpyDeviceToDevice, s));
-    GD_HIP(hipMemsetAsync(e->step_dev, 0, sizeof(int), s));
-    Bind b{e->xin, nullptr, e->epsb};
-    auto step_body = [&]() -> int {
-        GD_TRY(launch_blur_idct_pad(e->ystate, e->xin, batch, C, s));
-        GD_TRY(run_unet(e, b, batch, s));
-        GD_TRY(launch_blur_step(e->ystate, e->epsb, e->mean_dev, e->std_dev, e->step_dev, batch, C, s));
-        return launch_advance_step(e->step_dev, s);
-    };
     const bool graph = use_graph && !e->prof;
-    if (graph) {
-        gd_engine::Graphs &g = e->graphs[batch];
-        if (!g.step) {
-            GD_TRY(capture_begin(s));
-            int r = step_body();
-            int r2 = capture_end(s, &g.step);
-            if (r || r2) return 1;
-        }
-        for (int i = 0; i < e->num_step; ++i) GD_HIP(hipGraphLaunch(g.step, s));
-    } else {
-        for (int i = 0; i < e->num_step; ++i) GD_TRY(step_body());
+    int start[gd_engine::MAX_LANES], size[gd_engine::MAX_LANES];
+    const int nl = split_lanes(e, batch, !e->prof, start, size);
+    GD_HIP(hipEventRecord(e->ev_in, caller));
+    struct Lane {
+        hipStream_t s;
+        int b;
+        float *y, *xin, *eps;
+        int *step;
+        Bind bind;
+        gd_engine::Graphs *g;
+    } L[gd_engine::MAX_LANES];
+    for (int i = 0; i < nl; ++i) {
+        Lane &l = L[i];
+        l.s = e->stream[i];
+        l.b = size[i];
+        const size_t p0 = (size_t)start[i] * 1024;
+        l.y = e->ystate + p0 * C;
+        l.xin = e->xin + p0 * e->plan.CP;
+        l.eps = e->epsb + p0 * C;
+        l.step = e->step_dev + i;
+        l.bind = Bind{l.xin, nullptr, l.eps, e->arena + (size_t)e->plan.arena_per_image * start[i], l.step};
+        l.g = graph ? &e->graphs[((long long)size[i] << 40) | ((long long)start[i] << 8) | i] : nullptr;
+        GD_HIP(hipStreamWaitEvent(l.s, e->ev_in, 0));
+        GD_HIP(hipMemcpyAsync(l.y, y_in_dev + p0 * C, (size_t)l.b * 1024 * C * sizeof(float), hipMemcpyDeviceToDevice, l.s));
+        GD_HIP(hipMemsetAsync(l.step, 0, sizeof(int), l.s));
     }
-    GD_TRY(launch_blur_finish(e->ystate, x_out_dev, batch, C, inverse_scale, s));
-    GD_HIP(hipEventRecord(e->ev_out, s));
-    GD_HIP(hipStreamWaitEvent(caller, e->ev_out, 0));
+    auto step_body = [&](Lane &l) -> int {
+        GD_TRY(launch_blur_idct_pad(l.y, l.xin, l.b, C, l.s));
+        GD_TRY(run_unet(e, l.bind, l.b, l.s));
+        GD_TRY(launch_blur_step(l.y, l.eps, e->mean_dev, e->std_dev, l.step, l.b, C, l.s));
+        return launch_advance_step(l.step, l.s);
+    };
+    if (graph) {
+        for (int i = 0; i < nl; ++i) {
+            Lane &l = L[i];
+            if (!l.g->step) {
+                GD_TRY(capture_begin(l.s));
+                int r = step_body(l);
+                int r2 = capture_end(l.s, &l.g->step);
+                if (r || r2) return 1;
+            }
+        }
+        for (int k = 0; k < e->num_step; ++k)
+            for (int i = 0; i < nl; ++i) GD_HIP(hipGraphLaunch(L[i].g->step, L[i].s));
+    } else {
+        for (int k = 0; k < e->num_step; ++k)
+            for (int i = 0; i < nl; ++i) GD_TRY(step_body(L[i]));
+    }
+    for (int i = 0; i < nl; ++i) {
+        Lane &l = L[i];
+        GD_TRY(launch_blur_finish(l.y, x_out_dev + (size_t)start[i] * 1024 * C, l.b, C, inverse_scale, l.s));
+        GD_HIP(hipEventRecord(e->ev_out[i], l.s));
+        GD_HIP(hipStreamWaitEvent(caller, e->ev_out[i], 0));
+    }
     return 0;
 }
 

@@ -321,6 +321,13 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_kernel(const GemmParam
 // smaller than 2 GiB, no input activation.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+// n / d with a host-computed (magic, shift): exact for n < 2^31 (launch_igemm: fill_div)
+__device__ __forceinline__ unsigned fast_div(unsigned n, unsigned d, unsigned magic, unsigned shift) {
+    if (d == 1) return n;
+    const unsigned t = __umulhi(magic, n);
+    return (t + ((n - t) >> 1)) >> (shift - 1);
+}
+
 __device__ __forceinline__ f32x4 buf_load16(__amdgpu_buffer_rsrc_t rsrc, int voffset, int soffset) {
     u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voffset, soffset, 0);
     return __builtin_bit_cast(f32x4, v);
@@ -376,26 +383,26 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_fast_kernel(const Gemm
     int rb0[AJ], rb1[AJ];      // byte offset of (row's tap (0,0) pixel, channel kcol) in source 0 / 1, + bias
     unsigned inv[AJ];          // bit t set: tap t of this row lies outside the image (or the row is >= M)
     {
-        const int OHW = p.OH * p.OW;
+        const unsigned OHW = p.OH * p.OW;
+        const unsigned rowbits = (1u << p.KW) - 1u;
 #pragma unroll
         for (int j = 0; j < AJ; ++j) {
             const int m = m0 + arow + RPP * j;
             rb0[j] = 0; rb1[j] = 0; inv[j] = 0xFFFFFFFFu;
             if (m < p.M) {
-                const int img = m / OHW;
-                const int r = m - img * OHW;
-                const int oy = r / p.OW;
+                const int img = (int)fast_div((unsigned)m, OHW, p.mg_ohw, p.sh_ohw);
+                const int r = m - img * (int)OHW;
+                const int oy = (int)fast_div((unsigned)r, (unsigned)p.OW, p.mg_ow, p.sh_ow);
                 const int ox = r - oy * p.OW;
                 const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
                 const int pix = (img * p.H + iy0) * p.W + ix0;  // may be "negative" by at most pad*W + pad: the bias covers it
                 rb0[j] = pix * p.lda0 * 4 + bias0 + kcol * 4;
                 rb1[j] = pix * p.lda1 * 4 + bias1 + kcol * 4;
+                unsigned xb = 0;  // columns of the window outside the image
+                for (int tx = 0; tx < p.KW; ++tx) xb |= ((unsigned)(ix0 + tx) < (unsigned)p.W ? 0u : 1u) << tx;
                 unsigned mk = 0;
-                for (int t = 0; t < taps; ++t) {
-                    const int ty = t / p.KW, tx = t - ty * p.KW;
-                    const bool okt = (unsigned)(iy0 + ty) < (unsigned)p.H && (unsigned)(ix0 + tx) < (unsigned)p.W;
-                    mk |= (okt ? 0u : 1u) << t;
-                }
+                for (int ty = 0; ty < p.KH; ++ty)
+                    mk |= ((unsigned)(iy0 + ty) < (unsigned)p.H ? xb : rowbits) << (ty * p.KW);
                 inv[j] = mk;
             }
         }
@@ -414,14 +421,25 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_fast_kernel(const Gemm
 
     // ---- wave-uniform state of the chunk whose loads are issued next: tap (ty, tx), channel base c0 ----
     int s_tap = 0, s_ty = 0, s_tx = 0, s_c0 = 0, s_kc = 0;
-    const int nk = p.K / KC;
+    const int nk = p.diag == 2 ? 1 : p.K / KC;  // diag: diagnostic only (GDDIM_IGEMM_DIAG), results wrong
+    // K order: 32-channel slab outermost, the KH*KW taps of that slab innermost.  The taps re-read (shifted) the same
+    // activation lines, so keeping them adjacent in time turns 8 of 9 tap loads into L1/L2 hits (with taps outermost
+    // the lines are evicted between taps: ~4x HBM over-fetch in the PMC pass).  Any K permutation is legal as long as
+    // A and B agree; B is addressed through the scalar soffset, so the packed weight layout [n][tap][c] is unchanged.
+    const bool tap_minor = !(p.diag & 4);
     auto advance_k = [&]() {
-        s_c0 += KC;
         ++s_kc;
-        if (s_c0 >= Cin) {
-            s_c0 = 0;
+        if (tap_minor) {
             ++s_tap;
             if (++s_tx == p.KW) { s_tx = 0; ++s_ty; }
+            if (s_tap == taps) { s_tap = 0; s_ty = 0; s_tx = 0; s_c0 += KC; }
+        } else {
+            s_c0 += KC;
+            if (s_c0 >= Cin) {
+                s_c0 = 0;
+                ++s_tap;
+                if (++s_tx == p.KW) { s_tx = 0; ++s_ty; }
+            }
         }
     };
 
@@ -441,7 +459,8 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_fast_kernel(const Gemm
             }
         } else {
             const int j = pc - AJ;
-            const int soff = (B_KMAJOR ? s_kc * KC * p.ldb : s_kc * KC) * 4;
+            const int kb = s_tap * Cin + s_c0;  // first k of this chunk in the packed [tap][c] order
+            const int soff = (B_KMAJOR ? kb * p.ldb : kb) * 4;
             rb[j] = buf_load16(srd_b, s_kc < nk ? bvo[j] : OOB, soff);
         }
     };
@@ -530,50 +549,57 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_fast_kernel(const Gemm
         __syncthreads();
     }
 
-    // ---- epilogue (identical to the generic kernel) ----
-    float *outp = p.out + (size_t)z * p.sC;
-    const int rpi = p.rows_per_image;
+    // ---- epilogue: D[row][col], col = lane&31, row = (v&3) + 8*(v>>2) + 4*(lane>>5) ----
+    // Buffer addressed: the lane part of the offset ((4*lh)*ld + n) is computed once per column tile, the row part is a
+    // scalar soffset, rows >= M fall outside the descriptor (dropped by the bounds check), columns >= N are pushed out
+    // of bounds once.  fast_ok() guarantees rows_per_image % 8 == 0, so the two half-waves of one store (rows r0, r0+4)
+    // belong to the same image and the per-image bias row is wave-uniform.
+    {
+        char *outc = reinterpret_cast<char *>(p.out + (size_t)z * p.sC);
+        const __amdgpu_buffer_rsrc_t srd_o = __builtin_amdgcn_make_buffer_rsrc(outc, 0, p.M * p.ldc * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t srd_r =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(reinterpret_cast<const char *>(p.res ? p.res : p.out)), 0,
+                                              p.M * p.ldres * 4, 0x00020000);
+        const unsigned rpi = p.rows_per_image;
 #pragma unroll
-    for (int c = 0; c < RN; ++c) {
-        const int n = n0 + wn * (BN / WN) + c * 32 + li;
-        const bool nok = n < p.N;
-        const float bias = (p.bias && nok) ? p.bias[n] : 0.f;
+        for (int c = 0; c < RN; ++c) {
+            const int n = n0 + wn * (BN / WN) + c * 32 + li;
+            const bool nok = n < p.N;
+            const float bias = (p.bias && nok) ? p.bias[n] : 0.f;
+            const int vo_o = nok ? (4 * lh * p.ldc + n) * 4 : OOB;
+            const int vo_r = nok ? (4 * lh * p.ldres + n) * 4 : OOB;
 #pragma unroll
-        for (int r = 0; r < RM; ++r) {
-            const int mb = m0 + wm * (BM / WM) + r * 32 + 4 * lh;
-            float addv[16];
+            for (int r = 0; r < RM; ++r) {
+                const int mrow = m0 + wm * (BM / WM) + r * 32;  // wave-uniform
+                float addv[16];
 #pragma unroll
-            for (int v = 0; v < 16; ++v) addv[v] = bias;
-            if (p.res) {
-                float t[16];
+                for (int v = 0; v < 16; ++v) addv[v] = bias;
+                if (p.res) {
+                    float t[16];
 #pragma unroll
-                for (int v = 0; v < 16; ++v) {
-                    const int m = mb + (v & 3) + 8 * (v >> 2);
-                    const float *ptr = (nok && m < p.M) ? p.res + (size_t)m * p.ldres + n : p.res;
-                    t[v] = *ptr;
+                    for (int v = 0; v < 16; ++v)
+                        t[v] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_r, vo_r, (mrow + (v & 3) + 8 * (v >> 2)) * p.ldres * 4, 0));
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) addv[v] += t[v];
+                }
+                if (p.rowbias) {
+                    float t[16];
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) {
+                        const unsigned mr = (unsigned)(mrow + (v & 3) + 8 * (v >> 2));
+                        const unsigned img = mr < (unsigned)p.M ? fast_div(mr, rpi, p.mg_rpi, p.sh_rpi) : 0u;
+                        t[v] = nok ? p.rowbias[(size_t)img * p.ld_rowbias + n] : 0.f;
+                    }
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) addv[v] += t[v];
                 }
 #pragma unroll
-                for (int v = 0; v < 16; ++v) addv[v] += t[v];
-            }
-            if (p.rowbias) {
-                const int img_b = mb / rpi;
-                const int rem_b = mb - img_b * rpi;
-                float t[16];
-#pragma unroll
                 for (int v = 0; v < 16; ++v) {
-                    int q = rem_b + (v & 3) + 8 * (v >> 2), img = img_b;
-                    while (q >= rpi) { q -= rpi; ++img; }
-                    const int m = mb + (v & 3) + 8 * (v >> 2);
-                    const float *ptr = (nok && m < p.M) ? p.rowbias + (size_t)img * p.ld_rowbias + n : p.rowbias;
-                    t[v] = *ptr;
+                    const float val = (p.alpha * acc[r][c][v] + addv[v]) * p.out_scale;
+                    if (p.diag == 1) { asm volatile("" ::"v"(val)); continue; }
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), srd_o, vo_o,
+                                                          (mrow + (v & 3) + 8 * (v >> 2)) * p.ldc * 4, 0);
                 }
-#pragma unroll
-                for (int v = 0; v < 16; ++v) addv[v] += t[v];
-            }
-#pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const int m = mb + (v & 3) + 8 * (v >> 2);
-                if (nok && m < p.M) outp[(size_t)m * p.ldc + n] = (p.alpha * acc[r][c][v] + addv[v]) * p.out_scale;
             }
         }
     }
@@ -615,9 +641,17 @@ const char *igemm_variant_name(const GemmParams &p, int batch_z) {
         if (big_variant() == 2 && (long long)((p.M + 255) / 256) * ((p.N + bn - 1) / bn) * batch_z >= 512) { bm = 256; wmm = 4; wnn = 2; }
         else if (big_variant() != 1) { wmm = 2; wnn = 4; }
     }
+    if (bm == 128 && bn == 64 && !getenv("GDDIM_IGEMM_SMALL4")) { wmm = 4; wnn = 2; }
     if (fast_ok(p)) snprintf(buf, sizeof buf, "igemm_f32_fast_kernel<%d,%d,%d,%d,%s>", bm, bn, wmm, wnn, p.b_kmajor ? "true" : "false");
     else snprintf(buf, sizeof buf, "igemm_f32_kernel<%d,%d,%d,%d,%s,%s>", bm, bn, wmm, wnn, p.b_kmajor ? "true" : "false", p.in_act ? "true" : "false");
     return buf;
+}
+
+static void fill_div(unsigned d, unsigned &magic, unsigned &shift) {
+    unsigned s = 0;
+    while ((1ull << s) < d) ++s;
+    shift = s;
+    magic = (unsigned)((((1ull << 32) * ((1ull << s) - d)) / d) + 1);
 }
 
 // Eligibility of the VALU-free fast path (see igemm_f32_fast_kernel).  GDDIM_IGEMM_NOFAST=1 forces the generic kernel.
@@ -626,6 +660,8 @@ static bool fast_ok(const GemmParams &p) {
     if (off || p.in_act) return false;
     const int Cin = p.C0 + p.C1;
     if (Cin % 32 != 0 || (p.C1 > 0 && p.C0 % 32 != 0) || p.KH * p.KW > 32 || p.K % 32 != 0) return false;
+    if (p.rowbias && p.rows_per_image % 8 != 0) return false;
+    if ((long long)p.M * p.ldc * 4 + 64 >= (1LL << 31) || (p.res && (long long)p.M * p.ldres * 4 + 64 >= (1LL << 31))) return false;
     const long long ldmax = p.lda0 > p.lda1 ? p.lda0 : p.lda1;
     const long long imgs = (p.M + (long long)p.OH * p.OW - 1) / ((long long)p.OH * p.OW);
     const long long bias = ((long long)p.pad * p.W + p.pad) * ldmax * 4 + 64;
@@ -678,6 +714,11 @@ int launch_igemm(const GemmParams &p_in, int batch_z, hipStream_t s) {
         const long long b_elems = (long long)(p.b_kmajor ? p.K : p.N) * p.ldb;
         GD_CHECK(a_elems < (1LL << 31) && b_elems < (1LL << 31), "igemm: operand larger than 2^31 elements per z-slice");
     }
+    static const int diag = getenv("GDDIM_IGEMM_DIAG") ? atoi(getenv("GDDIM_IGEMM_DIAG")) : 0;
+    p.diag = diag;
+    fill_div((unsigned)(p.OH * p.OW), p.mg_ohw, p.sh_ohw);
+    fill_div((unsigned)p.OW, p.mg_ow, p.sh_ow);
+    fill_div((unsigned)(p.rows_per_image > 0 ? p.rows_per_image : 1), p.mg_rpi, p.sh_rpi);
     if (!p.zeros) p.zeros = igemm_zero_buffer();
     GD_CHECK(p.zeros != nullptr, "igemm: cannot allocate the zero buffer");
     int bm, bn;
@@ -693,7 +734,8 @@ int launch_igemm(const GemmParams &p_in, int batch_z, hipStream_t s) {
         if (big_variant() == 1) launch_variant<128, 128, 2, 2>(p, dim3(gx, 1, batch_z), s);
         else launch_variant<128, 128, 2, 4>(p, dim3(gx, 1, batch_z), s);
     } else if (bm == 128) {
-        launch_variant<128, 64, 2, 2>(p, dim3(gx, 1, batch_z), s);
+        if (getenv("GDDIM_IGEMM_SMALL4")) launch_variant<128, 64, 2, 2>(p, dim3(gx, 1, batch_z), s);
+        else launch_variant<128, 64, 4, 2>(p, dim3(gx, 1, batch_z), s);
     } else {
         launch_variant<64, 64, 2, 2>(p, dim3(gx, 1, batch_z), s);
     }

@@ -199,20 +199,34 @@ int Plan::attn(int idx, int x, int H, int W, int C) {
     const int HW = H * W;
     const float scale = desc.skip_rescale ? (float)(1.0 / std::sqrt(2.0)) : 1.f;
     int hn = gn(n + ".gn", n + "/GroupNorm_0", x, C, -1, 0, H, W, 0);
-    // q, k, v = NIN_0..2(h) as one GEMM with N = 3C
+    // q, k = NIN_0..1(h) as one GEMM with N = 2C.  v is produced directly TRANSPOSED per image, V^T[c][token] =
+    // sum_k W_v[c][k] h[token][k], so that the PV product below reads both operands k-contiguous; its bias moves to the
+    // PV epilogue (softmax rows sum to one: P (V + 1 b^T) = P V + b^T).
     int wq = new_slot(n + "/qkv_W", 3 * C, C), bq = new_slot(n + "/qkv_b", 1, 3 * C);
     for (int i = 0; i < 3; ++i) {
         add_param(n + "/NIN_" + std::to_string(i) + "/W", {C, C}, P_DENSE, wq, (long long)i * C);
         add_param(n + "/NIN_" + std::to_string(i) + "/b", {C}, P_VEC, bq, (long long)i * C);
     }
-    int qkv = new_tensor(n + ".qkv", H, W, 3 * C);
+    int qk = new_tensor(n + ".qk", H, W, 2 * C);
     {
         Op g;
-        g.kind = OP_GEMM; g.label = n + ".qkv";
+        g.kind = OP_GEMM; g.label = n + ".qk_proj";
         g.a0 = {hn, 0}; g.C0 = C; g.lda0 = C; g.H = H; g.W = W; g.OH = H; g.OW = W;
-        g.m_per_image = HW; g.N = 3 * C; g.K = C; g.w_slot = wq; g.ldb = C; g.bias_slot = bq;
-        g.out = {qkv, 0}; g.ldc = 3 * C;
-        g.flops_per_image = 2.0 * HW * 3 * C * C;
+        g.m_per_image = HW; g.N = 2 * C; g.K = C; g.w_slot = wq; g.ldb = C; g.bias_slot = bq;
+        g.out = {qk, 0}; g.ldc = 2 * C;
+        g.flops_per_image = 2.0 * HW * 2 * C * C;
+        ops.push_back(g);
+    }
+    int vT = new_tensor(n + ".vT", 1, 1, 1, EXT_NONE, (long long)C * HW);
+    {
+        Op g;
+        g.kind = OP_GEMM; g.label = n + ".v_proj_T";
+        g.a_slot = wq; g.a_off = 2LL * C * C; g.C0 = C; g.lda0 = C; g.H = 1; g.W = C; g.OH = 1; g.OW = C;
+        g.m_per_image = C; g.z_per_image = 1; g.N = HW; g.K = C;
+        g.bten = {hn, 0}; g.ldb = C; g.b_kmajor = 0;
+        g.sA = 0; g.sB = (long long)HW * C; g.sC = (long long)C * HW;
+        g.out = {vT, 0}; g.ldc = HW;
+        g.flops_per_image = 2.0 * HW * C * C;
         ops.push_back(g);
     }
     release(hn);
@@ -221,10 +235,10 @@ int Plan::attn(int idx, int x, int H, int W, int C) {
     {
         Op g;
         g.kind = OP_GEMM; g.label = n + ".qk";
-        g.a0 = {qkv, 0}; g.C0 = C; g.lda0 = 3 * C; g.H = 1; g.W = HW; g.OH = 1; g.OW = HW;
+        g.a0 = {qk, 0}; g.C0 = C; g.lda0 = 2 * C; g.H = 1; g.W = HW; g.OH = 1; g.OW = HW;
         g.m_per_image = HW; g.z_per_image = 1; g.N = HW; g.K = C;
-        g.bten = {qkv, C}; g.ldb = 3 * C; g.b_kmajor = 0;
-        g.sA = (long long)HW * 3 * C; g.sB = g.sA; g.sC = (long long)HW * HW;
+        g.bten = {qk, C}; g.ldb = 2 * C; g.b_kmajor = 0;
+        g.sA = (long long)HW * 2 * C; g.sB = g.sA; g.sC = (long long)HW * HW;
         g.out = {S, 0}; g.ldc = HW; g.alpha = (float)std::pow((double)C, -0.5);
         g.flops_per_image = 2.0 * HW * HW * C;
         ops.push_back(g);
@@ -232,21 +246,23 @@ int Plan::attn(int idx, int x, int H, int W, int C) {
         sm.kind = OP_SOFTMAX; sm.label = n + ".softmax"; sm.out = {S, 0}; sm.rows_per_image = HW; sm.cols = HW;
         ops.push_back(sm);
     }
-    // h = w v
+    release(qk);
+    // h = w v (+ b_v)
     int ho = new_tensor(n + ".av", H, W, C);
     {
         Op g;
         g.kind = OP_GEMM; g.label = n + ".av";
         g.a0 = {S, 0}; g.C0 = HW; g.lda0 = HW; g.H = 1; g.W = HW; g.OH = 1; g.OW = HW;
         g.m_per_image = HW; g.z_per_image = 1; g.N = C; g.K = HW;
-        g.bten = {qkv, 2 * C}; g.ldb = 3 * C; g.b_kmajor = 1;
-        g.sA = (long long)HW * HW; g.sB = (long long)HW * 3 * C; g.sC = (long long)HW * C;
+        g.bten = {vT, 0}; g.ldb = HW; g.b_kmajor = 0;
+        g.sA = (long long)HW * HW; g.sB = (long long)C * HW; g.sC = (long long)HW * C;
+        g.bias_slot = bq; g.bias_off = 2 * C;
         g.out = {ho, 0}; g.ldc = C;
         g.flops_per_image = 2.0 * HW * HW * C;
         ops.push_back(g);
     }
     release(S);
-    release(qkv);
+    release(vT);
     // (x + NIN_3(h)) / sqrt(2)
     int wo = new_slot(n + "/NIN_3/W", C, C), bo = new_slot(n + "/NIN_3/b", 1, C);
     add_param(n + "/NIN_3/W", {C, C}, P_DENSE, wo, 0);
@@ -554,7 +570,7 @@ std::string Plan::json() const {
         o << "\"C0\":" << p.C0 << ",\"C1\":" << p.C1 << ",\"lda0\":" << p.lda0 << ",\"lda1\":" << p.lda1 << ",\"H\":" << p.H
           << ",\"W\":" << p.W << ",\"OH\":" << p.OH << ",\"OW\":" << p.OW << ",\"KH\":" << p.KH << ",\"KW\":" << p.KW
           << ",\"stride\":" << p.stride << ",\"pad\":" << p.pad << ",\"m_per_image\":" << p.m_per_image
-          << ",\"z_per_image\":" << p.z_per_image << ",\"N\":" << p.N << ",\"K\":" << p.K << ",\"w_slot\":" << p.w_slot
+          << ",\"z_per_image\":" << p.z_per_image << ",\"N\":" << p.N << ",\"K\":" << p.K << ",\"a_slot\":" << p.a_slot << ",\"a_off\":" << p.a_off << ",\"w_slot\":" << p.w_slot
           << ",\"ldb\":" << p.ldb << ",\"b_kmajor\":" << p.b_kmajor << ",\"sA\":" << p.sA << ",\"sB\":" << p.sB
           << ",\"sC\":" << p.sC << ",\"bias_slot\":" << p.bias_slot << ",\"bias_off\":" << p.bias_off
           << ",\"ld_rowbias\":" << p.ld_rowbias << ",\"ldres\":" << p.ldres << ",\"ldc\":" << p.ldc << ",\"alpha\":" << p.alpha

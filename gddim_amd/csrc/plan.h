@@ -50,6 +50,8 @@ struct Op {
     int m_per_image = 1;  // rows contributed by one image
     int z_per_image = 0;  // 1: blockIdx.z = image, M = m_per_image (attention matmuls)
     int N = 0, K = 0;
+    int a_slot = -1;      // A rows from a weight slot instead of a tensor (V^T = W_v h^T in attention)
+    long long a_off = 0;  // float offset into that slot
     int w_slot = -1;      // B from a weight slot ([N][K] row-major) ...
     TRef bten;            // ... or from a tensor
     int ldb = 0, b_kmajor = 0;

@@ -93,7 +93,10 @@ class PlanInterp(object):
             o = dict(op)
             if op["z_per_image"]:
                 # shift base pointers by z * stride by slicing flats
-                a0 = self._flat(op["a0"], B)[z * op["sA"]:]
+                if op.get("a_slot", -1) >= 0:
+                    a0 = self.slots[op["a_slot"]].reshape(-1)[op["a_off"]:]
+                else:
+                    a0 = self._flat(op["a0"], B)[z * op["sA"]:]
                 H, W = op["H"], op["W"]
                 x = self._rows(a0, H * W, op["lda0"], op["C0"]).reshape(1, H, W, op["C0"])
                 A = x.reshape(Mz, K)
@@ -103,7 +106,8 @@ class PlanInterp(object):
                 bflat = None if op["w_slot"] >= 0 else self._flat(op["bten"], B)
             if op["w_slot"] >= 0:
                 Bm = self.slots[op["w_slot"]]
-                assert Bm.shape == (N, K), (op["label"], Bm.shape, N, K)
+                assert Bm.shape[0] >= N and Bm.shape[1] == K, (op["label"], Bm.shape, N, K)
+                Bm = Bm[:N]  # a GEMM may use the leading rows of a shared slot (q,k of the qkv slot)
             elif op["b_kmajor"]:
                 Bm = self._rows(bflat, K, op["ldb"], N).t()
             else:

@@ -7,6 +7,7 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
+KSWEEP = [(32, c, 128, 3, 0) for c in (32, 64, 128, 256, 384)] + [(16, c, 256, 3, 0) for c in (64, 128, 256, 512)]
 SHAPES = [  # H, Cin, Cout, k, count per U-Net eval
     (32, 128, 128, 3, 25), (32, 256, 128, 3, 8), (32, 256, 256, 3, 2), (32, 384, 128, 3, 1),
     (16, 256, 256, 3, 26), (16, 512, 256, 3, 8), (16, 384, 256, 3, 1),
@@ -20,12 +21,13 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--only", type=int, default=-1, help="index into SHAPES")
+    ap.add_argument("--ksweep", action="store_true")
     args = ap.parse_args()
     import torch
     from gddim_amd import ops
     dev = torch.device("cuda", 0)
     tot_ms, tot_fl = 0.0, 0.0
-    for H, Cin, Cout, k, cnt in (SHAPES if args.only < 0 else [SHAPES[args.only]]):
+    for H, Cin, Cout, k, cnt in (KSWEEP if args.ksweep else (SHAPES if args.only < 0 else [SHAPES[args.only]])):
         x = torch.randn(args.batch, H, H, Cin, device=dev)
         w = torch.randn(Cout, k * k * Cin, device=dev) / (k * k * Cin) ** 0.5
         b = torch.randn(Cout, device=dev)
