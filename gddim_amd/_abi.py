@@ -62,6 +62,7 @@ SIGNATURES = {
     "gd_engine_load_param": (_I, [_P, ctypes.c_char_p, _P, ctypes.POINTER(ctypes.c_int64), _I]),
     "gd_engine_params_ready": (_I, [_P]),
     "gd_engine_packed_weight": (_I, [_P, ctypes.c_char_p, _P, _SZ, ctypes.POINTER(_SZ)]),
+    "gd_engine_set_precision": (_I, [_P, _I]),
     "gd_unet_forward": (_I, [_P, _P, _P, _P, _I, _P]),
     "gd_cld_eps": (_I, [_P, _P, _P, _P, _I, _P]),
     "gd_engine_set_schedule_cld": (_I, [_P, _I, _I, _P, _P, _I, _F, _P, _P, _P]),

@@ -69,10 +69,17 @@ struct GemmParams {
     // magic numbers for division by OH*OW, OW and rows_per_image (filled in by launch_igemm)
     unsigned mg_ohw, sh_ohw, mg_ow, sh_ow, mg_rpi, sh_rpi;
     int diag;  // diagnostic ablations of the fast kernel (never set by the product path)
+    // bf16x3 path: the weights split as bf16 hi / lo arrays, same [N][ldb] indexing as b (null on the fp32 path)
+    const unsigned short *b_hi;
+    const unsigned short *b_lo;
 };
 
 int launch_igemm(const GemmParams &p, int batch_z, hipStream_t s);
 const char *igemm_variant_name(const GemmParams &p, int batch_z);
+// split-precision (bf16x3) variant for weight GEMMs (kernels/igemm_bf16x3.hip)
+bool igemm_bf16x3_ok(const GemmParams &p, int batch_z);
+const char *igemm_bf16x3_name(const GemmParams &p);
+int launch_igemm_bf16x3(const GemmParams &p, hipStream_t s);
 // per-device zero buffer used by the staging loads; allocates on first use (call once outside graph capture)
 const float *igemm_zero_buffer();
 

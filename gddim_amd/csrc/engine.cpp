@@ -51,6 +51,10 @@ struct gd_engine {
     // device memory
     float *arena = nullptr;
     float *wbuf = nullptr;
+    // precision mode: 0 = exact fp32 MFMA (default), 1 = bf16x3 split precision for the weight GEMMs
+    int precision = 0;
+    unsigned short *wsplit_hi = nullptr, *wsplit_lo = nullptr;  // bf16 hi / lo of wbuf, same element offsets
+    bool wsplit_valid = false;
     std::vector<long long> slot_off;  // floats into wbuf
     long long wbuf_floats = 0;
     float *xin = nullptr, *epsb = nullptr, *labels = nullptr, *eps_planar = nullptr;
@@ -130,8 +134,19 @@ struct ProfScope {
     }
 };
 
+// GD_PROF_BY_LABEL=1: profile entries are keyed by the op's plan label with digits removed (e.g. "AttnBlockpp_.qk")
+static std::string label_class(const Op &op) {
+    std::string r;
+    for (char c : op.label)
+        if (c < '0' || c > '9') r += c;
+    char buf[64];
+    snprintf(buf, sizeof buf, "@%dx%d:%d>%d", op.H, op.W, op.C0 + op.C1, op.N);
+    return r + buf;
+}
+
 static int run_op(gd_engine *e, const Op &op, const Bind &b, int batch, hipStream_t s) {
     const Plan &P = e->plan;
+    static const bool by_label = getenv("GD_PROF_BY_LABEL") != nullptr;
     switch (op.kind) {
         case OP_FOURIER: {
             ProfScope ps(e, s, "fourier", 0, 0);
@@ -156,7 +171,16 @@ static int run_op(gd_engine *e, const Op &op, const Bind &b, int batch, hipStrea
             g.rowbias = tptr(e, b, op.rowbias, batch); g.ld_rowbias = op.ld_rowbias; g.rows_per_image = op.m_per_image;
             g.res = tptr(e, b, op.res, batch); g.ldres = op.ldres;
             g.alpha = op.alpha; g.out_scale = op.out_scale; g.in_act = op.in_act;
-            ProfScope ps(e, s, e->prof ? igemm_variant_name(g, z) : "", op.flops_per_image * batch, 0);
+            if (e->precision == 1 && op.w_slot >= 0 && e->wsplit_valid) {
+                g.b_hi = e->wsplit_hi + e->slot_off[op.w_slot];
+                g.b_lo = e->wsplit_lo + e->slot_off[op.w_slot];
+                if (igemm_bf16x3_ok(g, z)) {
+                    ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(igemm_bf16x3_name(g)), op.flops_per_image * batch, 0);
+                    return launch_igemm_bf16x3(g, s);
+                }
+                g.b_hi = g.b_lo = nullptr;
+            }
+            ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(igemm_variant_name(g, z)), op.flops_per_image * batch, 0);
             return launch_igemm(g, z, s);
         }
         case OP_GN_STATS: {
@@ -265,6 +289,7 @@ int gd_engine_create(const gd_model_desc *desc, int device, gd_engine **out) {
         GD_ALLOC(e->step_dev, gd_engine::MAX_LANES);
 #undef GD_ALLOC
         (void)hipMemset(e->step_dev, 0, sizeof(int) * gd_engine::MAX_LANES);
+        if (const char *pm = getenv("GDDIM_PRECISION")) e->precision = (strcmp(pm, "bf16x3") == 0) ? 1 : 0;
         if (const char *ln = getenv("GD_LANES")) e->lanes = std::max(1, std::min((int)gd_engine::MAX_LANES, atoi(ln)));
         if (!igemm_zero_buffer()) return fail("zero buffer", hipErrorOutOfMemory);  // never allocate inside a graph capture
         if ((err = hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming)) != hipSuccess) return fail("hipEventCreate", err);
@@ -284,6 +309,8 @@ int gd_engine_destroy(gd_engine *e) {
         (void)hipDeviceSynchronize();
         drop_graphs(e);
         for (auto &p : e->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+        if (e->wsplit_hi) (void)hipFree(e->wsplit_hi);
+        if (e->wsplit_lo) (void)hipFree(e->wsplit_lo);
         float *bufs[] = {e->arena, e->wbuf, e->xin, e->epsb, e->eps_planar, e->labels, e->u8, e->ring, e->ystate,
                          e->ts_dev, e->coef_dev, e->dn_dev, e->mean_dev, e->std_dev, (float *)e->step_dev};
         for (float *b : bufs)
@@ -327,7 +354,57 @@ int gd_engine_param_info(gd_engine *e, int index, char *name_buf, size_t name_ca
 int gd_engine_load_param(gd_engine *e, const char *name, const float *host_data, const int64_t *shape, int ndim) {
     GD_CHECK(e && name && host_data && shape, "null argument");
     e->params_uploaded = false;
+    e->wsplit_valid = false;
     return e->plan.load_param(name, host_data, shape, ndim);
+}
+
+static inline unsigned short f32_to_bf16_rne(float x) {
+    unsigned u;
+    memcpy(&u, &x, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);  // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+
+// hi = bf16_rne(w), lo = bf16_rne(w - hi) for every packed weight; uploaded next to the fp32 copy
+static int upload_split_weights(gd_engine *e) {
+    GD_HIP(hipSetDevice(e->device));
+    if (!e->wsplit_hi) {
+        GD_HIP(hipMalloc((void **)&e->wsplit_hi, (size_t)e->wbuf_floats * 2));
+        GD_HIP(hipMalloc((void **)&e->wsplit_lo, (size_t)e->wbuf_floats * 2));
+    }
+    std::vector<unsigned short> hi, lo;
+    for (size_t i = 0; i < e->plan.slots.size(); ++i) {
+        const WSlot &sl = e->plan.slots[i];
+        hi.resize(sl.host.size());
+        lo.resize(sl.host.size());
+        for (size_t k = 0; k < sl.host.size(); ++k) {
+            const float w = sl.host[k];
+            const unsigned short h = f32_to_bf16_rne(w);
+            const unsigned hb = (unsigned)h << 16;
+            float hf;
+            memcpy(&hf, &hb, 4);
+            hi[k] = h;
+            lo[k] = f32_to_bf16_rne(w - hf);
+        }
+        GD_HIP(hipMemcpy(e->wsplit_hi + e->slot_off[i], hi.data(), hi.size() * 2, hipMemcpyHostToDevice));
+        GD_HIP(hipMemcpy(e->wsplit_lo + e->slot_off[i], lo.data(), lo.size() * 2, hipMemcpyHostToDevice));
+    }
+    e->wsplit_valid = true;
+    return 0;
+}
+
+int gd_engine_set_precision(gd_engine *e, int mode) {
+    GD_CHECK(e, "null engine");
+    GD_CHECK(mode == 0 || mode == 1, "unknown precision mode %d (0 = fp32, 1 = bf16x3)", mode);
+    if (!e->plan_only) {
+        GD_HIP(hipSetDevice(e->device));
+        GD_HIP(hipDeviceSynchronize());
+        drop_graphs(e);  // captured graphs bake the kernel choice
+        if (mode == 1 && e->params_uploaded && !e->wsplit_valid) GD_TRY(upload_split_weights(e));
+    }
+    e->precision = mode;
+    return 0;
 }
 
 int gd_engine_params_ready(gd_engine *e) {
@@ -347,6 +424,8 @@ int gd_engine_params_ready(gd_engine *e) {
             GD_HIP(hipMemcpy(e->wbuf + e->slot_off[i], s.host.data(), s.host.size() * sizeof(float), hipMemcpyHostToDevice));
         }
         e->params_uploaded = true;
+        e->wsplit_valid = false;
+        if (e->precision == 1) GD_TRY(upload_split_weights(e));
     }
     return 0;
 }

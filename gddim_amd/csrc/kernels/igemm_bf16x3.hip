@@ -1,0 +1,352 @@
+// Split-precision implicit GEMM on the gfx950 bf16 matrix core ("bf16x3"), opt-in via gd_engine_set_precision.
+//
+// Every fp32 operand is written as hi + lo with hi = bf16_rne(x), lo = bf16_rne(x - hi) (|x - hi - lo| <= 2^-16 |x|) and the
+// product is accumulated in fp32 as   a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi   -- three v_mfma_f32_32x32x16_bf16 per k16
+// step; the dropped a_lo*b_lo term is ~2^-16 relative.  On the NCSN++ forward and through a 20-step sampler the result is as
+// close to float64 as the plain fp32 path is (DESIGN.md "precision"), while the bf16 matrix core is 16x faster than the fp32
+// MFMA, so the contraction costs 3/16 of the fp32 one and, unlike the fp32 MFMA, co-executes with VALU work.
+//
+// Same implicit-im2col addressing as igemm_f32_fast_kernel (per-row byte offsets + tap-validity bit masks, scalar tap/channel
+// displacement in the buffer-load soffset, zero padding by the descriptor bounds check, 32-channel slab outermost / taps
+// innermost), same double-buffered software pipeline (loads two chunks ahead, staging pieces between MFMA groups) and the same
+// buffer-addressed epilogue.  Differences:
+//   * A (activations, fp32 in HBM) is split into bf16 hi/lo when the staged registers are written to LDS (12 VALU per float4);
+//   * B (weights) is split once on the host into two bf16 arrays [N][K];
+//   * LDS holds four bf16 tiles per stage (A_hi, A_lo, B_hi, B_lo), rows padded from 64 to 80 bytes so that the 16-byte
+//     fragment reads of a 16-lane group land on 16 distinct 16-byte slots (5*i mod 16) -- conflict free.
+// Weight GEMMs only (convolutions, NIN, dense); the attention QK^T / PV products and the generic-path layers stay on the fp32
+// kernels.
+#include <cstdio>
+#include <cstdlib>
+
+#include "../common.h"
+
+namespace gd {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int XKC = 32;   // K chunk (two k16 MFMA steps)
+constexpr int XLD = 40;   // LDS row stride in bf16 elements: 64 B of data + 16 B pad = 80 B
+
+__device__ __forceinline__ unsigned xfast_div(unsigned n, unsigned d, unsigned magic, unsigned shift) {
+    if (d == 1) return n;
+    const unsigned t = __umulhi(magic, n);
+    return (t + ((n - t) >> 1)) >> (shift - 1);
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void igemm_bf16x3_kernel(const GemmParams p) {
+    constexpr int NT = 64 * WM * WN;
+    constexpr int RM = BM / (32 * WM), RN = BN / (32 * WN);
+    constexpr int RPP = NT / 8;          // A rows staged per pass (8 threads x 16 B of fp32 per row)
+    constexpr int AJ = BM / RPP;         // fp32 float4 staged per thread for A
+    constexpr int BRP = NT / 4;          // B rows staged per pass (4 threads x 16 B of bf16 per row)
+    constexpr int BJ = (BN + BRP - 1) / BRP;
+    constexpr int NP = AJ + BJ;          // staging pieces per chunk (a B piece carries hi and lo)
+    constexpr int NG = 6;                // MFMA groups per chunk: 2 k16 steps x 3 product terms
+    constexpr int STAGE = (2 * BM + 2 * BN) * XLD;  // bf16 elements per LDS stage
+    constexpr int OOB = (int)0x80000000u;
+    static_assert(BM % RPP == 0 && RM >= 1 && RN >= 1 && NP <= NG, "bad tile geometry");
+    __shared__ __attribute__((aligned(16))) __bf16 smem[2 * STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+
+    const int nt = p.n_tiles;
+    const int id = blockIdx.x;
+    const int grp = id / (8 * nt);
+    const int rem = id - grp * 8 * nt;
+    const int ntile = rem >> 3;
+    const int mtile = grp * 8 + (rem & 7);
+    if (mtile >= p.m_tiles) return;
+    const int m0 = mtile * BM, n0 = ntile * BN;
+
+    const int Cin = p.C0 + p.C1;
+    const int taps = p.KH * p.KW;
+    const int a_imgs = (p.M + p.OH * p.OW - 1) / (p.OH * p.OW);
+    const int bias0 = (p.pad * p.W + p.pad) * p.lda0 * 4;
+    const int bias1 = (p.pad * p.W + p.pad) * p.lda1 * 4;
+    const char *a0c = reinterpret_cast<const char *>(p.a0);
+    const __amdgpu_buffer_rsrc_t srd_a0 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(a0c - bias0), 0, a_imgs * p.H * p.W * p.lda0 * 4 + bias0, 0x00020000);
+    const char *a1c = reinterpret_cast<const char *>(p.C1 ? p.a1 : p.a0);
+    const __amdgpu_buffer_rsrc_t srd_a1 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(a1c - bias1), 0, a_imgs * p.H * p.W * p.lda1 * 4 + bias1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srd_bh = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(reinterpret_cast<const char *>(p.b_hi)), 0, p.N * p.ldb * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srd_bl = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(reinterpret_cast<const char *>(p.b_lo)), 0, p.N * p.ldb * 2, 0x00020000);
+
+    // ---- per-thread, loop-invariant row data (identical to igemm_f32_fast_kernel) ----
+    const int arow = tid >> 3;
+    const int kcol = (tid & 7) * 4;
+    int rb0[AJ], rb1[AJ];
+    unsigned inv[AJ];
+    {
+        const unsigned OHW = p.OH * p.OW;
+        const unsigned rowbits = (1u << p.KW) - 1u;
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) {
+            const int m = m0 + arow + RPP * j;
+            rb0[j] = 0; rb1[j] = 0; inv[j] = 0xFFFFFFFFu;
+            if (m < p.M) {
+                const int img = (int)xfast_div((unsigned)m, OHW, p.mg_ohw, p.sh_ohw);
+                const int r = m - img * (int)OHW;
+                const int oy = (int)xfast_div((unsigned)r, (unsigned)p.OW, p.mg_ow, p.sh_ow);
+                const int ox = r - oy * p.OW;
+                const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+                const int pix = (img * p.H + iy0) * p.W + ix0;
+                rb0[j] = pix * p.lda0 * 4 + bias0 + kcol * 4;
+                rb1[j] = pix * p.lda1 * 4 + bias1 + kcol * 4;
+                unsigned xb = 0;
+                for (int tx = 0; tx < p.KW; ++tx) xb |= ((unsigned)(ix0 + tx) < (unsigned)p.W ? 0u : 1u) << tx;
+                unsigned mk = 0;
+                for (int ty = 0; ty < p.KH; ++ty)
+                    mk |= ((unsigned)(iy0 + ty) < (unsigned)p.H ? xb : rowbits) << (ty * p.KW);
+                inv[j] = mk;
+            }
+        }
+    }
+    const int brow = tid >> 2;        // B row inside a pass
+    const int bq = (tid & 3) * 8;     // bf16 offset inside the 32-wide chunk (16 B)
+    int bvo[BJ];
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) {
+        const int nl = brow + BRP * j;
+        const int n = n0 + nl;
+        bvo[j] = (nl < BN && n < p.N) ? (n * p.ldb + bq) * 2 : OOB;
+    }
+
+    int s_tap = 0, s_ty = 0, s_tx = 0, s_c0 = 0, s_kc = 0;
+    const int nk = p.K / XKC;
+    auto advance_k = [&]() {
+        ++s_kc;
+        ++s_tap;
+        if (++s_tx == p.KW) { s_tx = 0; ++s_ty; }
+        if (s_tap == taps) { s_tap = 0; s_ty = 0; s_tx = 0; s_c0 += XKC; }
+    };
+
+    f32x4 ra[AJ];
+    u32x4 rbh[BJ], rbl[BJ];
+
+    auto load_piece = [&](int pc) {
+        if (pc < AJ) {
+            const int j = pc;
+            const int bad = __builtin_amdgcn_sbfe(inv[j], s_tap < 32 ? s_tap : 31, 1) | (s_kc < nk ? 0 : -1);
+            if (s_c0 < p.C0) {
+                const int soff = ((s_ty * p.W + s_tx) * p.lda0 + s_c0) * 4;
+                ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_a0, rb0[j] | (bad & OOB), soff, 0));
+            } else {
+                const int soff = ((s_ty * p.W + s_tx) * p.lda1 + (s_c0 - p.C0)) * 4;
+                ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_a1, rb1[j] | (bad & OOB), soff, 0));
+            }
+        } else {
+            const int j = pc - AJ;
+            const int soff = (s_tap * Cin + s_c0) * 2;
+            const int vo = s_kc < nk ? bvo[j] : OOB;
+            rbh[j] = __builtin_amdgcn_raw_buffer_load_b128(srd_bh, vo, soff, 0);
+            rbl[j] = __builtin_amdgcn_raw_buffer_load_b128(srd_bl, vo, soff, 0);
+        }
+    };
+    // stage layout (bf16 elements): A_hi [BM][XLD] | A_lo [BM][XLD] | B_hi [BN][XLD] | B_lo [BN][XLD]
+    auto store_piece = [&](int pc, __bf16 *st) {
+        if (pc < AJ) {
+            const f32x4 v = ra[pc];
+            bf16x4 h, l;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                h[i] = (__bf16)v[i];
+                l[i] = (__bf16)(v[i] - (float)h[i]);
+            }
+            const int o = (arow + RPP * pc) * XLD + kcol;
+            *reinterpret_cast<bf16x4 *>(st + o) = h;
+            *reinterpret_cast<bf16x4 *>(st + BM * XLD + o) = l;
+        } else {
+            const int j = pc - AJ;
+            const int nl = brow + BRP * j;
+            if (nl < BN) {
+                const int o = 2 * BM * XLD + nl * XLD + bq;
+                *reinterpret_cast<u32x4 *>(st + o) = rbh[j];
+                *reinterpret_cast<u32x4 *>(st + BN * XLD + o) = rbl[j];
+            }
+        }
+    };
+
+    f32x16 acc[RM][RN];
+#pragma unroll
+    for (int r = 0; r < RM; ++r)
+#pragma unroll
+        for (int c = 0; c < RN; ++c)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[r][c][v] = 0.f;
+
+    const int li = lane & 31, lh = lane >> 5;
+    const int a_off = (wm * (BM / WM) + li) * XLD + lh * 8;
+    const int b_off = 2 * BM * XLD + (wn * (BN / WN) + li) * XLD + lh * 8;
+
+#pragma unroll
+    for (int pc = 0; pc < NP; ++pc) load_piece(pc);
+    advance_k();
+#pragma unroll
+    for (int pc = 0; pc < NP; ++pc) store_piece(pc, smem);
+#pragma unroll
+    for (int pc = 0; pc < NP; ++pc) load_piece(pc);
+    advance_k();
+    __syncthreads();
+
+    for (int kc = 0; kc < nk; ++kc) {
+        const __bf16 *cur = smem + (kc & 1) * STAGE;
+        __bf16 *nxt = smem + ((kc + 1) & 1) * STAGE;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 ah[RM], al[RM], bh[RN], bl[RN];
+#pragma unroll
+            for (int r = 0; r < RM; ++r) {
+                ah[r] = *reinterpret_cast<const bf16x8 *>(cur + a_off + r * 32 * XLD + s * 16);
+                al[r] = *reinterpret_cast<const bf16x8 *>(cur + BM * XLD + a_off + r * 32 * XLD + s * 16);
+            }
+#pragma unroll
+            for (int c = 0; c < RN; ++c) {
+                bh[c] = *reinterpret_cast<const bf16x8 *>(cur + b_off + c * 32 * XLD + s * 16);
+                bl[c] = *reinterpret_cast<const bf16x8 *>(cur + BN * XLD + b_off + c * 32 * XLD + s * 16);
+            }
+#pragma unroll
+            for (int term = 0; term < 3; ++term) {
+#pragma unroll
+                for (int r = 0; r < RM; ++r)
+#pragma unroll
+                    for (int c = 0; c < RN; ++c) {
+                        const bf16x8 a = term == 2 ? al[r] : ah[r];
+                        const bf16x8 b = term == 1 ? bl[c] : bh[c];
+                        acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[r][c], 0, 0, 0);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+                const int gap = s * 3 + term;
+                if (gap < NP) {
+                    store_piece(gap, nxt);
+                    load_piece(gap);
+                } else if (gap == NP) {
+                    advance_k();
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (NP == NG) advance_k();
+        __syncthreads();
+    }
+
+    // ---- epilogue (buffer addressed, as igemm_f32_fast_kernel) ----
+    {
+        char *outc = reinterpret_cast<char *>(p.out);
+        const __amdgpu_buffer_rsrc_t srd_o = __builtin_amdgcn_make_buffer_rsrc(outc, 0, p.M * p.ldc * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t srd_r =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(reinterpret_cast<const char *>(p.res ? p.res : p.out)), 0,
+                                              p.M * p.ldres * 4, 0x00020000);
+        const unsigned rpi = p.rows_per_image;
+#pragma unroll
+        for (int c = 0; c < RN; ++c) {
+            const int n = n0 + wn * (BN / WN) + c * 32 + li;
+            const bool nok = n < p.N;
+            const float bias = (p.bias && nok) ? p.bias[n] : 0.f;
+            const int vo_o = nok ? (4 * lh * p.ldc + n) * 4 : OOB;
+            const int vo_r = nok ? (4 * lh * p.ldres + n) * 4 : OOB;
+#pragma unroll
+            for (int r = 0; r < RM; ++r) {
+                const int mrow = m0 + wm * (BM / WM) + r * 32;
+                float addv[16];
+#pragma unroll
+                for (int v = 0; v < 16; ++v) addv[v] = bias;
+                if (p.res) {
+                    float t[16];
+#pragma unroll
+                    for (int v = 0; v < 16; ++v)
+                        t[v] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_r, vo_r, (mrow + (v & 3) + 8 * (v >> 2)) * p.ldres * 4, 0));
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) addv[v] += t[v];
+                }
+                if (p.rowbias) {
+                    float t[16];
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) {
+                        const unsigned mr = (unsigned)(mrow + (v & 3) + 8 * (v >> 2));
+                        const unsigned img = mr < (unsigned)p.M ? xfast_div(mr, rpi, p.mg_rpi, p.sh_rpi) : 0u;
+                        t[v] = nok ? p.rowbias[(size_t)img * p.ld_rowbias + n] : 0.f;
+                    }
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) addv[v] += t[v];
+                }
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const float val = (p.alpha * acc[r][c][v] + addv[v]) * p.out_scale;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), srd_o, vo_o,
+                                                          (mrow + (v & 3) + 8 * (v >> 2)) * p.ldc * 4, 0);
+                }
+            }
+        }
+    }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------------
+bool igemm_bf16x3_ok(const GemmParams &p, int batch_z) {
+    if (batch_z != 1 || p.b_kmajor || p.in_act || !p.b_hi || !p.b_lo) return false;
+    const int Cin = p.C0 + p.C1;
+    if (Cin % 32 != 0 || (p.C1 > 0 && p.C0 % 32 != 0) || p.KH * p.KW > 32 || p.K % 32 != 0 || p.ldb % 8 != 0) return false;
+    if (p.rowbias && p.rows_per_image % 8 != 0) return false;
+    const long long ldmax = p.lda0 > p.lda1 ? p.lda0 : p.lda1;
+    const long long imgs = (p.M + (long long)p.OH * p.OW - 1) / ((long long)p.OH * p.OW);
+    const long long bias = ((long long)p.pad * p.W + p.pad) * ldmax * 4 + 64;
+    const long long a_bytes = imgs * p.H * p.W * ldmax * 4 + bias;
+    const long long soff_max = ((long long)(p.KH * p.W + p.KW) * ldmax + Cin) * 4;
+    if (a_bytes + soff_max >= (1LL << 31) || (long long)p.N * p.ldb * 2 + (long long)p.K * 2 >= (1LL << 31)) return false;
+    if ((long long)p.M * p.ldc * 4 + 64 >= (1LL << 31) || (p.res && (long long)p.M * p.ldres * 4 + 64 >= (1LL << 31))) return false;
+    return true;
+}
+
+static void xpick(const GemmParams &p, int &bm, int &bn) {
+    auto blocks = [&](int BM_, int BN_) { return (long long)((p.M + BM_ - 1) / BM_) * ((p.N + BN_ - 1) / BN_); };
+    if (p.N > 64 && blocks(256, 128) >= 256) { bm = 256; bn = 128; return; }
+    if (p.N > 64 && blocks(128, 128) >= 192) { bm = 128; bn = 128; return; }
+    bm = 64; bn = 64;
+}
+
+const char *igemm_bf16x3_name(const GemmParams &p) {
+    int bm, bn;
+    xpick(p, bm, bn);
+    if (bm == 256) return "igemm_bf16x3_kernel<256,128,4,2>";
+    if (bm == 128) return "igemm_bf16x3_kernel<128,128,2,4>";
+    return "igemm_bf16x3_kernel<64,64,2,2>";
+}
+
+static void xfill_div(unsigned d, unsigned &magic, unsigned &shift) {
+    unsigned s = 0;
+    while ((1ull << s) < d) ++s;
+    shift = s;
+    magic = (unsigned)((((1ull << 32) * ((1ull << s) - d)) / d) + 1);
+}
+
+int launch_igemm_bf16x3(const GemmParams &p_in, hipStream_t s) {
+    GemmParams p = p_in;
+    GD_CHECK(igemm_bf16x3_ok(p, 1), "igemm_bf16x3: problem not eligible");
+    xfill_div((unsigned)(p.OH * p.OW), p.mg_ohw, p.sh_ohw);
+    xfill_div((unsigned)p.OW, p.mg_ow, p.sh_ow);
+    xfill_div((unsigned)(p.rows_per_image > 0 ? p.rows_per_image : 1), p.mg_rpi, p.sh_rpi);
+    int bm, bn;
+    xpick(p, bm, bn);
+    p.m_tiles = (p.M + bm - 1) / bm;
+    p.n_tiles = (p.N + bn - 1) / bn;
+    const int gx = ((p.m_tiles + 7) / 8) * 8 * p.n_tiles;
+    if (bm == 256) hipLaunchKernelGGL((igemm_bf16x3_kernel<256, 128, 4, 2>), dim3(gx), dim3(512), 0, s, p);
+    else if (bm == 128) hipLaunchKernelGGL((igemm_bf16x3_kernel<128, 128, 2, 4>), dim3(gx), dim3(512), 0, s, p);
+    else hipLaunchKernelGGL((igemm_bf16x3_kernel<64, 64, 2, 2>), dim3(gx), dim3(256), 0, s, p);
+    GD_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace gd

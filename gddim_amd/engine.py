@@ -152,6 +152,13 @@ class Engine(object):
         self._schedule_token = None
         return self
 
+    def set_precision(self, mode):
+        """'fp32' (exact fp32 MFMA, default) or 'bf16x3' (split-precision weight contractions on the bf16 matrix core)."""
+        code = {"fp32": 0, "f32": 0, 0: 0, "bf16x3": 1, 1: 1}[mode]
+        check(self._lib.gd_engine_set_precision(self._h, code))
+        self._schedule_token = None
+        return self
+
     # ---- score network ----
     def unet(self, x, labels, out=None):
         """eps = NCSNpp(x, labels); x (B,H,W,in_channels) fp32 on this engine's GPU."""
@@ -223,7 +230,7 @@ class Engine(object):
 
     def profile_read(self):
         n = ctypes.c_int()
-        arr = (_abi.ProfEntry * 64)()
-        check(self._lib.gd_engine_profile_read(self._h, arr, 64, ctypes.byref(n)))
+        arr = (_abi.ProfEntry * 256)()
+        check(self._lib.gd_engine_profile_read(self._h, arr, 256, ctypes.byref(n)))
         return [{"name": arr[i].name.decode(), "ms": arr[i].ms, "flops": arr[i].flops, "bytes": arr[i].bytes,
-                 "launches": arr[i].launches} for i in range(min(n.value, 64))]
+                 "launches": arr[i].launches} for i in range(min(n.value, 256))]

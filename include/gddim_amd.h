@@ -100,6 +100,14 @@ int gd_engine_params_ready(gd_engine *e);
 /* Export a packed weight slot to host memory (plan-only and GPU mode). */
 int gd_engine_packed_weight(gd_engine *e, const char *slot, float *host_out, size_t cap_floats, size_t *n_floats);
 
+/* Arithmetic of the weight contractions (convolutions, NIN, dense):
+ *   0  exact fp32 (v_mfma_f32_32x32x2_f32), the default and the mode every parity claim refers to;
+ *   1  "bf16x3": fp32 operands split into bf16 hi + lo, a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on the bf16 matrix
+ *      core with fp32 accumulation (per-product error ~2^-16, measured as close to float64 as mode 0 on this network).
+ * Also selectable with GDDIM_PRECISION=bf16x3 at engine creation.  The reference has one arithmetic only (XLA fp32);
+ * this switch has no counterpart there. */
+int gd_engine_set_precision(gd_engine *e, int mode);
+
 /* ---- score network ------------------------------------------------------------------------
  * eps = NCSNpp(x, labels): x_dev (B,H,W,in_channels), labels_dev (B,) = 999*t, out_dev like x.
  * Replaces: model.apply(variables, x, labels, train=False, mutable=False)
