@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgddim_amd.so")
+# GDDIM_LIB selects another build of the same library (A/B measurements of kernel variants inside one gpurun call)
+LIB_PATH = os.environ.get("GDDIM_LIB") or os.path.join(_HERE, "libgddim_amd.so")
 
 GD_MAX_LEVELS = 8
 

@@ -71,10 +71,16 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_kernel(const GemmParam
     // ---- XCD-aware block -> (mtile, ntile) ----
     const int nt = p.n_tiles;
     const int id = blockIdx.x;
-    const int grp = id / (8 * nt);
-    const int rem = id - grp * 8 * nt;
-    const int ntile = rem >> 3;
-    const int mtile = grp * 8 + (rem & 7);
+    int ntile, mtile;
+    if (p.flat_tiles) {  // small grids: no padding of the M-tile count to the XCD group size
+        mtile = id / nt;
+        ntile = id - mtile * nt;
+    } else {
+        const int grp = id / (8 * nt);
+        const int rem = id - grp * 8 * nt;
+        ntile = rem >> 3;
+        mtile = grp * 8 + (rem & 7);
+    }
     if (mtile >= p.m_tiles) return;
     const int m0 = mtile * BM, n0 = ntile * BN;
     const int z = blockIdx.z;
@@ -352,10 +358,16 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_fast_kernel(const Gemm
 
     const int nt = p.n_tiles;
     const int id = blockIdx.x;
-    const int grp = id / (8 * nt);
-    const int rem = id - grp * 8 * nt;
-    const int ntile = rem >> 3;
-    const int mtile = grp * 8 + (rem & 7);
+    int ntile, mtile;
+    if (p.flat_tiles) {  // small grids: no padding of the M-tile count to the XCD group size
+        mtile = id / nt;
+        ntile = id - mtile * nt;
+    } else {
+        const int grp = id / (8 * nt);
+        const int rem = id - grp * 8 * nt;
+        ntile = rem >> 3;
+        mtile = grp * 8 + (rem & 7);
+    }
     if (mtile >= p.m_tiles) return;
     const int m0 = mtile * BM, n0 = ntile * BN;
     const int z = blockIdx.z;
@@ -725,10 +737,12 @@ int launch_igemm(const GemmParams &p_in, int batch_z, hipStream_t s) {
     pick_tiles(p, batch_z, bm, bn);
     p.m_tiles = (p.M + bm - 1) / bm;
     p.n_tiles = (p.N + bn - 1) / bn;
-    int gx = ((p.m_tiles + 7) / 8) * 8 * p.n_tiles;
+    p.flat_tiles = p.m_tiles < 16;
+    int gx = p.flat_tiles ? p.m_tiles * p.n_tiles : ((p.m_tiles + 7) / 8) * 8 * p.n_tiles;
     if (bm == 128 && bn == 128 && big_variant() == 2 && (long long)((p.M + 255) / 256) * p.n_tiles * batch_z >= 512) {
         p.m_tiles = (p.M + 255) / 256;
-        gx = ((p.m_tiles + 7) / 8) * 8 * p.n_tiles;
+        p.flat_tiles = p.m_tiles < 16;
+        gx = p.flat_tiles ? p.m_tiles * p.n_tiles : ((p.m_tiles + 7) / 8) * 8 * p.n_tiles;
         launch_variant<256, 128, 4, 2>(p, dim3(gx, 1, batch_z), s);
     } else if (bm == 128 && bn == 128) {
         if (big_variant() == 1) launch_variant<128, 128, 2, 2>(p, dim3(gx, 1, batch_z), s);

@@ -61,10 +61,16 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16x3_kernel(const GemmPa
 
     const int nt = p.n_tiles;
     const int id = blockIdx.x;
-    const int grp = id / (8 * nt);
-    const int rem = id - grp * 8 * nt;
-    const int ntile = rem >> 3;
-    const int mtile = grp * 8 + (rem & 7);
+    int ntile, mtile;
+    if (p.flat_tiles) {  // small grids: no padding of the M-tile count to the XCD group size
+        mtile = id / nt;
+        ntile = id - mtile * nt;
+    } else {
+        const int grp = id / (8 * nt);
+        const int rem = id - grp * 8 * nt;
+        ntile = rem >> 3;
+        mtile = grp * 8 + (rem & 7);
+    }
     if (mtile >= p.m_tiles) return;
     const int m0 = mtile * BM, n0 = ntile * BN;
 
@@ -341,7 +347,8 @@ int launch_igemm_bf16x3(const GemmParams &p_in, hipStream_t s) {
     xpick(p, bm, bn);
     p.m_tiles = (p.M + bm - 1) / bm;
     p.n_tiles = (p.N + bn - 1) / bn;
-    const int gx = ((p.m_tiles + 7) / 8) * 8 * p.n_tiles;
+    p.flat_tiles = p.m_tiles < 16;
+    const int gx = p.flat_tiles ? p.m_tiles * p.n_tiles : ((p.m_tiles + 7) / 8) * 8 * p.n_tiles;
     if (bm == 256) hipLaunchKernelGGL((igemm_bf16x3_kernel<256, 128, 4, 2>), dim3(gx), dim3(512), 0, s, p);
     else if (bm == 128) hipLaunchKernelGGL((igemm_bf16x3_kernel<128, 128, 2, 4>), dim3(gx), dim3(512), 0, s, p);
     else hipLaunchKernelGGL((igemm_bf16x3_kernel<64, 64, 2, 2>), dim3(gx), dim3(256), 0, s, p);
