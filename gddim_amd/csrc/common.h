@@ -73,6 +73,11 @@ struct GemmParams {
     // bf16x3 path: the weights split as bf16 hi / lo arrays, same [N][ldb] indexing as b (null on the fp32 path)
     const unsigned short *b_hi;
     const unsigned short *b_lo;
+    // fused GroupNorm statistics of the OUTPUT: qstats[img][slice][n/4] = (sum, sum of squares) over the slice's rows of
+    // columns 4*(n/4)..+3; slice = 32 output rows (qs_slices = rows_per_image/32 per image), or one image when
+    // rows_per_image == 16 (qs_slices = 1).  Unique writer per entry: deterministic.  null = not requested.
+    float *qstats;
+    int qs_slices;
 };
 
 int launch_igemm(const GemmParams &p, int batch_z, hipStream_t s);
@@ -87,11 +92,13 @@ const float *igemm_zero_buffer();
 // ---- normalisation / activation / resampling (kernels/norm_act.hip) -----------------------------
 constexpr int GN_MAX_SLICES = 16;
 int gn_slices(int batch, int HW);
-// partial sums: part[b][slice][g][2] = (sum, sumsq); sources as in GemmParams (channel concat)
-int launch_gn_stats(const float *x0, int C0, const float *x1, int C1, float *part, int batch, int HW, int groups,
-                    int slices, hipStream_t s);
-int launch_gn_apply(const float *x0, int C0, const float *x1, int C1, const float *part, const float *gamma,
-                    const float *beta, float *out, int batch, int HW, int groups, int slices, int act, float eps,
+// quad partial sums of one NHWC tensor: qs[b][slice][c/4][2] = (sum, sumsq) over the slice's pixels (fallback for tensors
+// whose producer could not emit them in its epilogue)
+int launch_gn_stats(const float *x, int C, float *qs, int batch, int HW, int slices, hipStream_t s);
+// normalise (+ swish); (mean, rstd) per (b, group) are reduced in the kernel's prologue from the quad partial sums of up to
+// two channel-concatenated sources (S0 / S1 slices per image)
+int launch_gn_apply(const float *x0, int C0, const float *x1, int C1, const float *qs0, int S0, const float *qs1, int S1,
+                    const float *gamma, const float *beta, float *out, int batch, int HW, int groups, int act, float eps,
                     hipStream_t s);
 int launch_fir_up2(const float *x, float *out, int batch, int H, int W, int C, hipStream_t s);
 int launch_fir_down2(const float *x, float *out, int batch, int H, int W, int C, hipStream_t s);

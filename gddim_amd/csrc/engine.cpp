@@ -171,6 +171,7 @@ static int run_op(gd_engine *e, const Op &op, const Bind &b, int batch, hipStrea
             g.rowbias = tptr(e, b, op.rowbias, batch); g.ld_rowbias = op.ld_rowbias; g.rows_per_image = op.m_per_image;
             g.res = tptr(e, b, op.res, batch); g.ldres = op.ldres;
             g.alpha = op.alpha; g.out_scale = op.out_scale; g.in_act = op.in_act;
+            g.qstats = tptr(e, b, op.qstats, batch); g.qs_slices = op.qs_slices;
             if (e->precision == 1 && op.w_slot >= 0 && e->wsplit_valid) {
                 g.b_hi = e->wsplit_hi + e->slot_off[op.w_slot];
                 g.b_lo = e->wsplit_lo + e->slot_off[op.w_slot];
@@ -186,17 +187,17 @@ static int run_op(gd_engine *e, const Op &op, const Bind &b, int batch, hipStrea
         case OP_GN_STATS: {
             const int HW = op.H * op.W;
             const int sl = gn_slices(batch, HW);
-            ProfScope ps(e, s, "gn_stats", 0, 4.0 * batch * HW * (op.C0 + op.C1));
-            return launch_gn_stats(tptr(e, b, op.a0, batch), op.C0, tptr(e, b, op.a1, batch), op.C1, tptr(e, b, op.stats, batch),
-                                   batch, HW, op.groups, sl, s);
+            ProfScope ps(e, s, "gn_stats", 0, 4.0 * batch * HW * op.C0);
+            return launch_gn_stats(tptr(e, b, op.a0, batch), op.C0, tptr(e, b, op.stats, batch), batch, HW, sl, s);
         }
         case OP_GN_APPLY: {
             const int HW = op.H * op.W;
-            const int sl = gn_slices(batch, HW);
+            const int rt = gn_slices(batch, HW);
             ProfScope ps(e, s, "gn_apply", 0, 8.0 * batch * HW * (op.C0 + op.C1));
             return launch_gn_apply(tptr(e, b, op.a0, batch), op.C0, tptr(e, b, op.a1, batch), op.C1, tptr(e, b, op.stats, batch),
+                                   op.S0 > 0 ? op.S0 : rt, tptr(e, b, op.stats1, batch), op.S1 > 0 ? op.S1 : rt,
                                    slot_ptr(e, op.gamma_slot), slot_ptr(e, op.beta_slot), tptr(e, b, op.out, batch), batch, HW,
-                                   op.groups, sl, op.act, 1e-6f, s);
+                                   op.groups, op.act, 1e-6f, s);
         }
         case OP_FIR_UP: {
             ProfScope ps(e, s, "fir_up2", 0, 4.0 * batch * op.H * op.W * op.C0 * 5);
@@ -786,12 +787,12 @@ int gd_group_norm(const float *x_dev, const float *scale_dev, const float *bias_
     GD_CHECK(x_dev && scale_dev && bias_dev && out_dev, "null pointer");
     hipStream_t s = (hipStream_t)stream;
     const int sl = gn_slices(batch, HW);
-    float *part = nullptr;
-    GD_HIP(hipMalloc((void **)&part, (size_t)batch * sl * groups * 2 * sizeof(float)));
-    int r = launch_gn_stats(x_dev, C, nullptr, 0, part, batch, HW, groups, sl, s);
-    if (!r) r = launch_gn_apply(x_dev, C, nullptr, 0, part, scale_dev, bias_dev, out_dev, batch, HW, groups, sl, act, 1e-6f, s);
+    float *qs = nullptr;
+    GD_HIP(hipMalloc((void **)&qs, (size_t)batch * sl * (C / 4) * 2 * sizeof(float)));
+    int r = launch_gn_stats(x_dev, C, qs, batch, HW, sl, s);
+    if (!r) r = launch_gn_apply(x_dev, C, nullptr, 0, qs, sl, nullptr, 0, scale_dev, bias_dev, out_dev, batch, HW, groups, act, 1e-6f, s);
     (void)hipStreamSynchronize(s);
-    (void)hipFree(part);
+    (void)hipFree(qs);
     return r;
 }
 

@@ -31,6 +31,7 @@
 #include <cstdlib>
 
 #include "../common.h"
+#include "qstats.h"
 
 namespace gd {
 
@@ -304,11 +305,16 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_kernel(const GemmParam
 #pragma unroll
                 for (int v = 0; v < 16; ++v) addv[v] += t[v];
             }
+            float vals[16];
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
                 const int m = mb + (v & 3) + 8 * (v >> 2);
-                if (nok && m < p.M) outp[(size_t)m * p.ldc + n] = (p.alpha * acc[r][c][v] + addv[v]) * p.out_scale;
+                const float val = (p.alpha * acc[r][c][v] + addv[v]) * p.out_scale;
+                const bool ok = nok && m < p.M;
+                if (ok) outp[(size_t)m * p.ldc + n] = val;
+                vals[v] = ok ? val : 0.f;
             }
+            if (p.qstats) emit_qstats(p, vals, mb - 4 * lh, n, nok, li, lh);
         }
     }
 }
@@ -605,12 +611,22 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_fast_kernel(const Gemm
 #pragma unroll
                     for (int v = 0; v < 16; ++v) addv[v] += t[v];
                 }
+                float vals[16];
 #pragma unroll
                 for (int v = 0; v < 16; ++v) {
                     const float val = (p.alpha * acc[r][c][v] + addv[v]) * p.out_scale;
+                    vals[v] = val;
                     if (p.diag == 1) { asm volatile("" ::"v"(val)); continue; }
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), srd_o, vo_o,
                                                           (mrow + (v & 3) + 8 * (v >> 2)) * p.ldc * 4, 0);
+                }
+                if (p.qstats) {
+                    if (!nok || mrow + 32 > p.M) {  // edge tile: rows >= M / columns >= N contribute nothing
+#pragma unroll
+                        for (int v = 0; v < 16; ++v)
+                            if (!nok || mrow + (v & 3) + 8 * (v >> 2) + 4 * lh >= p.M) vals[v] = 0.f;
+                    }
+                    emit_qstats(p, vals, mrow, n, nok, li, lh);
                 }
             }
         }

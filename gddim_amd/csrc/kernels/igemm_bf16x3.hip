@@ -20,6 +20,7 @@
 #include <cstdlib>
 
 #include "../common.h"
+#include "qstats.h"
 
 namespace gd {
 
@@ -288,11 +289,21 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16x3_kernel(const GemmPa
 #pragma unroll
                     for (int v = 0; v < 16; ++v) addv[v] += t[v];
                 }
+                float vals[16];
 #pragma unroll
                 for (int v = 0; v < 16; ++v) {
                     const float val = (p.alpha * acc[r][c][v] + addv[v]) * p.out_scale;
+                    vals[v] = val;
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), srd_o, vo_o,
                                                           (mrow + (v & 3) + 8 * (v >> 2)) * p.ldc * 4, 0);
+                }
+                if (p.qstats) {
+                    if (!nok || mrow + 32 > p.M) {
+#pragma unroll
+                        for (int v = 0; v < 16; ++v)
+                            if (!nok || mrow + (v & 3) + 8 * (v >> 2) + 4 * lh >= p.M) vals[v] = 0.f;
+                    }
+                    emit_qstats(p, vals, mrow, n, nok, li, lh);
                 }
             }
         }

@@ -26,13 +26,17 @@ int gn_slices(int batch, int HW) {
     return s;
 }
 
-// ---- GroupNorm statistics: part[b][slice][g] = (sum, sumsq) over the slice's pixels -------------
-// grid (slices, B), 256 threads; T = (256 / C4) * C4 threads active so that each thread keeps one
-// fixed float4 column (4 channels) and strides over pixel rows; groups are reduced through LDS.
-__global__ __launch_bounds__(256) void gn_stats_kernel(const float *__restrict__ x0, int C0, const float *__restrict__ x1,
-                                                        int C1, float *__restrict__ part, int HW, int groups, int slices) {
+// ---- GroupNorm ----------------------------------------------------------------------------------------------------
+// Statistics arrive as "quad partial sums" qs[b][slice][c/4] = (sum, sumsq) over a slice of the image's pixels and four
+// consecutive channels.  Normally the GEMM that produced the tensor emits them in its epilogue (one slice per 32 output
+// rows); gn_stats_kernel is the stand-alone producer for tensors that have none.  gn_apply_kernel reduces slices and quads
+// to (mean, rstd) per (image, group) in its prologue and normalises (+ swish).  Every step is deterministic (no atomics).
+
+// grid (slices, B), 256 threads; T = (256 / C4) * C4 threads active so that each thread keeps one fixed float4 column
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float *__restrict__ x, int C, float *__restrict__ qs, int HW,
+                                                        int slices) {
     __shared__ float s_sum[256], s_sq[256];
-    const int C = C0 + C1, C4 = C >> 2;
+    const int C4 = C >> 2;
     const int rows_pp = 256 / C4;
     const int T = rows_pp * C4;
     const int tid = threadIdx.x;
@@ -42,13 +46,9 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float *__restrict__
     float s = 0.f, q = 0.f;
     if (tid < T) {
         const int f = tid % C4, rp = tid / C4;
-        const int c = f * 4;
-        const float *src;
-        int ld, cc;
-        if (c < C0) { src = x0; ld = C0; cc = c; } else { src = x1; ld = C1; cc = c - C0; }
-        src += (size_t)b * HW * ld + cc;
+        const float *src = x + (size_t)b * HW * C + f * 4;
         for (int p = p_beg + rp; p < p_end; p += rows_pp) {
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(src + (size_t)p * ld);
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(src + (size_t)p * C);
             s += (v[0] + v[1]) + (v[2] + v[3]);
             q += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
         }
@@ -56,49 +56,71 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float *__restrict__
     s_sum[tid] = s;
     s_sq[tid] = q;
     __syncthreads();
-    if (tid < groups) {
-        const int f4pg = C4 / groups;  // float4 columns per group
+    if (tid < C4) {
         float ts = 0.f, tq = 0.f;
-        for (int rp = 0; rp < rows_pp; ++rp)
-            for (int k = 0; k < f4pg; ++k) {
-                const int i = rp * C4 + tid * f4pg + k;
-                ts += s_sum[i];
-                tq += s_sq[i];
-            }
-        float *o = part + (((size_t)b * slices + sl) * groups + tid) * 2;
+        for (int rp = 0; rp < rows_pp; ++rp) { ts += s_sum[rp * C4 + tid]; tq += s_sq[rp * C4 + tid]; }
+        float *o = qs + (((size_t)b * slices + sl) * C4 + tid) * 2;
         o[0] = ts;
         o[1] = tq;
     }
 }
 
-// ---- GroupNorm apply (+ optional swish); reduces the slice partials in its prologue ---------------
+// grid (blocks per image, B), 256 threads.  Prologue: the block reduces the quad partial sums of its image to (mean, rstd)
+// per group in LDS (thread t -> group t % G, slice phase t / G), across two channel-concatenated sources when the GroupNorm
+// runs on a skip concat; then every thread normalises its fixed float4 column over the block's pixels.
 __global__ __launch_bounds__(256) void gn_apply_kernel(const float *__restrict__ x0, int C0, const float *__restrict__ x1,
-                                                        int C1, const float *__restrict__ part,
+                                                        int C1, const float *__restrict__ qs0, int S0,
+                                                        const float *__restrict__ qs1, int S1,
                                                         const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                        float *__restrict__ out, int HW, int groups, int slices,
-                                                        int act, float eps) {
+                                                        float *__restrict__ out, int HW, int groups, int act, float inv_n,
+                                                        float eps) {
+    __shared__ float s_sum[256], s_sq[256];
     const int C = C0 + C1, C4 = C >> 2;
+    const int Q0 = C0 >> 2, Q1 = C1 >> 2;
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y;
+    {
+        const int phases = 256 / groups;
+        const int g = tid % groups, ph = tid / groups;
+        const int qpg = C4 / groups;  // quads per group
+        float s = 0.f, q = 0.f;
+        if (ph < phases) {
+            for (int k = 0; k < qpg; ++k) {
+                const int qg = g * qpg + k;
+                const bool first = qg < Q0;
+                const float *base = first ? qs0 : qs1;
+                const int Q = first ? Q0 : Q1, S = first ? S0 : S1, ql = first ? qg : qg - Q0;
+                for (int sl = ph; sl < S; sl += phases) {
+                    const float *pp = base + (((size_t)b * S + sl) * Q + ql) * 2;
+                    s += pp[0];
+                    q += pp[1];
+                }
+            }
+        }
+        s_sum[tid] = s;
+        s_sq[tid] = q;
+        __syncthreads();
+        if (tid < groups) {
+            float ts = 0.f, tq = 0.f;
+            for (int k = 0; k < phases; ++k) { ts += s_sum[k * groups + tid]; tq += s_sq[k * groups + tid]; }
+            const float mean = ts * inv_n;
+            const float var = tq * inv_n - mean * mean;  // flax: E[x^2] - E[x]^2
+            s_sum[tid] = mean;
+            s_sq[tid] = rsqrtf(var + eps);
+        }
+        __syncthreads();
+    }
     const int rows_pp = 256 / C4;
     const int T = rows_pp * C4;
-    const int tid = threadIdx.x;
     if (tid >= T) return;
-    const int b = blockIdx.y;
     const int nblk = gridDim.x;
     const int per = (HW + nblk - 1) / nblk;
     const int p_beg = blockIdx.x * per, p_end = min(HW, p_beg + per);
     const int f = tid % C4, rp = tid / C4;
     const int c = f * 4;
     const int g = f / (C4 / groups);
-    float ts = 0.f, tq = 0.f;
-    for (int sl = 0; sl < slices; ++sl) {
-        const float *pp = part + (((size_t)b * slices + sl) * groups + g) * 2;
-        ts += pp[0];
-        tq += pp[1];
-    }
-    const float inv_n = 1.0f / ((float)HW * (float)(C / groups));
-    const float mean = ts * inv_n;
-    const float var = tq * inv_n - mean * mean;
-    const float rstd = rsqrtf(var + eps);
+    const float mean = s_sum[g];
+    const float rstd = s_sq[g];
     const f32x4 ga = *reinterpret_cast<const f32x4 *>(gamma + c);
     const f32x4 be = *reinterpret_cast<const f32x4 *>(beta + c);
     f32x4 sc, sh;
@@ -120,23 +142,24 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float *__restrict__
     }
 }
 
-int launch_gn_stats(const float *x0, int C0, const float *x1, int C1, float *part, int batch, int HW, int groups,
-                    int slices, hipStream_t s) {
-    const int C = C0 + C1;
-    GD_CHECK(C % 4 == 0 && C0 % 4 == 0 && C / 4 <= 256 && (C / 4) % groups == 0 && groups <= 256,
-             "group_norm: unsupported C=%d (C0=%d) groups=%d", C, C0, groups);
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(slices, batch), dim3(256), 0, s, x0, C0, x1, C1, part, HW, groups, slices);
+int launch_gn_stats(const float *x, int C, float *qs, int batch, int HW, int slices, hipStream_t s) {
+    GD_CHECK(C % 4 == 0 && C / 4 <= 256, "group_norm: unsupported C=%d", C);
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(slices, batch), dim3(256), 0, s, x, C, qs, HW, slices);
     GD_HIP(hipGetLastError());
     return 0;
 }
 
-int launch_gn_apply(const float *x0, int C0, const float *x1, int C1, const float *part, const float *gamma,
-                    const float *beta, float *out, int batch, int HW, int groups, int slices, int act, float eps,
+int launch_gn_apply(const float *x0, int C0, const float *x1, int C1, const float *qs0, int S0, const float *qs1, int S1,
+                    const float *gamma, const float *beta, float *out, int batch, int HW, int groups, int act, float eps,
                     hipStream_t s) {
+    const int C = C0 + C1;
+    GD_CHECK(C % 4 == 0 && C0 % 4 == 0 && C / 4 <= 256 && (C / 4) % groups == 0 && groups <= 256 && groups >= 1,
+             "group_norm: unsupported C=%d (C0=%d) groups=%d", C, C0, groups);
     int nblk = 1;
     while (nblk < 64 && (long long)batch * nblk < 4096 && HW / (nblk * 2) >= 16) nblk *= 2;
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(nblk, batch), dim3(256), 0, s, x0, C0, x1, C1, part, gamma, beta, out, HW,
-                       groups, slices, act, eps);
+    const float inv_n = 1.0f / ((float)HW * (float)(C / groups));
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(nblk, batch), dim3(256), 0, s, x0, C0, x1, C1, qs0, S0, qs1, S1, gamma, beta, out,
+                       HW, groups, act, inv_n, eps);
     GD_HIP(hipGetLastError());
     return 0;
 }

@@ -70,7 +70,22 @@ int Plan::new_tensor(const std::string &name, int H, int W, int C, int ext, long
 void Plan::release(int t) {
     if (t < 0) return;
     Tensor &T = tensors[t];
-    if (--T.refs == 0 && T.ext == EXT_NONE) arena_free(T.offset, T.per_image);
+    if (--T.refs == 0 && T.ext == EXT_NONE) {
+        arena_free(T.offset, T.per_image);
+        if (T.stats_t >= 0) release(T.stats_t);
+    }
+}
+
+// Give tensor t a companion for the quad statistics its producing GEMM will emit (kernels/qstats.h): one slice per 32
+// output rows, or per image when an image has 16 rows.  Other image sizes keep the stand-alone statistics kernel.
+void Plan::attach_stats(int t, int rows_per_image) {
+    int S = 0;
+    if (rows_per_image % 32 == 0) S = rows_per_image / 32;
+    else if (rows_per_image == 16) S = 1;
+    if (S == 0 || tensors[t].C % 4 != 0 || tensors[t].ext != EXT_NONE) return;
+    const int st = new_tensor(tensors[t].name + ".qstats", 1, 1, 1, EXT_NONE, (long long)S * (tensors[t].C / 4) * 2);
+    tensors[t].stats_t = st;
+    tensors[t].qs_slices = S;
 }
 
 int Plan::new_slot(const std::string &name, long long rows, long long cols) {
@@ -89,37 +104,55 @@ void Plan::add_param(const std::string &name, std::vector<int64_t> shape, int ki
     params.push_back(std::move(p));
 }
 
-// ---------------------------------------------------------------- GroupNorm (+swish): stats + apply
+// ---------------------------------------------------------------- GroupNorm (+swish): [stats] + apply
 // returns the normalised tensor (H, W, Ca+Cb); inputs are not released
 int Plan::gn(const std::string &label, const std::string &pname, int xa, int Ca, int xb, int Cb, int H, int W, int act) {
     const int C = Ca + Cb;
     const int G = std::min(C / 4, 32);  // nn.GroupNorm(num_groups=min(C // 4, 32))
-    int st = new_tensor(label + ".stats", 1, 1, 1, EXT_NONE, (long long)GN_MAX_SLICES * G * 2);
     int gs = new_slot(pname + "/scale", 1, C), bs = new_slot(pname + "/bias", 1, C);
     add_param(pname + "/scale", {C}, P_VEC, gs, 0);
     add_param(pname + "/bias", {C}, P_VEC, bs, 0);
-    Op s;
-    s.kind = OP_GN_STATS; s.label = label + ".stats";
-    s.a0 = {xa, 0}; s.C0 = Ca; s.a1 = {xb, 0}; s.C1 = Cb; s.H = H; s.W = W; s.groups = G; s.stats = {st, 0};
-    ops.push_back(s);
+    // quad statistics of each source: emitted by its producer, or computed here by the stand-alone kernel
+    int qs[2] = {-1, -1}, S[2] = {0, 0}, tmp[2] = {-1, -1};
+    const int src[2] = {xa, xb}, Cs[2] = {Ca, Cb};
+    for (int i = 0; i < 2; ++i) {
+        if (src[i] < 0 || Cs[i] == 0) continue;
+        if (tensors[src[i]].stats_t >= 0) {
+            qs[i] = tensors[src[i]].stats_t;
+            S[i] = tensors[src[i]].qs_slices;
+        } else {
+            tmp[i] = new_tensor(label + ".qstats" + std::to_string(i), 1, 1, 1, EXT_NONE, (long long)GN_MAX_SLICES * (Cs[i] / 4) * 2);
+            Op st;
+            st.kind = OP_GN_STATS; st.label = label + ".stats" + std::to_string(i);
+            st.a0 = {src[i], 0}; st.C0 = Cs[i]; st.H = H; st.W = W; st.stats = {tmp[i], 0};
+            ops.push_back(st);
+            qs[i] = tmp[i];
+            S[i] = 0;  // run-time slice count
+        }
+    }
     int out = new_tensor(label + ".out", H, W, C);
-    Op a = s;
-    a.kind = OP_GN_APPLY; a.label = label + ".apply"; a.act = act; a.gamma_slot = gs; a.beta_slot = bs; a.out = {out, 0};
+    Op a;
+    a.kind = OP_GN_APPLY; a.label = label + ".apply";
+    a.a0 = {xa, 0}; a.C0 = Ca; a.a1 = {xb, 0}; a.C1 = Cb; a.H = H; a.W = W; a.groups = G;
+    a.stats = {qs[0], 0}; a.S0 = S[0]; a.stats1 = {qs[1], 0}; a.S1 = S[1];
+    a.act = act; a.gamma_slot = gs; a.beta_slot = bs; a.out = {out, 0};
     ops.push_back(a);
-    release(st);
+    release(tmp[0]);
+    release(tmp[1]);
     return out;
 }
 
 // ---------------------------------------------------------------- nn.Conv (SAME) as implicit GEMM
 // pname: flax module path holding {kernel, bias}.  out_t >= 0 writes into an existing (external) tensor.
 int Plan::conv(const std::string &label, const std::string &pname, int xa, int Ca, int xb, int Cb, int H, int W, int ksize,
-               int O, int res_t, float out_scale, int rowbias_t, int rowbias_col, int out_t) {
+               int O, int res_t, float out_scale, int rowbias_t, int rowbias_col, int out_t, bool want_stats) {
     const int Cin = Ca + Cb;
     int ws = new_slot(pname + "/kernel", O, (long long)ksize * ksize * Cin);
     int bs = new_slot(pname + "/bias", 1, O);
     add_param(pname + "/kernel", {ksize, ksize, Cin, O}, P_CONV, ws, 0, Cin);
     add_param(pname + "/bias", {O}, P_VEC, bs, 0);
     int out = out_t >= 0 ? out_t : new_tensor(label + ".out", H, W, O);
+    if (want_stats && out_t < 0) attach_stats(out, H * W);
     Op g;
     g.kind = OP_GEMM; g.label = label;
     g.a0 = {xa, 0}; g.C0 = Ca; g.lda0 = tensors[xa].C;
@@ -130,6 +163,7 @@ int Plan::conv(const std::string &label, const std::string &pname, int xa, int C
     if (rowbias_t >= 0) { g.rowbias = {rowbias_t, rowbias_col}; g.ld_rowbias = tensors[rowbias_t].C; }
     if (res_t >= 0) { g.res = {res_t, 0}; g.ldres = tensors[res_t].C; }
     g.out = {out, 0}; g.ldc = tensors[out].C; g.out_scale = out_scale;
+    if (tensors[out].stats_t >= 0) { g.qstats = {tensors[out].stats_t, 0}; g.qs_slices = tensors[out].qs_slices; }
     g.flops_per_image = 2.0 * H * W * O * g.K;
     g.is_conv3x3 = ksize == 3;
     ops.push_back(g);
@@ -165,7 +199,7 @@ int Plan::resblock(int idx, int xa, int Ca, int xb, int Cb, int H, int W, int O,
     }
     // h = Conv_0(h) + Dense_0(act(temb))[:, None, None, :]
     const int tcol = tproj_t_ >= 0 ? rb_tproj_off_[idx] : 0;
-    int h1 = conv(n + ".conv0", n + "/Conv_0", h0, C, -1, 0, H2, W2, 3, O, -1, 1.f, tproj_t_, tcol);
+    int h1 = conv(n + ".conv0", n + "/Conv_0", h0, C, -1, 0, H2, W2, 3, O, -1, 1.f, tproj_t_, tcol, -1, true);
     release(h0);
     if (tproj_t_ >= 0) {
         add_param(n + "/Dense_0/kernel", {desc.nf * 4, O}, P_DENSE, tproj_slot_w_, tcol);
@@ -185,7 +219,7 @@ int Plan::resblock(int idx, int xa, int Ca, int xb, int Cb, int H, int W, int O,
         res_t = xa;
     }
     // (x + Conv_1(h)) / sqrt(2)
-    int out = conv(n + ".conv1", n + "/Conv_1", h2, O, -1, 0, H2, W2, 3, O, res_t, scale, -1, 0);
+    int out = conv(n + ".conv1", n + "/Conv_1", h2, O, -1, 0, H2, W2, 3, O, res_t, scale, -1, 0, -1, true);
     release(h2);
     release(xs);
     release(xr);
@@ -268,12 +302,14 @@ int Plan::attn(int idx, int x, int H, int W, int C) {
     add_param(n + "/NIN_3/W", {C, C}, P_DENSE, wo, 0);
     add_param(n + "/NIN_3/b", {C}, P_VEC, bo, 0);
     int out = new_tensor(n + ".out", H, W, C);
+    attach_stats(out, HW);
     {
         Op g;
         g.kind = OP_GEMM; g.label = n + ".proj";
         g.a0 = {ho, 0}; g.C0 = C; g.lda0 = C; g.H = H; g.W = W; g.OH = H; g.OW = W;
         g.m_per_image = HW; g.N = C; g.K = C; g.w_slot = wo; g.ldb = C; g.bias_slot = bo;
         g.res = {x, 0}; g.ldres = C; g.out = {out, 0}; g.ldc = C; g.out_scale = scale;
+        if (tensors[out].stats_t >= 0) { g.qstats = {tensors[out].stats_t, 0}; g.qs_slices = tensors[out].qs_slices; }
         g.flops_per_image = 2.0 * HW * C * C;
         ops.push_back(g);
     }
@@ -375,7 +411,7 @@ int Plan::build(const gd_model_desc &d) {
     struct Skip { int t, C; };
     std::vector<Skip> hs;
     // stem conv: K uses the padded channel count; algorithmic FLOPs count the real ones
-    int h = conv("stem", "Conv_0", x, CP, -1, 0, res, res, 3, nf, -1, 1.f, -1, 0);
+    int h = conv("stem", "Conv_0", x, CP, -1, 0, res, res, 3, nf, -1, 1.f, -1, 0, -1, true);
     params[param_index["Conv_0/kernel"]].shape = {3, 3, d.in_channels, nf};
     ops.back().flops_per_image = 2.0 * res * res * nf * 9 * d.in_channels;
     release(x);
@@ -406,12 +442,14 @@ int Plan::build(const gd_model_desc &d) {
                 add_param(pn + "/weight", {3, 3, real_in, C}, P_CONV_FIR6, ws, 0, pyrC);
                 add_param(pn + "/bias", {C}, P_VEC, bs, 0);
                 int np = new_tensor(pn + ".out", res, res, C);
+                attach_stats(np, res * res);
                 Op g;
                 g.kind = OP_GEMM; g.label = "pyramid_down_" + std::to_string(dn - 1);
                 g.a0 = {pyr, 0}; g.C0 = pyrC; g.lda0 = pyrC; g.H = 2 * res; g.W = 2 * res; g.OH = res; g.OW = res;
                 g.KH = g.KW = 6; g.stride = 2; g.pad = 2; g.m_per_image = res * res; g.N = C; g.K = 36 * pyrC;
                 g.w_slot = ws; g.ldb = g.K; g.bias_slot = bs; g.res = {o, 0}; g.ldres = C; g.out = {np, 0}; g.ldc = C;
                 g.out_scale = d.skip_rescale ? (float)(1.0 / std::sqrt(2.0)) : 1.f;
+                if (tensors[np].stats_t >= 0) { g.qstats = {tensors[np].stats_t, 0}; g.qs_slices = tensors[np].qs_slices; }
                 g.flops_per_image = 2.0 * res * res * C * 9 * real_in;
                 g.is_conv3x3 = 1;
                 ops.push_back(g);
@@ -566,7 +604,7 @@ std::string Plan::json() const {
         const Op &p = ops[i];
         o << (i ? "," : "") << "{\"kind\":" << p.kind << ",\"label\":\"" << p.label << "\",";
         jref(o, "a0", p.a0); jref(o, "a1", p.a1); jref(o, "bten", p.bten); jref(o, "rowbias", p.rowbias);
-        jref(o, "res", p.res); jref(o, "out", p.out); jref(o, "stats", p.stats);
+        jref(o, "res", p.res); jref(o, "out", p.out); jref(o, "stats", p.stats); jref(o, "stats1", p.stats1); jref(o, "qstats", p.qstats);
         o << "\"C0\":" << p.C0 << ",\"C1\":" << p.C1 << ",\"lda0\":" << p.lda0 << ",\"lda1\":" << p.lda1 << ",\"H\":" << p.H
           << ",\"W\":" << p.W << ",\"OH\":" << p.OH << ",\"OW\":" << p.OW << ",\"KH\":" << p.KH << ",\"KW\":" << p.KW
           << ",\"stride\":" << p.stride << ",\"pad\":" << p.pad << ",\"m_per_image\":" << p.m_per_image
@@ -574,7 +612,7 @@ std::string Plan::json() const {
           << ",\"ldb\":" << p.ldb << ",\"b_kmajor\":" << p.b_kmajor << ",\"sA\":" << p.sA << ",\"sB\":" << p.sB
           << ",\"sC\":" << p.sC << ",\"bias_slot\":" << p.bias_slot << ",\"bias_off\":" << p.bias_off
           << ",\"ld_rowbias\":" << p.ld_rowbias << ",\"ldres\":" << p.ldres << ",\"ldc\":" << p.ldc << ",\"alpha\":" << p.alpha
-          << ",\"out_scale\":" << p.out_scale << ",\"in_act\":" << p.in_act << ",\"groups\":" << p.groups
+          << ",\"out_scale\":" << p.out_scale << ",\"in_act\":" << p.in_act << ",\"qs_slices\":" << p.qs_slices << ",\"S0\":" << p.S0 << ",\"S1\":" << p.S1 << ",\"groups\":" << p.groups
           << ",\"act\":" << p.act << ",\"gamma_slot\":" << p.gamma_slot << ",\"beta_slot\":" << p.beta_slot
           << ",\"rows_per_image\":" << p.rows_per_image << ",\"cols\":" << p.cols << ",\"cin\":" << p.cin
           << ",\"cpad\":" << p.cpad << ",\"mul\":" << p.mul << ",\"add\":" << p.add << ",\"flops_per_image\":" << p.flops_per_image

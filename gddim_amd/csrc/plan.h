@@ -33,6 +33,10 @@ struct Tensor {
     long long offset = -1;    // arena offset (floats per image); address = arena + offset * batch
     int ext = EXT_NONE;
     int refs = 0;
+    // companion tensor holding the fused GroupNorm quad statistics of this tensor (emitted by the producing GEMM), and
+    // its slices per image; -1 when the producer does not emit them
+    int stats_t = -1;
+    int qs_slices = 0;
 };
 
 struct TRef {
@@ -66,9 +70,15 @@ struct Op {
     int ldc = 0;
     float alpha = 1.f, out_scale = 1.f;
     int in_act = 0;
+    TRef qstats;          // GEMM: quad statistics of the output (fused GroupNorm statistics), t = -1: none
+    int qs_slices = 0;
     // ---- GroupNorm ----
+    // GN_STATS: a0 -> stats (quad partial sums, slices chosen at run time)
+    // GN_APPLY: a0 [+ a1] normalised; statistics from the quad sums stats (S0 slices per image) [+ stats1 (S1 slices)];
+    //           S = 0 means "the run-time slice count of GN_STATS"
     int groups = 0, act = 0, gamma_slot = -1, beta_slot = -1;
-    TRef stats;
+    int S0 = 0, S1 = 0;
+    TRef stats, stats1;
     // ---- softmax ----
     int rows_per_image = 0, cols = 0;
     // ---- affine pad ----
@@ -132,7 +142,8 @@ struct Plan {
     void add_param(const std::string &name, std::vector<int64_t> shape, int kind, int slot, long long row_off, int ipad = 0);
     int gn(const std::string &prefix, const std::string &pname, int xa, int Ca, int xb, int Cb, int H, int W, int act);
     int conv(const std::string &label, const std::string &pname, int xa, int Ca, int xb, int Cb, int H, int W, int ksize,
-             int O, int res_t, float out_scale, int rowbias_t, int rowbias_col, int out_t = -1);
+             int O, int res_t, float out_scale, int rowbias_t, int rowbias_col, int out_t = -1, bool want_stats = false);
+    void attach_stats(int t, int rows_per_image);
     int resblock(int idx, int xa, int Ca, int xb, int Cb, int H, int W, int O, bool up, bool down, int &outH);
     int attn(int idx, int x, int H, int W, int C);
     int temb_t_ = -1, tproj_t_ = -1, tproj_slot_w_ = -1, tproj_slot_b_ = -1;

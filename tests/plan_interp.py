@@ -121,7 +121,18 @@ class PlanInterp(object):
             if op["res"][0] >= 0:
                 acc = acc + self._rows(self._flat(op["res"], B), Mz, op["ldres"], N)
             oflat = self._flat(op["out"], B)[z * op["sC"]:]
-            self._rows(oflat, Mz, op["ldc"], N)[:] = acc * op["out_scale"]
+            res_out = acc * op["out_scale"]
+            self._rows(oflat, Mz, op["ldc"], N)[:] = res_out
+            if op["qstats"][0] >= 0:
+                # fused GroupNorm statistics (kernels/qstats.h): per image, per slice (32 rows; the whole image when it has
+                # 16 rows), per 4 consecutive channels: (sum, sum of squares)
+                rpi, S, Q = op["m_per_image"], op["qs_slices"], N // 4
+                rows_per_slice = 32 if rpi % 32 == 0 else rpi
+                assert S == rpi // rows_per_slice and not op["z_per_image"]
+                v = res_out.reshape(B, S, rows_per_slice, Q, 4)
+                qs = self._rows(self._flat(op["qstats"], B), B * S * Q, 2, 2).reshape(B, S, Q, 2)
+                qs[..., 0] = v.sum(dim=(2, 4))
+                qs[..., 1] = (v * v).sum(dim=(2, 4))
 
     def _gn_src(self, op, B):
         HW = op["H"] * op["W"]
@@ -131,23 +142,36 @@ class PlanInterp(object):
                 srcs.append(self._rows(self._flat(tref, B), B * HW, C, C).reshape(B, HW, C))
         return torch.cat(srcs, dim=-1) if len(srcs) > 1 else srcs[0]
 
-    def _op2(self, op, B):  # gn stats: (sum, sumsq) per (b, slice 0, g); the emulation uses a single slice
-        x = self._gn_src(op, B)
-        G = op["groups"]
-        Bn, HW, C = x.shape
-        xg = x.reshape(Bn, HW, G, C // G)
-        st = self._rows(self._flat(op["stats"], B), B, self.plan["gn_max_slices"] * G * 2, G * 2).reshape(B, G, 2)
-        st[:, :, 0] = xg.sum(dim=(1, 3))
-        st[:, :, 1] = (xg * xg).sum(dim=(1, 3))
+    RT_SLICES = 2  # the emulation's stand-in for the run-time slice count of the stand-alone statistics kernel
 
-    def _op3(self, op, B):  # gn apply
+    def _op2(self, op, B):  # gn stats (stand-alone): quad partial sums qs[b][slice][c/4] = (sum, sumsq)
+        HW, C = op["H"] * op["W"], op["C0"]
+        x = self._rows(self._flat(op["a0"], B), B * HW, C, C).reshape(B, HW, C)
+        S, Q = self.RT_SLICES, C // 4
+        per = (HW + S - 1) // S
+        qs = self._rows(self._flat(op["stats"], B), B * S * Q, 2, 2).reshape(B, S, Q, 2)
+        for sl in range(S):
+            v = x[:, sl * per:min(HW, (sl + 1) * per)].reshape(B, -1, Q, 4)
+            qs[:, sl, :, 0] = v.sum(dim=(1, 3))
+            qs[:, sl, :, 1] = (v * v).sum(dim=(1, 3))
+
+    def _op3(self, op, B):  # gn apply: statistics from the quad sums of up to two sources, then normalise (+ swish)
         x = self._gn_src(op, B)
         G = op["groups"]
         Bn, HW, C = x.shape
-        st = self._rows(self._flat(op["stats"], B), B, self.plan["gn_max_slices"] * G * 2, G * 2).reshape(B, G, 2)
+        parts = []
+        for tref, Cs, S in ((op["stats"], op["C0"], op["S0"]), (op["stats1"], op["C1"], op["S1"])):
+            if Cs == 0:
+                continue
+            S = S if S > 0 else self.RT_SLICES
+            Q = Cs // 4
+            qs = self._rows(self._flat(tref, B), B * S * Q, 2, 2).reshape(B, S, Q, 2)
+            parts.append(qs.sum(dim=1))  # (B, Q, 2)
+        q = torch.cat(parts, dim=1)  # channel-concat order
+        g = q.reshape(B, G, (C // 4) // G, 2).sum(dim=2)
         n = HW * (C // G)
-        mean = st[:, :, 0] / n
-        var = st[:, :, 1] / n - mean * mean
+        mean = g[..., 0] / n
+        var = g[..., 1] / n - mean * mean
         rstd = torch.rsqrt(var + 1e-6)
         xg = x.reshape(Bn, HW, G, C // G)
         y = ((xg - mean[:, None, :, None]) * rstd[:, None, :, None]).reshape(Bn, HW, C)

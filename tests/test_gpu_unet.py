@@ -41,6 +41,14 @@ def test_unet_variants_match_oracle(native_lib):
     eng.close()
 
 
+def test_unet_standalone_statistics_fallback(native_lib):
+    """8x8 input: the 2x2 level uses the stand-alone GroupNorm statistics kernel, the others the fused epilogue statistics."""
+    cfg = tiny_config("cld", nf=32, num_res_blocks=1, image_size=8, ch_mult=(1, 2, 2), attn=(4,))
+    eng, params, x, t, got, want = _forward_pair(cfg, 6, B=5, seed=12)
+    assert np.abs(got - want).max() < 1e-4 * max(1.0, np.abs(want).max())
+    eng.close()
+
+
 def test_unet_full_architecture_matches_oracle(native_lib):
     """The benchmarked accr_dcifar10 architecture (107.6 M parameters), per-sample t, against float64 and against
     the float32 oracle: the HIP forward must sit as close to float64 as the float32 oracle does (x4)."""

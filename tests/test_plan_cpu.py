@@ -51,6 +51,19 @@ def test_plan_matches_oracle_variants(native_lib):
     assert err < 2e-5 * max(1.0, want.abs().max().item()), err
 
 
+def test_plan_standalone_statistics_fallback(native_lib):
+    """8x8 images: the 2x2 level has 4 rows per image, which the fused epilogue statistics do not cover (they need 16 or a
+    multiple of 32 rows per image) -> the planner falls back to the stand-alone statistics kernel there."""
+    from gddim_amd.engine import Engine
+    cfg = tiny_config("cld", nf=16, num_res_blocks=1, image_size=8, ch_mult=(1, 2, 2), attn=(4,))
+    eng = Engine(cfg, 6, max_batch=1, plan_only=True)
+    kinds = [op["kind"] for op in eng.plan()["ops"]]
+    eng.close()
+    assert 0 < kinds.count(2) < kinds.count(3)  # some stand-alone GN_STATS ops, fewer than GroupNorms
+    got, want = _run(cfg, 6, B=2, seed=7)
+    assert (got - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item())
+
+
 def test_scale_by_sigma_and_unconditional(native_lib):
     cfg = tiny_config("cld")
     cfg.model.scale_by_sigma = True
