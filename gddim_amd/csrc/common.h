@@ -73,6 +73,9 @@ struct GemmParams {
     // bf16x3 path: the weights split as bf16 hi / lo arrays, same [N][ldb] indexing as b (null on the fp32 path)
     const unsigned short *b_hi;
     const unsigned short *b_lo;
+    // bf16x3 path: 1 = a0 already holds split activations, row m = [lda0 bf16 hi | lda0 bf16 lo] (same bytes per row as fp32),
+    // written by the producing GroupNorm-apply / FIR kernel
+    int a_presplit;
     // fused GroupNorm statistics of the OUTPUT: qstats[img][slice][n/4] = (sum, sum of squares) over the slice's rows of
     // columns 4*(n/4)..+3; slice = 32 output rows (qs_slices = rows_per_image/32 per image), or one image when
     // rows_per_image == 16 (qs_slices = 1).  Unique writer per entry: deterministic.  null = not requested.
@@ -97,9 +100,10 @@ int gn_slices(int batch, int HW);
 int launch_gn_stats(const float *x, int C, float *qs, int batch, int HW, int slices, hipStream_t s);
 // normalise (+ swish); (mean, rstd) per (b, group) are reduced in the kernel's prologue from the quad partial sums of up to
 // two channel-concatenated sources (S0 / S1 slices per image)
+// split_out = 1: out rows are written as [C bf16 hi | C bf16 lo] (the A operand layout of the pre-split bf16x3 GEMM)
 int launch_gn_apply(const float *x0, int C0, const float *x1, int C1, const float *qs0, int S0, const float *qs1, int S1,
                     const float *gamma, const float *beta, float *out, int batch, int HW, int groups, int act, float eps,
-                    hipStream_t s);
+                    int split_out, hipStream_t s);
 int launch_fir_up2(const float *x, float *out, int batch, int H, int W, int C, hipStream_t s);
 int launch_fir_down2(const float *x, float *out, int batch, int H, int W, int C, hipStream_t s);
 int launch_softmax_rows(float *x, long long rows, int cols, hipStream_t s);

@@ -175,12 +175,15 @@ static int run_op(gd_engine *e, const Op &op, const Bind &b, int batch, hipStrea
             if (e->precision == 1 && op.w_slot >= 0 && e->wsplit_valid) {
                 g.b_hi = e->wsplit_hi + e->slot_off[op.w_slot];
                 g.b_lo = e->wsplit_lo + e->slot_off[op.w_slot];
+                g.a_presplit = op.a_split;
+                GD_CHECK(!op.a_split || igemm_bf16x3_ok(g, z), "%s: pre-split input but the GEMM is not eligible for bf16x3", op.label.c_str());
                 if (igemm_bf16x3_ok(g, z)) {
                     ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(igemm_bf16x3_name(g)), op.flops_per_image * batch, 0);
                     return launch_igemm_bf16x3(g, s);
                 }
                 g.b_hi = g.b_lo = nullptr;
             }
+            GD_CHECK(!(e->precision == 1 && op.a_split), "%s: pre-split input without split weights", op.label.c_str());
             ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(igemm_variant_name(g, z)), op.flops_per_image * batch, 0);
             return launch_igemm(g, z, s);
         }
@@ -197,7 +200,7 @@ static int run_op(gd_engine *e, const Op &op, const Bind &b, int batch, hipStrea
             return launch_gn_apply(tptr(e, b, op.a0, batch), op.C0, tptr(e, b, op.a1, batch), op.C1, tptr(e, b, op.stats, batch),
                                    op.S0 > 0 ? op.S0 : rt, tptr(e, b, op.stats1, batch), op.S1 > 0 ? op.S1 : rt,
                                    slot_ptr(e, op.gamma_slot), slot_ptr(e, op.beta_slot), tptr(e, b, op.out, batch), batch, HW,
-                                   op.groups, op.act, 1e-6f, s);
+                                   op.groups, op.act, 1e-6f, (e->precision == 1 && e->wsplit_valid) ? op.split_out : 0, s);
         }
         case OP_FIR_UP: {
             ProfScope ps(e, s, "fir_up2", 0, 4.0 * batch * op.H * op.W * op.C0 * 5);
@@ -790,7 +793,7 @@ int gd_group_norm(const float *x_dev, const float *scale_dev, const float *bias_
     float *qs = nullptr;
     GD_HIP(hipMalloc((void **)&qs, (size_t)batch * sl * (C / 4) * 2 * sizeof(float)));
     int r = launch_gn_stats(x_dev, C, qs, batch, HW, sl, s);
-    if (!r) r = launch_gn_apply(x_dev, C, nullptr, 0, qs, sl, nullptr, 0, scale_dev, bias_dev, out_dev, batch, HW, groups, act, 1e-6f, s);
+    if (!r) r = launch_gn_apply(x_dev, C, nullptr, 0, qs, sl, nullptr, 0, scale_dev, bias_dev, out_dev, batch, HW, groups, act, 1e-6f, 0, s);
     (void)hipStreamSynchronize(s);
     (void)hipFree(qs);
     return r;

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_kernel(const GemmParam
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keeps the epilogue row offsets in SGPRs
     const int wm = wave / WN, wn = wave % WN;
 
     // ---- XCD-aware block -> (mtile, ntile) ----
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_fast_kernel(const Gemm
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keeps the epilogue row offsets in SGPRs
     const int wm = wave / WN, wn = wave % WN;
 
     const int nt = p.n_tiles;
@@ -444,21 +444,11 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_fast_kernel(const Gemm
     // activation lines, so keeping them adjacent in time turns 8 of 9 tap loads into L1/L2 hits (with taps outermost
     // the lines are evicted between taps: ~4x HBM over-fetch in the PMC pass).  Any K permutation is legal as long as
     // A and B agree; B is addressed through the scalar soffset, so the packed weight layout [n][tap][c] is unchanged.
-    const bool tap_minor = !(p.diag & 4);
     auto advance_k = [&]() {
         ++s_kc;
-        if (tap_minor) {
-            ++s_tap;
-            if (++s_tx == p.KW) { s_tx = 0; ++s_ty; }
-            if (s_tap == taps) { s_tap = 0; s_ty = 0; s_tx = 0; s_c0 += KC; }
-        } else {
-            s_c0 += KC;
-            if (s_c0 >= Cin) {
-                s_c0 = 0;
-                ++s_tap;
-                if (++s_tx == p.KW) { s_tx = 0; ++s_ty; }
-            }
-        }
+        ++s_tap;
+        if (++s_tx == p.KW) { s_tx = 0; ++s_ty; }
+        if (s_tap == taps) { s_tap = 0; s_ty = 0; s_tx = 0; s_c0 += KC; }
     };
 
     f32x4 ra[AJ], rb[BJ];

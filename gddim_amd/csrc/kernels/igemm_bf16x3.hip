@@ -40,7 +40,11 @@ __device__ __forceinline__ unsigned xfast_div(unsigned n, unsigned d, unsigned m
     return (t + ((n - t) >> 1)) >> (shift - 1);
 }
 
-template <int BM, int BN, int WM, int WN>
+// DIAG instantiations (GDDIM_IGEMM_DIAG, results wrong) switch parts of the kernel off for ablation timing:
+//   1 no output stores, 2 one K chunk only, 8 no MFMAs, 16 no split / LDS stores, 32 no global loads, 64 no fragment reads
+// PRE: the A operand is already split (rows of [lda0 bf16 hi | lda0 bf16 lo], written by gn_apply_kernel): staging is a plain
+// 16-byte copy per thread -- no conversion work in the K loop.
+template <int BM, int BN, int WM, int WN, bool PRE = false, bool DIAG = false>
 __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16x3_kernel(const GemmParams p) {
     constexpr int NT = 64 * WM * WN;
     constexpr int RM = BM / (32 * WM), RN = BN / (32 * WN);
@@ -50,14 +54,18 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16x3_kernel(const GemmPa
     constexpr int BJ = (BN + BRP - 1) / BRP;
     constexpr int NP = AJ + BJ;          // staging pieces per chunk (a B piece carries hi and lo)
     constexpr int NG = 6;                // MFMA groups per chunk: 2 k16 steps x 3 product terms
-    constexpr int STAGE = (2 * BM + 2 * BN) * XLD;  // bf16 elements per LDS stage
+    constexpr int ALO = BM * XLD;        // A_lo tile offset
+    constexpr int BBASE = 2 * BM * XLD;
+    constexpr int STAGE = BBASE + 2 * BN * XLD;  // bf16 elements per LDS stage
     constexpr int OOB = (int)0x80000000u;
+    int dg = DIAG ? p.diag : 0;
+    if (DIAG) asm volatile("" : "+s"(dg));  // keep the switch word in an SGPR instead of re-reading the kernel arguments
     static_assert(BM % RPP == 0 && RM >= 1 && RN >= 1 && NP <= NG, "bad tile geometry");
     __shared__ __attribute__((aligned(16))) __bf16 smem[2 * STAGE];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keeps the epilogue row offsets in SGPRs
     const int wm = wave / WN, wn = wave % WN;
 
     const int nt = p.n_tiles;
@@ -92,8 +100,13 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16x3_kernel(const GemmPa
         const_cast<char *>(reinterpret_cast<const char *>(p.b_lo)), 0, p.N * p.ldb * 2, 0x00020000);
 
     // ---- per-thread, loop-invariant row data (identical to igemm_f32_fast_kernel) ----
-    const int arow = tid >> 3;
-    const int kcol = (tid & 7) * 4;
+    // fp32 source: 8 threads x float4 per row.  Pre-split source: the first half of the workgroup copies the hi halves of the
+    // rows, the second half the lo halves, 4 threads x 16 B per row (8 consecutive lanes = two rows of one tile, 80 B apart:
+    // their b128 LDS stores are bank-conflict free)
+    const int aplane = PRE ? tid / (NT / 2) : 0;
+    const int arow = PRE ? (tid % (NT / 2)) >> 2 : tid >> 3;
+    const int kcol = (tid & 7) * 4;           // fp32 source: float offset inside the 32-channel chunk
+    const int aq = (tid & 3) * 8;             // pre-split source: bf16 offset inside the chunk (16 B)
     int rb0[AJ], rb1[AJ];
     unsigned inv[AJ];
     {
@@ -110,7 +123,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16x3_kernel(const GemmPa
                 const int ox = r - oy * p.OW;
                 const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
                 const int pix = (img * p.H + iy0) * p.W + ix0;
-                rb0[j] = pix * p.lda0 * 4 + bias0 + kcol * 4;
+                rb0[j] = pix * p.lda0 * 4 + bias0 + (PRE ? (aplane * p.lda0 + aq) * 2 : kcol * 4);
                 rb1[j] = pix * p.lda1 * 4 + bias1 + kcol * 4;
                 unsigned xb = 0;
                 for (int tx = 0; tx < p.KW; ++tx) xb |= ((unsigned)(ix0 + tx) < (unsigned)p.W ? 0u : 1u) << tx;
@@ -132,7 +145,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16x3_kernel(const GemmPa
     }
 
     int s_tap = 0, s_ty = 0, s_tx = 0, s_c0 = 0, s_kc = 0;
-    const int nk = p.K / XKC;
+    const int nk = (DIAG && (dg & 2)) ? 1 : p.K / XKC;
     auto advance_k = [&]() {
         ++s_kc;
         ++s_tap;
@@ -144,10 +157,14 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16x3_kernel(const GemmPa
     u32x4 rbh[BJ], rbl[BJ];
 
     auto load_piece = [&](int pc) {
+        if (DIAG && (dg & 32)) return;
         if (pc < AJ) {
             const int j = pc;
             const int bad = __builtin_amdgcn_sbfe(inv[j], s_tap < 32 ? s_tap : 31, 1) | (s_kc < nk ? 0 : -1);
-            if (s_c0 < p.C0) {
+            if (PRE) {
+                const int soff = (s_ty * p.W + s_tx) * p.lda0 * 4 + s_c0 * 2;
+                ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_a0, rb0[j] | (bad & OOB), soff, 0));
+            } else if (s_c0 < p.C0) {
                 const int soff = ((s_ty * p.W + s_tx) * p.lda0 + s_c0) * 4;
                 ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_a0, rb0[j] | (bad & OOB), soff, 0));
             } else {
@@ -164,7 +181,10 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16x3_kernel(const GemmPa
     };
     // stage layout (bf16 elements): A_hi [BM][XLD] | A_lo [BM][XLD] | B_hi [BN][XLD] | B_lo [BN][XLD]
     auto store_piece = [&](int pc, __bf16 *st) {
-        if (pc < AJ) {
+        if (DIAG && (dg & 16)) return;
+        if (pc < AJ && PRE) {
+            *reinterpret_cast<f32x4 *>(st + aplane * ALO + (arow + RPP * pc) * XLD + aq) = ra[pc];
+        } else if (pc < AJ) {
             const f32x4 v = ra[pc];
             bf16x4 h, l;
 #pragma unroll
@@ -174,12 +194,12 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16x3_kernel(const GemmPa
             }
             const int o = (arow + RPP * pc) * XLD + kcol;
             *reinterpret_cast<bf16x4 *>(st + o) = h;
-            *reinterpret_cast<bf16x4 *>(st + BM * XLD + o) = l;
+            *reinterpret_cast<bf16x4 *>(st + ALO + o) = l;
         } else {
             const int j = pc - AJ;
             const int nl = brow + BRP * j;
             if (nl < BN) {
-                const int o = 2 * BM * XLD + nl * XLD + bq;
+                const int o = BBASE + nl * XLD + bq;
                 *reinterpret_cast<u32x4 *>(st + o) = rbh[j];
                 *reinterpret_cast<u32x4 *>(st + BN * XLD + o) = rbl[j];
             }
@@ -196,7 +216,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16x3_kernel(const GemmPa
 
     const int li = lane & 31, lh = lane >> 5;
     const int a_off = (wm * (BM / WM) + li) * XLD + lh * 8;
-    const int b_off = 2 * BM * XLD + (wn * (BN / WN) + li) * XLD + lh * 8;
+    const int b_off = BBASE + (wn * (BN / WN) + li) * XLD + lh * 8;
 
 #pragma unroll
     for (int pc = 0; pc < NP; ++pc) load_piece(pc);
@@ -214,15 +234,22 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16x3_kernel(const GemmPa
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             bf16x8 ah[RM], al[RM], bh[RN], bl[RN];
+            if (DIAG && (dg & 64)) {
+#pragma unroll
+                for (int r = 0; r < RM; ++r) { ah[r] = bf16x8{}; al[r] = bf16x8{}; }
+#pragma unroll
+                for (int c = 0; c < RN; ++c) { bh[c] = bf16x8{}; bl[c] = bf16x8{}; }
+            } else {
 #pragma unroll
             for (int r = 0; r < RM; ++r) {
                 ah[r] = *reinterpret_cast<const bf16x8 *>(cur + a_off + r * 32 * XLD + s * 16);
-                al[r] = *reinterpret_cast<const bf16x8 *>(cur + BM * XLD + a_off + r * 32 * XLD + s * 16);
+                al[r] = *reinterpret_cast<const bf16x8 *>(cur + ALO + a_off + r * 32 * XLD + s * 16);
             }
 #pragma unroll
             for (int c = 0; c < RN; ++c) {
                 bh[c] = *reinterpret_cast<const bf16x8 *>(cur + b_off + c * 32 * XLD + s * 16);
                 bl[c] = *reinterpret_cast<const bf16x8 *>(cur + BN * XLD + b_off + c * 32 * XLD + s * 16);
+            }
             }
 #pragma unroll
             for (int term = 0; term < 3; ++term) {
@@ -232,7 +259,11 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16x3_kernel(const GemmPa
                     for (int c = 0; c < RN; ++c) {
                         const bf16x8 a = term == 2 ? al[r] : ah[r];
                         const bf16x8 b = term == 1 ? bl[c] : bh[c];
-                        acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[r][c], 0, 0, 0);
+                        if (DIAG && (dg & 8)) {
+                            asm volatile("" ::"v"(a), "v"(b));
+                        } else {
+                            acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[r][c], 0, 0, 0);
+                        }
                     }
                 __builtin_amdgcn_sched_barrier(0);
                 const int gap = s * 3 + term;
@@ -294,6 +325,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16x3_kernel(const GemmPa
                 for (int v = 0; v < 16; ++v) {
                     const float val = (p.alpha * acc[r][c][v] + addv[v]) * p.out_scale;
                     vals[v] = val;
+                    if (DIAG && (dg & 1)) { asm volatile("" ::"v"(val)); continue; }
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), srd_o, vo_o,
                                                           (mrow + (v & 3) + 8 * (v >> 2)) * p.ldc * 4, 0);
                 }
@@ -315,6 +347,7 @@ bool igemm_bf16x3_ok(const GemmParams &p, int batch_z) {
     if (batch_z != 1 || p.b_kmajor || p.in_act || !p.b_hi || !p.b_lo) return false;
     const int Cin = p.C0 + p.C1;
     if (Cin % 32 != 0 || (p.C1 > 0 && p.C0 % 32 != 0) || p.KH * p.KW > 32 || p.K % 32 != 0 || p.ldb % 8 != 0) return false;
+    if (p.a_presplit && (p.C1 != 0 || p.lda0 % 8 != 0)) return false;
     if (p.rowbias && p.rows_per_image % 8 != 0) return false;
     const long long ldmax = p.lda0 > p.lda1 ? p.lda0 : p.lda1;
     const long long imgs = (p.M + (long long)p.OH * p.OW - 1) / ((long long)p.OH * p.OW);
@@ -336,9 +369,9 @@ static void xpick(const GemmParams &p, int &bm, int &bn) {
 const char *igemm_bf16x3_name(const GemmParams &p) {
     int bm, bn;
     xpick(p, bm, bn);
-    if (bm == 256) return "igemm_bf16x3_kernel<256,128,4,2>";
-    if (bm == 128) return "igemm_bf16x3_kernel<128,128,2,4>";
-    return "igemm_bf16x3_kernel<64,64,2,2>";
+    if (bm == 256) return p.a_presplit ? "igemm_bf16x3_kernel<256,128,4,2,pre>" : "igemm_bf16x3_kernel<256,128,4,2>";
+    if (bm == 128) return p.a_presplit ? "igemm_bf16x3_kernel<128,128,2,4,pre>" : "igemm_bf16x3_kernel<128,128,2,4>";
+    return p.a_presplit ? "igemm_bf16x3_kernel<64,64,2,2,pre>" : "igemm_bf16x3_kernel<64,64,2,2>";
 }
 
 static void xfill_div(unsigned d, unsigned &magic, unsigned &shift) {
@@ -360,8 +393,15 @@ int launch_igemm_bf16x3(const GemmParams &p_in, hipStream_t s) {
     p.n_tiles = (p.N + bn - 1) / bn;
     p.flat_tiles = p.m_tiles < 16;
     const int gx = p.flat_tiles ? p.m_tiles * p.n_tiles : ((p.m_tiles + 7) / 8) * 8 * p.n_tiles;
-    if (bm == 256) hipLaunchKernelGGL((igemm_bf16x3_kernel<256, 128, 4, 2>), dim3(gx), dim3(512), 0, s, p);
+    static const int diag = getenv("GDDIM_IGEMM_DIAG") ? atoi(getenv("GDDIM_IGEMM_DIAG")) : 0;
+    p.diag = diag;
+    if (bm == 256 && diag && p.a_presplit) hipLaunchKernelGGL((igemm_bf16x3_kernel<256, 128, 4, 2, true, true>), dim3(gx), dim3(512), 0, s, p);
+    else if (bm == 256 && diag) hipLaunchKernelGGL((igemm_bf16x3_kernel<256, 128, 4, 2, false, true>), dim3(gx), dim3(512), 0, s, p);
+    else if (bm == 256 && p.a_presplit) hipLaunchKernelGGL((igemm_bf16x3_kernel<256, 128, 4, 2, true>), dim3(gx), dim3(512), 0, s, p);
+    else if (bm == 256) hipLaunchKernelGGL((igemm_bf16x3_kernel<256, 128, 4, 2>), dim3(gx), dim3(512), 0, s, p);
+    else if (bm == 128 && p.a_presplit) hipLaunchKernelGGL((igemm_bf16x3_kernel<128, 128, 2, 4, true>), dim3(gx), dim3(512), 0, s, p);
     else if (bm == 128) hipLaunchKernelGGL((igemm_bf16x3_kernel<128, 128, 2, 4>), dim3(gx), dim3(512), 0, s, p);
+    else if (p.a_presplit) hipLaunchKernelGGL((igemm_bf16x3_kernel<64, 64, 2, 2, true>), dim3(gx), dim3(256), 0, s, p);
     else hipLaunchKernelGGL((igemm_bf16x3_kernel<64, 64, 2, 2>), dim3(gx), dim3(256), 0, s, p);
     GD_HIP(hipGetLastError());
     return 0;

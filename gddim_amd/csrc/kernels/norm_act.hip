@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float *__restrict__
                                                         const float *__restrict__ qs1, int S1,
                                                         const float *__restrict__ gamma, const float *__restrict__ beta,
                                                         float *__restrict__ out, int HW, int groups, int act, float inv_n,
-                                                        float eps) {
+                                                        float eps, int split_out) {
     __shared__ float s_sum[256], s_sq[256];
     const int C = C0 + C1, C4 = C >> 2;
     const int Q0 = C0 >> 2, Q1 = C1 >> 2;
@@ -138,7 +138,20 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float *__restrict__
             float y = v[i] * sc[i] + sh[i];
             v[i] = act ? swish_e(y) : y;
         }
-        *reinterpret_cast<f32x4 *>(dst + (size_t)p * C) = v;
+        if (split_out) {  // row = [C bf16 hi | C bf16 lo], hi = rne(x), lo = rne(x - hi)
+            typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+            bf16x4 h, l;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                h[i] = (__bf16)v[i];
+                l[i] = (__bf16)(v[i] - (float)h[i]);
+            }
+            __bf16 *row = reinterpret_cast<__bf16 *>(out + ((size_t)b * HW + p) * C);
+            *reinterpret_cast<bf16x4 *>(row + c) = h;
+            *reinterpret_cast<bf16x4 *>(row + C + c) = l;
+        } else {
+            *reinterpret_cast<f32x4 *>(dst + (size_t)p * C) = v;
+        }
     }
 }
 
@@ -151,7 +164,7 @@ int launch_gn_stats(const float *x, int C, float *qs, int batch, int HW, int sli
 
 int launch_gn_apply(const float *x0, int C0, const float *x1, int C1, const float *qs0, int S0, const float *qs1, int S1,
                     const float *gamma, const float *beta, float *out, int batch, int HW, int groups, int act, float eps,
-                    hipStream_t s) {
+                    int split_out, hipStream_t s) {
     const int C = C0 + C1;
     GD_CHECK(C % 4 == 0 && C0 % 4 == 0 && C / 4 <= 256 && (C / 4) % groups == 0 && groups <= 256 && groups >= 1,
              "group_norm: unsupported C=%d (C0=%d) groups=%d", C, C0, groups);
@@ -159,7 +172,7 @@ int launch_gn_apply(const float *x0, int C0, const float *x1, int C1, const floa
     while (nblk < 64 && (long long)batch * nblk < 4096 && HW / (nblk * 2) >= 16) nblk *= 2;
     const float inv_n = 1.0f / ((float)HW * (float)(C / groups));
     hipLaunchKernelGGL(gn_apply_kernel, dim3(nblk, batch), dim3(256), 0, s, x0, C0, x1, C1, qs0, S0, qs1, S1, gamma, beta, out,
-                       HW, groups, act, inv_n, eps);
+                       HW, groups, act, inv_n, eps, split_out);
     GD_HIP(hipGetLastError());
     return 0;
 }

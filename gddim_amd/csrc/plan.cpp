@@ -517,12 +517,43 @@ int Plan::build(const gd_model_desc &d) {
     if (tproj_t_ >= 0) release(tproj_t_);
     GD_CHECK((int)rb_tproj_off_.size() == rb, "internal: resblock count mismatch (%d vs %d)", (int)rb_tproj_off_.size(), rb);
 
+    mark_split();
     flops_per_image = conv3x3_flops_per_image = 0;
     for (const Op &o : ops) {
         flops_per_image += o.flops_per_image;
         if (o.is_conv3x3) conv3x3_flops_per_image += o.flops_per_image;
     }
     return 0;
+}
+
+// A GroupNorm-apply output may be stored split (bf16 hi|lo rows) in bf16x3 mode when all of its readers are weight GEMMs the
+// split-precision kernel accepts with a pre-split A operand: whole tensor as the single source, 32-channel slabs.
+void Plan::mark_split() {
+    for (size_t i = 0; i < ops.size(); ++i) {
+        Op &ap = ops[i];
+        if (ap.kind != OP_GN_APPLY || tensors[ap.out.t].ext != EXT_NONE) continue;
+        const int t = ap.out.t;
+        const int C = ap.C0 + ap.C1;
+        std::vector<size_t> readers;
+        bool ok = C % 32 == 0;
+        for (size_t j = 0; j < ops.size() && ok; ++j) {
+            if (j == i) continue;
+            const Op &o = ops[j];
+            const bool reads = o.a0.t == t || o.a1.t == t || o.bten.t == t || o.res.t == t || o.rowbias.t == t ||
+                               (o.kind != OP_GEMM && o.out.t == t);
+            if (!reads) continue;
+            if (o.kind == OP_GEMM && o.a0.t == t && o.a0.col == 0 && o.a1.t < 0 && o.C1 == 0 && o.C0 == C && o.lda0 == C &&
+                o.bten.t != t && o.res.t != t && o.rowbias.t != t && o.a_slot < 0 && o.w_slot >= 0 && !o.z_per_image &&
+                !o.b_kmajor && !o.in_act && o.KH * o.KW <= 32 && o.K % 32 == 0 && o.ldb % 8 == 0 &&
+                !(o.rowbias.t >= 0 && o.m_per_image % 8 != 0))
+                readers.push_back(j);
+            else
+                ok = false;
+        }
+        if (!ok || readers.empty()) continue;
+        ap.split_out = 1;
+        for (size_t j : readers) ops[j].a_split = 1;
+    }
 }
 
 // ---------------------------------------------------------------- parameter packing
@@ -605,6 +636,7 @@ std::string Plan::json() const {
         o << (i ? "," : "") << "{\"kind\":" << p.kind << ",\"label\":\"" << p.label << "\",";
         jref(o, "a0", p.a0); jref(o, "a1", p.a1); jref(o, "bten", p.bten); jref(o, "rowbias", p.rowbias);
         jref(o, "res", p.res); jref(o, "out", p.out); jref(o, "stats", p.stats); jref(o, "stats1", p.stats1); jref(o, "qstats", p.qstats);
+        o << "\"split_out\":" << p.split_out << ",\"a_split\":" << p.a_split << ",";
         o << "\"C0\":" << p.C0 << ",\"C1\":" << p.C1 << ",\"lda0\":" << p.lda0 << ",\"lda1\":" << p.lda1 << ",\"H\":" << p.H
           << ",\"W\":" << p.W << ",\"OH\":" << p.OH << ",\"OW\":" << p.OW << ",\"KH\":" << p.KH << ",\"KW\":" << p.KW
           << ",\"stride\":" << p.stride << ",\"pad\":" << p.pad << ",\"m_per_image\":" << p.m_per_image

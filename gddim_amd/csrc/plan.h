@@ -70,6 +70,9 @@ struct Op {
     int ldc = 0;
     float alpha = 1.f, out_scale = 1.f;
     int in_act = 0;
+    // split precision (bf16x3 mode only): GN_APPLY writes its output as bf16 hi|lo rows (split_out) when every consumer is
+    // a weight GEMM that can read them (a_split); decided by Plan::mark_split at build time
+    int split_out = 0, a_split = 0;
     TRef qstats;          // GEMM: quad statistics of the output (fused GroupNorm statistics), t = -1: none
     int qs_slices = 0;
     // ---- GroupNorm ----
@@ -125,6 +128,7 @@ struct Plan {
     double flops_per_image = 0, conv3x3_flops_per_image = 0;
 
     int build(const gd_model_desc &d);  // 0 ok
+    void mark_split();
     int load_param(const std::string &name, const float *data, const int64_t *shape, int ndim);
     std::string json() const;
 

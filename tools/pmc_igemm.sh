@@ -4,7 +4,7 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/pmc_igemm_$1_$2
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $REPO/tools/bench_igemm.py --only $1 --iters 5"
+CMD=${PMC_CMD:-"python $REPO/tools/bench_igemm.py --only $1 --iters 5"}  # PMC_CMD: profile another command (e.g. a short bench.py run)
 export GDDIM_IGEMM_VARIANT=$2
 i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM" \
