@@ -591,22 +591,23 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_fast_kernel(const Gemm
                     for (int v = 0; v < 16; ++v) addv[v] += t[v];
                 }
                 if (p.rowbias) {
-                    float t[16];
+                    // rows_per_image is a multiple of 8: the 8 rows (v & 3) + 4*lh of a row group v >> 2 belong to one image
+                    // and that image index is wave-uniform -> four scalar divisions and four loads per tile
+                    float t[4];
 #pragma unroll
-                    for (int v = 0; v < 16; ++v) {
-                        const unsigned mr = (unsigned)(mrow + (v & 3) + 8 * (v >> 2));
+                    for (int g = 0; g < 4; ++g) {
+                        const unsigned mr = (unsigned)(mrow + 8 * g);
                         const unsigned img = mr < (unsigned)p.M ? fast_div(mr, rpi, p.mg_rpi, p.sh_rpi) : 0u;
-                        t[v] = nok ? p.rowbias[(size_t)img * p.ld_rowbias + n] : 0.f;
+                        t[g] = nok ? p.rowbias[(size_t)img * p.ld_rowbias + n] : 0.f;
                     }
 #pragma unroll
-                    for (int v = 0; v < 16; ++v) addv[v] += t[v];
+                    for (int v = 0; v < 16; ++v) addv[v] += t[v >> 2];
                 }
                 float vals[16];
 #pragma unroll
                 for (int v = 0; v < 16; ++v) {
                     const float val = (p.alpha * acc[r][c][v] + addv[v]) * p.out_scale;
                     vals[v] = val;
-                    if (p.diag == 1) { asm volatile("" ::"v"(val)); continue; }
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), srd_o, vo_o,
                                                           (mrow + (v & 3) + 8 * (v >> 2)) * p.ldc * 4, 0);
                 }

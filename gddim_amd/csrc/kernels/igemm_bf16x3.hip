@@ -310,15 +310,17 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16x3_kernel(const GemmPa
                     for (int v = 0; v < 16; ++v) addv[v] += t[v];
                 }
                 if (p.rowbias) {
-                    float t[16];
+                    // rows_per_image is a multiple of 8: the 8 rows (v & 3) + 4*lh of a row group v >> 2 belong to one image
+                    // and that image index is wave-uniform -> four scalar divisions and four loads per tile
+                    float t[4];
 #pragma unroll
-                    for (int v = 0; v < 16; ++v) {
-                        const unsigned mr = (unsigned)(mrow + (v & 3) + 8 * (v >> 2));
+                    for (int g = 0; g < 4; ++g) {
+                        const unsigned mr = (unsigned)(mrow + 8 * g);
                         const unsigned img = mr < (unsigned)p.M ? xfast_div(mr, rpi, p.mg_rpi, p.sh_rpi) : 0u;
-                        t[v] = nok ? p.rowbias[(size_t)img * p.ld_rowbias + n] : 0.f;
+                        t[g] = nok ? p.rowbias[(size_t)img * p.ld_rowbias + n] : 0.f;
                     }
 #pragma unroll
-                    for (int v = 0; v < 16; ++v) addv[v] += t[v];
+                    for (int v = 0; v < 16; ++v) addv[v] += t[v >> 2];
                 }
                 float vals[16];
 #pragma unroll
