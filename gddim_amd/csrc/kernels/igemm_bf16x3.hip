@@ -31,6 +31,9 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
+#ifndef X3_ABL
+#define X3_ABL 0  // compile-time ablation mask for timing experiments (tools/ablate_bf16x3.sh); 0 in the product build
+#endif
 constexpr int XKC = 32;   // K chunk (two k16 MFMA steps)
 constexpr int XLD = 40;   // LDS row stride in bf16 elements: 64 B of data + 16 B pad = 80 B
 
@@ -158,6 +161,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16x3_kernel(const GemmPa
 
     auto load_piece = [&](int pc) {
         if (DIAG && (dg & 32)) return;
+        if (X3_ABL & 2) { if (pc < AJ) ra[pc] = f32x4{0.f, 0.f, 0.f, 0.f}; else { rbh[pc - AJ] = u32x4{0, 0, 0, 0}; rbl[pc - AJ] = u32x4{0, 0, 0, 0}; } return; }
         if (pc < AJ) {
             const int j = pc;
             const int bad = __builtin_amdgcn_sbfe(inv[j], s_tap < 32 ? s_tap : 31, 1) | (s_kc < nk ? 0 : -1);
@@ -182,6 +186,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16x3_kernel(const GemmPa
     // stage layout (bf16 elements): A_hi [BM][XLD] | A_lo [BM][XLD] | B_hi [BN][XLD] | B_lo [BN][XLD]
     auto store_piece = [&](int pc, __bf16 *st) {
         if (DIAG && (dg & 16)) return;
+        if (X3_ABL & 4) return;
         if (pc < AJ && PRE) {
             *reinterpret_cast<f32x4 *>(st + aplane * ALO + (arow + RPP * pc) * XLD + aq) = ra[pc];
         } else if (pc < AJ) {
@@ -234,7 +239,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16x3_kernel(const GemmPa
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             bf16x8 ah[RM], al[RM], bh[RN], bl[RN];
-            if (DIAG && (dg & 64)) {
+            if ((X3_ABL & 8) || (DIAG && (dg & 64))) {
 #pragma unroll
                 for (int r = 0; r < RM; ++r) { ah[r] = bf16x8{}; al[r] = bf16x8{}; }
 #pragma unroll
@@ -259,7 +264,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16x3_kernel(const GemmPa
                     for (int c = 0; c < RN; ++c) {
                         const bf16x8 a = term == 2 ? al[r] : ah[r];
                         const bf16x8 b = term == 1 ? bl[c] : bh[c];
-                        if (DIAG && (dg & 8)) {
+                        if ((X3_ABL & 16) || (DIAG && (dg & 8))) {
                             asm volatile("" ::"v"(a), "v"(b));
                         } else {
                             acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[r][c], 0, 0, 0);
@@ -281,20 +286,45 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16x3_kernel(const GemmPa
     }
 
     // ---- epilogue (buffer addressed, as igemm_f32_fast_kernel) ----
-    {
+    if (X3_ABL & 1) {
+        float sink = 0.f;
+#pragma unroll
+        for (int r = 0; r < RM; ++r)
+#pragma unroll
+            for (int c = 0; c < RN; ++c)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) sink += acc[r][c][v];
+        if (sink == 1.2345e-30f) p.out[0] = sink;
+    } else {
         char *outc = reinterpret_cast<char *>(p.out);
         const __amdgpu_buffer_rsrc_t srd_o = __builtin_amdgcn_make_buffer_rsrc(outc, 0, p.M * p.ldc * 4, 0x00020000);
         const __amdgpu_buffer_rsrc_t srd_r =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(reinterpret_cast<const char *>(p.res ? p.res : p.out)), 0,
                                               p.M * p.ldres * 4, 0x00020000);
         const unsigned rpi = p.rows_per_image;
+        // all residual values of the wave's tile are requested at once (RM*RN*16 loads in flight) before any is consumed
+        float resv[RN][RM][16];
+        if (p.res) {
+#pragma unroll
+            for (int c = 0; c < RN; ++c) {
+                const int n = n0 + wn * (BN / WN) + c * 32 + li;
+                const int vo_r = n < p.N ? (4 * lh * p.ldres + n) * 4 : OOB;
+#pragma unroll
+                for (int r = 0; r < RM; ++r) {
+                    const int mrow = m0 + wm * (BM / WM) + r * 32;
+#pragma unroll
+                    for (int v = 0; v < 16; ++v)
+                        resv[c][r][v] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_r, vo_r, (mrow + (v & 3) + 8 * (v >> 2)) * p.ldres * 4, 0));
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int c = 0; c < RN; ++c) {
             const int n = n0 + wn * (BN / WN) + c * 32 + li;
             const bool nok = n < p.N;
             const float bias = (p.bias && nok) ? p.bias[n] : 0.f;
             const int vo_o = nok ? (4 * lh * p.ldc + n) * 4 : OOB;
-            const int vo_r = nok ? (4 * lh * p.ldres + n) * 4 : OOB;
 #pragma unroll
             for (int r = 0; r < RM; ++r) {
                 const int mrow = m0 + wm * (BM / WM) + r * 32;
@@ -302,12 +332,8 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16x3_kernel(const GemmPa
 #pragma unroll
                 for (int v = 0; v < 16; ++v) addv[v] = bias;
                 if (p.res) {
-                    float t[16];
 #pragma unroll
-                    for (int v = 0; v < 16; ++v)
-                        t[v] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_r, vo_r, (mrow + (v & 3) + 8 * (v >> 2)) * p.ldres * 4, 0));
-#pragma unroll
-                    for (int v = 0; v < 16; ++v) addv[v] += t[v];
+                    for (int v = 0; v < 16; ++v) addv[v] += resv[c][r][v];
                 }
                 if (p.rowbias) {
                     // rows_per_image is a multiple of 8: the 8 rows (v & 3) + 4*lh of a row group v >> 2 belong to one image
@@ -397,6 +423,13 @@ int launch_igemm_bf16x3(const GemmParams &p_in, hipStream_t s) {
     const int gx = p.flat_tiles ? p.m_tiles * p.n_tiles : ((p.m_tiles + 7) / 8) * 8 * p.n_tiles;
     static const int diag = getenv("GDDIM_IGEMM_DIAG") ? atoi(getenv("GDDIM_IGEMM_DIAG")) : 0;
     p.diag = diag;
+    static const int variant = getenv("GDDIM_X3_VARIANT") ? atoi(getenv("GDDIM_X3_VARIANT")) : 0;  // A/B measurements only
+    if (variant == 1 && bm == 256 && p.a_presplit) {  // 128x128 tiles, 4 waves, 80 KB LDS: two workgroups per CU
+        p.m_tiles = (p.M + 127) / 128;
+        p.flat_tiles = p.m_tiles < 16;
+        const int gx1 = p.flat_tiles ? p.m_tiles * p.n_tiles : ((p.m_tiles + 7) / 8) * 8 * p.n_tiles;
+        hipLaunchKernelGGL((igemm_bf16x3_kernel<128, 128, 2, 2, true>), dim3(gx1), dim3(256), 0, s, p);
+    } else
     if (bm == 256 && diag && p.a_presplit) hipLaunchKernelGGL((igemm_bf16x3_kernel<256, 128, 4, 2, true, true>), dim3(gx), dim3(512), 0, s, p);
     else if (bm == 256 && diag) hipLaunchKernelGGL((igemm_bf16x3_kernel<256, 128, 4, 2, false, true>), dim3(gx), dim3(512), 0, s, p);
     else if (bm == 256 && p.a_presplit) hipLaunchKernelGGL((igemm_bf16x3_kernel<256, 128, 4, 2, true>), dim3(gx), dim3(512), 0, s, p);
