@@ -54,6 +54,7 @@ SIGNATURES = {
     "gd_version": (_I, []),
     "gd_device_count": (_I, []),
     "gd_cld_r_table": (_I, [_D, _D, _D, _D, _D, _I, _D, _SZ, _P]),
+    "gd_cld_psi2_table": (_I, [_D, _D, _D, _D, _SZ, _P]),
     "gd_engine_create": (_I, [ctypes.POINTER(ModelDesc), _I, ctypes.POINTER(_P)]),
     "gd_engine_destroy": (_I, [_P]),
     "gd_engine_plan_json": (_I, [_P, _P, _SZ, ctypes.POINTER(_SZ)]),
@@ -67,6 +68,7 @@ SIGNATURES = {
     "gd_unet_forward": (_I, [_P, _P, _P, _P, _I, _P]),
     "gd_cld_eps": (_I, [_P, _P, _P, _P, _I, _P]),
     "gd_engine_set_schedule_cld": (_I, [_P, _I, _I, _P, _P, _I, _F, _P, _P, _P]),
+    "gd_engine_set_transforms_cld": (_I, [_P, _P, _P, _P, _P, _P]),
     "gd_sample_cld": (_I, [_P, _I, _P, _P, _P, _I, _I, _P]),
     "gd_engine_set_schedule_blur": (_I, [_P, _I, _P, _P, _P]),
     "gd_sample_blur": (_I, [_P, _I, _P, _P, _I, _I, _P]),

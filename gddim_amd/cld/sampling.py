@@ -19,8 +19,10 @@ The returned callable is `sampling_fn(rng, state, batch_size, u=None)`:
 
 Inside the callable nothing but the native engine runs: the whole NFE loop (U-Net forward + fused
 2x2 exponential-integrator update per step, denoising step, inverse scaling) is `gd_sample_cld`, replayed
-from a hipGraph.  The other samplers of the reference's factory (sdeis, ldeis, mldeis, ode, sscs, em) are
-outside this round's scope and raise NotImplementedError.
+from a hipGraph.  get_L_deis_sampler (:533-540, the Cholesky parametrisation of eps) and get_mldeis_sampler (:322-378, the
+rotated frame y = psi1(t)^-1 x) run on the same fused loop through per-step 2x2 maps (gd_engine_set_transforms_cld), and so does
+sde.mixed_score=True (models/utils.py:174-176).  The stochastic samplers of the reference's factory (sdeis, sscs, em) and the
+adaptive `ode` solver are outside this round's scope and raise NotImplementedError.
 """
 import itertools
 
@@ -90,10 +92,24 @@ def _seed_of(rng):
     return int(np.bitwise_xor.reduce(a * np.uint64(0x9E3779B97F4A7C15) + np.arange(a.size, dtype=np.uint64)) >> np.uint64(2))
 
 
-def _make_sampler(sde, model, data_shape, nfe, inverse_scaler, rev_ts, coef, denoising, is_p, tag):
-    """Shared closure builder: `coef` is (num_step, n_slots, 2, 2) = [Psi_i, C_i0, ...]."""
+def _make_sampler(sde, model, data_shape, nfe, inverse_scaler, rev_ts, coef, denoising, is_p, tag, pre=None, eps_lin=None,
+                  init=None, post=None, dn_sde=None):
+    """Shared closure builder: `coef` is (num_step, n_slots, 2, 2) = [Psi_i, C_i0, ...].
+    pre / eps_lin: optional (num_step, 2, 2) maps (network input P_i u; eps <- E_i eps); init / post: 2x2 maps applied to the
+    initial noise / to the state after the denoising step; dn_sde: the SDE whose F, G, R the denoising step uses."""
     num_step = coef.shape[0]
-    dn = _denoise_mats(sde, sde.sampling_eps) if denoising else (None, None, None)
+    dn_sde = sde if dn_sde is None else dn_sde
+    dn = _denoise_mats(dn_sde, dn_sde.sampling_eps) if denoising else (None, None, None)
+    # mixed score (models/utils.py:174-176): eps_fn(x, t) = net(x, t) + X(t) x with X = invR(t) diag(0, 1), x = P_i u
+    u_lin = dn_u_lin = None
+    if getattr(sde, 'mixed_score', False):
+        base = dn_sde if hasattr(dn_sde, 'mixed_u_matrix') else sde.sde
+        X = np.stack([base.mixed_u_matrix(t) for t in rev_ts[:num_step]]) if num_step else np.zeros((0, 2, 2))
+        if pre is not None:
+            X = X @ pre
+        u_lin = X if eps_lin is None else eps_lin @ X
+        dn_u_lin = base.mixed_u_matrix(dn_sde.sampling_eps) if denoising else None
+    transforms = any(m is not None for m in (pre, eps_lin, u_lin, dn_u_lin, post))
     # the reference applies `inverse_scaler` after the loop; the engine fuses the centered one, (x+1)/2
     probe = np.array([-1.0, 0.0, 1.0])
     scaled = np.asarray(inverse_scaler(probe), dtype=np.float64)
@@ -118,7 +134,12 @@ def _make_sampler(sde, model, data_shape, nfe, inverse_scaler, rev_ts, coef, den
         u = u.to(torch.float32)
         assert tuple(u.shape) == (batch_size,) + tuple(data_shape) + (2,), "u must be (B, *data_shape, 2)"
         eng = model.engine_for(state.params_ema, 2 * data_shape[-1], batch_size, u.device.index)
-        eng.set_schedule_cld(ts32, coef32, denoising, sde.sampling_eps, dn[0], dn[1], dn[2], token=token)
+        if init is not None:
+            u = utils.sbmm(init, u)
+        if eng._schedule_token != token:
+            eng.set_schedule_cld(ts32, coef32, denoising, sde.sampling_eps, dn[0], dn[1], dn[2], token=token)
+            if transforms:
+                eng.set_transforms_cld(pre, eps_lin, u_lin, dn_u_lin, post)
         x, v = eng.sample_cld(u, inverse_scale=fuse_scale, use_graph=use_graph)
         if post_scale is not None:
             x = post_scale(x)
@@ -169,6 +190,39 @@ def get_hyd_deis_sampler(sde, model, data_shape, nfe, inverse_scaler, deis_order
     return _impl_deis_sampler(sde, model, data_shape, nfe, inverse_scaler, deis_order, rev_ts, denoising, is_p)
 
 
+def _impl_Ldeis_sampler(sde, model, data_shape, nfe, inverse_scaler, deis_order, rev_ts, denoising=False, is_p=False):
+    """cld_jax/sampling.py:497-531: eps is mapped by epsR2epsL before every AB step; `sde` is an LSDE."""
+    if denoising:
+        # the reference builds get_denoising_step(sde=LSDE, ...) here, which reads sde.s_F: the LSDE class has none
+        raise AttributeError("'LSDE' object has no attribute 's_F'")
+    num_step = nfe
+    deis_coef = sde.get_deis_coef(deis_order, rev_ts)
+    eps_lin = np.stack([sde.epsR2epsL_matrix(t) for t in rev_ts[:num_step]])
+    return _make_sampler(sde, model, data_shape, nfe, inverse_scaler, rev_ts, deis_coef, denoising, is_p, "ldeis", eps_lin=eps_lin,
+                         dn_sde=sde.sde)
+
+
+def get_L_deis_sampler(sde, model, data_shape, nfe, inverse_scaler, deis_order, ts_order=2, denoising=False, is_p=False):
+    from .sde_lib import LSDE
+    rev_ts = get_rev_ts(sde, ts_order, nfe - 1 if denoising else nfe)
+    new_sde = LSDE(sde)
+    return _impl_Ldeis_sampler(new_sde, model, data_shape, nfe, inverse_scaler, deis_order, rev_ts, denoising, is_p)
+
+
+def get_mldeis_sampler(sde, model, data_shape, nfe, inverse_scaler, deis_order, ts_order=2, denoising=False, is_p=False):
+    """cld_jax/sampling.py:322-378: the loop runs on y = psi1(t)^-1 x.  As in the reference the denoising step is applied to
+    the y-frame state with the x-frame formula, and the final change of frame uses psi1(sampling_eps / 2)."""
+    from .sde_lib import MLCLD
+    num_step = nfe - 1 if denoising else nfe
+    rev_ts = np.power(np.linspace(np.power(sde.T, 1.0 / ts_order), np.power(sde.sampling_eps, 1.0 / ts_order), num_step + 1),
+                      ts_order)
+    mlsde = MLCLD(sde)
+    deis_coef = mlsde.get_deis_coef(deis_order, rev_ts)
+    pre = np.stack([mlsde.y2x_matrix(t) for t in rev_ts[:num_step]])
+    return _make_sampler(mlsde, model, data_shape, nfe, inverse_scaler, rev_ts, deis_coef, denoising, is_p, "mldeis", pre=pre,
+                         init=mlsde.x2y_matrix(sde.T), post=mlsde.y2x_matrix(sde.sampling_eps / 2), dn_sde=sde)
+
+
 def get_sampling_fn(config, sde, model, shape, inverse_scaler):
     """Create a sampling function (cld_jax/sampling.py:41-154)."""
     del shape
@@ -189,6 +243,14 @@ def get_sampling_fn(config, sde, model, shape, inverse_scaler):
                                     noise_nfe_ratio=config.sampling.noise_nfe_ratio,
                                     img_t_ratio=config.sampling.img_t_ratio, ts_order=config.sampling.ts_order,
                                     denoising=config.sampling.noise_removal, is_p=True)
-    if name in ('sdeis', 'ldeis', 'mldeis', 'ode', 'sscs', 'em'):
+    if name == 'ldeis':
+        return get_L_deis_sampler(sde=sde, model=model, data_shape=data_shape, nfe=config.sampling.nfe,
+                                  inverse_scaler=inverse_scaler, deis_order=config.sampling.deis_order,
+                                  ts_order=config.sampling.ts_order, denoising=config.sampling.noise_removal, is_p=True)
+    if name == 'mldeis':
+        return get_mldeis_sampler(sde=sde, model=model, data_shape=data_shape, nfe=config.sampling.nfe,
+                                  inverse_scaler=inverse_scaler, deis_order=config.sampling.deis_order,
+                                  ts_order=config.sampling.ts_order, denoising=config.sampling.noise_removal, is_p=True)
+    if name in ('sdeis', 'ode', 'sscs', 'em'):
         raise NotImplementedError("sampling.method=%r is not built yet (SURVEY.md section 8f, N3)" % sampler_name)
     raise RuntimeError

@@ -125,6 +125,34 @@ class CLD(object):
     def s_eps_integrand(self, t):
         return self.v_eps_integrand(t)[0]
 
+    # ---- F = F1 + F2 split of the rotated-frame sampler (sde_lib.py:121-180) ----
+    def s_f1_psi(self, s, t):
+        """expm(int_s^t F1): a rotation-like matrix, F1 = [[0, beta m_inv], [-beta, 0]]."""
+        b = float(self.beta_int(t) - self.beta_int(s))
+        sqrt_m, inv_sqrt_m = np.sqrt(1.0 / self.m_inv), np.sqrt(self.m_inv)
+        c, sn = np.cos(b * inv_sqrt_m), np.sin(b * inv_sqrt_m)
+        return np.array([[c, inv_sqrt_m * sn], [-sqrt_m * sn, c]])
+
+    def s_psi1(self, t):
+        return self.s_f1_psi(0.0, t)
+
+    def s_inv_psi1(self, t):
+        return self.s_f1_psi(t, 0.0)
+
+    def s_F1(self, t):
+        b = float(self.beta(t))
+        return np.array([[0.0, b * self.m_inv], [-b, 0.0]])
+
+    def s_F2(self, t):
+        b = float(self.beta(t))
+        return np.array([[0.0, 0.0], [0.0, -self.Gamma * b * self.m_inv]])
+
+    def mixed_u_matrix(self, t):
+        """mixed score: eps_fn adds bmm(invR(t), u with its x part zeroed) = (invR(t) diag(0, 1)) u (models/utils.py:174-176)."""
+        m = self.s_invR(t).copy()
+        m[:, 0] = 0.0
+        return m
+
     # ---- device-side helpers ----
     def eps2score(self, eps, ts):
         """score = -R(t)^-T eps, per-sample t (sde_lib.py:246-253); eps is a device tensor (B,...,d,2)."""
@@ -155,6 +183,139 @@ class CLD(object):
 
     def get_deis_coef(self, order, rev_timesteps, used_cache=True):
         """(N, order+3, 2, 2) = [Psi_i, C_i0 .. C_i(order+1)] (sde_lib.py:308-319; highest_order = order+1)."""
+        ts = np.asarray(rev_timesteps, dtype=np.float64)
+        x_coef = self.vv_psi(ts[:-1], ts[1:])
+        eps_coef = deis.get_ab_eps_coef(self, order + 1, ts, order)
+        return np.concatenate([x_coef[:, None], eps_coef], axis=1)
+
+
+class LSDE(object):
+    """Cholesky ("L") parametrisation of the noise prediction (cld_jax/sde_lib.py:469-520): eps_L = L^T R^-T eps_R with
+    L = chol(R R^T); the DEIS integrand becomes 1/2 G G L^-T.  Has no s_F, exactly like the reference class."""
+
+    def __init__(self, sde, used_cache=True):
+        self.sde = sde
+        self.mixed_score = sde.mixed_score
+        self.prior_sampling = sde.prior_sampling
+        self.v_invR = sde.v_invR
+        self.s_G = sde.s_G
+        self.used_cache = sde.used_cache and used_cache
+        self.x64 = sde.x64
+        self.vs_psi = sde.vs_psi
+        self.vv_psi = sde.vv_psi
+        self.T = sde.T
+        self.sampling_eps = sde.sampling_eps
+
+    def v_L(self, t_vec):
+        R = self.sde.v_R(t_vec)
+        return np.linalg.cholesky(R @ np.swapaxes(R, -1, -2))
+
+    def s_L(self, t):
+        return self.v_L(t)[0]
+
+    def epsR2epsL_matrix(self, t):
+        """coef of epsR2epsL: L(t)^T inv(R(t)^T)."""
+        return self.s_L(t).T @ inv_2x2(self.sde.s_R(t).T)
+
+    def epsR2epsL(self, s_t, eps):
+        from . import utils
+        return utils.sbmm(self.epsR2epsL_matrix(s_t), eps)
+
+    def v_eps_integrand(self, t_vec):
+        t_vec = np.atleast_1d(np.asarray(t_vec, dtype=np.float64))
+        invLT = np.swapaxes(inv_2x2(self.v_L(t_vec)), -1, -2)
+        out = np.zeros_like(invLT)
+        out[:, 1, :] = (self.sde.Gamma * self.sde.beta(t_vec))[:, None] * invLT[:, 1, :]  # 1/2 G G = diag(0, Gamma beta)
+        return out
+
+    def s_eps_integrand(self, t):
+        return self.v_eps_integrand(t)[0]
+
+    def get_deis_coef(self, order, rev_timesteps, used_cache=True):
+        ts = np.asarray(rev_timesteps, dtype=np.float64)
+        x_coef = self.vv_psi(ts[:-1], ts[1:])
+        eps_coef = deis.get_ab_eps_coef(self, order + 1, ts, order)
+        return np.concatenate([x_coef[:, None], eps_coef], axis=1)
+
+
+_PSI2_CACHE = {}
+
+
+class MLCLD(object):
+    """Rotated-frame CLD (cld_jax/sampling.py:272-320): y = psi1(t)^-1 x removes the oscillatory part F1 of the drift; the
+    remaining transition psi2 comes from a 100 000-step RK4 scan (native gd_cld_psi2_table) and linear interpolation."""
+
+    N = 100000
+
+    def __init__(self, sde):
+        assert isinstance(sde, CLD)
+        assert sde.beta_1 == 0
+        self.sde = sde
+        self.sampling_eps = sde.sampling_eps
+        self.T = sde.T
+        self.mixed_score = sde.mixed_score
+        self.s_G = sde.s_G
+        self.prior_sampling = sde.prior_sampling
+        key = (sde.m_inv, sde.beta_0, sde.beta_1)
+        if key not in _PSI2_CACHE:
+            n = self.N + 1
+            table = np.empty((n, 2, 2))
+            _abi.check(_abi.lib().gd_cld_psi2_table(sde.m_inv, sde.beta_0, sde.beta_1, 1.0 / self.N, n,
+                                                    table.ctypes.data_as(ctypes.c_void_p)))
+            _PSI2_CACHE[key] = (np.arange(n) * (1.0 / self.N), table)
+        self._xp, self._fp = _PSI2_CACHE[key]
+
+    def v_psi2(self, t):
+        t = np.atleast_1d(np.asarray(t, dtype=np.float64))
+        xp, fp = self._xp, self._fp
+        i = np.clip(np.searchsorted(xp, t, side='right'), 1, len(xp) - 1)
+        dx = xp[i] - xp[i - 1]
+        w = (t - xp[i - 1]) / dx
+        return fp[i - 1] + w[:, None, None] * (fp[i] - fp[i - 1])
+
+    def s_psi2_fn(self, t):
+        return self.v_psi2(t)[0]
+
+    def y2x_matrix(self, t):
+        return self.sde.s_psi1(t)
+
+    def x2y_matrix(self, t):
+        return self.sde.s_inv_psi1(t)
+
+    def y2x(self, y, t):
+        from . import utils
+        return utils.sbmm(self.y2x_matrix(t), y)
+
+    def x2y(self, x, t):
+        from . import utils
+        return utils.sbmm(self.x2y_matrix(t), x)
+
+    def vs_psi(self, s_vec, t):
+        return self.v_psi2(t) @ inv_2x2(self.v_psi2(s_vec))
+
+    def vv_psi(self, s_vec, t_vec):
+        return self.v_psi2(t_vec) @ inv_2x2(self.v_psi2(s_vec))
+
+    def s_psi(self, s, t):
+        return self.vs_psi(s, t)[0]
+
+    def v_eps_integrand(self, t_vec):
+        t_vec = np.atleast_1d(np.asarray(t_vec, dtype=np.float64))
+        sde = self.sde
+        b = sde.beta_int(t_vec)
+        sqrt_m, inv_sqrt_m = np.sqrt(1.0 / sde.m_inv), np.sqrt(sde.m_inv)
+        c, sn = np.cos(b * inv_sqrt_m), np.sin(b * inv_sqrt_m)
+        ip1 = np.empty((len(t_vec), 2, 2))  # s_f1_psi(t, 0): the angle changes sign
+        ip1[:, 0, 0], ip1[:, 0, 1], ip1[:, 1, 0], ip1[:, 1, 1] = c, -inv_sqrt_m * sn, sqrt_m * sn, c
+        invT = np.swapaxes(inv_2x2(sde.v_R(t_vec)), -1, -2)
+        gg = np.zeros_like(invT)
+        gg[:, 1, :] = (sde.Gamma * sde.beta(t_vec))[:, None] * invT[:, 1, :]  # 1/2 G G^T R^-T
+        return ip1 @ gg
+
+    def s_eps_integrand(self, t):
+        return self.v_eps_integrand(t)[0]
+
+    def get_deis_coef(self, order, rev_timesteps):
         ts = np.asarray(rev_timesteps, dtype=np.float64)
         x_coef = self.vv_psi(ts[:-1], ts[1:])
         eps_coef = deis.get_ab_eps_coef(self, order + 1, ts, order)

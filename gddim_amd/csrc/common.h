@@ -126,11 +126,13 @@ int launch_dct2d_32(const float *in, float *out, int batch, int channels, int in
 // CLD fused-sampler kernels on the channel-planar state (B*HW, 8) = [x_0..x_{C-1}, v_0..v_{C-1}, 0..]
 int launch_cld_pack(const float *u, float *u8, float *ring, int ring_slots, long long pixels, int C, hipStream_t s);
 int launch_cld_unpack_pairs(const float *planar, int ld, float *pairs, long long pixels, int C, hipStream_t s);
+// tf (nullable): per-step rows of 12 floats [P_i, E_i, U_i] (2x2 each): U-Net input P_i u, eps <- E_i eps_net + U_i u
 int launch_cld_ab_step(float *u8, const float *eps, float *ring, int ring_slots, const float *coef_table, int n_slots,
-                       const int *step, long long pixels, int C, hipStream_t s);
-int launch_cld_finish(const float *u8, const float *eps, const float *dn /*12 floats: F, GG, RinvT*/, float dt,
-                      int denoise, int inverse_scale, float *x_out, float *v_out, long long pixels, int C,
-                      hipStream_t s);
+                       const int *step, long long pixels, int C, const float *tf, hipStream_t s);
+int launch_cld_pre(const float *u8, float *xin, const float *tf, const int *step, long long pixels, int C, hipStream_t s);
+// dn: 20 floats F, GG, RinvT, X (mixed score, flags & 1), POST (final frame change, flags & 2)
+int launch_cld_finish(const float *u8, const float *eps, const float *dn, float dt, int denoise, int inverse_scale,
+                      float *x_out, float *v_out, long long pixels, int C, int flags, hipStream_t s);
 int launch_advance_step(int *step, hipStream_t s);
 // blur fused-sampler kernels
 int launch_blur_idct_pad(const float *y, float *x8, int batch, int C, hipStream_t s);

@@ -62,6 +62,9 @@ struct gd_engine {
     float *u8 = nullptr, *ring = nullptr, *ystate = nullptr;
     long long ring_cap = 0;
     float *ts_dev = nullptr, *coef_dev = nullptr, *dn_dev = nullptr, *mean_dev = nullptr, *std_dev = nullptr;
+    float *tf_dev = nullptr;      // per-step [P, E, U] rows of the CLD sampler (gd_engine_set_transforms_cld), null = none
+    bool tf_pre = false;          // the rows carry a non-identity P: the U-Net reads xin = P u instead of u
+    int fin_flags = 0;            // cld_finish: 1 mixed-score term, 2 final frame change
     int *step_dev = nullptr;  // GD_MAX_LANES counters (one per concurrent sub-batch)
     int sched_kind = 0;  // 1 cld, 2 blur
     int num_step = 0, n_slots = 0, denoise = 0;
@@ -289,7 +292,7 @@ int gd_engine_create(const gd_model_desc *desc, int device, gd_engine **out) {
         GD_ALLOC(e->labels, B);
         GD_ALLOC(e->u8, pix * CP);
         GD_ALLOC(e->ystate, pix * desc->in_channels);
-        GD_ALLOC(e->dn_dev, 12);
+        GD_ALLOC(e->dn_dev, 20);
         GD_ALLOC(e->step_dev, gd_engine::MAX_LANES);
 #undef GD_ALLOC
         (void)hipMemset(e->step_dev, 0, sizeof(int) * gd_engine::MAX_LANES);
@@ -316,7 +319,7 @@ int gd_engine_destroy(gd_engine *e) {
         if (e->wsplit_hi) (void)hipFree(e->wsplit_hi);
         if (e->wsplit_lo) (void)hipFree(e->wsplit_lo);
         float *bufs[] = {e->arena, e->wbuf, e->xin, e->epsb, e->eps_planar, e->labels, e->u8, e->ring, e->ystate,
-                         e->ts_dev, e->coef_dev, e->dn_dev, e->mean_dev, e->std_dev, (float *)e->step_dev};
+                         e->ts_dev, e->coef_dev, e->dn_dev, e->mean_dev, e->std_dev, e->tf_dev, (float *)e->step_dev};
         for (float *b : bufs)
             if (b) (void)hipFree(b);
         if (e->ev_in) (void)hipEventDestroy(e->ev_in);
@@ -511,6 +514,37 @@ int gd_engine_set_schedule_cld(gd_engine *e, int num_step, int n_slots, const fl
         e->ring_cap = need;
     }
     e->sched_kind = 1; e->num_step = num_step; e->n_slots = n_slots; e->denoise = denoise; e->t_denoise = t_denoise;
+    if (e->tf_dev) { (void)hipFree(e->tf_dev); e->tf_dev = nullptr; }
+    e->tf_pre = false; e->fin_flags = 0;
+    return 0;
+}
+
+int gd_engine_set_transforms_cld(gd_engine *e, const float *pre, const float *eps_lin, const float *u_lin, const float *dn_u_lin,
+                                 const float *post) {
+    GD_CHECK(e && !e->plan_only, "engine has no GPU");
+    GD_CHECK(e->sched_kind == 1, "install the CLD schedule first (gd_engine_set_schedule_cld)");
+    GD_HIP(hipSetDevice(e->device));
+    GD_HIP(hipDeviceSynchronize());
+    drop_graphs(e);
+    if (e->tf_dev) { (void)hipFree(e->tf_dev); e->tf_dev = nullptr; }
+    e->tf_pre = false; e->fin_flags = 0;
+    if (pre || eps_lin || u_lin) {
+        const int n = std::max(1, e->num_step);
+        std::vector<float> rows((size_t)n * 12, 0.f);
+        for (int i = 0; i < n; ++i) {
+            float *r = rows.data() + (size_t)i * 12;
+            r[0] = r[3] = r[4] = r[7] = 1.f;  // P = E = I, U = 0
+            if (pre && i < e->num_step) memcpy(r, pre + (size_t)i * 4, 16);
+            if (eps_lin && i < e->num_step) memcpy(r + 4, eps_lin + (size_t)i * 4, 16);
+            if (u_lin && i < e->num_step) memcpy(r + 8, u_lin + (size_t)i * 4, 16);
+        }
+        GD_TRY(upload(&e->tf_dev, rows.data(), rows.size()));
+        e->tf_pre = pre != nullptr;
+    }
+    float tail[8] = {0, 0, 0, 0, 1, 0, 0, 1};
+    if (dn_u_lin) { memcpy(tail, dn_u_lin, 16); e->fin_flags |= 1; }
+    if (post) { memcpy(tail + 4, post, 16); e->fin_flags |= 2; }
+    GD_HIP(hipMemcpy(e->dn_dev + 12, tail, sizeof tail, hipMemcpyHostToDevice));
     return 0;
 }
 
@@ -560,9 +594,9 @@ int gd_sample_cld(gd_engine *e, int batch, const float *u_in_dev, float *x_out_d
         hipStream_t s;
         int b;
         long long pix;
-        float *u8, *eps, *ring;
+        float *u8, *eps, *ring, *xin;
         int *step;
-        Bind bind;
+        Bind bind, bind_u;  // bind: U-Net reads the (possibly transformed) step input; bind_u: reads the state itself
         gd_engine::Graphs *g;
     } L[gd_engine::MAX_LANES];
     for (int i = 0; i < nl; ++i) {
@@ -572,18 +606,22 @@ int gd_sample_cld(gd_engine *e, int batch, const float *u_in_dev, float *x_out_d
         l.pix = (long long)size[i] * HW;
         const size_t p0 = (size_t)start[i] * HW;
         l.u8 = e->u8 + p0 * e->plan.CP;
+        l.xin = e->xin + p0 * e->plan.CP;
         l.eps = e->epsb + p0 * d.in_channels;
         l.ring = e->ring ? e->ring + p0 * d.in_channels * ring_slots : nullptr;
         l.step = e->step_dev + i;
-        l.bind = Bind{l.u8, nullptr, l.eps, e->arena + (size_t)e->plan.arena_per_image * start[i], l.step};
+        l.bind_u = Bind{l.u8, nullptr, l.eps, e->arena + (size_t)e->plan.arena_per_image * start[i], l.step};
+        l.bind = l.bind_u;
+        if (e->tf_pre) l.bind.x_in = l.xin;
         l.g = graph ? &e->graphs[((long long)size[i] << 40) | ((long long)start[i] << 8) | i] : nullptr;
         GD_HIP(hipStreamWaitEvent(l.s, e->ev_in, 0));
         GD_TRY(launch_cld_pack(u_in_dev + p0 * C * 2, l.u8, l.ring, ring_slots, l.pix, C, l.s));
         GD_HIP(hipMemsetAsync(l.step, 0, sizeof(int), l.s));
     }
     auto step_body = [&](Lane &l) -> int {
+        if (e->tf_pre) GD_TRY(launch_cld_pre(l.u8, l.xin, e->tf_dev, l.step, l.pix, C, l.s));
         GD_TRY(run_unet(e, l.bind, l.b, l.s));
-        GD_TRY(launch_cld_ab_step(l.u8, l.eps, l.ring, ring_slots, e->coef_dev, e->n_slots, l.step, l.pix, C, l.s));
+        GD_TRY(launch_cld_ab_step(l.u8, l.eps, l.ring, ring_slots, e->coef_dev, e->n_slots, l.step, l.pix, C, e->tf_dev, l.s));
         return launch_advance_step(l.step, l.s);
     };
     if (graph) {
@@ -597,7 +635,7 @@ int gd_sample_cld(gd_engine *e, int batch, const float *u_in_dev, float *x_out_d
             }
             if (e->denoise && !l.g->fin) {
                 GD_TRY(capture_begin(l.s));
-                int r = run_unet(e, l.bind, l.b, l.s);
+                int r = run_unet(e, l.bind_u, l.b, l.s);  // the denoising evaluation reads the state as it is
                 int r2 = capture_end(l.s, &l.g->fin);
                 if (r || r2) return 1;
             }
@@ -610,13 +648,13 @@ int gd_sample_cld(gd_engine *e, int batch, const float *u_in_dev, float *x_out_d
         for (int k = 0; k < e->num_step; ++k)
             for (int i = 0; i < nl; ++i) GD_TRY(step_body(L[i]));
         if (e->denoise)
-            for (int i = 0; i < nl; ++i) GD_TRY(run_unet(e, L[i].bind, L[i].b, L[i].s));  // step == num_step -> t = t_denoise
+            for (int i = 0; i < nl; ++i) GD_TRY(run_unet(e, L[i].bind_u, L[i].b, L[i].s));  // step == num_step -> t = t_denoise
     }
     for (int i = 0; i < nl; ++i) {
         Lane &l = L[i];
         const size_t o0 = (size_t)start[i] * HW * C;
         GD_TRY(launch_cld_finish(l.u8, l.eps, e->dn_dev, -e->t_denoise, e->denoise, inverse_scale, x_out_dev + o0, v_out_dev + o0,
-                                 l.pix, C, l.s));
+                                 l.pix, C, e->fin_flags, l.s));
         GD_HIP(hipEventRecord(e->ev_out[i], l.s));
         GD_HIP(hipStreamWaitEvent(caller, e->ev_out[i], 0));
     }

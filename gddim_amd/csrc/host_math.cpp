@@ -73,3 +73,30 @@ extern "C" int gd_cld_r_table(double m_inv, double beta_0, double beta_1, double
     }
     return 0;
 }
+
+// psi2 table of the rotated-frame sampler (cld_jax/sampling.py:272-285): d psi2/dt = psi1(t)^-1 F2(t) psi1(t) psi2.
+extern "C" int gd_cld_psi2_table(double m_inv, double beta_0, double beta_1, double dt, size_t n, double *out_host) {
+    GD_CHECK(out_host && n > 0 && dt > 0 && m_inv > 0, "gd_cld_psi2_table: bad argument");
+    const double Gamma = 2.0 / std::sqrt(m_inv), ism = std::sqrt(m_inv), sm = std::sqrt(1.0 / m_inv);
+    auto A = [&](double t) {  // psi1(t)^-1 F2(t) psi1(t)
+        const double bi = beta_0 * t + 0.5 * beta_1 * t * t;  // beta_int(t) - beta_int(0)
+        const double c = std::cos(bi * ism), sn = std::sin(bi * ism);
+        const M2 p1{c, ism * sn, -sm * sn, c};      // s_f1_psi(0, t)
+        const M2 ip1{c, -ism * sn, sm * sn, c};     // s_f1_psi(t, 0)
+        const M2 F2{0.0, 0.0, 0.0, -Gamma * (beta_0 + beta_1 * t) * m_inv};
+        return mul(ip1, mul(F2, p1));
+    };
+    M2 x{1.0, 0.0, 0.0, 1.0};
+    double t = 0.0;
+    for (size_t i = 0; i < n; ++i) {
+        out_host[4 * i + 0] = x.a; out_host[4 * i + 1] = x.b; out_host[4 * i + 2] = x.c; out_host[4 * i + 3] = x.d;
+        const M2 g1 = mul(A(t), x);
+        const M2 g2 = mul(A(t + dt / 2), axpy(x, dt / 2, g1));
+        const M2 g3 = mul(A(t + dt / 2), axpy(x, dt / 2, g2));
+        const M2 g4 = mul(A(t + dt), axpy(x, dt, g3));
+        x = {x.a + dt / 6 * (g1.a + 2 * g2.a + 2 * g3.a + g4.a), x.b + dt / 6 * (g1.b + 2 * g2.b + 2 * g3.b + g4.b),
+             x.c + dt / 6 * (g1.c + 2 * g2.c + 2 * g3.c + g4.c), x.d + dt / 6 * (g1.d + 2 * g2.d + 2 * g3.d + g4.d)};
+        t += dt;  // the reference accumulates cur_t + dt in the scan carry
+    }
+    return 0;
+}

@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void cld_ab_step_kernel(float *__restrict__ u8
                                                            float *__restrict__ ring, int ring_slots,
                                                            const float *__restrict__ coef_table, int n_slots,
                                                            const int *__restrict__ step_ptr, long long pixels, int C,
-                                                           int CP) {
+                                                           int CP, const float *__restrict__ tf) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= pixels * C) return;
     const long long p = i / C;
@@ -160,7 +160,14 @@ __global__ __launch_bounds__(256) void cld_ab_step_kernel(float *__restrict__ u8
     const float *coef = coef_table + (size_t)step * n_slots * 4;
     const float x = u8[p * CP + c], v = u8[p * CP + C + c];
     const size_t eo = (size_t)p * 2 * C + c;
-    const float ex = eps[eo], ev = eps[eo + C];
+    float ex = eps[eo], ev = eps[eo + C];
+    if (tf) {  // eps <- E_i eps_net + U_i u  (L-parametrised / mixed-score / rotated-frame samplers; tf row = [P, E, U])
+        const float *E = tf + (size_t)step * 12 + 4, *U = E + 4;
+        const float nx = E[0] * ex + E[1] * ev + U[0] * x + U[1] * v;
+        const float nv = E[2] * ex + E[3] * ev + U[2] * x + U[3] * v;
+        ex = nx;
+        ev = nv;
+    }
     float ox = coef[0] * x + coef[1] * v;
     float ov = coef[2] * x + coef[3] * v;
     ox += coef[4] * ex + coef[5] * ev;
@@ -185,11 +192,35 @@ __global__ __launch_bounds__(256) void cld_ab_step_kernel(float *__restrict__ u8
 }
 
 int launch_cld_ab_step(float *u8, const float *eps, float *ring, int ring_slots, const float *coef_table, int n_slots,
-                       const int *step, long long pixels, int C, hipStream_t s) {
+                       const int *step, long long pixels, int C, const float *tf, hipStream_t s) {
     const int CP = (2 * C + 3) / 4 * 4;
     const long long n = pixels * C;
     hipLaunchKernelGGL(cld_ab_step_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, u8, eps, ring, ring_slots,
-                       coef_table, n_slots, step, pixels, C, CP);
+                       coef_table, n_slots, step, pixels, C, CP, tf);
+    GD_HIP(hipGetLastError());
+    return 0;
+}
+
+// U-Net input of step i when the sampler integrates in a transformed frame: xin = P_i u (P = first matrix of the tf row)
+__global__ __launch_bounds__(256) void cld_pre_kernel(const float *__restrict__ u8, float *__restrict__ xin,
+                                                       const float *__restrict__ tf, const int *__restrict__ step_ptr,
+                                                       long long pixels, int C, int CP) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= pixels * C) return;
+    const long long p = i / C;
+    const int c = (int)(i - p * C);
+    const float *P = tf + (size_t)(*step_ptr) * 12;
+    const float x = u8[p * CP + c], v = u8[p * CP + C + c];
+    xin[p * CP + c] = P[0] * x + P[1] * v;
+    xin[p * CP + C + c] = P[2] * x + P[3] * v;
+    if (c == 0)
+        for (int k = 2 * C; k < CP; ++k) xin[p * CP + k] = 0.f;
+}
+
+int launch_cld_pre(const float *u8, float *xin, const float *tf, const int *step, long long pixels, int C, hipStream_t s) {
+    const int CP = (2 * C + 3) / 4 * 4;
+    const long long n = pixels * C;
+    hipLaunchKernelGGL(cld_pre_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, u8, xin, tf, step, pixels, C, CP);
     GD_HIP(hipGetLastError());
     return 0;
 }
@@ -197,15 +228,21 @@ int launch_cld_ab_step(float *u8, const float *eps, float *ring, int ring_slots,
 __global__ __launch_bounds__(256) void cld_finish_kernel(const float *__restrict__ u8, const float *__restrict__ eps,
                                                           const float *__restrict__ dn, float dt, int denoise,
                                                           int inverse_scale, float *__restrict__ x_out,
-                                                          float *__restrict__ v_out, long long pixels, int C, int CP) {
+                                                          float *__restrict__ v_out, long long pixels, int C, int CP,
+                                                          int flags) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= pixels * C) return;
     const long long p = i / C;
     const int c = (int)(i - p * C);
     float x = u8[p * CP + c], v = u8[p * CP + C + c];
     if (denoise) {
-        const float ex = eps[(size_t)p * 2 * C + c], ev = eps[(size_t)p * 2 * C + C + c];
+        float ex = eps[(size_t)p * 2 * C + c], ev = eps[(size_t)p * 2 * C + C + c];
         const float *F = dn, *GG = dn + 4, *Rt = dn + 8;
+        if (flags & 1) {  // mixed score: eps += X u (dn + 12)
+            const float *X = dn + 12;
+            ex += X[0] * x + X[1] * v;
+            ev += X[2] * x + X[3] * v;
+        }
         // score = -R^-T eps
         const float sx = -(Rt[0] * ex + Rt[1] * ev), sv = -(Rt[2] * ex + Rt[3] * ev);
         const float fx = F[0] * x + F[1] * v, fv = F[2] * x + F[3] * v;
@@ -213,16 +250,22 @@ __global__ __launch_bounds__(256) void cld_finish_kernel(const float *__restrict
         x = x + fx * dt - gx * dt;
         v = v + fv * dt - gv * dt;
     }
+    if (flags & 2) {  // leave the transformed frame: u <- POST u (dn + 16)
+        const float *Q = dn + 16;
+        const float nx = Q[0] * x + Q[1] * v, nv = Q[2] * x + Q[3] * v;
+        x = nx;
+        v = nv;
+    }
     x_out[i] = inverse_scale ? (x + 1.0f) / 2.0f : x;
     v_out[i] = v;
 }
 
 int launch_cld_finish(const float *u8, const float *eps, const float *dn, float dt, int denoise, int inverse_scale,
-                      float *x_out, float *v_out, long long pixels, int C, hipStream_t s) {
+                      float *x_out, float *v_out, long long pixels, int C, int flags, hipStream_t s) {
     const int CP = (2 * C + 3) / 4 * 4;
     const long long n = pixels * C;
     hipLaunchKernelGGL(cld_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, u8, eps, dn, dt, denoise,
-                       inverse_scale, x_out, v_out, pixels, C, CP);
+                       inverse_scale, x_out, v_out, pixels, C, CP, flags);
     GD_HIP(hipGetLastError());
     return 0;
 }

@@ -195,6 +195,11 @@ class Engine(object):
                                                    float(t_denoise), keep[0][1], keep[1][1], keep[2][1]))
         self._schedule_token = token
 
+    def set_transforms_cld(self, pre=None, eps_lin=None, u_lin=None, dn_u_lin=None, post=None):
+        """Per-step 2x2 maps of the installed CLD schedule (include/gddim_amd.h: gd_engine_set_transforms_cld)."""
+        keep = [None if m is None else _host_f32(m) for m in (pre, eps_lin, u_lin, dn_u_lin, post)]
+        check(self._lib.gd_engine_set_transforms_cld(self._h, *[None if k is None else k[1] for k in keep]))
+
     def sample_cld(self, u, inverse_scale=True, use_graph=True):
         import torch
         u = u.contiguous()

@@ -4,7 +4,7 @@
   register_model/get_model   :43-66
   init_model                 :109-125   (blur: blur_jax/models/utils.py:85-101, no velocity channels)
   get_model_fn               :128-166   'b ... d g -> b ... (g d)' packing for CLD
-  get_eps_fn                 :168-182   labels = 999 t (+ mixed_score, not built: SURVEY.md N4)
+  get_eps_fn                 :168-182   labels = 999 t (+ the mixed_score term)
   get_score_fn               :184-211
   get_yeps_fn                blur_jax/models/utils.py:155-160
 """
@@ -102,8 +102,6 @@ def get_model_fn(model, params, states, train=False, packed_pairs=True):
 
 def get_eps_fn(sde, model, params, states, train=False, continuous=False, return_state=False):
     cld = hasattr(sde, 'mixed_score')
-    if cld and sde.mixed_score:
-        raise GddimError("mixed_score=True is not built (SURVEY.md section 8f, N4)")
 
     def eps_fn(x, t, rng=None):
         if train:
@@ -111,6 +109,12 @@ def get_eps_fn(sde, model, params, states, train=False, continuous=False, return
         if cld:
             eng = model.engine_for(params, 2 * x.shape[-2], x.shape[0], x.device.index)
             out = eng.cld_eps(x, t)  # labels = t * 999 inside (models/utils.py:172)
+            if sde.mixed_score:  # + bmm(v_invR(t), x.at[..., 0].set(0)) (models/utils.py:174-176)
+                from .. import ops
+                tt = t.detach().cpu().numpy() if hasattr(t, 'detach') else np.asarray(t)
+                m = np.array(sde.v_invR(tt), dtype=np.float32)
+                m[:, :, 0] = 0.0
+                out = out + ops.bmm(m, x)
         else:
             labels = sde.encode_t(t)
             out = model.apply({'params': params, **states}, sde.encode_x(x), labels, train=False, mutable=False)

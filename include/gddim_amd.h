@@ -71,6 +71,12 @@ int gd_device_count(void);
 int gd_cld_r_table(double m_inv, double beta_0, double beta_1, double vv_gamma, double numerical_eps,
                    int is_rk, double R_dt, size_t n, double *out_host);
 
+/* psi2(t) table of the rotated-frame ("ML") CLD sampler: RK4 scan of d psi2/dt = psi1(t)^-1 F2(t) psi1(t) psi2 from
+ * psi2(0) = I with step dt, emitting the state before each of n steps (out: n x 4 doubles).  psi1(t) = expm(int_0^t F1),
+ * F = F1 + F2 is the split of cld_jax/sde_lib.py:121-180.
+ * Replaces: get_ml_psi2_fn (cld_jax/sampling.py:272-285; lax.scan of runge_kutta, N = 100000). */
+int gd_cld_psi2_table(double m_inv, double beta_0, double beta_1, double dt, size_t n, double *out_host);
+
 /* ---- engine life cycle ------------------------------------------------------------------ */
 /* device >= 0: build the plan, allocate weights + activation arena on that GPU.
  * device <  0: plan-only (host) mode -- no GPU touched; used to inspect the plan / packed
@@ -130,6 +136,16 @@ int gd_cld_eps(gd_engine *e, const float *u_dev, const float *t_dev, float *eps_
 int gd_engine_set_schedule_cld(gd_engine *e, int num_step, int n_slots, const float *ts_host, const float *coef_host,
                                int denoise, float t_denoise, const float *dn_F, const float *dn_GG,
                                const float *dn_RinvT);
+/* Optional per-step 2x2 maps of the installed CLD schedule (call after gd_engine_set_schedule_cld, which resets them; all
+ * arrays host, row-major, NULL = identity / zero):
+ *   pre[num_step][4]      the network is evaluated on P_i u instead of u              (mldeis: y2x, cld_jax/sampling.py:349-351)
+ *   eps_lin[num_step][4]  eps <- E_i eps_net + U_i u before the AB step               (ldeis: epsR2epsL, sde_lib.py:494-500)
+ *   u_lin[num_step][4]    U_i above                                                   (mixed score: models/utils.py:174-176)
+ *   dn_u_lin[4]           eps <- eps_net + X u in the denoising step                  (mixed score at t_denoise)
+ *   post[4]               u <- POST u after the denoising step, before inverse scaling (mldeis: y2x at eps/2, sampling.py:363)
+ * Replaces: the extra closure state of _impl_Ldeis_sampler / get_mldeis_sampler / get_eps_fn(mixed_score=True). */
+int gd_engine_set_transforms_cld(gd_engine *e, const float *pre, const float *eps_lin, const float *u_lin,
+                                 const float *dn_u_lin, const float *post);
 /* One sampler call: u_in_dev (B,H,W,C,2) initial noise -> x_out_dev (B,H,W,C) = (u_x+1)/2 when
  * inverse_scale != 0 else u_x, v_out_dev (B,H,W,C).  use_graph: 0 eager launches, 1 replay a
  * captured hipGraph per step (captured on first use for this batch size).

@@ -199,8 +199,10 @@ def _eps_single_coef(sde, t_start, t_end, ts_poly, coef_idx, num_item=10000):
     T = sde.dtype.type
     dt = (t_end - t_start) / T(num_item)
     t_inter = np.linspace(t_start, t_end, num_item, endpoint=False).astype(sde.dtype)
-    psi_coef = vs_psi(sde, t_inter, t_end)            # sde.vs_psi(t_inter, t_end)      (n,2,2)
-    integrand = v_eps_integrand(sde, t_inter)          # sde.v_eps_integrand(t_inter)    (n,2,2)
+    # sde.vs_psi(t_inter, t_end) / sde.v_eps_integrand(t_inter): the LSDE / MLCLD restatements (oracle/cld_ext.py) bring
+    # their own, the plain CLD uses the closed forms below
+    psi_coef = sde.vs_psi(t_inter, t_end) if hasattr(sde, "vs_psi") else vs_psi(sde, t_inter, t_end)                    # (n,2,2)
+    integrand = sde.v_eps_integrand(t_inter) if hasattr(sde, "v_eps_integrand") else v_eps_integrand(sde, t_inter)      # (n,2,2)
     prod = np.einsum("bij,bjk->bik", psi_coef, integrand)
     poly = vec_poly_coef(t_inter, ts_poly, coef_idx)   # (n,)
     acc = np.sum(prod * poly[:, None, None], axis=0)   # summation order is XLA's, not reproducible

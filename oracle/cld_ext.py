@@ -1,0 +1,219 @@
+"""ORACLE (test infrastructure only): the CLD sampler variants that share the DEIS loop.
+
+Restates, in numpy float64, deliberately literal (python loops):
+
+  /root/reference/cld_jax/sde_lib.py:121-180   s_f1_psi, s_psi1, s_inv_psi1, s_F1, s_F2
+  /root/reference/cld_jax/sde_lib.py:469-520   class LSDE (s_L, epsR2epsL, s_eps_integrand, get_deis_coef)
+  /root/reference/cld_jax/sampling.py:272-320  get_ml_psi2_fn, class MLCLD
+  /root/reference/cld_jax/sampling.py:322-378  get_mldeis_sampler
+  /root/reference/cld_jax/sampling.py:497-540  _impl_Ldeis_sampler, get_L_deis_sampler
+  /root/reference/cld_jax/models/utils.py:168-182  get_eps_fn with sde.mixed_score=True
+
+PARITY UNPINNED -- see oracle/__init__.py.  What pins these restatements without the reference: psi2(t) against the closed
+form psi1(t)^-1 expm(int_0^t F) (the two frames describe the same flow), L L^T = R R^T, and agreement of the three
+samplers with each other in the NFE -> infinity limit on an analytic eps (tests/test_oracle_cld_ext.py).
+"""
+import numpy as np
+
+from . import cld as ocld
+
+
+def s_f1_psi(sde, s, t):
+    # sde_lib.py:121-143 (the un-commented return)
+    beta_int = sde._beta_int(t) - sde._beta_int(s)
+    sqrt_m = np.sqrt(1.0 / sde.m_inv)
+    inv_sqrt_m = np.sqrt(sde.m_inv)
+    return np.asarray([[np.cos(beta_int * inv_sqrt_m), inv_sqrt_m * np.sin(beta_int * inv_sqrt_m)],
+                       [-sqrt_m * np.sin(beta_int * inv_sqrt_m), np.cos(beta_int * inv_sqrt_m)]], dtype=np.float64)
+
+
+def s_psi1(sde, t):
+    return s_f1_psi(sde, 0.0, t)  # :146-149
+
+
+def s_inv_psi1(sde, t):
+    return s_f1_psi(sde, t, 0.0)  # :152-155
+
+
+def s_F2(sde, t):
+    cur_beta = sde._beta(t)  # :169-179
+    return np.asarray([[0.0, 0.0], [0.0, -sde.Gamma * cur_beta * sde.m_inv]], dtype=np.float64)
+
+
+def runge_kutta(x, t, dt, fn):
+    # deis.py:6-17
+    grad_1 = fn(x, t)
+    x_2 = x + grad_1 * dt / 2
+    grad_2 = fn(x_2, t + dt / 2)
+    x_3 = x + grad_2 * dt / 2
+    grad_3 = fn(x_3, t + dt / 2)
+    x_4 = x + grad_3 * dt
+    grad_4 = fn(x_4, t + dt)
+    return x + dt / 6 * (grad_1 + 2 * grad_2 + 2 * grad_3 + grad_4)
+
+
+def mixed_eps_fn(sde, eps_fn):
+    """get_eps_fn with sde.mixed_score (models/utils.py:174-176): + bmm(v_invR(t), x.at[..., 0].set(0))."""
+
+    def fn(x, t):
+        out = eps_fn(x, t)
+        x0 = x.copy()
+        x0[..., 0] = 0.0
+        inv_r = np.stack([ocld.inv_2x2(sde.s_R(np.float64(tb))) for tb in t])
+        return out + ocld.bmm(inv_r, x0)
+
+    return fn
+
+
+class LSDE:
+    # sde_lib.py:469-520
+    def __init__(self, sde):
+        self.sde = sde
+        self.dtype = sde.dtype
+        self.T, self.sampling_eps = sde.T, sde.sampling_eps
+        self.s_G = sde.s_G
+
+    def s_L(self, s_t):
+        R = self.sde.s_R(np.float64(s_t))
+        return np.linalg.cholesky(R @ R.T)  # :489-492
+
+    def epsR2epsL(self, s_t, eps):
+        cur_L = self.s_L(s_t)
+        cur_R = self.sde.s_R(np.float64(s_t))
+        coef = cur_L.T @ ocld.inv_2x2(cur_R.T)  # :494-500
+        return ocld.sbmm(coef, eps)
+
+    def s_eps_integrand(self, s_t):
+        cur_G = self.s_G(s_t)
+        return 0.5 * cur_G @ cur_G @ ocld.inv_2x2(self.s_L(s_t)).T  # :503-507
+
+    def vs_psi(self, s_vec, t):
+        return ocld.vs_psi(self.sde, s_vec, t)
+
+    def v_eps_integrand(self, t_vec):
+        # vmap(s_eps_integrand), batched (tests check it against the scalar form above)
+        Rs = self.sde.v_R(t_vec)
+        Ls = np.linalg.cholesky(Rs @ np.swapaxes(Rs, 1, 2))
+        invLT = np.swapaxes(np.linalg.inv(Ls), 1, 2)
+        g2 = 2 * self.sde.Gamma * self.sde._beta(np.asarray(t_vec, dtype=np.float64))
+        out = np.zeros_like(Rs)
+        out[:, 1, :] = 0.5 * g2[:, None] * invLT[:, 1, :]
+        return out
+
+    def get_deis_coef(self, order, rev_timesteps):
+        rev_timesteps = np.asarray(rev_timesteps, dtype=np.float64)
+        x_coef = np.stack([self.sde.s_psi(rev_timesteps[i], rev_timesteps[i + 1]) for i in range(len(rev_timesteps) - 1)])
+        eps_coef = ocld.get_ab_eps_coef(self, order + 1, rev_timesteps, order)
+        return np.concatenate([x_coef[:, None], eps_coef], axis=1)
+
+
+_PSI2 = {}
+
+
+def get_ml_psi2_fn(sde, N=100000):
+    # sampling.py:272-285: scan of runge_kutta over N + 1 steps of size 1/N from (eye(2), 0.0), recording the carry
+    key = (float(sde.m_inv), float(sde.beta_0), float(sde.beta_1), N)
+    if key not in _PSI2:
+        def fn(psi2, cur_t):
+            return s_inv_psi1(sde, cur_t) @ s_F2(sde, cur_t) @ s_psi1(sde, cur_t) @ psi2
+        psi2, cur_t = np.eye(2), 0.0
+        psi2s = np.empty((N + 1, 2, 2))
+        ts = np.empty(N + 1)
+        dt = 1 / N
+        for k in range(N + 1):
+            psi2s[k], ts[k] = psi2, cur_t
+            psi2 = runge_kutta(psi2, cur_t, dt, fn)
+            cur_t = cur_t + dt
+        _PSI2[key] = ocld.get_interp_fn(ts, psi2s)
+    return _PSI2[key]
+
+
+class MLCLD:
+    # sampling.py:287-320
+    def __init__(self, sde, N=100000):
+        assert sde.beta_1 == 0
+        self.sde = sde
+        self.dtype = sde.dtype
+        self.s_psi2_fn = get_ml_psi2_fn(sde, N)
+        self.sampling_eps, self.T = sde.sampling_eps, sde.T
+        self.s_G = sde.s_G
+
+    def y2x(self, y, t):
+        return ocld.sbmm(s_psi1(self.sde, t), y)
+
+    def x2y(self, x, t):
+        return ocld.sbmm(s_inv_psi1(self.sde, t), x)
+
+    def s_psi(self, s, t):
+        return self.s_psi2_fn(np.float64(t)) @ np.linalg.inv(self.s_psi2_fn(np.float64(s)))
+
+    def s_eps_integrand(self, s_t):
+        cur_G = self.s_G(s_t)
+        cur_inv_psi1 = s_inv_psi1(self.sde, s_t)
+        return 0.5 * cur_inv_psi1 @ cur_G @ cur_G.T @ ocld.inv_2x2(self.sde.s_R(np.float64(s_t))).T
+
+    def vs_psi(self, s_vec, t):
+        # vmap(s_psi, (0, None)), batched (tests check it against the scalar form above)
+        return self.s_psi2_fn(np.float64(t)) @ np.linalg.inv(self.s_psi2_fn(np.asarray(s_vec, dtype=np.float64)))
+
+    def v_eps_integrand(self, t_vec):
+        t_vec = np.asarray(t_vec, dtype=np.float64)
+        b = self.sde._beta_int(t_vec)
+        sqrt_m, inv_sqrt_m = np.sqrt(1.0 / self.sde.m_inv), np.sqrt(self.sde.m_inv)
+        ip1 = np.empty((len(t_vec), 2, 2))  # s_f1_psi(t, 0): beta_int changes sign
+        ip1[:, 0, 0], ip1[:, 0, 1] = np.cos(-b * inv_sqrt_m), inv_sqrt_m * np.sin(-b * inv_sqrt_m)
+        ip1[:, 1, 0], ip1[:, 1, 1] = -sqrt_m * np.sin(-b * inv_sqrt_m), np.cos(-b * inv_sqrt_m)
+        return ip1 @ ocld.v_eps_integrand(self.sde, t_vec)  # G G^T = G G for the diagonal G
+
+    def get_deis_coef(self, order, rev_timesteps):
+        rev_timesteps = np.asarray(rev_timesteps, dtype=np.float64)
+        x_coef = np.stack([self.s_psi(rev_timesteps[i], rev_timesteps[i + 1]) for i in range(len(rev_timesteps) - 1)])
+        eps_coef = ocld.get_ab_eps_coef(self, order + 1, rev_timesteps, order)
+        return np.concatenate([x_coef[:, None], eps_coef], axis=1)
+
+
+def ldeis_sampler(sde, eps_fn, u, nfe, deis_order, ts_order=2, inverse_scaler=None, deis_coef=None):
+    """get_L_deis_sampler with denoising=False (with denoising the reference raises: LSDE has no s_F)."""
+    rev_ts = ocld.get_rev_ts(sde, ts_order, nfe)
+    new_sde = LSDE(sde)
+    if deis_coef is None:
+        deis_coef = new_sde.get_deis_coef(deis_order, rev_ts)
+    ones = np.ones(u.shape[0], dtype=u.dtype)
+    eps_pred = np.stack([u] * (deis_order + 1))
+    for i in range(nfe):
+        cur_eps_pred = eps_fn(u, ones * u.dtype.type(rev_ts[i]))
+        cur_eps_pred = new_sde.epsR2epsL(rev_ts[i], cur_eps_pred).astype(u.dtype)
+        u, eps_pred = ocld.multistep_ab_step(u, deis_coef[i].astype(u.dtype), cur_eps_pred, eps_pred)
+    x, v = u[..., 0], u[..., 1]
+    if inverse_scaler is not None:
+        x = inverse_scaler(x)
+    return x, v, nfe
+
+
+def mldeis_sampler(sde, eps_fn, u, nfe, deis_order, ts_order=2, denoising=False, inverse_scaler=None, deis_coef=None,
+                   mlsde=None):
+    """get_mldeis_sampler (sampling.py:322-378), non-pmapped."""
+    num_step = nfe - 1 if denoising else nfe
+    rev_ts = np.power(np.linspace(np.power(sde.T, 1.0 / ts_order), np.power(sde.sampling_eps, 1.0 / ts_order), num_step + 1),
+                      ts_order)
+    mlsde = MLCLD(sde) if mlsde is None else mlsde
+    if deis_coef is None:
+        deis_coef = mlsde.get_deis_coef(deis_order, rev_ts)
+    u = mlsde.x2y(u, sde.T).astype(u.dtype)
+    ones = np.ones(u.shape[0], dtype=u.dtype)
+
+    def y_eps_fn(y_u, s_t):
+        x_u = mlsde.y2x(y_u, s_t).astype(y_u.dtype)
+        return eps_fn(x_u, s_t * ones)
+
+    eps_pred = np.stack([u] * (deis_order + 1))
+    for i in range(num_step):
+        cur_eps_pred = y_eps_fn(u, u.dtype.type(rev_ts[i]))
+        u, eps_pred = ocld.multistep_ab_step(u, deis_coef[i].astype(u.dtype), cur_eps_pred, eps_pred)
+    if denoising:
+        u = ocld.get_denoising_step(sde, eps_fn, sde.sampling_eps, sde.sampling_eps)(u)
+    u = mlsde.y2x(u, sde.sampling_eps / 2).astype(u.dtype)
+    x, v = u[..., 0], u[..., 1]
+    if inverse_scaler is not None:
+        x = inverse_scaler(x)
+    return x, v, nfe

@@ -1,0 +1,123 @@
+"""CPU checks of the oracle's restatement of the L-parametrised and rotated-frame CLD samplers (oracle/cld_ext.py) and of the
+product's vectorised host math for them (gddim_amd/cld/sde_lib.py: LSDE, MLCLD)."""
+import numpy as np
+import pytest
+
+from oracle import cld as ocld
+from oracle import cld_ext as ox
+
+N_SCAN = 20000  # RK4 steps of the psi2 table in these tests (the samplers use 100 000; RK4 is converged long before)
+
+
+@pytest.fixture(scope="module")
+def osde():
+    return ocld.CLD(is_R_rk=True, R_dt=1e-5, dtype=np.float64)
+
+
+@pytest.fixture(scope="module")
+def oml(osde):
+    return ox.MLCLD(osde, N=N_SCAN)
+
+
+def test_psi2_scan_is_the_frame_change_of_the_matrix_exponential(osde, oml):
+    """x = psi1(t) y and y(t) = psi2(t) y(0) describe the flow expm(int_0^t F): psi2(t) = psi1(t)^-1 Psi(0, t)."""
+    for t in (1e-3, 0.05, 0.37, 1.0):
+        closed = ox.s_inv_psi1(osde, t) @ osde.s_psi(0.0, t)
+        assert np.abs(oml.s_psi2_fn(np.float64(t)) - closed).max() < 1e-9
+        # psi1 is the exponential of F1 alone
+        assert np.abs(ox.s_psi1(osde, t) @ ox.s_inv_psi1(osde, t) - np.eye(2)).max() < 1e-14
+    # transition in the rotated frame composed with the frame changes is the plain transition
+    s, t = 0.8, 0.3
+    assert np.abs(ox.s_psi1(osde, t) @ oml.s_psi(s, t) @ ox.s_inv_psi1(osde, s) - osde.s_psi(s, t)).max() < 1e-8
+
+
+def test_batched_forms_equal_scalar_forms(osde, oml):
+    ts = np.array([1e-3, 0.02, 0.5, 0.97])
+    L = ox.LSDE(osde)
+    assert np.abs(L.v_eps_integrand(ts) - np.stack([L.s_eps_integrand(t) for t in ts])).max() < 1e-10
+    assert np.abs(oml.v_eps_integrand(ts) - np.stack([oml.s_eps_integrand(t) for t in ts])).max() < 1e-10
+    assert np.abs(oml.vs_psi(ts, 0.3) - np.stack([oml.s_psi(s, 0.3) for s in ts])).max() < 1e-12
+
+
+def test_cholesky_parametrisation(osde):
+    L = ox.LSDE(osde)
+    for t in (1e-3, 0.2, 1.0):
+        R = osde.s_R(np.float64(t))
+        l = L.s_L(t)
+        assert np.abs(l @ l.T - R @ R.T).max() < 1e-14 and l[0, 1] == 0
+        E = l.T @ ocld.inv_2x2(R.T)  # epsR2epsL: an orthogonal map (both L and R are square roots of the covariance)
+        assert np.abs(E @ E.T - np.eye(2)).max() < 1e-9
+        # 1/2 G G L^-T E = 1/2 G G R^-T: the two parametrisations integrate the same score term
+        assert np.abs(L.s_eps_integrand(t) @ E - osde.s_eps_integrand(t)).max() < 1e-9 * np.abs(osde.s_eps_integrand(t)).max()
+
+
+def test_product_host_math_matches_oracle(native_lib, osde):
+    from gddim_amd.cld import sde_lib
+    sde = sde_lib.CLD(is_R_rk=True, R_dt=1e-5)
+    rev = ocld.get_rev_ts(osde, 2, 5)
+    pl, ol = sde_lib.LSDE(sde), ox.LSDE(osde)
+    cl, co = pl.get_deis_coef(2, rev), ol.get_deis_coef(2, rev)
+    assert cl.shape == (5, 5, 2, 2) and np.abs(cl - co).max() < 1e-10 * np.abs(co).max()
+    for t in rev[:-1]:
+        want = ol.s_L(t).T @ ocld.inv_2x2(osde.s_R(np.float64(t)).T)
+        assert np.abs(pl.epsR2epsL_matrix(t) - want).max() < 1e-12
+    pm, om = sde_lib.MLCLD(sde), ox.MLCLD(osde, N=N_SCAN)
+    for t in (1e-3, 0.4, 1.0):
+        assert np.abs(pm.s_psi2_fn(t) - om.s_psi2_fn(np.float64(t))).max() < 1e-8
+        assert np.abs(pm.y2x_matrix(t) - ox.s_psi1(osde, t)).max() == 0 and np.abs(pm.x2y_matrix(t) - ox.s_inv_psi1(osde, t)).max() == 0
+    cm, co = pm.get_deis_coef(1, rev[:4]), om.get_deis_coef(1, rev[:4])
+    assert np.abs(cm - co).max() < 1e-7 * np.abs(co).max()
+    m = sde.mixed_u_matrix(0.3)
+    assert np.abs(m[:, 1] - sde.s_invR(0.3)[:, 1]).max() == 0 and np.abs(m[:, 0]).max() == 0
+
+
+def _dirac(osde):
+    c = 0.3
+    z = np.random.default_rng(0).standard_normal((5, 1, 1, 1, 2))
+
+    def mu(t):
+        return osde.s_psi(0.0, t) @ np.array([c, 0.0])
+
+    def eps_fn(u, tvec):
+        t = float(tvec[0])
+        return np.einsum("ij,b...j->b...i", ocld.inv_2x2(osde.s_R(t)), u - mu(t))
+
+    u0 = mu(1.0) + np.einsum("ij,b...j->b...i", osde.s_R(1.0), z)
+    want = mu(1e-3) + np.einsum("ij,b...j->b...i", osde.s_R(1e-3), z)
+    return eps_fn, u0, want
+
+
+def test_dirac_data_trajectories(osde, oml):
+    """With the exact eps of Dirac data every sampler must land on mu_eps + R_eps z up to its quadrature error; the rotated
+    frame additionally carries the reference's own psi1(eps/2)-instead-of-psi1(eps) frame change (an O(eps) rotation)."""
+    eps_fn, u0, want = _dirac(osde)
+    # The ODE's R(t) is a square root that rotates quickly as t -> 0 while chol(R R^T) does not, so the exact eps_R = z of this
+    # problem turns into a rotating eps_L = E(t) z: the L-parametrised extrapolation needs more steps here (it is aimed at
+    # networks whose output is smoother in the L frame) but converges to the same point.
+    err = []
+    for nfe in (25, 100):
+        x, v, n = ox.ldeis_sampler(osde, eps_fn, u0, nfe, 2)
+        err.append(max(np.abs(x - want[..., 0]).max(), np.abs(v - want[..., 1]).max()))
+    assert n == 100 and err[1] < 5e-3 and err[1] < 0.1 * err[0]
+    x, v, n = ox.mldeis_sampler(osde, eps_fn, u0, 12, 1, mlsde=oml)
+    assert np.abs(x - want[..., 0]).max() < 2e-2 and np.abs(v - want[..., 1]).max() < 2e-2
+    # undoing the frame quirk leaves only quadrature error
+    u = np.stack([x, v], axis=-1)
+    fix = ox.s_psi1(osde, 1e-3) @ ox.s_inv_psi1(osde, 0.5e-3)
+    u = np.einsum("ij,b...j->b...i", fix, u)
+    assert np.abs(u - want).max() < 6e-3
+
+
+def test_mixed_score_is_a_reparametrisation(osde):
+    """A network trained with mixed_score predicts eps - invR(t) [0, v]; wrapping it restores eps exactly."""
+    eps_fn, u0, _ = _dirac(osde)
+
+    def net(u, tvec):
+        x0 = u.copy()
+        x0[..., 0] = 0.0
+        inv_r = ocld.inv_2x2(osde.s_R(np.float64(tvec[0])))
+        return eps_fn(u, tvec) - np.einsum("ij,b...j->b...i", inv_r, x0)
+
+    a = ocld.deis_sampler(osde, eps_fn, u0, 8, 2, denoising=True)
+    b = ocld.deis_sampler(osde, ox.mixed_eps_fn(osde, net), u0, 8, 2, denoising=True)
+    assert np.abs(a[0] - b[0]).max() < 1e-9 and np.abs(a[1] - b[1]).max() < 1e-9
