@@ -1,0 +1,106 @@
+"""Sampling rounds and the FID report: the two evaluation entry points of the reference's run driver.
+
+  sample_data(config, ckpt_file, result_folder, is_continue=False)   cld_jax/run_lib.py:674-731 (blur_jax/run_lib.py:300-345)
+  check_fid(config, result_folder, ...)                              cld_jax/run_lib.py:735-791
+
+Same files on disk: `samples_<r>.npz` with keys samples (uint8, clip(x*255, 0, 255) truncated), nfe_cnt, samples_v, samples_x;
+`statistics_<r>.npz` with pool_3, logits, nfe_cnt; `report.npz` with IS, fid, nfe.  The reference shards one round over
+`jax.local_device_count()` devices with pmap; here one process drives one GPU (launch with torchrun), every rank samples
+`eval.batch_size // world_size` images of the round and the shards meet in one all-gather (RCCL) before rank 0 writes the file.
+Training, logging and the rest of run_lib are out of scope."""
+import os
+
+import numpy as np
+
+from . import checkpoints, datasets, distributed, evaluation
+from ._abi import GddimError
+
+
+def _modules(config):
+    """The CLD and blur packages expose the same factory API; the SDE family is read off the config like main.py does."""
+    if 'sigma_blur_max' in config.model:  # blur_jax/configs/default_cifar10_config.py; the CLD configs carry m_inv instead
+        from .blur import sampling, sde_lib
+    else:
+        from .cld import sampling, sde_lib
+    return sampling, sde_lib
+
+
+def sample_data(config, ckpt_file, result_folder, is_continue=False, state=None):
+    """Generate eval.num_samples // eval.batch_size + 1 rounds of eval.batch_size images.  `state` overrides the checkpoint
+    (synthetic weights); otherwise a missing `ckpt_file` raises RuntimeError like the reference."""
+    import torch
+    from .models import utils as mutils
+    rank, world, local_rank = distributed.init_from_env()
+    os.makedirs(result_folder, exist_ok=True)
+    inverse_scaler = datasets.get_data_inverse_scaler(config)
+    score_model = mutils.get_model(config.model.name)(config=config)
+    sampling, sde_lib = _modules(config)
+    sde = sde_lib.from_config(config)
+    sampling_fn = sampling.get_sampling_fn(config, sde, score_model, None, inverse_scaler)
+    num_sampling_rounds = config.eval.num_samples // config.eval.batch_size + 1
+    if state is None:
+        if not os.path.exists(ckpt_file):
+            raise RuntimeError("%s not exist" % ckpt_file)
+        state = checkpoints.restore_checkpoint(ckpt_file, mutils.State(lr=config.optim.lr, ema_rate=config.model.ema_rate))
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local_rank)
+    per_rank = config.eval.batch_size // world
+    if per_rank < 1:
+        raise GddimError("eval.batch_size %d is smaller than the number of ranks %d" % (config.eval.batch_size, world))
+    written = []
+    for r in range(num_sampling_rounds):
+        f_sample = os.path.join(result_folder, "samples_%d.npz" % r)
+        if os.path.exists(f_sample) and is_continue:
+            continue
+        out = sampling_fn([distributed.rank_seed(config.seed + 1, r, rank)], state, per_rank)
+        samples_org_x, nfe_cnt = out[0], out[-1]
+        samples_v = out[1] if len(out) == 3 else None
+        x = samples_org_x.reshape((-1,) + tuple(samples_org_x.shape[2:]))
+        u8 = distributed.all_gather_samples(distributed.to_uint8(x))
+        xf = distributed.all_gather_samples(x)
+        vf = distributed.all_gather_samples(samples_v.reshape(x.shape)) if samples_v is not None else None
+        if rank == 0:
+            keys = dict(samples=u8.cpu().numpy().reshape((-1, config.data.image_size, config.data.image_size, config.data.num_channels)),
+                        nfe_cnt=nfe_cnt, samples_x=xf.cpu().numpy()[None])
+            if vf is not None:
+                keys['samples_v'] = vf.cpu().numpy()[None]
+            tmp = f_sample + ".tmp.npz"
+            np.savez_compressed(tmp, **keys)
+            os.replace(tmp, f_sample)
+            written.append(f_sample)
+    return written
+
+
+def check_fid(config, result_folder, inception_fn=None, stats_root=None):
+    """FID / IS over the rounds of `result_folder`.  inception_fn(uint8 images (N,H,W,C)) -> {'pool_3': (N,2048), 'logits':
+    (N,1008)} stands for evaluation.run_inception_distributed; without it the `statistics_<r>.npz` files must already exist."""
+    inceptionv3 = config.data.image_size >= 256
+    all_logits, all_pools, all_nfe_cnt = [], [], []
+    num_sampling_rounds = config.eval.num_samples // config.eval.batch_size + 1
+    for r in range(num_sampling_rounds):
+        f_stat = os.path.join(result_folder, "statistics_%d.npz" % r)
+        if inception_fn is not None:
+            info = np.load(os.path.join(result_folder, "samples_%d.npz" % r))
+            latents = inception_fn(info["samples"])
+            cur_nfe = info["nfe_cnt"]
+            np.savez_compressed(f_stat, pool_3=latents["pool_3"], logits=latents.get("logits", np.zeros((0,))), nfe_cnt=cur_nfe)
+        elif os.path.exists(f_stat):
+            latents = np.load(f_stat)
+            cur_nfe = latents["nfe_cnt"]
+        else:
+            raise GddimError("%s is missing and no inception_fn was given: the TF-Hub Inception network "
+                             "(tfgan/eval/inception/1) is an external asset that is not part of this package" % f_stat)
+        if not inceptionv3:
+            all_logits.append(latents["logits"])
+        all_pools.append(latents["pool_3"])
+        all_nfe_cnt.append(cur_nfe)
+    all_pools = np.concatenate(all_pools, axis=0)[:config.eval.num_samples]
+    data_pools = evaluation.load_dataset_stats(config, stats_root)["pool_3"]
+    if not inceptionv3:
+        inception_score = evaluation.classifier_score_from_logits(np.concatenate(all_logits, axis=0)[:config.eval.num_samples])
+    else:
+        inception_score = -1
+    fid = evaluation.frechet_classifier_distance_from_activations(data_pools, all_pools)
+    avg_nfe_cnt = float(np.mean(all_nfe_cnt))
+    np.savez_compressed(os.path.join(result_folder, "report.npz"), IS=inception_score, fid=fid, nfe=avg_nfe_cnt)
+    return {"IS": inception_score, "fid": fid, "nfe": avg_nfe_cnt}
