@@ -223,6 +223,82 @@ def get_mldeis_sampler(sde, model, data_shape, nfe, inverse_scaler, deis_order, 
                          init=mlsde.x2y_matrix(sde.T), post=mlsde.y2x_matrix(sde.sampling_eps / 2), dn_sde=sde)
 
 
+def _em_coef(sde, rev_ts, lambda_coef):
+    """Euler-Maruyama step of cld_jax/sampling.py:625-655 in the [Psi_i, C_i0] form of the fused loop:
+    u' = u + (F u - (1+lambda)/2 G G^T score) dt + lambda G xi sqrt|dt|, score = -R^-T eps."""
+    n = len(rev_ts) - 1
+    coef = np.empty((n, 2, 2, 2))
+    noise = np.empty((n, 2, 2))
+    for i in range(n):
+        t, dt = rev_ts[i], rev_ts[i + 1] - rev_ts[i]
+        G = sde.s_G(t)
+        coef[i, 0] = np.eye(2) + sde.s_F(t) * dt
+        coef[i, 1] = (1.0 + lambda_coef) / 2.0 * (G @ G.T) @ sde.s_invR(t).T * dt
+        noise[i] = lambda_coef * G * np.sqrt(abs(dt))
+    return coef, noise
+
+
+def get_em_sampler(sde, model, data_shape, nfe, inverse_scaler, lambda_coef=0, ts_order=2, denoising=False, is_p=False):
+    rev_ts = get_rev_ts(sde, ts_order, nfe - 1 if denoising else nfe)
+    coef, noise = _em_coef(sde, rev_ts, lambda_coef)
+    if lambda_coef != 0:
+        raise NotImplementedError("em with lambda_coef != 0 draws Gaussian noise per step: outside this round's scope (N3)")
+    return _make_sampler(sde, model, data_shape, nfe, inverse_scaler, rev_ts, coef, denoising, is_p, "em")
+
+
+def get_ode_sampler(sde, model, data_shape, inverse_scaler, denoising=False, rtol=1e-5, atol=1e-5, method='RK45', is_p=False):
+    """Adaptive probability-flow ODE solve (cld_jax/sampling.py:432-495): scipy's solve_ivp on the host drives the drift
+    F u - 1/2 G G score evaluated on the GPU.  As in the reference, the pmapped variant (is_p=True, what get_sampling_fn
+    builds) divides batch_size by the device count and skips the denoising step."""
+    from scipy import integrate
+    step_fn = get_denoising_step(sde, model, sde.sampling_eps, sde.sampling_eps) if denoising else (lambda _, u: u)
+
+    def _solve(state, u):
+        import torch
+        score_fn = mutils.get_score_fn(sde, model, state.params_ema, state.model_state, train=False, continuous=True)
+        d_shape = tuple(u.shape)
+        ones = torch.ones(d_shape[0], device=u.device, dtype=torch.float32)
+
+        def ode_func(t, x):
+            xt = torch.as_tensor(np.asarray(x, dtype=np.float32).reshape(d_shape), device=u.device)
+            score = score_fn(xt, ones * float(t))
+            cur_F, cur_G = sde.s_F(t), sde.s_G(t)
+            grad = utils.sbmm(cur_F, xt) - 0.5 * utils.sbmm(cur_G @ cur_G, score)
+            return grad.reshape(-1).double().cpu().numpy()
+
+        solution = integrate.solve_ivp(ode_func, (sde.T, sde.sampling_eps), u.reshape(-1).double().cpu().numpy(), rtol=rtol,
+                                       atol=atol, method=method)
+        out = torch.as_tensor(solution.y[:, -1].reshape(d_shape), device=u.device, dtype=torch.float32)
+        return out, solution.nfev
+
+    def _prep(rng, u, shape):
+        import torch
+        if u is None:
+            u = sde.prior_sampling(_seed_of(rng), shape)
+        if not hasattr(u, 'is_cuda'):
+            u = torch.as_tensor(np.asarray(u), dtype=torch.float32)
+        if not u.is_cuda:
+            u = u.to(torch.device('cuda', torch.cuda.current_device()))
+        return u.to(torch.float32)
+
+    def sampler(rng, state, batch_size, u=None):
+        u = _prep(rng, u, (batch_size,) + tuple(data_shape))
+        u, nfe = _solve(state, u)
+        u = step_fn(state, u)
+        x, v = u[..., 0], u[..., 1]
+        return inverse_scaler(x), v, nfe
+
+    def psampler(prng, pstate, batch_size, u=None):
+        batch_size = batch_size // _LOCAL_DEVICE_COUNT
+        u = _prep(_unreplicate_rng(prng), u, (_LOCAL_DEVICE_COUNT, batch_size) + tuple(data_shape))
+        assert u.shape[0] == _LOCAL_DEVICE_COUNT, "one process drives one GPU: leading device axis must be 1"
+        out, nfe = _solve(pstate, u[0])
+        x, v = out[..., 0], out[..., 1]
+        return inverse_scaler(x)[None], v[None], nfe
+
+    return psampler if is_p else sampler
+
+
 def get_sampling_fn(config, sde, model, shape, inverse_scaler):
     """Create a sampling function (cld_jax/sampling.py:41-154)."""
     del shape
@@ -251,6 +327,14 @@ def get_sampling_fn(config, sde, model, shape, inverse_scaler):
         return get_mldeis_sampler(sde=sde, model=model, data_shape=data_shape, nfe=config.sampling.nfe,
                                   inverse_scaler=inverse_scaler, deis_order=config.sampling.deis_order,
                                   ts_order=config.sampling.ts_order, denoising=config.sampling.noise_removal, is_p=True)
-    if name in ('sdeis', 'ode', 'sscs', 'em'):
+    if name == 'ode':
+        return get_ode_sampler(sde=sde, model=model, data_shape=data_shape, inverse_scaler=inverse_scaler,
+                               denoising=config.sampling.noise_removal, atol=config.sampling.atol, rtol=config.sampling.rtol,
+                               method=config.sampling.ode_method, is_p=True)
+    if name == 'em':
+        return get_em_sampler(sde=sde, model=model, data_shape=data_shape, nfe=config.sampling.nfe, inverse_scaler=inverse_scaler,
+                              lambda_coef=config.sampling.lambda_coef, ts_order=config.sampling.ts_order,
+                              denoising=config.sampling.noise_removal, is_p=True)
+    if name in ('sdeis', 'sscs'):
         raise NotImplementedError("sampling.method=%r is not built yet (SURVEY.md section 8f, N3)" % sampler_name)
     raise RuntimeError

@@ -8,6 +8,9 @@ Restates, in numpy float64, deliberately literal (python loops):
   /root/reference/cld_jax/sampling.py:322-378  get_mldeis_sampler
   /root/reference/cld_jax/sampling.py:497-540  _impl_Ldeis_sampler, get_L_deis_sampler
   /root/reference/cld_jax/models/utils.py:168-182  get_eps_fn with sde.mixed_score=True
+  /root/reference/cld_jax/sampling.py:432-463  get_ode_sampler (the non-pmapped `sampler`)
+  /root/reference/cld_jax/sampling.py:625-655  get_em_sampler (noise injected by the caller: jax's threefry stream is not
+                                               reproducible, see oracle/__init__.py)
 
 PARITY UNPINNED -- see oracle/__init__.py.  What pins these restatements without the reference: psi2(t) against the closed
 form psi1(t)^-1 expm(int_0^t F) (the two frames describe the same flow), L L^T = R R^T, and agreement of the three
@@ -213,6 +216,53 @@ def mldeis_sampler(sde, eps_fn, u, nfe, deis_order, ts_order=2, denoising=False,
     if denoising:
         u = ocld.get_denoising_step(sde, eps_fn, sde.sampling_eps, sde.sampling_eps)(u)
     u = mlsde.y2x(u, sde.sampling_eps / 2).astype(u.dtype)
+    x, v = u[..., 0], u[..., 1]
+    if inverse_scaler is not None:
+        x = inverse_scaler(x)
+    return x, v, nfe
+
+
+def ode_sampler(sde, eps_fn, u, denoising=False, rtol=1e-5, atol=1e-5, method="RK45", inverse_scaler=None):
+    """get_ode_sampler.sampler (sampling.py:437-463)."""
+    from scipy import integrate
+    d_shape = u.shape
+    ones = np.ones(u.shape[0], dtype=u.dtype)
+
+    def drift_fn(x, s_t):
+        vec_t = ones * s_t
+        score = sde.eps2score(eps_fn(x, vec_t), vec_t)
+        cur_F, cur_G = sde.s_F(s_t), sde.s_G(s_t)
+        return ocld.sbmm(cur_F, x) - 0.5 * ocld.sbmm(cur_G @ cur_G, score)
+
+    def ode_func(t, x):
+        return drift_fn(x.reshape(d_shape), t).reshape(-1)
+
+    solution = integrate.solve_ivp(ode_func, (sde.T, sde.sampling_eps), u.reshape(-1), rtol=rtol, atol=atol, method=method)
+    nfe = solution.nfev
+    u = solution.y[:, -1].reshape(d_shape)
+    if denoising:
+        u = ocld.get_denoising_step(sde, eps_fn, sde.sampling_eps, sde.sampling_eps)(u)
+    x, v = u[..., 0], u[..., 1]
+    if inverse_scaler is not None:
+        x = inverse_scaler(x)
+    return x, v, nfe
+
+
+def em_sampler(sde, eps_fn, u, nfe, lambda_coef=0, ts_order=2, denoising=False, inverse_scaler=None, noise_fn=None):
+    """get_em_sampler.sampler (sampling.py:633-655); noise_fn(i, shape) stands for random.normal(rng_i, shape)."""
+    num_step = nfe - 1 if denoising else nfe
+    rev_ts = ocld.get_rev_ts(sde, ts_order, num_step)
+    ones = np.ones(u.shape[0], dtype=u.dtype)
+    for i in range(num_step):
+        cur_t, next_t = rev_ts[i], rev_ts[i + 1]
+        delta_t = next_t - cur_t
+        cur_G = sde.s_G(cur_t)
+        cur_score = sde.eps2score(eps_fn(u, cur_t * ones), cur_t * ones)
+        grad = ocld.sbmm(sde.s_F(cur_t), u) - (1.0 + lambda_coef) / 2.0 * ocld.sbmm(cur_G @ cur_G.T, cur_score)
+        noise = (noise_fn(i, u.shape) if lambda_coef != 0 else np.zeros_like(u)) * np.sqrt(np.abs(delta_t))
+        u = u + grad * delta_t + ocld.sbmm(cur_G, noise) * lambda_coef
+    if denoising:
+        u = ocld.get_denoising_step(sde, eps_fn, sde.sampling_eps, sde.sampling_eps)(u)
     x, v = u[..., 0], u[..., 1]
     if inverse_scaler is not None:
         x = inverse_scaler(x)

@@ -270,3 +270,44 @@ def test_mixed_score_matches_oracle(cld_setup):
     ex, ev = np.abs(x.cpu().numpy() - wx).max(), np.abs(v.cpu().numpy() - wv).max()
     print("mixed score: max|dx| %.3e max|dv| %.3e (|x| %.3e |v| %.3e)" % (ex, ev, np.abs(wx).max(), np.abs(wv).max()))
     assert np.isfinite(wx).all() and ex < _tol(wx) and ev < _tol(wv)
+
+
+def test_em_sampler_lambda0_matches_oracle(cld_setup):
+    from gddim_amd.cld import sampling
+    from gddim_amd.datasets import get_data_inverse_scaler
+    from oracle import cld_ext as ox
+    cfg, params, sde, osde, model, state, u = cld_setup
+    nfe = 8
+    fn = sampling.get_em_sampler(sde, model, (16, 16, 3), nfe, get_data_inverse_scaler(cfg), lambda_coef=0, ts_order=2, denoising=True)
+    x, v, n = fn(0, state, u.shape[0], torch.as_tensor(u, device="cuda:0"))
+    eps64 = onet.cld_eps_fn(params, cfg, dtype=torch.float64)
+    wx, wv, _ = ox.em_sampler(osde, eps64, u.astype(np.float64), nfe, 0, ts_order=2, denoising=True, inverse_scaler=ocld.inverse_scaler_centered)
+    ex, ev = np.abs(x.cpu().numpy() - wx).max(), np.abs(v.cpu().numpy() - wv).max()
+    print("em lambda=0: max|dx| %.3e max|dv| %.3e (|x| %.3e |v| %.3e)" % (ex, ev, np.abs(wx).max(), np.abs(wv).max()))
+    assert n == nfe and np.isfinite(wx).all() and ex < _tol(wx) and ev < _tol(wv)
+
+
+def test_ode_sampler_matches_oracle(cld_setup):
+    """Adaptive RK45 on the host with the drift on the GPU.  fp32 and fp64 drifts pick slightly different step sizes, so the
+    two solutions agree to the solver tolerance, not to roundoff: the bar is 20 x rtol of the solution scale."""
+    from gddim_amd.cld import sampling
+    from gddim_amd.datasets import get_data_inverse_scaler
+    from oracle import cld_ext as ox
+    cfg, params, sde, osde, model, state, u = cld_setup
+    rtol = atol = 1e-4
+    fn = sampling.get_ode_sampler(sde, model, (16, 16, 3), get_data_inverse_scaler(cfg), denoising=True, rtol=rtol, atol=atol)
+    x, v, n = fn(0, state, 2, torch.as_tensor(u[:2], device="cuda:0"))
+    eps64 = onet.cld_eps_fn(params, cfg, dtype=torch.float64)
+    wx, wv, wn = ox.ode_sampler(osde, eps64, u[:2].astype(np.float64), denoising=True, rtol=rtol, atol=atol,
+                                inverse_scaler=ocld.inverse_scaler_centered)
+    ex, ev = np.abs(x.cpu().numpy() - wx).max(), np.abs(v.cpu().numpy() - wv).max()
+    print("ode: nfev %d vs %d, max|dx| %.3e max|dv| %.3e (|x| %.3e |v| %.3e)" % (n, wn, ex, ev, np.abs(wx).max(), np.abs(wv).max()))
+    assert abs(n - wn) <= 0.2 * wn and ex < 20 * rtol * max(1.0, np.abs(wx).max()) and ev < 20 * rtol * max(1.0, np.abs(wv).max())
+    # the factory's pmapped variant: leading device axis, no denoising step
+    cfg = cfg.copy_and_resolve_references()
+    cfg.sampling.method, cfg.sampling.rtol, cfg.sampling.atol = 'ode', rtol, atol
+    pfn = sampling.get_sampling_fn(cfg, sde, model, None, get_data_inverse_scaler(cfg))
+    xs, vs, pn = pfn([0], state, 2, torch.as_tensor(u[None, :2], device="cuda:0"))
+    px, pv, _ = ox.ode_sampler(osde, eps64, u[:2].astype(np.float64), denoising=False, rtol=rtol, atol=atol,
+                               inverse_scaler=ocld.inverse_scaler_centered)
+    assert xs.shape == (1, 2, 16, 16, 3) and np.abs(xs[0].cpu().numpy() - px).max() < 20 * rtol * max(1.0, np.abs(px).max())
