@@ -69,6 +69,9 @@ SIGNATURES = {
     "gd_cld_eps": (_I, [_P, _P, _P, _P, _I, _P]),
     "gd_engine_set_schedule_cld": (_I, [_P, _I, _I, _P, _P, _I, _F, _P, _P, _P]),
     "gd_engine_set_transforms_cld": (_I, [_P, _P, _P, _P, _P, _P]),
+    "gd_engine_set_noise_cld": (_I, [_P, _P, _P, _P]),
+    "gd_engine_set_seed": (_I, [_P, ctypes.c_ulonglong]),
+    "gd_randn_pairs": (_I, [_P, _LL, ctypes.c_ulonglong, ctypes.c_uint, ctypes.c_ulonglong, _P]),
     "gd_sample_cld": (_I, [_P, _I, _P, _P, _P, _I, _I, _P]),
     "gd_engine_set_schedule_blur": (_I, [_P, _I, _P, _P, _P]),
     "gd_sample_blur": (_I, [_P, _I, _P, _P, _I, _I, _P]),

@@ -21,8 +21,10 @@ Inside the callable nothing but the native engine runs: the whole NFE loop (U-Ne
 2x2 exponential-integrator update per step, denoising step, inverse scaling) is `gd_sample_cld`, replayed
 from a hipGraph.  get_L_deis_sampler (:533-540, the Cholesky parametrisation of eps) and get_mldeis_sampler (:322-378, the
 rotated frame y = psi1(t)^-1 x) run on the same fused loop through per-step 2x2 maps (gd_engine_set_transforms_cld), and so does
-sde.mixed_score=True (models/utils.py:174-176).  The stochastic samplers of the reference's factory (sdeis, sscs, em) and the
-adaptive `ode` solver are outside this round's scope and raise NotImplementedError.
+sde.mixed_score=True (models/utils.py:174-176).  get_em_sampler (:625-655) and get_sscs_sampler (:563-621) add per-step Gaussian
+noise from the engine's counter-based generator (same law as the reference's jax.random draws, not the same stream);
+get_ode_sampler (:432-495) integrates on the host with the drift on the GPU.  Only `sdeis` (the LambdaSDE family, sde_lib.py:334-466)
+is not built and raises NotImplementedError.
 """
 import itertools
 
@@ -93,10 +95,12 @@ def _seed_of(rng):
 
 
 def _make_sampler(sde, model, data_shape, nfe, inverse_scaler, rev_ts, coef, denoising, is_p, tag, pre=None, eps_lin=None,
-                  init=None, post=None, dn_sde=None):
+                  init=None, post=None, dn_sde=None, noise=None):
     """Shared closure builder: `coef` is (num_step, n_slots, 2, 2) = [Psi_i, C_i0, ...].
     pre / eps_lin: optional (num_step, 2, 2) maps (network input P_i u; eps <- E_i eps); init / post: 2x2 maps applied to the
-    initial noise / to the state after the denoising step; dn_sde: the SDE whose F, G, R the denoising step uses."""
+    initial noise / to the state after the denoising step; dn_sde: the SDE whose F, G, R the denoising step uses;
+    noise: (pre_lin, pre_noise, post_noise) per-step maps of the stochastic samplers (Engine.set_noise_cld), seeded per call
+    from `rng`."""
     num_step = coef.shape[0]
     dn_sde = sde if dn_sde is None else dn_sde
     dn = _denoise_mats(dn_sde, dn_sde.sampling_eps) if denoising else (None, None, None)
@@ -140,6 +144,10 @@ def _make_sampler(sde, model, data_shape, nfe, inverse_scaler, rev_ts, coef, den
             eng.set_schedule_cld(ts32, coef32, denoising, sde.sampling_eps, dn[0], dn[1], dn[2], token=token)
             if transforms:
                 eng.set_transforms_cld(pre, eps_lin, u_lin, dn_u_lin, post)
+            if noise is not None:
+                eng.set_noise_cld(*noise)
+        if noise is not None:
+            eng.set_seed(_seed_of(rng))
         x, v = eng.sample_cld(u, inverse_scale=fuse_scale, use_graph=use_graph)
         if post_scale is not None:
             x = post_scale(x)
@@ -241,9 +249,54 @@ def _em_coef(sde, rev_ts, lambda_coef):
 def get_em_sampler(sde, model, data_shape, nfe, inverse_scaler, lambda_coef=0, ts_order=2, denoising=False, is_p=False):
     rev_ts = get_rev_ts(sde, ts_order, nfe - 1 if denoising else nfe)
     coef, noise = _em_coef(sde, rev_ts, lambda_coef)
-    if lambda_coef != 0:
-        raise NotImplementedError("em with lambda_coef != 0 draws Gaussian noise per step: outside this round's scope (N3)")
-    return _make_sampler(sde, model, data_shape, nfe, inverse_scaler, rev_ts, coef, denoising, is_p, "em")
+    return _make_sampler(sde, model, data_shape, nfe, inverse_scaler, rev_ts, coef, denoising, is_p, "em",
+                         noise=(None, None, noise) if lambda_coef != 0 else None)
+
+
+def noise_factor(cov):
+    """A square root S of a 2x2 covariance (S S^T = cov): Cholesky, falling back to the symmetric root when round-off makes
+    the matrix indefinite.  The reference samples multivariate_normal(..., method='svd'); any root gives the same law."""
+    try:
+        return np.linalg.cholesky(cov)
+    except np.linalg.LinAlgError:
+        w, v = np.linalg.eigh((cov + cov.T) / 2)
+        return (v * np.sqrt(np.clip(w, 0.0, None))) @ v.T
+
+
+def sscs_ou(sde, s_t, s_t_next):
+    """Mean matrix and covariance of the analytic Ornstein-Uhlenbeck half step (cld_jax/sampling.py:542-561)."""
+    beta_int = -1 * (sde.beta_int(1 - s_t_next) - sde.beta_int(1 - s_t))
+    G_ = sde.Gamma
+    coeff = np.exp(-2. * beta_int / G_)
+    mean_matrix = np.array([[1 + 2 * beta_int / G_, -4 * beta_int / G_ / G_], [beta_int, 1 - 2 * beta_int / G_]]) * coeff
+    coeff = np.exp(-4 * beta_int / G_)
+    cov_xx = np.exp(4 * beta_int / G_) - 1 - 4 * beta_int / G_ - 8 * beta_int ** 2 / G_ / G_
+    cov_xv = -4 * beta_int ** 2 / G_
+    cov_vv = (G_ / 2) ** 2 * (np.exp(4 * beta_int / G_) - 1) + beta_int * G_ - 2 * beta_int ** 2
+    return mean_matrix, np.array([[cov_xx, cov_xv], [cov_xv, cov_vv]]) * coeff
+
+
+def get_sscs_sampler(sde, model, data_shape, nfe, inverse_scaler, ts_order=2, denoising=False, is_p=False):
+    """Symmetric splitting CLD sampler (cld_jax/sampling.py:563-621): OU half step, score step on v, OU half step.  In the
+    fused loop: u <- M1 u + S1 xi before the network, then u <- M2 (A u + B eps) + S2 xi' with A, B the score step."""
+    num_step = nfe - 1 if denoising else nfe
+    rev_ts = get_rev_ts(sde, ts_order, num_step)
+    ts = 1 - rev_ts
+    coef = np.empty((num_step, 2, 2, 2))
+    pre_lin, pre_noise, post_noise = (np.empty((num_step, 2, 2)) for _ in range(3))
+    for i in range(num_step):
+        cur_t, next_t = ts[i], ts[i + 1]
+        mid = (cur_t + next_t) / 2.0
+        M1, cov1 = sscs_ou(sde, cur_t, mid)
+        M2, cov2 = sscs_ou(sde, mid, next_t)
+        k = 2 * float(sde.beta(cur_t)) * sde.Gamma * (next_t - cur_t)
+        A = np.eye(2) + np.array([[0.0, 0.0], [0.0, k * sde.m_inv]])
+        RinvT = sde.s_invR(sde.T - cur_t).T  # score = -R^-T eps at time T - s_t; only its v component enters
+        B = k * np.array([[0.0, 0.0], [-RinvT[1, 0], -RinvT[1, 1]]])
+        coef[i, 0], coef[i, 1] = M2 @ A, M2 @ B
+        pre_lin[i], pre_noise[i], post_noise[i] = M1, noise_factor(cov1), noise_factor(cov2)
+    return _make_sampler(sde, model, data_shape, nfe, inverse_scaler, rev_ts, coef, denoising, is_p, "sscs",
+                         noise=(pre_lin, pre_noise, post_noise))
 
 
 def get_ode_sampler(sde, model, data_shape, inverse_scaler, denoising=False, rtol=1e-5, atol=1e-5, method='RK45', is_p=False):
@@ -335,6 +388,9 @@ def get_sampling_fn(config, sde, model, shape, inverse_scaler):
         return get_em_sampler(sde=sde, model=model, data_shape=data_shape, nfe=config.sampling.nfe, inverse_scaler=inverse_scaler,
                               lambda_coef=config.sampling.lambda_coef, ts_order=config.sampling.ts_order,
                               denoising=config.sampling.noise_removal, is_p=True)
-    if name in ('sdeis', 'sscs'):
+    if name == 'sscs':
+        return get_sscs_sampler(sde=sde, model=model, data_shape=data_shape, nfe=config.sampling.nfe, inverse_scaler=inverse_scaler,
+                                ts_order=config.sampling.ts_order, denoising=config.sampling.noise_removal, is_p=True)
+    if name == 'sdeis':
         raise NotImplementedError("sampling.method=%r is not built yet (SURVEY.md section 8f, N3)" % sampler_name)
     raise RuntimeError

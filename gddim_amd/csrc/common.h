@@ -127,8 +127,15 @@ int launch_dct2d_32(const float *in, float *out, int batch, int channels, int in
 int launch_cld_pack(const float *u, float *u8, float *ring, int ring_slots, long long pixels, int C, hipStream_t s);
 int launch_cld_unpack_pairs(const float *planar, int ld, float *pairs, long long pixels, int C, hipStream_t s);
 // tf (nullable): per-step rows of 12 floats [P_i, E_i, U_i] (2x2 each): U-Net input P_i u, eps <- E_i eps_net + U_i u
+// nz (nullable): per-step rows of 12 floats [M_pre, S_pre, S_post]; the step adds S_post xi with xi the counter-based Gaussian
+// pair of (seed, elem0 + element, draw 2 step + 1) (kernels/rng.h)
 int launch_cld_ab_step(float *u8, const float *eps, float *ring, int ring_slots, const float *coef_table, int n_slots,
-                       const int *step, long long pixels, int C, const float *tf, hipStream_t s);
+                       const int *step, long long pixels, int C, const float *tf, const float *nz, const unsigned *seed,
+                       unsigned long long elem0, hipStream_t s);
+// u <- M_pre u + S_pre xi (draw 2 step), before the network evaluation of the step
+int launch_cld_noise_pre(float *u8, const float *nz, const int *step, const unsigned *seed, unsigned long long elem0,
+                         long long pixels, int C, hipStream_t s);
+int launch_randn_pairs(float *out, long long n, const unsigned *seed, unsigned draw, unsigned long long elem0, hipStream_t s);
 int launch_cld_pre(const float *u8, float *xin, const float *tf, const int *step, long long pixels, int C, hipStream_t s);
 // dn: 20 floats F, GG, RinvT, X (mixed score, flags & 1), POST (final frame change, flags & 2)
 int launch_cld_finish(const float *u8, const float *eps, const float *dn, float dt, int denoise, int inverse_scale,

@@ -65,6 +65,11 @@ struct gd_engine {
     float *tf_dev = nullptr;      // per-step [P, E, U] rows of the CLD sampler (gd_engine_set_transforms_cld), null = none
     bool tf_pre = false;          // the rows carry a non-identity P: the U-Net reads xin = P u instead of u
     int fin_flags = 0;            // cld_finish: 1 mixed-score term, 2 final frame change
+    float *nz_dev = nullptr;      // per-step [M_pre, S_pre, S_post] rows of the stochastic samplers (gd_engine_set_noise_cld)
+    bool nz_pre = false;          // the rows carry a state update before the network evaluation
+    unsigned *seed_dev = nullptr; // 2 words, rewritten by every sampler call (graph replays read it from memory)
+    unsigned long long seed = 0;
+    unsigned seed_words[2] = {0, 0};  // host staging of seed_dev (must outlive the async copy)
     int *step_dev = nullptr;  // GD_MAX_LANES counters (one per concurrent sub-batch)
     int sched_kind = 0;  // 1 cld, 2 blur
     int num_step = 0, n_slots = 0, denoise = 0;
@@ -293,6 +298,7 @@ int gd_engine_create(const gd_model_desc *desc, int device, gd_engine **out) {
         GD_ALLOC(e->u8, pix * CP);
         GD_ALLOC(e->ystate, pix * desc->in_channels);
         GD_ALLOC(e->dn_dev, 20);
+        GD_HIP(hipMalloc((void **)&e->seed_dev, 2 * sizeof(unsigned)));
         GD_ALLOC(e->step_dev, gd_engine::MAX_LANES);
 #undef GD_ALLOC
         (void)hipMemset(e->step_dev, 0, sizeof(int) * gd_engine::MAX_LANES);
@@ -319,7 +325,8 @@ int gd_engine_destroy(gd_engine *e) {
         if (e->wsplit_hi) (void)hipFree(e->wsplit_hi);
         if (e->wsplit_lo) (void)hipFree(e->wsplit_lo);
         float *bufs[] = {e->arena, e->wbuf, e->xin, e->epsb, e->eps_planar, e->labels, e->u8, e->ring, e->ystate,
-                         e->ts_dev, e->coef_dev, e->dn_dev, e->mean_dev, e->std_dev, e->tf_dev, (float *)e->step_dev};
+                         e->ts_dev, e->coef_dev, e->dn_dev, e->mean_dev, e->std_dev, e->tf_dev, e->nz_dev, (float *)e->seed_dev,
+                         (float *)e->step_dev};
         for (float *b : bufs)
             if (b) (void)hipFree(b);
         if (e->ev_in) (void)hipEventDestroy(e->ev_in);
@@ -516,7 +523,54 @@ int gd_engine_set_schedule_cld(gd_engine *e, int num_step, int n_slots, const fl
     e->sched_kind = 1; e->num_step = num_step; e->n_slots = n_slots; e->denoise = denoise; e->t_denoise = t_denoise;
     if (e->tf_dev) { (void)hipFree(e->tf_dev); e->tf_dev = nullptr; }
     e->tf_pre = false; e->fin_flags = 0;
+    if (e->nz_dev) { (void)hipFree(e->nz_dev); e->nz_dev = nullptr; }
+    e->nz_pre = false;
     return 0;
+}
+
+int gd_engine_set_noise_cld(gd_engine *e, const float *pre_lin, const float *pre_noise, const float *post_noise) {
+    GD_CHECK(e && !e->plan_only, "engine has no GPU");
+    GD_CHECK(e->sched_kind == 1, "install the CLD schedule first (gd_engine_set_schedule_cld)");
+    GD_CHECK((pre_lin == nullptr) == (pre_noise == nullptr), "pre_lin and pre_noise come together");
+    GD_HIP(hipSetDevice(e->device));
+    GD_HIP(hipDeviceSynchronize());
+    drop_graphs(e);
+    if (e->nz_dev) { (void)hipFree(e->nz_dev); e->nz_dev = nullptr; }
+    e->nz_pre = false;
+    if (!pre_lin && !post_noise) return 0;
+    const int n = std::max(1, e->num_step);
+    std::vector<float> rows((size_t)n * 12, 0.f);
+    for (int i = 0; i < n; ++i) {
+        float *r = rows.data() + (size_t)i * 12;
+        r[0] = r[3] = 1.f;  // M_pre = I, S_pre = S_post = 0
+        if (i >= e->num_step) continue;
+        if (pre_lin) { memcpy(r, pre_lin + (size_t)i * 4, 16); memcpy(r + 4, pre_noise + (size_t)i * 4, 16); }
+        if (post_noise) memcpy(r + 8, post_noise + (size_t)i * 4, 16);
+    }
+    GD_TRY(upload(&e->nz_dev, rows.data(), rows.size()));
+    e->nz_pre = pre_lin != nullptr;
+    return 0;
+}
+
+int gd_engine_set_seed(gd_engine *e, unsigned long long seed) {
+    GD_CHECK(e != nullptr, "null engine");
+    e->seed = seed;
+    return 0;
+}
+
+int gd_randn_pairs(float *out_dev, long long n_pairs, unsigned long long seed, unsigned draw, unsigned long long elem0,
+                   void *stream) {
+    GD_CHECK(out_dev && n_pairs >= 0, "bad argument");
+    if (n_pairs == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    unsigned *sd = nullptr;
+    const unsigned words[2] = {(unsigned)seed, (unsigned)(seed >> 32)};
+    GD_HIP(hipMalloc((void **)&sd, sizeof words));
+    GD_HIP(hipMemcpyAsync(sd, words, sizeof words, hipMemcpyHostToDevice, s));
+    int r = launch_randn_pairs(out_dev, n_pairs, sd, draw, elem0, s);
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(sd);
+    return r;
 }
 
 int gd_engine_set_transforms_cld(gd_engine *e, const float *pre, const float *eps_lin, const float *u_lin, const float *dn_u_lin,
@@ -588,12 +642,18 @@ int gd_sample_cld(gd_engine *e, int batch, const float *u_in_dev, float *x_out_d
     const bool graph = use_graph && !e->prof;
     int start[gd_engine::MAX_LANES], size[gd_engine::MAX_LANES];
     const int nl = split_lanes(e, batch, !e->prof, start, size);
+    if (e->nz_dev) {  // the seed of this call, in device memory so that captured graphs read the current one
+        e->seed_words[0] = (unsigned)e->seed;
+        e->seed_words[1] = (unsigned)(e->seed >> 32);
+        GD_HIP(hipMemcpyAsync(e->seed_dev, e->seed_words, 2 * sizeof(unsigned), hipMemcpyHostToDevice, caller));
+    }
     GD_HIP(hipEventRecord(e->ev_in, caller));
 
     struct Lane {
         hipStream_t s;
         int b;
         long long pix;
+        unsigned long long elem0;
         float *u8, *eps, *ring, *xin;
         int *step;
         Bind bind, bind_u;  // bind: U-Net reads the (possibly transformed) step input; bind_u: reads the state itself
@@ -607,6 +667,7 @@ int gd_sample_cld(gd_engine *e, int batch, const float *u_in_dev, float *x_out_d
         const size_t p0 = (size_t)start[i] * HW;
         l.u8 = e->u8 + p0 * e->plan.CP;
         l.xin = e->xin + p0 * e->plan.CP;
+        l.elem0 = (unsigned long long)p0 * C;
         l.eps = e->epsb + p0 * d.in_channels;
         l.ring = e->ring ? e->ring + p0 * d.in_channels * ring_slots : nullptr;
         l.step = e->step_dev + i;
@@ -619,9 +680,11 @@ int gd_sample_cld(gd_engine *e, int batch, const float *u_in_dev, float *x_out_d
         GD_HIP(hipMemsetAsync(l.step, 0, sizeof(int), l.s));
     }
     auto step_body = [&](Lane &l) -> int {
+        if (e->nz_pre) GD_TRY(launch_cld_noise_pre(l.u8, e->nz_dev, l.step, e->seed_dev, l.elem0, l.pix, C, l.s));
         if (e->tf_pre) GD_TRY(launch_cld_pre(l.u8, l.xin, e->tf_dev, l.step, l.pix, C, l.s));
         GD_TRY(run_unet(e, l.bind, l.b, l.s));
-        GD_TRY(launch_cld_ab_step(l.u8, l.eps, l.ring, ring_slots, e->coef_dev, e->n_slots, l.step, l.pix, C, e->tf_dev, l.s));
+        GD_TRY(launch_cld_ab_step(l.u8, l.eps, l.ring, ring_slots, e->coef_dev, e->n_slots, l.step, l.pix, C, e->tf_dev, e->nz_dev,
+                                  e->seed_dev, l.elem0, l.s));
         return launch_advance_step(l.step, l.s);
     };
     if (graph) {

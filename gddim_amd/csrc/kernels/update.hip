@@ -15,6 +15,7 @@
 // ring of n_hist slots in the U-Net output layout (pixels, 2C); the ring head and the coefficient
 // row are derived from a device-side step counter so one captured hipGraph serves every step.
 #include "../common.h"
+#include "rng.h"
 
 namespace gd {
 
@@ -151,7 +152,9 @@ __global__ __launch_bounds__(256) void cld_ab_step_kernel(float *__restrict__ u8
                                                            float *__restrict__ ring, int ring_slots,
                                                            const float *__restrict__ coef_table, int n_slots,
                                                            const int *__restrict__ step_ptr, long long pixels, int C,
-                                                           int CP, const float *__restrict__ tf) {
+                                                           int CP, const float *__restrict__ tf,
+                                                           const float *__restrict__ nz, const unsigned *__restrict__ seed,
+                                                           unsigned long long elem0) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= pixels * C) return;
     const long long p = i / C;
@@ -187,16 +190,64 @@ __global__ __launch_bounds__(256) void cld_ab_step_kernel(float *__restrict__ u8
         ring[nh * slot + eo] = ex;
         ring[nh * slot + eo + C] = ev;
     }
+    if (nz) {  // + S_i xi: the stochastic samplers' noise of this step (draw 2 i + 1; nz row = [M_pre, S_pre, S_post])
+        const float *S = nz + (size_t)step * 12 + 8;
+        const Normal2 xi = normal_pair(seed, elem0 + (unsigned long long)i, 2u * (unsigned)step + 1u);
+        ox += S[0] * xi.a + S[1] * xi.b;
+        ov += S[2] * xi.a + S[3] * xi.b;
+    }
     u8[p * CP + c] = ox;
     u8[p * CP + C + c] = ov;
 }
 
+// State update before the network evaluation of step i (first Ornstein-Uhlenbeck half step of the SSCS sampler):
+// u <- M_i u + S_i xi (draw 2 i)
+__global__ __launch_bounds__(256) void cld_noise_pre_kernel(float *__restrict__ u8, const float *__restrict__ nz,
+                                                             const int *__restrict__ step_ptr, const unsigned *__restrict__ seed,
+                                                             unsigned long long elem0, long long pixels, int C, int CP) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= pixels * C) return;
+    const long long p = i / C;
+    const int c = (int)(i - p * C);
+    const int step = *step_ptr;
+    const float *M = nz + (size_t)step * 12, *S = M + 4;
+    const float x = u8[p * CP + c], v = u8[p * CP + C + c];
+    const Normal2 xi = normal_pair(seed, elem0 + (unsigned long long)i, 2u * (unsigned)step);
+    u8[p * CP + c] = M[0] * x + M[1] * v + S[0] * xi.a + S[1] * xi.b;
+    u8[p * CP + C + c] = M[2] * x + M[3] * v + S[2] * xi.a + S[3] * xi.b;
+}
+
+int launch_cld_noise_pre(float *u8, const float *nz, const int *step, const unsigned *seed, unsigned long long elem0,
+                         long long pixels, int C, hipStream_t s) {
+    const int CP = (2 * C + 3) / 4 * 4;
+    const long long n = pixels * C;
+    hipLaunchKernelGGL(cld_noise_pre_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, u8, nz, step, seed, elem0, pixels,
+                       C, CP);
+    GD_HIP(hipGetLastError());
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void randn_pairs_kernel(float2 *__restrict__ out, long long n, const unsigned *__restrict__ seed,
+                                                           unsigned draw, unsigned long long elem0) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const Normal2 xi = normal_pair(seed, elem0 + (unsigned long long)i, draw);
+    out[i] = make_float2(xi.a, xi.b);
+}
+
+int launch_randn_pairs(float *out, long long n, const unsigned *seed, unsigned draw, unsigned long long elem0, hipStream_t s) {
+    hipLaunchKernelGGL(randn_pairs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (float2 *)out, n, seed, draw, elem0);
+    GD_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_cld_ab_step(float *u8, const float *eps, float *ring, int ring_slots, const float *coef_table, int n_slots,
-                       const int *step, long long pixels, int C, const float *tf, hipStream_t s) {
+                       const int *step, long long pixels, int C, const float *tf, const float *nz, const unsigned *seed,
+                       unsigned long long elem0, hipStream_t s) {
     const int CP = (2 * C + 3) / 4 * 4;
     const long long n = pixels * C;
     hipLaunchKernelGGL(cld_ab_step_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, u8, eps, ring, ring_slots,
-                       coef_table, n_slots, step, pixels, C, CP, tf);
+                       coef_table, n_slots, step, pixels, C, CP, tf, nz, seed, elem0);
     GD_HIP(hipGetLastError());
     return 0;
 }

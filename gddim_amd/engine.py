@@ -200,6 +200,14 @@ class Engine(object):
         keep = [None if m is None else _host_f32(m) for m in (pre, eps_lin, u_lin, dn_u_lin, post)]
         check(self._lib.gd_engine_set_transforms_cld(self._h, *[None if k is None else k[1] for k in keep]))
 
+    def set_noise_cld(self, pre_lin=None, pre_noise=None, post_noise=None):
+        """Per-step noise maps of the stochastic CLD samplers (include/gddim_amd.h: gd_engine_set_noise_cld)."""
+        keep = [None if m is None else _host_f32(m) for m in (pre_lin, pre_noise, post_noise)]
+        check(self._lib.gd_engine_set_noise_cld(self._h, *[None if k is None else k[1] for k in keep]))
+
+    def set_seed(self, seed):
+        check(self._lib.gd_engine_set_seed(self._h, int(seed) & 0xFFFFFFFFFFFFFFFF))
+
     def sample_cld(self, u, inverse_scale=True, use_graph=True):
         import torch
         u = u.contiguous()

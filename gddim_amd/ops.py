@@ -139,3 +139,12 @@ def attention(qkv):
     out = torch.empty((B, N, C), dtype=torch.float32, device=qkv.device)
     check(_abi.lib().gd_attention(_ptr(qkv), _ptr(scratch), _ptr(out), B, N, C, _stream(qkv)))
     return out
+
+
+def randn_pairs(n_pairs, seed, draw=0, elem0=0, device=None):
+    """(n_pairs, 2) standard normals from the engine's counter-based generator (gd_randn_pairs)."""
+    import torch
+    device = torch.device('cuda', torch.cuda.current_device()) if device is None else device
+    out = torch.empty((int(n_pairs), 2), dtype=torch.float32, device=device)
+    check(_abi.lib().gd_randn_pairs(_ptr(out), int(n_pairs), int(seed) & 0xFFFFFFFFFFFFFFFF, int(draw), int(elem0), _stream(out)))
+    return out

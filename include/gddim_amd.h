@@ -146,6 +146,21 @@ int gd_engine_set_schedule_cld(gd_engine *e, int num_step, int n_slots, const fl
  * Replaces: the extra closure state of _impl_Ldeis_sampler / get_mldeis_sampler / get_eps_fn(mixed_score=True). */
 int gd_engine_set_transforms_cld(gd_engine *e, const float *pre, const float *eps_lin, const float *u_lin,
                                  const float *dn_u_lin, const float *post);
+/* Per-step Gaussian noise of the stochastic CLD samplers (call after gd_engine_set_schedule_cld, which resets it; host arrays of
+ * num_step x 4 floats, row-major 2x2, NULL = none):
+ *   pre_lin, pre_noise   u <- M_i u + S_i xi before the network evaluation of step i  (SSCS: first OU half step,
+ *                        cld_jax/sampling.py:542-561,595)
+ *   post_noise           + S_i xi' added by the update of step i                       (em: lambda G sqrt|dt| noise, :648-650;
+ *                        SSCS: second OU half step, :597)
+ * xi, xi' are standard normal pairs from a counter-based generator keyed by (seed of the call, element, step): Philox4x32-10 +
+ * Box-Muller (gddim_amd/csrc/kernels/rng.h).  The reference draws from jax's threefry stream, which cannot be reproduced;
+ * only the distribution is matched.  gd_engine_set_seed selects the stream of the following gd_sample_cld calls. */
+int gd_engine_set_noise_cld(gd_engine *e, const float *pre_lin, const float *pre_noise, const float *post_noise);
+int gd_engine_set_seed(gd_engine *e, unsigned long long seed);
+/* n_pairs standard normal pairs of that generator: out_dev[2 i], out_dev[2 i + 1] = pair of element elem0 + i, draw `draw`.
+ * Replaces: jax.random.normal at the call sites above (stand-alone, for tests and for prior_sampling-style draws). */
+int gd_randn_pairs(float *out_dev, long long n_pairs, unsigned long long seed, unsigned draw, unsigned long long elem0,
+                   void *stream);
 /* One sampler call: u_in_dev (B,H,W,C,2) initial noise -> x_out_dev (B,H,W,C) = (u_x+1)/2 when
  * inverse_scale != 0 else u_x, v_out_dev (B,H,W,C).  use_graph: 0 eager launches, 1 replay a
  * captured hipGraph per step (captured on first use for this batch size).

@@ -11,6 +11,8 @@ Restates, in numpy float64, deliberately literal (python loops):
   /root/reference/cld_jax/sampling.py:432-463  get_ode_sampler (the non-pmapped `sampler`)
   /root/reference/cld_jax/sampling.py:625-655  get_em_sampler (noise injected by the caller: jax's threefry stream is not
                                                reproducible, see oracle/__init__.py)
+  /root/reference/cld_jax/sampling.py:542-621  get_sscs_ou_fn, get_sscs_score_fn, get_sscs_sampler (noise injected likewise;
+                                               multivariate_normal(method="svd") is replaced by a Cholesky root: same law)
 
 PARITY UNPINNED -- see oracle/__init__.py.  What pins these restatements without the reference: psi2(t) against the closed
 form psi1(t)^-1 expm(int_0^t F) (the two frames describe the same flow), L L^T = R R^T, and agreement of the three
@@ -249,7 +251,8 @@ def ode_sampler(sde, eps_fn, u, denoising=False, rtol=1e-5, atol=1e-5, method="R
 
 
 def em_sampler(sde, eps_fn, u, nfe, lambda_coef=0, ts_order=2, denoising=False, inverse_scaler=None, noise_fn=None):
-    """get_em_sampler.sampler (sampling.py:633-655); noise_fn(i, shape) stands for random.normal(rng_i, shape)."""
+    """get_em_sampler.sampler (sampling.py:633-655); noise_fn(draw, shape) stands for random.normal(rng_i, shape), draw = 2 i + 1
+    for step i (the engine's numbering: even draws belong to pre-network updates, which this sampler has none of)."""
     num_step = nfe - 1 if denoising else nfe
     rev_ts = ocld.get_rev_ts(sde, ts_order, num_step)
     ones = np.ones(u.shape[0], dtype=u.dtype)
@@ -259,8 +262,50 @@ def em_sampler(sde, eps_fn, u, nfe, lambda_coef=0, ts_order=2, denoising=False, 
         cur_G = sde.s_G(cur_t)
         cur_score = sde.eps2score(eps_fn(u, cur_t * ones), cur_t * ones)
         grad = ocld.sbmm(sde.s_F(cur_t), u) - (1.0 + lambda_coef) / 2.0 * ocld.sbmm(cur_G @ cur_G.T, cur_score)
-        noise = (noise_fn(i, u.shape) if lambda_coef != 0 else np.zeros_like(u)) * np.sqrt(np.abs(delta_t))
+        noise = (noise_fn(2 * i + 1, u.shape) if lambda_coef != 0 else np.zeros_like(u)) * np.sqrt(np.abs(delta_t))
         u = u + grad * delta_t + ocld.sbmm(cur_G, noise) * lambda_coef
+    if denoising:
+        u = ocld.get_denoising_step(sde, eps_fn, sde.sampling_eps, sde.sampling_eps)(u)
+    x, v = u[..., 0], u[..., 1]
+    if inverse_scaler is not None:
+        x = inverse_scaler(x)
+    return x, v, nfe
+
+
+def sscs_ou(sde, u, s_t, s_t_next, xi):
+    # get_sscs_ou_fn._fn (sampling.py:543-560); xi: standard normal pairs standing for the multivariate_normal draw
+    beta_int = sde._beta_int(1 - s_t_next) - sde._beta_int(1 - s_t)
+    beta_int = -1 * beta_int
+    coeff = np.exp(-2. * beta_int / sde.Gamma)
+    mean_matrix = np.asarray([[1 + 2 * beta_int / sde.Gamma, -4 * beta_int / sde.Gamma / sde.Gamma],
+                              [beta_int, 1 - 2 * beta_int / sde.Gamma]]) * coeff
+    mean = ocld.sbmm(mean_matrix, u)
+    coeff = np.exp(-4 * beta_int / sde.Gamma)
+    cov_xx = np.exp(4 * beta_int / sde.Gamma) - 1 - 4 * beta_int / sde.Gamma - 8 * beta_int ** 2 / sde.Gamma / sde.Gamma
+    cov_xv = -4 * beta_int ** 2 / sde.Gamma
+    cov_vv = (sde.Gamma / 2) ** 2 * (np.exp(4 * beta_int / sde.Gamma) - 1) + beta_int * sde.Gamma - 2 * beta_int ** 2
+    cov = np.asarray([[cov_xx, cov_xv], [cov_xv, cov_vv]]) * coeff
+    return mean + ocld.sbmm(np.linalg.cholesky(cov), xi), cov
+
+
+def sscs_sampler(sde, eps_fn, u, nfe, ts_order=2, denoising=False, inverse_scaler=None, noise_fn=None):
+    """get_sscs_sampler.sampler (sampling.py:573-600); noise_fn(draw, shape): standard normals, draws 2 i (first OU half step)
+    and 2 i + 1 (second) of step i."""
+    num_step = nfe - 1 if denoising else nfe
+    rev_ts = ocld.get_rev_ts(sde, ts_order, num_step)
+    ts = 1 - rev_ts
+    ones = np.ones(u.shape[0], dtype=u.dtype)
+    for i in range(num_step):
+        cur_t, next_t = ts[i], ts[i + 1]
+        u, _ = sscs_ou(sde, u, cur_t, (cur_t + next_t) / 2.0, noise_fn(2 * i, u.shape))
+        # get_sscs_score_fn._fn (:564-572)
+        x, v = u[..., 0], u[..., 1]
+        t_net = (sde.T - cur_t) * ones
+        v_score = sde.eps2score(eps_fn(u, t_net), t_net)[..., 1]
+        v_dot = 2 * sde._beta(cur_t) * sde.Gamma * (v_score + sde.m_inv * v)
+        v = v + v_dot * (next_t - cur_t)
+        u = np.stack([x, v], axis=-1)
+        u, _ = sscs_ou(sde, u, (cur_t + next_t) / 2.0, next_t, noise_fn(2 * i + 1, u.shape))
     if denoising:
         u = ocld.get_denoising_step(sde, eps_fn, sde.sampling_eps, sde.sampling_eps)(u)
     x, v = u[..., 0], u[..., 1]

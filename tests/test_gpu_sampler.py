@@ -311,3 +311,51 @@ def test_ode_sampler_matches_oracle(cld_setup):
     px, pv, _ = ox.ode_sampler(osde, eps64, u[:2].astype(np.float64), denoising=False, rtol=rtol, atol=atol,
                                inverse_scaler=ocld.inverse_scaler_centered)
     assert xs.shape == (1, 2, 16, 16, 3) and np.abs(xs[0].cpu().numpy() - px).max() < 20 * rtol * max(1.0, np.abs(px).max())
+
+
+# ---- stochastic samplers: the engine's counter-based noise (kernels/rng.h), restated by oracle/rng.py ------------------------
+def test_device_noise_matches_restatement(native_lib):
+    from gddim_amd import ops
+    from oracle import rng as orng
+    seed, n = 0x1234567890ABCDEF, 100000
+    got = ops.randn_pairs(n, seed, draw=5, elem0=7).cpu().numpy()
+    want = orng.normal_pairs(seed, np.arange(7, 7 + n, dtype=np.uint64), 5)
+    # integer side bit exact; float32 angle (2 pi u2 carries ~5e-7 absolute error) and log against float64, times |z| up to ~5.7
+    assert np.abs(got - want).max() < 5e-5 and np.abs(got - want).mean() < 5e-7
+    assert abs(got.mean()) < 1e-2 and abs(got.var() - 1) < 1e-2
+    big = ops.randn_pairs(4, seed, draw=5, elem0=(1 << 32) + 3).cpu().numpy()  # the high counter word is used
+    assert np.abs(big - orng.normal_pairs(seed, np.arange(4, dtype=np.uint64) + np.uint64((1 << 32) + 3), 5)).max() < 5e-5
+
+
+@pytest.mark.parametrize("name", ["em", "sscs"])
+def test_stochastic_samplers_match_oracle_with_the_same_noise(cld_setup, name):
+    from gddim_amd.cld import sampling
+    from gddim_amd.datasets import get_data_inverse_scaler
+    from oracle import cld_ext as ox
+    from oracle import rng as orng
+    cfg, params, sde, osde, model, state, u = cld_setup
+    inv = get_data_inverse_scaler(cfg)
+    nfe, seed = 6, 991
+    if name == "em":
+        fn = sampling.get_em_sampler(sde, model, (16, 16, 3), nfe, inv, lambda_coef=1.0, ts_order=2, denoising=True)
+    else:
+        fn = sampling.get_sscs_sampler(sde, model, (16, 16, 3), nfe, inv, ts_order=2, denoising=True)
+    ut = torch.as_tensor(u, device="cuda:0")
+    x, v, n = fn(seed, state, u.shape[0], ut)
+    eps64 = onet.cld_eps_fn(params, cfg, dtype=torch.float64)
+    noise_fn = lambda draw, shape: orng.noise_like(seed, shape, draw)
+    if name == "em":
+        wx, wv, _ = ox.em_sampler(osde, eps64, u.astype(np.float64), nfe, 1.0, ts_order=2, denoising=True,
+                                  inverse_scaler=ocld.inverse_scaler_centered, noise_fn=noise_fn)
+    else:
+        wx, wv, _ = ox.sscs_sampler(osde, eps64, u.astype(np.float64), nfe, ts_order=2, denoising=True,
+                                    inverse_scaler=ocld.inverse_scaler_centered, noise_fn=noise_fn)
+    ex, ev = np.abs(x.cpu().numpy() - wx).max(), np.abs(v.cpu().numpy() - wv).max()
+    print("%s: max|dx| %.3e max|dv| %.3e (|x| %.3e |v| %.3e)" % (name, ex, ev, np.abs(wx).max(), np.abs(wv).max()))
+    assert n == nfe and np.isfinite(wx).all() and ex < _tol(wx) and ev < _tol(wv)
+    # same seed -> same sample (graph replay and eager), another seed -> another sample, and independent of the lane split
+    x2, _, _ = fn(seed, state, u.shape[0], ut, use_graph=False)
+    x3, _, _ = fn(seed + 1, state, u.shape[0], ut)
+    assert torch.equal(x, x2) and not torch.equal(x, x3)
+    xh, _, _ = fn(seed, state, 2, ut[:2])
+    assert torch.equal(xh, x[:2])

@@ -121,3 +121,37 @@ def test_mixed_score_is_a_reparametrisation(osde):
     a = ocld.deis_sampler(osde, eps_fn, u0, 8, 2, denoising=True)
     b = ocld.deis_sampler(osde, ox.mixed_eps_fn(osde, net), u0, 8, 2, denoising=True)
     assert np.abs(a[0] - b[0]).max() < 1e-9 and np.abs(a[1] - b[1]).max() < 1e-9
+
+
+def test_sscs_ou_half_step_is_the_exact_ou_transition(osde):
+    """The OU part of the splitting (drift F u, diffusion G in the time convention t' = 1 - t) has the closed-form transition the
+    sampler hard-codes: mean expm(-F b) and the covariance solving the Lyapunov equation; checked against scipy."""
+    import scipy.linalg
+    s_t, s_next = 0.3, 0.35
+    u = np.random.default_rng(0).standard_normal((3, 1, 2))
+    zero = np.zeros_like(u)
+    mean, cov = ox.sscs_ou(osde, u, s_t, s_next, zero)
+    b = -(osde._beta_int(1 - s_next) - osde._beta_int(1 - s_t))  # integral of beta over the half step
+    # sampling-direction OU: du = beta [[0, -m_inv], [1, -Gamma m_inv]] u dt + sqrt(2 Gamma beta) dW_v  (CLD paper eq. 2, reversed x<->drift sign)
+    A = np.array([[0.0, -float(osde.m_inv)], [1.0, -float(osde.Gamma * osde.m_inv)]])
+    want_mean = np.einsum("ij,b...j->b...i", scipy.linalg.expm(A * b), u)
+    assert np.abs(mean - want_mean).max() < 1e-12
+    # covariance: int_0^b expm(A s) diag(0, 2 Gamma) expm(A s)^T ds by adaptive quadrature
+    import scipy.integrate
+    Q = np.array([[0.0, 0.0], [0.0, 2 * float(osde.Gamma)]])
+    want_cov, _ = scipy.integrate.quad_vec(lambda s: scipy.linalg.expm(A * s) @ Q @ scipy.linalg.expm(A * s).T, 0.0, b, epsabs=1e-13)
+    assert np.abs(cov - want_cov).max() < 1e-10
+    assert np.all(np.linalg.eigvalsh(cov) > 0)
+
+
+def test_product_sscs_and_em_maps_match_oracle(native_lib, osde):
+    from gddim_amd.cld import sampling, sde_lib
+    sde = sde_lib.CLD(is_R_rk=True, R_dt=1e-5)
+    M, cov = sampling.sscs_ou(sde, 0.3, 0.35)
+    _, ocov = ox.sscs_ou(osde, np.zeros((1, 1, 2)), 0.3, 0.35, np.zeros((1, 1, 2)))
+    assert np.abs(cov - ocov).max() < 1e-15
+    S = sampling.noise_factor(cov)
+    assert np.abs(S @ S.T - cov).max() < 1e-15 and S[0, 1] == 0
+    bad = np.array([[1.0, 1.0], [1.0, 1.0 - 1e-17]])  # singular up to round-off: falls back to the symmetric root
+    Sb = sampling.noise_factor(bad)
+    assert np.abs(Sb @ Sb.T - bad).max() < 1e-12
