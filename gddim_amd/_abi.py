@@ -55,6 +55,8 @@ SIGNATURES = {
     "gd_device_count": (_I, []),
     "gd_cld_r_table": (_I, [_D, _D, _D, _D, _D, _I, _D, _SZ, _P]),
     "gd_cld_psi2_table": (_I, [_D, _D, _D, _D, _SZ, _P]),
+    "gd_cld_lambda_hat_psi_table": (_I, [_D, _D, _D, _D, _P, _P, _SZ, _D, _SZ, _P]),
+    "gd_cld_lambda_cond_rev_cov": (_I, [_D, _D, _D, _D, _P, _P, _SZ, _D, _D, _I, _P]),
     "gd_engine_create": (_I, [ctypes.POINTER(ModelDesc), _I, ctypes.POINTER(_P)]),
     "gd_engine_destroy": (_I, [_P]),
     "gd_engine_plan_json": (_I, [_P, _P, _SZ, ctypes.POINTER(_SZ)]),

@@ -23,8 +23,8 @@ from a hipGraph.  get_L_deis_sampler (:533-540, the Cholesky parametrisation of 
 rotated frame y = psi1(t)^-1 x) run on the same fused loop through per-step 2x2 maps (gd_engine_set_transforms_cld), and so does
 sde.mixed_score=True (models/utils.py:174-176).  get_em_sampler (:625-655) and get_sscs_sampler (:563-621) add per-step Gaussian
 noise from the engine's counter-based generator (same law as the reference's jax.random draws, not the same stream);
-get_ode_sampler (:432-495) integrates on the host with the drift on the GPU.  Only `sdeis` (the LambdaSDE family, sde_lib.py:334-466)
-is not built and raises NotImplementedError.
+get_ode_sampler (:432-495) integrates on the host with the drift on the GPU; get_sdeis_sampler (:380-427) uses the LambdaSDE tables
+(sde_lib.py:334-466).  Every name of the reference's factory is built.
 """
 import itertools
 
@@ -253,6 +253,35 @@ def get_em_sampler(sde, model, data_shape, nfe, inverse_scaler, lambda_coef=0, t
                          noise=(None, None, noise) if lambda_coef != 0 else None)
 
 
+def svd_noise_factor(cov):
+    """The factor jax.random.multivariate_normal(..., method='svd') multiplies its normal draws with: U sqrt(s) of cov = U s V^T.
+    Used for sdeis, whose reference "covariance" is not symmetric (see sde_lib.LambdaSDE): only this rule reproduces its law."""
+    u_, s_, _ = np.linalg.svd(cov)
+    return u_ * np.sqrt(s_)[None, :]
+
+
+def _impl_sdeis_update_fn(sde, model, data_shape, nfe, inverse_scaler, deis_order, rev_ts, deis_coef, denoising=False, is_p=False):
+    """cld_jax/sampling.py:380-416: AB mean from deis_coef[i][:-1], plus noise of covariance deis_coef[i][-1]."""
+    mean_coef = deis_coef[:, :-1]
+    noise = np.stack([svd_noise_factor(c) for c in deis_coef[:, -1]])
+    return _make_sampler(sde, model, data_shape, nfe, inverse_scaler, rev_ts, mean_coef, denoising, is_p, "sdeis",
+                         noise=(None, None, noise), dn_sde=sde.sde)
+
+
+def _impl_sdeis_sampler(sde, model, data_shape, nfe, inverse_scaler, deis_order, rev_ts, denoising=False, is_p=False):
+    deis_coef = np.array(sde.get_deis_coef(deis_order, rev_ts))
+    deis_coef[-1, -1] = 0.0  # "avoid numerical error, if we have accurate integral, it should be zero" (:420-421)
+    return _impl_sdeis_update_fn(sde, model, data_shape, nfe, inverse_scaler, deis_order, rev_ts, deis_coef, denoising, is_p)
+
+
+def get_sdeis_sampler(sde, model, data_shape, nfe, inverse_scaler, deis_order, lambda_coef=0, use_order0=True, ts_order=2,
+                      denoising=False, is_p=False):
+    from .sde_lib import LambdaSDE
+    rev_ts = get_rev_ts(sde, ts_order, nfe - 1 if denoising else nfe)
+    new_sde = LambdaSDE(sde, lambda_coef, use_order0)
+    return _impl_sdeis_sampler(new_sde, model, data_shape, nfe, inverse_scaler, deis_order, rev_ts, denoising, is_p)
+
+
 def noise_factor(cov):
     """A square root S of a 2x2 covariance (S S^T = cov): Cholesky, falling back to the symmetric root when round-off makes
     the matrix indefinite.  The reference samples multivariate_normal(..., method='svd'); any root gives the same law."""
@@ -392,5 +421,8 @@ def get_sampling_fn(config, sde, model, shape, inverse_scaler):
         return get_sscs_sampler(sde=sde, model=model, data_shape=data_shape, nfe=config.sampling.nfe, inverse_scaler=inverse_scaler,
                                 ts_order=config.sampling.ts_order, denoising=config.sampling.noise_removal, is_p=True)
     if name == 'sdeis':
-        raise NotImplementedError("sampling.method=%r is not built yet (SURVEY.md section 8f, N3)" % sampler_name)
+        return get_sdeis_sampler(sde=sde, model=model, data_shape=data_shape, nfe=config.sampling.nfe, inverse_scaler=inverse_scaler,
+                                 deis_order=config.sampling.deis_order, lambda_coef=config.sampling.lambda_coef,
+                                 use_order0=config.sampling.sdeis_use_order0, ts_order=config.sampling.ts_order,
+                                 denoising=config.sampling.noise_removal, is_p=True)
     raise RuntimeError

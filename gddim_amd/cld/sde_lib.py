@@ -322,6 +322,101 @@ class MLCLD(object):
         return np.concatenate([x_coef[:, None], eps_coef], axis=1)
 
 
+class LambdaSDE(object):
+    """The lambda-family of reverse SDEs (cld_jax/sde_lib.py:334-466): lambda = 0 is the probability-flow ODE, 1 the reverse
+    diffusion.  \\hat F = F + (1 + lambda^2)/2 G G^T Sigma^-1; the transition \\hat psi and the conditional covariance of a step come
+    from the native RK4 scans (gd_cld_lambda_hat_psi_table / gd_cld_lambda_cond_rev_cov), which follow the reference's code
+    literally -- including `P @ \\hat F` where its own comment says `P \\hat F^T`, so the "covariance" it feeds to the sampler is
+    not symmetric (reference quirks)."""
+
+    def __init__(self, sde, lambda_coef=0.1, use_order0=True, used_cache=True):
+        self.sde = sde
+        self.mixed_score = sde.mixed_score
+        self.prior_sampling = sde.prior_sampling
+        self.v_invR = sde.v_invR
+        self.used_cache = sde.used_cache and used_cache
+        self.x64 = sde.x64
+        self.use_order0 = use_order0
+        self.lambda_coef = float(lambda_coef)
+        self.T, self.sampling_eps = sde.T, sde.sampling_eps
+        dt = 1e-5
+        n = int(1.0 / dt) + 1
+        table = np.empty((n, 2, 2))
+        self._rx = np.ascontiguousarray(sde._xp, dtype=np.float64)
+        self._rf = np.ascontiguousarray(sde._fp, dtype=np.float64)
+        _abi.check(_abi.lib().gd_cld_lambda_hat_psi_table(sde.m_inv, sde.beta_0, sde.beta_1, self.lambda_coef,
+                                                          self._rx.ctypes.data_as(ctypes.c_void_p),
+                                                          self._rf.ctypes.data_as(ctypes.c_void_p), len(self._rx), dt, n,
+                                                          table.ctypes.data_as(ctypes.c_void_p)))
+        self._xp, self._fp = np.linspace(0, 1.0 + dt, n, endpoint=False), table
+
+    def v_hat_psi_02t(self, t):
+        t = np.atleast_1d(np.asarray(t, dtype=np.float64))
+        xp, fp = self._xp, self._fp
+        i = np.clip(np.searchsorted(xp, t, side='right'), 1, len(xp) - 1)
+        w = (t - xp[i - 1]) / (xp[i] - xp[i - 1])
+        return fp[i - 1] + w[:, None, None] * (fp[i] - fp[i - 1])
+
+    def s_hat_F(self, t):
+        G = self.sde.s_G(t)
+        return self.sde.s_F(t) + 0.5 * (1 + self.lambda_coef ** 2) * G @ G.T @ inv_2x2(self.sde.s_cov(t))
+
+    def s_hat_psi(self, s, t):
+        return self.v_hat_psi_02t(t)[0] @ inv_2x2(self.v_hat_psi_02t(s)[0])
+
+    def vs_hat_psi(self, s_vec, t):
+        return self.v_hat_psi_02t(t) @ inv_2x2(self.v_hat_psi_02t(s_vec))
+
+    def cond_rev_cov(self, s, t, n_step=10_000):
+        out = np.empty((2, 2))
+        _abi.check(_abi.lib().gd_cld_lambda_cond_rev_cov(self.sde.m_inv, self.sde.beta_0, self.sde.beta_1, self.lambda_coef,
+                                                         self._rx.ctypes.data_as(ctypes.c_void_p),
+                                                         self._rf.ctypes.data_as(ctypes.c_void_p), len(self._rx), float(s), float(t),
+                                                         int(n_step), out.ctypes.data_as(ctypes.c_void_p)))
+        return out
+
+    def update_coef(self, s, t):
+        x_coef = self.sde.s_psi(s, t)
+        eps_coef = (self.s_hat_psi(s, t) - x_coef) @ self.sde.s_R(s)
+        return np.stack([x_coef, eps_coef, self.cond_rev_cov(s, t)])
+
+    def get_poly_eps_coef(self, order, rev_timesteps):
+        outer = self
+
+        class _sde(object):
+            @staticmethod
+            def vs_psi(ss, t):
+                return outer.vs_hat_psi(ss, t)
+
+            @staticmethod
+            def v_eps_integrand(ts):
+                ts = np.atleast_1d(np.asarray(ts, dtype=np.float64))
+                R = outer.sde.v_R(ts)
+                inv_cov = inv_2x2(R @ np.swapaxes(R, -1, -2))
+                gg = np.zeros_like(inv_cov)  # 1/2 (1 + lambda^2) G G^T inv_cov: only the v row of G G^T is non-zero
+                gg[:, 1, :] = ((1 + outer.lambda_coef ** 2) * outer.sde.Gamma * outer.sde.beta(ts))[:, None] * inv_cov[:, 1, :]
+                return gg @ outer.sde.vs_psi(np.zeros_like(ts), ts)
+
+        ab_eps_coef = deis.get_ab_eps_coef(_sde, order + 1, rev_timesteps, order)
+        ts = np.asarray(rev_timesteps, dtype=np.float64)[:-1]
+        last_term = self.sde.vs_psi(ts, 0.0) @ self.sde.v_R(ts)
+        return np.einsum("b...ij,bjk->b...ik", ab_eps_coef, last_term)
+
+    def get_order0_coef(self, rev_timesteps, used_cache=True):
+        ts = np.asarray(rev_timesteps, dtype=np.float64)
+        return np.stack([self.update_coef(ts[i], ts[i + 1]) for i in range(len(ts) - 1)])
+
+    def get_deis_coef(self, order, rev_timesteps, used_cache=True):
+        ts = np.asarray(rev_timesteps, dtype=np.float64)
+        if self.use_order0 and order == 0:
+            c = self.get_order0_coef(ts)
+            return np.stack([c[:, 0], c[:, 1], np.zeros(c[:, 0].shape), c[:, 2]], axis=1)
+        x_coef = self.sde.vv_psi(ts[:-1], ts[1:])
+        eps_coef = self.get_poly_eps_coef(order, ts)
+        covs = np.stack([self.cond_rev_cov(ts[i], ts[i + 1]) for i in range(len(ts) - 1)])
+        return np.concatenate([x_coef[:, None], eps_coef, covs[:, None]], axis=1)
+
+
 def from_config(config):
     return CLD(m_inv=config.model.m_inv, beta_0=config.model.beta_0, beta_1=config.model.beta_1,
                vv_gamma=config.model.vv_gamma, mixed_score=config.model.mixed_score, is_R_rk=config.model.is_R_rk,

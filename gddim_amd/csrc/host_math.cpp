@@ -100,3 +100,95 @@ extern "C" int gd_cld_psi2_table(double m_inv, double beta_0, double beta_1, dou
     }
     return 0;
 }
+
+// ---- LambdaSDE tables (cld_jax/sde_lib.py:334-399) -------------------------------------------------------------------------
+namespace {
+
+// get_interp_fn (sde_lib.py:32-43) on a knot table of 2x2 matrices: searchsorted(side='right') clipped to [1, n-1], linear
+struct Knots {
+    const double *xp, *fp;
+    size_t n;
+    M2 at(double x) const {
+        size_t lo = 0, hi = n;  // first index with xp[i] > x
+        while (lo < hi) {
+            const size_t mid = (lo + hi) / 2;
+            if (xp[mid] <= x) lo = mid + 1; else hi = mid;
+        }
+        size_t i = lo < 1 ? 1 : (lo > n - 1 ? n - 1 : lo);
+        const double dx = xp[i] - xp[i - 1];
+        const double *a = fp + 4 * (i - 1), *b = fp + 4 * i;
+        if (dx == 0) return {b[0], b[1], b[2], b[3]};
+        const double w = (x - xp[i - 1]) / dx;
+        return {a[0] + w * (b[0] - a[0]), a[1] + w * (b[1] - a[1]), a[2] + w * (b[2] - a[2]), a[3] + w * (b[3] - a[3])};
+    }
+};
+
+// \hat F(t) = F + (1 + lambda^2)/2 G G^T Sigma(t)^-1, Sigma = R R^T (sde_lib.py:351-355)
+inline M2 hat_F(const Cld &s, const Knots &R, double lambda, double t) {
+    const M2 r = R.at(t);
+    const M2 cov{r.a * r.a + r.b * r.b, r.a * r.c + r.b * r.d, r.c * r.a + r.d * r.b, r.c * r.c + r.d * r.d};
+    const double det = cov.a * cov.d - cov.b * cov.c;
+    const double gg = s.g(t) * s.g(t) * 0.5 * (1.0 + lambda * lambda);
+    M2 f = s.F(t);
+    f.c += gg * (-cov.c / det);  // second row of G G^T inv(cov): gg * [ -c, a ] / det
+    f.d += gg * (cov.a / det);
+    return f;
+}
+
+inline M2 add4(const M2 &x, double h, const M2 &g1, const M2 &g2, const M2 &g3, const M2 &g4) {
+    return {x.a + h / 6 * (g1.a + 2 * g2.a + 2 * g3.a + g4.a), x.b + h / 6 * (g1.b + 2 * g2.b + 2 * g3.b + g4.b),
+            x.c + h / 6 * (g1.c + 2 * g2.c + 2 * g3.c + g4.c), x.d + h / 6 * (g1.d + 2 * g2.d + 2 * g3.d + g4.d)};
+}
+
+}  // namespace
+
+extern "C" int gd_cld_lambda_hat_psi_table(double m_inv, double beta_0, double beta_1, double lambda, const double *r_xp,
+                                           const double *r_fp, size_t r_n, double dt, size_t n, double *out_host) {
+    GD_CHECK(out_host && r_xp && r_fp && r_n >= 2 && n > 0 && dt > 0, "gd_cld_lambda_hat_psi_table: bad argument");
+    const Cld s{m_inv, 2.0 / std::sqrt(m_inv), beta_0, beta_1};
+    const Knots R{r_xp, r_fp, r_n};
+    const double h = (1.0 + dt) / (double)n;  // grid linspace(0, 1 + dt, n, endpoint=False); the RK4 step is dt
+    M2 x{1.0, 0.0, 0.0, 1.0};
+    for (size_t i = 0; i < n; ++i) {
+        const double t = h * (double)i;
+        out_host[4 * i + 0] = x.a; out_host[4 * i + 1] = x.b; out_host[4 * i + 2] = x.c; out_host[4 * i + 3] = x.d;
+        const M2 g1 = mul(hat_F(s, R, lambda, t), x);
+        const M2 g2 = mul(hat_F(s, R, lambda, t + dt / 2), axpy(x, dt / 2, g1));
+        const M2 g3 = mul(hat_F(s, R, lambda, t + dt / 2), axpy(x, dt / 2, g2));
+        const M2 g4 = mul(hat_F(s, R, lambda, t + dt), axpy(x, dt, g3));
+        x = add4(x, dt, g1, g2, g3, g4);
+    }
+    return 0;
+}
+
+// cond_rev_cov (sde_lib.py:382-399) exactly as coded: dP/dtau = \hat F P + P \hat F (no transpose) + sign lambda^2 G G^T from
+// P = 0, n_step RK4 steps of size (t - s)/n_step evaluated on the grid s + i (t - s)/(n_step + 1).
+extern "C" int gd_cld_lambda_cond_rev_cov(double m_inv, double beta_0, double beta_1, double lambda, const double *r_xp,
+                                          const double *r_fp, size_t r_n, double s_time, double t_time, int n_step,
+                                          double *out4) {
+    GD_CHECK(out4 && r_xp && r_fp && r_n >= 2 && n_step > 0, "gd_cld_lambda_cond_rev_cov: bad argument");
+    const Cld s{m_inv, 2.0 / std::sqrt(m_inv), beta_0, beta_1};
+    const Knots R{r_xp, r_fp, r_n};
+    const double sign = t_time > s_time ? 1.0 : -1.0;
+    const double dt = (t_time - s_time) / (double)n_step;
+    const double hgrid = (t_time - s_time) / (double)(n_step + 1);
+    auto ode = [&](const M2 &x, double t) {
+        const M2 f = hat_F(s, R, lambda, t);
+        M2 r = mul(f, x);
+        const M2 xf = mul(x, f);
+        r.a += xf.a; r.b += xf.b; r.c += xf.c; r.d += xf.d;
+        r.d += sign * lambda * lambda * s.g(t) * s.g(t);
+        return r;
+    };
+    M2 x{0.0, 0.0, 0.0, 0.0};
+    for (int i = 0; i < n_step; ++i) {
+        const double t = s_time + hgrid * (double)i;
+        const M2 g1 = ode(x, t);
+        const M2 g2 = ode(axpy(x, dt / 2, g1), t + dt / 2);
+        const M2 g3 = ode(axpy(x, dt / 2, g2), t + dt / 2);
+        const M2 g4 = ode(axpy(x, dt, g3), t + dt);
+        x = add4(x, dt, g1, g2, g3, g4);
+    }
+    out4[0] = x.a; out4[1] = x.b; out4[2] = x.c; out4[3] = x.d;
+    return 0;
+}

@@ -77,6 +77,16 @@ int gd_cld_r_table(double m_inv, double beta_0, double beta_1, double vv_gamma, 
  * Replaces: get_ml_psi2_fn (cld_jax/sampling.py:272-285; lax.scan of runge_kutta, N = 100000). */
 int gd_cld_psi2_table(double m_inv, double beta_0, double beta_1, double dt, size_t n, double *out_host);
 
+/* Tables of the lambda-family reverse SDE (cld_jax/sde_lib.py:334-399, class LambdaSDE); r_xp / r_fp are the knots of the R(t)
+ * interpolant (r_n times, r_n x 4 values), exactly what get_interp_fn holds.
+ *   hat_psi_table: RK4 scan of d psi/dt = \hat F(t) psi from I with step dt on linspace(0, 1 + dt, n, endpoint=False), emitting
+ *                  the state before each step (replaces _get_hat_psi_02t, :357-376);
+ *   cond_rev_cov:  the 10 000-step RK4 integration of cond_rev_cov(s, t) as coded (:382-399), out4 = 2x2 row-major. */
+int gd_cld_lambda_hat_psi_table(double m_inv, double beta_0, double beta_1, double lambda, const double *r_xp,
+                                const double *r_fp, size_t r_n, double dt, size_t n, double *out_host);
+int gd_cld_lambda_cond_rev_cov(double m_inv, double beta_0, double beta_1, double lambda, const double *r_xp,
+                               const double *r_fp, size_t r_n, double s_time, double t_time, int n_step, double *out4);
+
 /* ---- engine life cycle ------------------------------------------------------------------ */
 /* device >= 0: build the plan, allocate weights + activation arena on that GPU.
  * device <  0: plan-only (host) mode -- no GPU touched; used to inspect the plan / packed

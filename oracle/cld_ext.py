@@ -312,3 +312,138 @@ def sscs_sampler(sde, eps_fn, u, nfe, ts_order=2, denoising=False, inverse_scale
     if inverse_scaler is not None:
         x = inverse_scaler(x)
     return x, v, nfe
+
+
+class LambdaSDE:
+    """sde_lib.py:334-466: the lambda-family of reverse SDEs (lambda = 0: probability flow; 1: the reverse diffusion)."""
+
+    def __init__(self, sde, lambda_coef=0.1, use_order0=True, dt=1e-5):
+        self.sde = sde
+        self.dtype = sde.dtype
+        self.use_order0 = use_order0
+        self.lambda_coef = lambda_coef
+        self.T, self.sampling_eps = sde.T, sde.sampling_eps
+        self.s_hat_psi_02t = self._get_hat_psi_02t(dt)
+
+    def s_cov(self, t):
+        R = self.sde.s_R(np.float64(t))
+        return R @ R.T  # sde_lib.py:242-244
+
+    def s_hat_F(self, t):
+        cur_G = self.sde.s_G(t)
+        inv_cov = ocld.inv_2x2(self.s_cov(t))
+        return self.sde.s_F(t) + 0.5 * (1 + self.lambda_coef ** 2) * cur_G @ cur_G.T @ inv_cov  # :351-355
+
+    def _get_hat_psi_02t(self, dt):
+        # :357-376: scan of runge_kutta(step dt) over linspace(0, 1 + dt, int(1/dt) + 1, endpoint=False), emitting the carry
+        n = int(1.0 / dt) + 1
+        ts = np.linspace(0, 1.0 + dt, n, endpoint=False)
+        Rs = np.empty((n, 2, 2))
+        x = np.eye(2)
+        fn = lambda _x, _t: self.s_hat_F(_t) @ _x
+        for k in range(n):
+            Rs[k] = x
+            x = runge_kutta(x, ts[k], dt, fn)
+        return ocld.get_interp_fn(ts, Rs)
+
+    def s_hat_psi(self, s, t):
+        return self.s_hat_psi_02t(np.float64(t)) @ ocld.inv_2x2(self.s_hat_psi_02t(np.float64(s)))  # :378-380
+
+    def cond_rev_cov(self, s, t, n_step=10_000):
+        # :382-399 (as coded: `_x @ cur_hat_F` without the transpose of the comment above it, and a time grid of n_step + 1
+        # points for n_step steps of size (t - s) / n_step)
+        dir_sign = 1 if t > s else -1
+        dt = (t - s) * 1.0 / n_step
+        ts = np.linspace(s, t, n_step + 1, endpoint=False)
+
+        def _ode_fn(_x, _t):
+            cur_hat_F = self.s_hat_F(_t)
+            cur_G = self.sde.s_G(_t)
+            return cur_hat_F @ _x + _x @ cur_hat_F + dir_sign * self.lambda_coef ** 2 * cur_G @ cur_G.T
+
+        val = np.zeros((2, 2))
+        for i in range(n_step):
+            val = runge_kutta(val, ts[i], dt, _ode_fn)
+        return val
+
+    def update_coef(self, s, t):
+        x_coef = self.sde.s_psi(s, t)
+        eps_coef = (self.s_hat_psi(s, t) - x_coef) @ self.sde.s_R(np.float64(s))
+        return np.stack([x_coef, eps_coef, self.cond_rev_cov(s, t)])  # :401-407
+
+    def get_poly_eps_coef(self, order, rev_timesteps):
+        outer = self
+
+        class _sde:  # :409-424
+            dtype = self.dtype
+
+            @staticmethod
+            def vs_psi(ss, t):
+                return np.stack([outer.s_hat_psi(s, t) for s in ss])
+
+            @staticmethod
+            def v_eps_integrand(ts):
+                out = []
+                for _t in ts:
+                    cur_G = outer.sde.s_G(_t)
+                    inv_cov = ocld.inv_2x2(outer.s_cov(_t))
+                    out.append(0.5 * (1 + outer.lambda_coef ** 2) * cur_G @ cur_G.T @ inv_cov @ outer.sde.s_psi(0, _t))
+                return np.stack(out)
+
+        ab_eps_coef = ocld.get_ab_eps_coef(_sde, order + 1, rev_timesteps, order)
+        last_term = np.stack([self.sde.s_psi(s, 0) @ self.sde.s_R(np.float64(s)) for s in rev_timesteps[:-1]])  # :426-432
+        return np.einsum("b...ij,bjk->b...ik", ab_eps_coef, last_term)
+
+    def get_order0_coef(self, rev_timesteps):
+        return np.stack([self.update_coef(rev_timesteps[i], rev_timesteps[i + 1]) for i in range(len(rev_timesteps) - 1)])
+
+    def get_deis_coef(self, order, rev_timesteps):
+        rev_timesteps = np.asarray(rev_timesteps, dtype=np.float64)
+        if self.use_order0 and order == 0:
+            c = self.get_order0_coef(rev_timesteps)
+            return np.stack([c[:, 0], c[:, 1], np.zeros(c[:, 0].shape), c[:, 2]], axis=1)  # :436-445
+        x_coef = np.stack([self.sde.s_psi(rev_timesteps[i], rev_timesteps[i + 1]) for i in range(len(rev_timesteps) - 1)])
+        eps_coef = self.get_poly_eps_coef(order, rev_timesteps)
+        covs = np.stack([self.cond_rev_cov(rev_timesteps[i], rev_timesteps[i + 1]) for i in range(len(rev_timesteps) - 1)])
+        return np.concatenate([x_coef[:, None], eps_coef, covs[:, None]], axis=1)  # :451-454
+
+
+def sdeis_sampler(sde, eps_fn, u, nfe, deis_order, lambda_coef=0, use_order0=True, ts_order=2, denoising=False, inverse_scaler=None,
+                  noise_fn=None, new_sde=None, deis_coef=None):
+    """get_sdeis_sampler -> _impl_sdeis_sampler -> _impl_sdeis_update_fn.sampler (sampling.py:380-427).  noise_fn(draw, shape):
+    standard normals for step i at draw 2 i + 1.  The reference samples random.multivariate_normal(rng, 0, cov, method="svd"), whose
+    published definition is factor = U sqrt(s) for cov = U s V^T; cond_rev_cov as coded is not symmetric, so only that rule (not a
+    Cholesky root) reproduces the law of the reference's draws."""
+    num_step = nfe - 1 if denoising else nfe
+    rev_ts = ocld.get_rev_ts(sde, ts_order, num_step)
+    if deis_coef is None:
+        new_sde = LambdaSDE(sde, lambda_coef, use_order0) if new_sde is None else new_sde
+        deis_coef = new_sde.get_deis_coef(deis_order, rev_ts)
+    deis_coef = deis_coef.copy()
+    deis_coef[-1, -1] = 0.0  # :420-421
+    ones = np.ones(u.shape[0], dtype=u.dtype)
+    eps_pred = np.stack([u] * (deis_order + 1))
+    for i in range(num_step):
+        cur_eps_pred = eps_fn(u, ones * u.dtype.type(rev_ts[i]))
+        mean, eps_pred = ocld.multistep_ab_step(u, deis_coef[i][:-1].astype(u.dtype), cur_eps_pred, eps_pred)
+        u = mean + ocld.sbmm(svd_factor(deis_coef[i][-1]), noise_fn(2 * i + 1, mean.shape))
+    if denoising:
+        u = ocld.get_denoising_step(sde, eps_fn, sde.sampling_eps, sde.sampling_eps)(u)
+    x, v = u[..., 0], u[..., 1]
+    if inverse_scaler is not None:
+        x = inverse_scaler(x)
+    return x, v, nfe
+
+
+def svd_factor(cov):
+    u_, s_, _ = np.linalg.svd(cov)
+    return u_ * np.sqrt(s_)[None, :]
+
+
+def noise_root(cov):
+    """S with S S^T = cov: Cholesky, or the symmetric root when round-off leaves cov indefinite (e.g. the zeroed last step)."""
+    try:
+        return np.linalg.cholesky(cov)
+    except np.linalg.LinAlgError:
+        w, v = np.linalg.eigh((cov + cov.T) / 2)
+        return (v * np.sqrt(np.clip(w, 0.0, None))) @ v.T

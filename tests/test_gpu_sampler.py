@@ -359,3 +359,28 @@ def test_stochastic_samplers_match_oracle_with_the_same_noise(cld_setup, name):
     assert torch.equal(x, x2) and not torch.equal(x, x3)
     xh, _, _ = fn(seed, state, 2, ut[:2])
     assert torch.equal(xh, x[:2])
+
+
+@pytest.mark.parametrize("order,use_order0", [(0, True), (1, True)])
+def test_sdeis_sampler_matches_oracle_with_the_same_noise(cld_setup, order, use_order0):
+    """The LambdaSDE tables are compared with the oracle's on the CPU (tests/test_oracle_cld_ext.py); here the oracle's loop runs
+    on the product's table so that the 10 000-step covariance integrations are not repeated in python."""
+    from gddim_amd.cld import sampling, sde_lib
+    from gddim_amd.datasets import get_data_inverse_scaler
+    from oracle import cld_ext as ox
+    from oracle import rng as orng
+    cfg, params, sde, osde, model, state, u = cld_setup
+    nfe, seed, lam = 5, 77, 1.0
+    fn = sampling.get_sdeis_sampler(sde, model, (16, 16, 3), nfe, get_data_inverse_scaler(cfg), order, lambda_coef=lam,
+                                    use_order0=use_order0, ts_order=2, denoising=True)
+    ut = torch.as_tensor(u, device="cuda:0")
+    x, v, n = fn(seed, state, u.shape[0], ut)
+    rev_ts = sampling.get_rev_ts(sde, 2, nfe - 1)
+    table = sde_lib.LambdaSDE(sde, lam, use_order0).get_deis_coef(order, rev_ts)
+    eps64 = onet.cld_eps_fn(params, cfg, dtype=torch.float64)
+    wx, wv, _ = ox.sdeis_sampler(osde, eps64, u.astype(np.float64), nfe, order, lambda_coef=lam,
+                                 use_order0=use_order0, denoising=True, inverse_scaler=ocld.inverse_scaler_centered,
+                                 noise_fn=lambda draw, shape: orng.noise_like(seed, shape, draw), deis_coef=table)
+    ex, ev = np.abs(x.cpu().numpy() - wx).max(), np.abs(v.cpu().numpy() - wv).max()
+    print("sdeis order=%d: max|dx| %.3e max|dv| %.3e (|x| %.3e |v| %.3e)" % (order, ex, ev, np.abs(wx).max(), np.abs(wv).max()))
+    assert n == nfe and np.isfinite(wx).all() and ex < _tol(wx) and ev < _tol(wv)

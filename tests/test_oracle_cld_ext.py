@@ -155,3 +155,58 @@ def test_product_sscs_and_em_maps_match_oracle(native_lib, osde):
     bad = np.array([[1.0, 1.0], [1.0, 1.0 - 1e-17]])  # singular up to round-off: falls back to the symmetric root
     Sb = sampling.noise_factor(bad)
     assert np.abs(Sb @ Sb.T - bad).max() < 1e-12
+
+
+# ---- the lambda-family reverse SDE (sdeis) --------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def olam(osde):
+    # dt = 1e-5 like the reference (~20 s of python RK4): hat_F is stiff near t = 0 (Sigma^-1 blows up) and the scan's grid
+    # linspace(0, 1 + dt, int(1/dt) + 1, endpoint=False) has spacing 1.00001e-5 for steps of 1e-5 -- both are part of its results
+    return ox.LambdaSDE(osde, 1.0, use_order0=True, dt=1e-5)
+
+
+def test_lambda_sde_reverse_transition_keeps_the_marginal(osde, olam):
+    """For Dirac data at 0 the reverse SDE is linear, du = hat_F u dt + lambda G dw, and must carry N(0, Sigma_s) into N(0, Sigma_t):
+    hat_psi Sigma_s hat_psi^T + P = Sigma_t with dP/dtau = hat_F P + P hat_F^T - lambda^2 G G^T.  That pins hat_psi.  The reference's
+    cond_rev_cov integrates hat_F P + P hat_F instead (no transpose, contrary to its own comment): its result is not symmetric,
+    which this test records; the restatement follows the code."""
+    s, t = 0.5, 0.4
+    hp = olam.s_hat_psi(s, t)
+
+    def with_transpose(n_step=1000):
+        dt, val, tt = (t - s) / n_step, np.zeros((2, 2)), s
+        fn = lambda _x, _t: olam.s_hat_F(_t) @ _x + _x @ olam.s_hat_F(_t).T - osde.s_G(_t) @ osde.s_G(_t).T
+        for _ in range(n_step):
+            val = ox.runge_kutta(val, tt, dt, fn)
+            tt += dt
+        return val
+
+    assert np.abs(hp @ olam.s_cov(s) @ hp.T + with_transpose() - olam.s_cov(t)).max() < 1e-5
+    as_coded = olam.cond_rev_cov(s, t, n_step=1000)
+    assert abs(as_coded[0, 1] - as_coded[1, 0]) > 0.05  # the quirk
+    # lambda = 0: no noise at all, and hat_psi is the probability-flow transition of the same linear problem
+    l0 = ox.LambdaSDE(osde, 0.0, dt=1e-3)
+    assert np.abs(l0.cond_rev_cov(s, t, n_step=50)).max() == 0
+
+
+def test_product_lambda_sde_matches_oracle(native_lib, osde, olam):
+    from gddim_amd.cld import sampling, sde_lib
+    sde = sde_lib.CLD(is_R_rk=True, R_dt=1e-5)
+    pl = sde_lib.LambdaSDE(sde, 1.0, use_order0=True)
+    for s, t in ((1.0, 0.7), (0.3, 0.1), (0.01, 0.001)):
+        assert np.abs(pl.s_hat_psi(s, t) - olam.s_hat_psi(s, t)).max() < 1e-6 * max(1.0, np.abs(olam.s_hat_psi(s, t)).max())
+        assert np.abs(pl.s_hat_F(t) - olam.s_hat_F(t)).max() < 1e-9 * np.abs(olam.s_hat_F(t)).max()
+        a, b = pl.cond_rev_cov(s, t, n_step=400), olam.cond_rev_cov(s, t, n_step=400)
+        assert np.abs(a - b).max() < 1e-9 * max(1.0, np.abs(b).max())
+    rev = ocld.get_rev_ts(osde, 2, 3)
+    pc, oc = pl.get_poly_eps_coef(1, rev), olam.get_poly_eps_coef(1, rev)
+    assert pc.shape == (3, 3, 2, 2) and np.abs(pc - oc).max() < 1e-5 * np.abs(oc).max()
+    u0 = pl.update_coef(rev[0], rev[1])
+    want_eps = (olam.s_hat_psi(rev[0], rev[1]) - osde.s_psi(rev[0], rev[1])) @ osde.s_R(np.float64(rev[0]))
+    assert np.abs(u0[0] - osde.s_psi(rev[0], rev[1])).max() < 1e-12 and np.abs(u0[1] - want_eps).max() < 1e-6
+    # table layouts: order 0 with use_order0 -> [Psi, eps, 0, cov]; order q otherwise -> [Psi, q + 2 eps slots, cov]
+    assert pl.get_deis_coef(0, rev).shape == (3, 4, 2, 2) and np.abs(pl.get_deis_coef(0, rev)[:, 2]).max() == 0
+    assert pl.get_deis_coef(1, rev).shape == (3, 5, 2, 2)
+    f = sampling.svd_noise_factor(np.array([[2.0, 0.3], [0.3, 1.0]]))
+    assert np.abs(f @ f.T - np.array([[2.0, 0.3], [0.3, 1.0]])).max() < 1e-12  # a root when the matrix is a covariance
+    assert np.abs(f - ox.svd_factor(np.array([[2.0, 0.3], [0.3, 1.0]]))).max() == 0
