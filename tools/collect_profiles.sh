@@ -9,6 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 BENCH="python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-alt"
 SHORT="python $REPO/bench.py --nfe 3 --steps 1 --warmup 0 --no-profile --no-cpu-baseline --no-graph --no-alt"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- $BENCH > $OUT/trace_bench.log 2>&1
+grep -a "^{\"metric" $OUT/trace_bench.log | tail -1 > $OUT/trace_bench_line.json  # the JSON line of the traced process itself
 python $REPO/tools/summarize_rocprof.py $OUT/trace --out $OUT/trace_summary.json > /dev/null 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/pmc_fetch -o b -- $SHORT > $OUT/pmc_fetch.log 2>&1
 python $REPO/tools/summarize_rocprof.py $OUT/pmc_fetch --out $OUT/pmc_fetch_summary.json > /dev/null 2>&1

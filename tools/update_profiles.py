@@ -1,0 +1,36 @@
+#!/usr/bin/env python
+"""Copy the summaries tools/collect_profiles.sh left under gpurun_out/prof into profiles/ (tracked) and derive the per-launch HBM
+traffic table bench.py reads: python tools/update_profiles.py [round tag, default r01]"""
+import json
+import os
+import shutil
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(REPO, "gpurun_out", "prof")
+DST = os.path.join(REPO, "profiles")
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+
+for name in ("bench_kernel_stats.csv", "bench_bf16x3_kernel_stats.csv", "trace_summary.json", "pmc_fetch_summary.json",
+             "pmc_write_summary.json", "pmc_sq_summary.json", "trace_bench_line.json"):
+    p = os.path.join(SRC, name)
+    if os.path.exists(p):
+        shutil.copy(p, os.path.join(DST, "%s_%s" % (tag, name)))
+line = os.path.join(REPO, "gpurun_out", "bench_line.json")
+if os.path.exists(line):
+    shutil.copy(line, os.path.join(DST, "%s_bench_line.json" % tag))
+
+fetch = json.load(open(os.path.join(SRC, "pmc_fetch_summary.json")))["kernels"]
+write = json.load(open(os.path.join(SRC, "pmc_write_summary.json")))["kernels"]
+trace = json.load(open(os.path.join(SRC, "trace_summary.json")))["kernels"]
+out = {"note": "per-launch HBM traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 B, separate --pmc passes of `bench.py --nfe 3 --steps 1 "
+               "--warmup 0 --no-graph` (same B=256 shapes as the headline run); see profiles/README.md", "kernels": {}}
+for k, v in fetch.items():
+    fs = v.get("counters_mean_per_dispatch", {}).get("FETCH_SIZE")
+    ws = write.get(k, {}).get("counters_mean_per_dispatch", {}).get("WRITE_SIZE")
+    if fs is None or ws is None:
+        continue
+    out["kernels"][k] = {"fetch_size_kib": fs, "write_size_kib": ws, "hbm_bytes_per_launch": (2 * fs + ws) * 1024,
+                         "avg_us_in_trace": trace.get(k, {}).get("avg_us")}
+json.dump(out, open(os.path.join(DST, "%s_hbm_traffic.json" % tag), "w"), indent=1)
+print("updated", DST)
