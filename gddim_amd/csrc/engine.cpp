@@ -185,6 +185,10 @@ static int run_op(gd_engine *e, const Op &op, const Bind &b, int batch, hipStrea
                 g.b_lo = e->wsplit_lo + e->slot_off[op.w_slot];
                 g.a_presplit = op.a_split;
                 GD_CHECK(!op.a_split || igemm_bf16x3_ok(g, z), "%s: pre-split input but the GEMM is not eligible for bf16x3", op.label.c_str());
+                if (z == 1 && conv3x3_halo_ok(g)) {
+                    ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(conv3x3_halo_name()), op.flops_per_image * batch, 0);
+                    return launch_conv3x3_halo(g, s);
+                }
                 if (igemm_bf16x3_ok(g, z)) {
                     ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(igemm_bf16x3_name(g)), op.flops_per_image * batch, 0);
                     return launch_igemm_bf16x3(g, s);

@@ -1,0 +1,246 @@
+// 3x3 / stride 1 / pad 1 convolution in split precision (bf16x3) with the input staged ONCE per 32-channel slab.
+//
+// igemm_bf16x3_kernel fetches every activation element once per tap (nine times) from L2 into LDS; that traffic, not the matrix
+// pipe, bounds it (profiles/r01_igemm_investigation.md).  Here a workgroup's 256 output pixels are `rows` complete image rows of one
+// image (W = 32: 8 rows, W = 16: the whole 16x16 image), so their receptive field is a (rows + 2) x (W + 2) pixel halo; the halo of a
+// 32-channel slab (pre-split bf16 hi and lo planes, written by gn_apply_kernel) is copied to LDS once and the nine taps read their A
+// fragments from it at shifted addresses: tap (ty, tx) of output pixel (y, x) is halo pixel (y + ty, x + tx).  Activation traffic
+// L2 -> LDS drops from 9 x 256 to (rows + 2)(W + 2) pixels per slab (x 6.8 less at 32x32); the weight chunk of a (tap, slab) is
+// staged per tap as before.  Image borders are zeros in the halo (buffer bounds check / out-of-image mask), so the K loop has no
+// predication at all.
+//
+// Tile 256 x 128, 8 waves (4 x 2), each 2 x 2 accumulators of v_mfma_f32_32x32x16_bf16, three MFMAs per product term
+// (a_hi b_hi + a_hi b_lo + a_lo b_hi).  LDS: halo [2 stages][hi | lo][HP pixels][80 B] + weights [2 stages][hi | lo][128][80 B]
+// (80-byte records: the 16-byte fragment reads of consecutive pixels fall on distinct bank groups).
+// K order: slab outermost, taps innermost -- the same order as the packed weights' scalar addressing assumes ([n][tap][c]).
+#include <cstdio>
+#include <cstdlib>
+
+#include "../common.h"
+#include "epilogue.h"
+
+namespace gd {
+
+typedef float hf32x16 __attribute__((ext_vector_type(16)));
+typedef float hf32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int hu32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 hbf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int HBM_ = 256, HBN_ = 128;      // tile
+constexpr int HREC = 40;                   // LDS record stride in bf16 elements: 64 B of data + 16 B pad
+constexpr int HP_MAX = 10 * 34;            // halo pixels: max over (W = 32: 10 x 34 = 340, W = 16: 18 x 18 = 324)
+constexpr int HA_PLANE = HP_MAX * HREC;    // one plane (hi or lo) of the halo, elements
+constexpr int HB_PLANE = HBN_ * HREC;      // one plane of the weight chunk
+constexpr int HSTAGE = 2 * HA_PLANE + 2 * HB_PLANE;  // elements per stage: A_hi | A_lo | B_hi | B_lo
+constexpr int HAJ = (HP_MAX * 8 + 511) / 512;        // 16-byte halo pieces per thread per slab (8 per pixel: 4 hi + 4 lo)
+
+__global__ __launch_bounds__(512) void conv3x3_halo_bf16x3_kernel(const GemmParams p) {
+    constexpr int NT = 512, WN = 2, RM = 2, RN = 2;
+    constexpr int OOB = (int)0x80000000u;
+    __shared__ __attribute__((aligned(16))) __bf16 smem[2 * HSTAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+
+    const int nt = p.n_tiles;
+    const int id = blockIdx.x;
+    int ntile, mtile;
+    if (p.flat_tiles) {
+        mtile = id / nt;
+        ntile = id - mtile * nt;
+    } else {
+        const int grp = id / (8 * nt);
+        const int rem = id - grp * 8 * nt;
+        ntile = rem >> 3;
+        mtile = grp * 8 + (rem & 7);
+    }
+    if (mtile >= p.m_tiles) return;
+    const int m0 = mtile * HBM_, n0 = ntile * HBN_;
+
+    const int W = p.W, H = p.H, C = p.C0;
+    const int HW2 = W + 2;
+    const int rows = HBM_ / W;                 // complete image rows per tile (H*W is a multiple of 256)
+    const int HP = (rows + 2) * HW2;           // halo pixels
+    const int img = m0 / (H * W);
+    const int y0 = (m0 - img * H * W) / W;     // first output row of the tile inside its image
+
+    const char *ac = reinterpret_cast<const char *>(p.a0);
+    const int a_imgs = (p.M + H * W - 1) / (H * W);
+    const __amdgpu_buffer_rsrc_t srd_a =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(ac), 0, a_imgs * H * W * p.lda0 * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srd_bh = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(reinterpret_cast<const char *>(p.b_hi)), 0, p.N * p.ldb * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srd_bl = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(reinterpret_cast<const char *>(p.b_lo)), 0, p.N * p.ldb * 2, 0x00020000);
+
+    // ---- halo pieces of this thread (loop invariant): piece q = tid + 512 j -> (plane, pixel, 16-byte slot) ----
+    int avo[HAJ];   // global voffset (bytes, without the channel slab), OOB for out-of-image / unused pieces
+    int alds[HAJ];  // LDS element offset inside a stage
+#pragma unroll
+    for (int j = 0; j < HAJ; ++j) {
+        const int q = tid + NT * j;
+        const int plane = q >= HP * 4 ? 1 : 0;
+        const int r = q - plane * HP * 4;
+        const int pix = r >> 2, slot = r & 3;
+        avo[j] = OOB;
+        alds[j] = 0;
+        if (q < HP * 8) {
+            const int hy = pix / HW2, hx = pix - hy * HW2;
+            const int y = y0 + hy - 1, x = hx - 1;
+            alds[j] = plane * HA_PLANE + pix * HREC + slot * 8;
+            if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W && img < a_imgs)
+                avo[j] = ((img * H + y) * W + x) * p.lda0 * 4 + plane * p.lda0 * 2 + slot * 16;
+            else
+                avo[j] = OOB;  // inside the halo but outside the image: the load returns zero and the zero is stored
+        }
+    }
+    const int brow = tid >> 2;        // weight row inside the chunk (128 rows x 4 threads)
+    const int bq = (tid & 3) * 8;
+    const int bn = n0 + brow;
+    const int bvo = (brow < HBN_ && bn < p.N) ? (bn * p.ldb + bq) * 2 : OOB;
+
+    hu32x4 ra[HAJ], rbh, rbl;
+    const int nslab = C / 32;
+    auto load_halo = [&](int j, int slab) {
+        const bool ok = slab < nslab;
+        ra[j] = __builtin_amdgcn_raw_buffer_load_b128(srd_a, ok ? avo[j] : OOB, slab * 64, 0);
+    };
+    auto store_halo = [&](int j, __bf16 *st) {
+        if (tid + NT * j < HP * 8) *reinterpret_cast<hu32x4 *>(st + alds[j]) = ra[j];
+    };
+    auto load_b = [&](int tap, int slab) {
+        const int soff = (tap * C + slab * 32) * 2;
+        const int vo = slab < nslab ? bvo : OOB;
+        rbh = __builtin_amdgcn_raw_buffer_load_b128(srd_bh, vo, soff, 0);
+        rbl = __builtin_amdgcn_raw_buffer_load_b128(srd_bl, vo, soff, 0);
+    };
+    auto store_b = [&](__bf16 *st) {
+        if (brow < HBN_) {
+            const int o = 2 * HA_PLANE + brow * HREC + bq;
+            *reinterpret_cast<hu32x4 *>(st + o) = rbh;
+            *reinterpret_cast<hu32x4 *>(st + HB_PLANE + o) = rbl;
+        }
+    };
+
+    hf32x16 acc[RM][RN];
+#pragma unroll
+    for (int r = 0; r < RM; ++r)
+#pragma unroll
+        for (int c = 0; c < RN; ++c)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[r][c][v] = 0.f;
+
+    const int li = lane & 31, lh = lane >> 5;
+    // A fragment base per r tile: output pixel m_local = wm*64 + r*32 + li -> (ly, x) -> halo pixel (ly, x) for tap (0, 0)
+    int a_off[RM];
+#pragma unroll
+    for (int r = 0; r < RM; ++r) {
+        const int ml = wm * 64 + r * 32 + li;
+        const int ly = ml / W, x = ml - ly * W;
+        a_off[r] = (ly * HW2 + x) * HREC + lh * 8;
+    }
+    const int b_off = 2 * HA_PLANE + (wn * 64 + li) * HREC + lh * 8;
+
+    // ---- prologue: halo of slab 0 and weight chunk (tap 0, slab 0) into stage 0; prefetch chunk (tap 1, slab 0) ----
+#pragma unroll
+    for (int j = 0; j < HAJ; ++j) load_halo(j, 0);
+    load_b(0, 0);
+#pragma unroll
+    for (int j = 0; j < HAJ; ++j) store_halo(j, smem);
+    store_b(smem);
+    load_b(1, 0);
+    __syncthreads();
+
+    // Iteration (slab, tap) reads A from halo stage (slab & 1) and B from weight stage ((slab + tap) & 1) (9 taps: the parity of
+    // slab*9 + tap); during it the weight chunk of the next iteration (already in registers) is stored to the other B stage and the
+    // one after that is requested; the halo of slab + 1 is requested during taps 0..HAJ-1 (one piece per tap) and stored into the
+    // other halo stage during taps 9-HAJ..8.  The tap loop is unrolled so that every register-array index is a constant.
+    for (int slab = 0; slab < nslab; ++slab) {
+        const __bf16 *curA = smem + (slab & 1) * HSTAGE;
+        __bf16 *nxtA = smem + ((slab + 1) & 1) * HSTAGE;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const __bf16 *curB = smem + ((slab + tap) & 1) * HSTAGE;
+            __bf16 *nxtB = smem + ((slab + tap + 1) & 1) * HSTAGE;
+            const int ty = tap / 3, tx = tap - ty * 3;
+            const int tap_off = (ty * HW2 + tx) * HREC;
+            const int tap2 = (tap + 2) % 9, slab2 = slab + (tap + 2) / 9;  // the chunk two iterations ahead
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                hbf16x8 ah[RM], al[RM], bh[RN], bl[RN];
+#pragma unroll
+                for (int r = 0; r < RM; ++r) {
+                    ah[r] = *reinterpret_cast<const hbf16x8 *>(curA + a_off[r] + tap_off + s * 16);
+                    al[r] = *reinterpret_cast<const hbf16x8 *>(curA + HA_PLANE + a_off[r] + tap_off + s * 16);
+                }
+#pragma unroll
+                for (int c = 0; c < RN; ++c) {
+                    bh[c] = *reinterpret_cast<const hbf16x8 *>(curB + b_off + c * 32 * HREC + s * 16);
+                    bl[c] = *reinterpret_cast<const hbf16x8 *>(curB + HB_PLANE + b_off + c * 32 * HREC + s * 16);
+                }
+#pragma unroll
+                for (int term = 0; term < 3; ++term) {
+#pragma unroll
+                    for (int r = 0; r < RM; ++r)
+#pragma unroll
+                        for (int c = 0; c < RN; ++c) {
+                            const hbf16x8 a = term == 2 ? al[r] : ah[r];
+                            const hbf16x8 b = term == 1 ? bl[c] : bh[c];
+                            acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[r][c], 0, 0, 0);
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int gap = s * 3 + term;
+                    if (gap == 0) {
+                        store_b(nxtB);
+                        load_b(tap2, slab2);
+                    } else if (gap == 1) {
+                        if (tap < HAJ) load_halo(tap, slab + 1);
+                    } else if (gap == 2) {
+                        if (tap >= 9 - HAJ) store_halo(tap - (9 - HAJ), nxtA);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    epilogue_rows<RM, RN>(p, acc, m0 + wm * 64, n0 + wn * 64, li, lh, false);
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------------------
+bool conv3x3_halo_ok(const GemmParams &p) {
+    static const int off = getenv("GDDIM_X3_NOHALO") ? atoi(getenv("GDDIM_X3_NOHALO")) : 0;
+    if (off || !p.a_presplit || !p.b_hi || !p.b_lo) return false;
+    if (p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1 || p.C1 != 0 || p.C0 % 32 != 0 || p.lda0 != p.C0) return false;
+    if (p.H != p.W || p.OH != p.H || p.OW != p.W || (p.W != 32 && p.W != 16)) return false;
+    if ((p.H * p.W) % HBM_ != 0 || p.M % HBM_ != 0 || p.N <= 64) return false;
+    const long long blocks = (long long)(p.M / HBM_) * ((p.N + HBN_ - 1) / HBN_);
+    return blocks >= 256 && igemm_bf16x3_ok(p, 1);
+}
+
+const char *conv3x3_halo_name() { return "conv3x3_halo_bf16x3_kernel"; }
+
+static void hfill_div(unsigned d, unsigned &magic, unsigned &shift) {
+    unsigned s = 0;
+    while ((1ull << s) < d) ++s;
+    shift = s;
+    magic = (unsigned)((((1ull << 32) * ((1ull << s) - d)) / d) + 1);
+}
+
+int launch_conv3x3_halo(const GemmParams &p_in, hipStream_t s) {
+    GemmParams p = p_in;
+    GD_CHECK(conv3x3_halo_ok(p), "conv3x3_halo: problem not eligible");
+    hfill_div((unsigned)(p.rows_per_image > 0 ? p.rows_per_image : 1), p.mg_rpi, p.sh_rpi);
+    p.m_tiles = p.M / HBM_;
+    p.n_tiles = (p.N + HBN_ - 1) / HBN_;
+    p.flat_tiles = p.m_tiles < 16;
+    const int gx = p.flat_tiles ? p.m_tiles * p.n_tiles : ((p.m_tiles + 7) / 8) * 8 * p.n_tiles;
+    hipLaunchKernelGGL(conv3x3_halo_bf16x3_kernel, dim3(gx), dim3(512), 0, s, p);
+    GD_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace gd

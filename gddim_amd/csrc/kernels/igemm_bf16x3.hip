@@ -20,7 +20,7 @@
 #include <cstdlib>
 
 #include "../common.h"
-#include "qstats.h"
+#include "epilogue.h"
 
 namespace gd {
 
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16x3_kernel(const GemmPa
         __syncthreads();
     }
 
-    // ---- epilogue (buffer addressed, as igemm_f32_fast_kernel) ----
+    // ---- epilogue (kernels/epilogue.h) ----
     if (X3_ABL & 1) {
         float sink = 0.f;
 #pragma unroll
@@ -296,77 +296,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16x3_kernel(const GemmPa
                 for (int v = 0; v < 16; ++v) sink += acc[r][c][v];
         if (sink == 1.2345e-30f) p.out[0] = sink;
     } else {
-        char *outc = reinterpret_cast<char *>(p.out);
-        const __amdgpu_buffer_rsrc_t srd_o = __builtin_amdgcn_make_buffer_rsrc(outc, 0, p.M * p.ldc * 4, 0x00020000);
-        const __amdgpu_buffer_rsrc_t srd_r =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(reinterpret_cast<const char *>(p.res ? p.res : p.out)), 0,
-                                              p.M * p.ldres * 4, 0x00020000);
-        const unsigned rpi = p.rows_per_image;
-        // all residual values of the wave's tile are requested at once (RM*RN*16 loads in flight) before any is consumed
-        float resv[RN][RM][16];
-        if (p.res) {
-#pragma unroll
-            for (int c = 0; c < RN; ++c) {
-                const int n = n0 + wn * (BN / WN) + c * 32 + li;
-                const int vo_r = n < p.N ? (4 * lh * p.ldres + n) * 4 : OOB;
-#pragma unroll
-                for (int r = 0; r < RM; ++r) {
-                    const int mrow = m0 + wm * (BM / WM) + r * 32;
-#pragma unroll
-                    for (int v = 0; v < 16; ++v)
-                        resv[c][r][v] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_r, vo_r, (mrow + (v & 3) + 8 * (v >> 2)) * p.ldres * 4, 0));
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int c = 0; c < RN; ++c) {
-            const int n = n0 + wn * (BN / WN) + c * 32 + li;
-            const bool nok = n < p.N;
-            const float bias = (p.bias && nok) ? p.bias[n] : 0.f;
-            const int vo_o = nok ? (4 * lh * p.ldc + n) * 4 : OOB;
-#pragma unroll
-            for (int r = 0; r < RM; ++r) {
-                const int mrow = m0 + wm * (BM / WM) + r * 32;
-                float addv[16];
-#pragma unroll
-                for (int v = 0; v < 16; ++v) addv[v] = bias;
-                if (p.res) {
-#pragma unroll
-                    for (int v = 0; v < 16; ++v) addv[v] += resv[c][r][v];
-                }
-                if (p.rowbias) {
-                    // rows_per_image is a multiple of 8: the 8 rows (v & 3) + 4*lh of a row group v >> 2 belong to one image
-                    // and that image index is wave-uniform -> four scalar divisions and four loads per tile
-                    float t[4];
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const unsigned mr = (unsigned)(mrow + 8 * g);
-                        const unsigned img = mr < (unsigned)p.M ? xfast_div(mr, rpi, p.mg_rpi, p.sh_rpi) : 0u;
-                        t[g] = nok ? p.rowbias[(size_t)img * p.ld_rowbias + n] : 0.f;
-                    }
-#pragma unroll
-                    for (int v = 0; v < 16; ++v) addv[v] += t[v >> 2];
-                }
-                float vals[16];
-#pragma unroll
-                for (int v = 0; v < 16; ++v) {
-                    const float val = (p.alpha * acc[r][c][v] + addv[v]) * p.out_scale;
-                    vals[v] = val;
-                    if (DIAG && (dg & 1)) { asm volatile("" ::"v"(val)); continue; }
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), srd_o, vo_o,
-                                                          (mrow + (v & 3) + 8 * (v >> 2)) * p.ldc * 4, 0);
-                }
-                if (p.qstats) {
-                    if (!nok || mrow + 32 > p.M) {
-#pragma unroll
-                        for (int v = 0; v < 16; ++v)
-                            if (!nok || mrow + (v & 3) + 8 * (v >> 2) + 4 * lh >= p.M) vals[v] = 0.f;
-                    }
-                    emit_qstats(p, vals, mrow, n, nok, li, lh);
-                }
-            }
-        }
+        epilogue_rows<RM, RN>(p, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), li, lh, DIAG && (dg & 1));
     }
 }
 
