@@ -55,6 +55,7 @@ struct gd_engine {
     int precision = 0;
     unsigned short *wsplit_hi = nullptr, *wsplit_lo = nullptr;  // bf16 hi / lo of wbuf, same element offsets
     bool wsplit_valid = false;
+    std::map<int, std::vector<char>> presplit_ok;  // batch size -> per tensor: may be stored pre-split (see presplit_allowed)
     std::vector<long long> slot_off;  // floats into wbuf
     long long wbuf_floats = 0;
     float *xin = nullptr, *epsb = nullptr, *labels = nullptr, *eps_planar = nullptr;
@@ -152,6 +153,48 @@ static std::string label_class(const Op &op) {
     return r + buf;
 }
 
+// GemmParams of a GEMM op for this batch; returns the z-batch count
+static int fill_gemm(gd_engine *e, const Op &op, const Bind &b, int batch, GemmParams &g) {
+    g.a0 = op.a_slot >= 0 ? slot_ptr(e, op.a_slot) + op.a_off : tptr(e, b, op.a0, batch);
+    g.a1 = tptr(e, b, op.a1, batch);
+    g.C0 = op.C0; g.C1 = op.C1; g.lda0 = op.lda0; g.lda1 = op.lda1 ? op.lda1 : 4;
+    g.H = op.H; g.W = op.W; g.OH = op.OH; g.OW = op.OW; g.KH = op.KH; g.KW = op.KW; g.stride = op.stride; g.pad = op.pad;
+    g.N = op.N; g.K = op.K;
+    int z = 1;
+    if (op.z_per_image) { g.M = op.m_per_image; z = batch; g.sA = op.sA; g.sB = op.sB; g.sC = op.sC; }
+    else g.M = op.m_per_image * batch;
+    if (op.w_slot >= 0) g.b = slot_ptr(e, op.w_slot);
+    else g.b = tptr(e, b, op.bten, batch);
+    g.ldb = op.ldb; g.b_kmajor = op.b_kmajor;
+    g.out = tptr(e, b, op.out, batch); g.ldc = op.ldc;
+    g.bias = op.bias_slot >= 0 ? slot_ptr(e, op.bias_slot) + op.bias_off : nullptr;
+    g.rowbias = tptr(e, b, op.rowbias, batch); g.ld_rowbias = op.ld_rowbias; g.rows_per_image = op.m_per_image;
+    g.res = tptr(e, b, op.res, batch); g.ldres = op.ldres;
+    g.alpha = op.alpha; g.out_scale = op.out_scale; g.in_act = op.in_act;
+    g.qstats = tptr(e, b, op.qstats, batch); g.qs_slices = op.qs_slices;
+    return z;
+}
+
+// A tensor is stored pre-split (bf16x3 mode) only when every GEMM that reads it is eligible for the split-precision kernels at
+// THIS batch size (the 2 GiB buffer-addressing limit depends on it); decided once per batch size, per tensor.
+static bool presplit_allowed(gd_engine *e, const Bind &b, int batch, int tensor) {
+    auto it = e->presplit_ok.find(batch);
+    if (it == e->presplit_ok.end()) {
+        std::vector<char> ok(e->plan.tensors.size(), 1);
+        for (const Op &op : e->plan.ops) {
+            if (op.kind != OP_GEMM || !op.a_split) continue;
+            GemmParams g{};
+            const int z = fill_gemm(e, op, b, batch, g);
+            g.b_hi = e->wsplit_hi + e->slot_off[op.w_slot];
+            g.b_lo = e->wsplit_lo + e->slot_off[op.w_slot];
+            g.a_presplit = 1;
+            if (!igemm_bf16x3_ok(g, z)) ok[op.a0.t] = 0;
+        }
+        it = e->presplit_ok.emplace(batch, std::move(ok)).first;
+    }
+    return tensor >= 0 && it->second[tensor] != 0;
+}
+
 static int run_op(gd_engine *e, const Op &op, const Bind &b, int batch, hipStream_t s) {
     const Plan &P = e->plan;
     static const bool by_label = getenv("GD_PROF_BY_LABEL") != nullptr;
@@ -163,28 +206,12 @@ static int run_op(gd_engine *e, const Op &op, const Bind &b, int batch, hipStrea
         }
         case OP_GEMM: {
             GemmParams g{};
-            g.a0 = op.a_slot >= 0 ? slot_ptr(e, op.a_slot) + op.a_off : tptr(e, b, op.a0, batch);
-            g.a1 = tptr(e, b, op.a1, batch);
-            g.C0 = op.C0; g.C1 = op.C1; g.lda0 = op.lda0; g.lda1 = op.lda1 ? op.lda1 : 4;
-            g.H = op.H; g.W = op.W; g.OH = op.OH; g.OW = op.OW; g.KH = op.KH; g.KW = op.KW; g.stride = op.stride; g.pad = op.pad;
-            g.N = op.N; g.K = op.K;
-            int z = 1;
-            if (op.z_per_image) { g.M = op.m_per_image; z = batch; g.sA = op.sA; g.sB = op.sB; g.sC = op.sC; }
-            else g.M = op.m_per_image * batch;
-            if (op.w_slot >= 0) g.b = slot_ptr(e, op.w_slot);
-            else g.b = tptr(e, b, op.bten, batch);
-            g.ldb = op.ldb; g.b_kmajor = op.b_kmajor;
-            g.out = tptr(e, b, op.out, batch); g.ldc = op.ldc;
-            g.bias = op.bias_slot >= 0 ? slot_ptr(e, op.bias_slot) + op.bias_off : nullptr;
-            g.rowbias = tptr(e, b, op.rowbias, batch); g.ld_rowbias = op.ld_rowbias; g.rows_per_image = op.m_per_image;
-            g.res = tptr(e, b, op.res, batch); g.ldres = op.ldres;
-            g.alpha = op.alpha; g.out_scale = op.out_scale; g.in_act = op.in_act;
-            g.qstats = tptr(e, b, op.qstats, batch); g.qs_slices = op.qs_slices;
+            const int z = fill_gemm(e, op, b, batch, g);
             if (e->precision == 1 && op.w_slot >= 0 && e->wsplit_valid) {
                 g.b_hi = e->wsplit_hi + e->slot_off[op.w_slot];
                 g.b_lo = e->wsplit_lo + e->slot_off[op.w_slot];
-                g.a_presplit = op.a_split;
-                GD_CHECK(!op.a_split || igemm_bf16x3_ok(g, z), "%s: pre-split input but the GEMM is not eligible for bf16x3", op.label.c_str());
+                g.a_presplit = op.a_split && presplit_allowed(e, b, batch, op.a0.t);
+                GD_CHECK(!g.a_presplit || igemm_bf16x3_ok(g, z), "%s: pre-split input but the GEMM is not eligible for bf16x3", op.label.c_str());
                 if (z == 1 && conv3x3_halo_ok(g)) {
                     ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(conv3x3_halo_name()), op.flops_per_image * batch, 0);
                     return launch_conv3x3_halo(g, s);
@@ -195,7 +222,7 @@ static int run_op(gd_engine *e, const Op &op, const Bind &b, int batch, hipStrea
                 }
                 g.b_hi = g.b_lo = nullptr;
             }
-            GD_CHECK(!(e->precision == 1 && op.a_split), "%s: pre-split input without split weights", op.label.c_str());
+            GD_CHECK(!g.a_presplit, "%s: pre-split input without a split-precision kernel", op.label.c_str());
             ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(igemm_variant_name(g, z)), op.flops_per_image * batch, 0);
             return launch_igemm(g, z, s);
         }
@@ -212,7 +239,8 @@ static int run_op(gd_engine *e, const Op &op, const Bind &b, int batch, hipStrea
             return launch_gn_apply(tptr(e, b, op.a0, batch), op.C0, tptr(e, b, op.a1, batch), op.C1, tptr(e, b, op.stats, batch),
                                    op.S0 > 0 ? op.S0 : rt, tptr(e, b, op.stats1, batch), op.S1 > 0 ? op.S1 : rt,
                                    slot_ptr(e, op.gamma_slot), slot_ptr(e, op.beta_slot), tptr(e, b, op.out, batch), batch, HW,
-                                   op.groups, op.act, 1e-6f, (e->precision == 1 && e->wsplit_valid) ? op.split_out : 0, s);
+                                   op.groups, op.act, 1e-6f,
+                                   (e->precision == 1 && e->wsplit_valid && op.split_out && presplit_allowed(e, b, batch, op.out.t)) ? 1 : 0, s);
         }
         case OP_FIR_UP: {
             ProfScope ps(e, s, "fir_up2", 0, 4.0 * batch * op.H * op.W * op.C0 * 5);
