@@ -182,3 +182,24 @@ def test_ops_refuse_cpu_tensors(native_lib):
     from gddim_amd._abi import GddimError
     with pytest.raises(GddimError):
         ops.sbmm(np.eye(2, dtype=np.float32), torch.zeros(1, 2, 2))
+
+
+# ---- shape fuzzing of the implicit-GEMM entry point (hypothesis) -----------------------------------------------------------------
+def test_conv2d_shape_fuzz(dev):
+    """Random shapes across both kernel paths (fast: Cin % 32 == 0; generic: anything % 4 == 0), ragged M / N tiles, strides and
+    paddings, against torch float64 through gd_conv2d."""
+    from hypothesis import HealthCheck, given, settings
+    from hypothesis import strategies as st
+
+    @settings(max_examples=30, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+    @given(B=st.integers(1, 3), H=st.integers(3, 20), W=st.integers(3, 20), cin4=st.integers(1, 24), Cout=st.integers(1, 150),
+           k=st.sampled_from([1, 3]), stride=st.sampled_from([1, 2]), bias=st.booleans(), res=st.booleans(),
+           fast=st.booleans())
+    def run(B, H, W, cin4, Cout, k, stride, bias, res, fast):
+        Cin = (cin4 % 6 + 1) * 32 if fast else cin4 * 4
+        pad = k // 2
+        err = _conv_case(dev, B, H, W, Cin, Cout, k, stride, pad, bias, res, seed=B * 7 + H * 11 + W * 13 + Cin + Cout,
+                         alpha=1.0, out_scale=0.5 if res else 1.0)
+        assert err < 2e-5, (B, H, W, Cin, Cout, k, stride, bias, res, err)
+
+    run()
