@@ -131,8 +131,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float *__restrict__
     if (c < C0) { src = x0; ld = C0; cc = c; } else { src = x1; ld = C1; cc = c - C0; }
     src += (size_t)b * HW * ld + cc;
     float *dst = out + (size_t)b * HW * C + c;
-    for (int p = p_beg + rp; p < p_end; p += rows_pp) {
-        f32x4 v = *reinterpret_cast<const f32x4 *>(src + (size_t)p * ld);
+    auto finish = [&](f32x4 v, int p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             float y = v[i] * sc[i] + sh[i];
@@ -152,7 +151,17 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float *__restrict__
         } else {
             *reinterpret_cast<f32x4 *>(dst + (size_t)p * C) = v;
         }
+    };
+    // four independent 16-byte loads in flight per thread (one per iteration leaves the kernel latency bound)
+    int p = p_beg + rp;
+    for (; p + 3 * rows_pp < p_end; p += 4 * rows_pp) {
+        f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4 *>(src + (size_t)(p + u * rows_pp) * ld);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) finish(v[u], p + u * rows_pp);
     }
+    for (; p < p_end; p += rows_pp) finish(*reinterpret_cast<const f32x4 *>(src + (size_t)p * ld), p);
 }
 
 int launch_gn_stats(const float *x, int C, float *qs, int batch, int HW, int slices, hipStream_t s) {
