@@ -21,6 +21,8 @@ sys.path.insert(0, os.path.dirname(HERE))
 from conftest import tiny_config  # noqa: E402
 from oracle import blur as oblur  # noqa: E402
 from oracle import cld as ocld  # noqa: E402
+from oracle import cld_ext as ox  # noqa: E402
+from oracle import rng as orng  # noqa: E402
 from oracle import ncsnpp as onet  # noqa: E402
 
 
@@ -63,6 +65,24 @@ def main():
     np.savez_compressed(os.path.join(HERE, "tiny_blur.npz"), params_seed=13, y=y, nfe=4, sample_x=bx,
                         rev_ts=oblur.get_rev_ts(bsde, 2, 4), mean_coef=bsde.y_mean_coef(oblur.get_rev_ts(bsde, 2, 4))[..., 0],
                         std_coef=bsde.y_std_coef(oblur.get_rev_ts(bsde, 2, 4)))
+    # 4. sampler variants: coefficient tables (R scan with the reference default R_dt = 1e-5) and the counter-based noise
+    esde = ocld.CLD(is_R_rk=True, R_dt=1e-5, dtype=np.float64)
+    rev = ocld.get_rev_ts(esde, 2, 4)
+    lam = ox.LambdaSDE(esde, 1.0, use_order0=True, dt=1e-5)
+    ext = {"rev_ts": rev,
+           "ldeis_coef_order1": ox.LSDE(esde).get_deis_coef(1, rev),
+           "ldeis_eps_map": np.stack([ox.LSDE(esde).s_L(t).T @ ocld.inv_2x2(esde.s_R(np.float64(t)).T) for t in rev[:-1]]),
+           "mldeis_coef_order1": ox.MLCLD(esde).get_deis_coef(1, rev),
+           "mldeis_psi1": np.stack([ox.s_psi1(esde, t) for t in rev]),
+           "sdeis_coef_order0": lam.get_deis_coef(0, rev), "sdeis_coef_order1": lam.get_deis_coef(1, rev),
+           "sscs_ou_03_035_cov": ox.sscs_ou(esde, np.zeros((1, 1, 2)), 0.3, 0.35, np.zeros((1, 1, 2)))[1],
+           "noise_seed": np.uint64(20240611), "noise_draw3_first8": orng.normal_pairs(20240611, np.arange(8), 3)}
+    # an sscs trajectory of the tiny network with that noise source (what the GPU test reproduces through the C ABI)
+    sx, sv, _ = ox.sscs_sampler(esde, onet.cld_eps_fn(params, cfg, dtype=torch.float64), u.astype(np.float64), 4, ts_order=2, denoising=True,
+                                inverse_scaler=ocld.inverse_scaler_centered,
+                                noise_fn=lambda draw, shape: orng.noise_like(20240611, shape, draw))
+    ext["sscs_sample_x"], ext["sscs_sample_v"] = sx, sv
+    np.savez_compressed(os.path.join(HERE, "cld_variants.npz"), **ext)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
