@@ -37,8 +37,12 @@ def hbm_traffic(kernel_name):
     except (OSError, ValueError, KeyError):
         return None
     key = kernel_name.replace(" ", "")
+    # the engine's profile names abbreviate the template tail of the split-precision kernel (<..., pre> = <..., true, false>)
+    keys = {key, key.replace(",pre>", ",true,false>")}
+    if key.startswith("igemm_bf16x3_kernel<") and key.count(",") == 3:
+        keys.add(key[:-1] + ",false,false>")
     for k, v in table.items():
-        if k.replace(" ", "") == key:
+        if k.replace(" ", "") in keys:
             return v["hbm_bytes_per_launch"]
     return None
 

@@ -12,7 +12,8 @@ DST = os.path.join(REPO, "profiles")
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 
 for name in ("bench_kernel_stats.csv", "bench_bf16x3_kernel_stats.csv", "trace_summary.json", "pmc_fetch_summary.json",
-             "pmc_write_summary.json", "pmc_sq_summary.json", "trace_bench_line.json"):
+             "pmc_write_summary.json", "pmc_sq_summary.json", "trace_bench_line.json", "pmc_fetch_x3_summary.json",
+             "pmc_write_x3_summary.json"):
     p = os.path.join(SRC, name)
     if os.path.exists(p):
         shutil.copy(p, os.path.join(DST, "%s_%s" % (tag, name)))
@@ -32,5 +33,16 @@ for k, v in fetch.items():
         continue
     out["kernels"][k] = {"fetch_size_kib": fs, "write_size_kib": ws, "hbm_bytes_per_launch": (2 * fs + ws) * 1024,
                          "avg_us_in_trace": trace.get(k, {}).get("avg_us")}
+# kernels that only run in the split-precision mode
+fx, wx = os.path.join(SRC, "pmc_fetch_x3_summary.json"), os.path.join(SRC, "pmc_write_x3_summary.json")
+if os.path.exists(fx) and os.path.exists(wx):
+    f3, w3 = json.load(open(fx))["kernels"], json.load(open(wx))["kernels"]
+    for k, v in f3.items():
+        fs = v.get("counters_mean_per_dispatch", {}).get("FETCH_SIZE")
+        ws = w3.get(k, {}).get("counters_mean_per_dispatch", {}).get("WRITE_SIZE")
+        if fs is None or ws is None or k in out["kernels"]:
+            continue
+        out["kernels"][k] = {"fetch_size_kib": fs, "write_size_kib": ws, "hbm_bytes_per_launch": (2 * fs + ws) * 1024,
+                             "avg_us_in_trace": v.get("avg_us"), "mode": "bf16x3"}
 json.dump(out, open(os.path.join(DST, "%s_hbm_traffic.json" % tag), "w"), indent=1)
 print("updated", DST)
