@@ -643,8 +643,10 @@ static void pick_tiles(const GemmParams &p, int batch_z, int &bm, int &bn) {
     };
     // Largest tile that still gives every CU of the 256 at least ~1.5 blocks; the small spatial
     // levels (8x8, 4x4) of the U-Net otherwise leave most of the chip idle.
-    if (p.N > 64 && blocks(128, 128) >= 384) { bm = 128; bn = 128; return; }
-    if (blocks(128, 64) >= 384) { bm = 128; bn = 64; return; }
+    static const long long big_min = getenv("GDDIM_IGEMM_BIGMIN") ? atoll(getenv("GDDIM_IGEMM_BIGMIN")) : 384;  // A/B only
+    static const long long mid_min = getenv("GDDIM_IGEMM_MIDMIN") ? atoll(getenv("GDDIM_IGEMM_MIDMIN")) : 384;
+    if (p.N > 64 && blocks(128, 128) >= big_min) { bm = 128; bn = 128; return; }
+    if (blocks(128, 64) >= mid_min) { bm = 128; bn = 64; return; }
     bm = 64; bn = 64;
 }
 
