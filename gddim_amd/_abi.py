@@ -33,6 +33,8 @@ class ModelDesc(ctypes.Structure):
         ("scale_by_sigma", ctypes.c_int),
         ("centered", ctypes.c_int),
         ("max_batch", ctypes.c_int),
+        ("positional_embedding", ctypes.c_int),
+        ("no_fir", ctypes.c_int),
     ]
 
 

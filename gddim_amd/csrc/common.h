@@ -109,13 +109,17 @@ int launch_gn_stats(const float *x, int C, float *qs, int batch, int HW, int sli
 int launch_gn_apply(const float *x0, int C0, const float *x1, int C1, const float *qs0, int S0, const float *qs1, int S1,
                     const float *gamma, const float *beta, float *out, int batch, int HW, int groups, int act, float eps,
                     int split_out, hipStream_t s);
+// GroupNorm for group sizes that are not a multiple of 4 channels: direct statistics + element-wise apply
+int launch_gn_generic(const float *x0, int C0, const float *x1, int C1, float *mr, const float *gamma, const float *beta,
+                      float *out, int batch, int HW, int groups, int act, float eps, hipStream_t s);
 int launch_fir_up2(const float *x, float *out, int batch, int H, int W, int C, hipStream_t s);
+int launch_naive_resample2(const float *x, float *out, int batch, int H, int W, int C, int up, hipStream_t s);
 int launch_fir_down2(const float *x, float *out, int batch, int H, int W, int C, hipStream_t s);
 int launch_softmax_rows(float *x, long long rows, int cols, hipStream_t s);
 int launch_swish(const float *x, float *out, long long n, hipStream_t s);
 // temb0[b][0:E] = sin(2 pi W log(label_b)), [E:2E] = cos(...); label_b = labels[b] or 999*ts[*step]
 int launch_fourier(const float *labels, const float *ts_table, const int *step, const float *W, float *out, int batch,
-                   int E, hipStream_t s);
+                   int E, int positional, hipStream_t s);
 int launch_pad_channels(const float *x, int ld_in, float *out, long long pixels, int Cin, int Cpad, float mul,
                         float add, hipStream_t s);
 int launch_scale_rows(float *x, const float *labels, int batch, long long per_image, hipStream_t s);

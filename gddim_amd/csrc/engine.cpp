@@ -202,7 +202,7 @@ static int run_op(gd_engine *e, const Op &op, const Bind &b, int batch, hipStrea
         case OP_FOURIER: {
             ProfScope ps(e, s, "fourier", 0, 0);
             return launch_fourier(b.labels, e->ts_dev, b.step, slot_ptr(e, op.w_slot), tptr(e, b, op.out, batch), batch,
-                                  op.N, s);
+                                  op.N, op.act, s);
         }
         case OP_GEMM: {
             GemmParams g{};
@@ -242,12 +242,20 @@ static int run_op(gd_engine *e, const Op &op, const Bind &b, int batch, hipStrea
                                    op.groups, op.act, 1e-6f,
                                    (e->precision == 1 && e->wsplit_valid && op.split_out && presplit_allowed(e, b, batch, op.out.t)) ? 1 : 0, s);
         }
+        case OP_GN_GENERIC: {
+            ProfScope ps(e, s, "gn_generic", 0, 12.0 * batch * op.H * op.W * (op.C0 + op.C1));
+            return launch_gn_generic(tptr(e, b, op.a0, batch), op.C0, tptr(e, b, op.a1, batch), op.C1, tptr(e, b, op.stats, batch),
+                                     slot_ptr(e, op.gamma_slot), slot_ptr(e, op.beta_slot), tptr(e, b, op.out, batch), batch,
+                                     op.H * op.W, op.groups, op.act, 1e-6f, s);
+        }
         case OP_FIR_UP: {
             ProfScope ps(e, s, "fir_up2", 0, 4.0 * batch * op.H * op.W * op.C0 * 5);
+            if (op.act) return launch_naive_resample2(tptr(e, b, op.a0, batch), tptr(e, b, op.out, batch), batch, op.H, op.W, op.C0, 1, s);
             return launch_fir_up2(tptr(e, b, op.a0, batch), tptr(e, b, op.out, batch), batch, op.H, op.W, op.C0, s);
         }
         case OP_FIR_DOWN: {
             ProfScope ps(e, s, "fir_down2", 0, 4.0 * batch * op.H * op.W * op.C0 * 1.25);
+            if (op.act) return launch_naive_resample2(tptr(e, b, op.a0, batch), tptr(e, b, op.out, batch), batch, op.H, op.W, op.C0, 0, s);
             return launch_fir_down2(tptr(e, b, op.a0, batch), tptr(e, b, op.out, batch), batch, op.H, op.W, op.C0, s);
         }
         case OP_SOFTMAX: {
@@ -922,6 +930,15 @@ int gd_group_norm(const float *x_dev, const float *scale_dev, const float *bias_
                   int groups, int act, void *stream) {
     GD_CHECK(x_dev && scale_dev && bias_dev && out_dev, "null pointer");
     hipStream_t s = (hipStream_t)stream;
+    GD_CHECK(groups >= 1 && C % groups == 0, "group_norm: %d channels do not split into %d groups", C, groups);
+    if (C % 4 != 0 || (C / groups) % 4 != 0) {  // groups that are not whole float4 columns: the generic path
+        float *mr = nullptr;
+        GD_HIP(hipMalloc((void **)&mr, (size_t)batch * groups * 2 * sizeof(float)));
+        int r = launch_gn_generic(x_dev, C, nullptr, 0, mr, scale_dev, bias_dev, out_dev, batch, HW, groups, act, 1e-6f, s);
+        (void)hipStreamSynchronize(s);
+        (void)hipFree(mr);
+        return r;
+    }
     const int sl = gn_slices(batch, HW);
     float *qs = nullptr;
     GD_HIP(hipMalloc((void **)&qs, (size_t)batch * sl * (C / 4) * 2 * sizeof(float)));
@@ -934,6 +951,7 @@ int gd_group_norm(const float *x_dev, const float *scale_dev, const float *bias_
 
 int gd_fir_resample(const float *x_dev, float *out_dev, int batch, int H, int W, int C, int up, void *stream) {
     GD_CHECK(x_dev && out_dev, "null pointer");
+    if (up >= 2) return launch_naive_resample2(x_dev, out_dev, batch, H, W, C, up == 3, (hipStream_t)stream);
     return up ? launch_fir_up2(x_dev, out_dev, batch, H, W, C, (hipStream_t)stream)
               : launch_fir_down2(x_dev, out_dev, batch, H, W, C, (hipStream_t)stream);
 }

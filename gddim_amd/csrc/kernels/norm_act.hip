@@ -164,6 +164,65 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float *__restrict__
     for (; p < p_end; p += rows_pp) finish(*reinterpret_cast<const f32x4 *>(src + (size_t)p * ld), p);
 }
 
+// ---- generic GroupNorm: any group size, up to two channel-concatenated sources (rare configurations) ----
+// grid (G, B): (mean, rstd) of group g of image b
+__global__ __launch_bounds__(256) void gn_group_stats_kernel(const float *__restrict__ x0, int C0, const float *__restrict__ x1,
+                                                              int C1, float *__restrict__ mr, int HW, int groups, float eps) {
+    __shared__ float s_sum[256], s_sq[256];
+    const int C = C0 + C1, cpg = C / groups;
+    const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    float s = 0.f, q = 0.f;
+    for (long long i = tid; i < (long long)HW * cpg; i += 256) {
+        const int p = (int)(i / cpg), c = g * cpg + (int)(i - (long long)p * cpg);
+        const float v = c < C0 ? x0[((size_t)b * HW + p) * C0 + c] : x1[((size_t)b * HW + p) * C1 + (c - C0)];
+        s += v;
+        q += v * v;
+    }
+    s_sum[tid] = s;
+    s_sq[tid] = q;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) { s_sum[tid] += s_sum[tid + o]; s_sq[tid] += s_sq[tid + o]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const float n = (float)HW * (float)cpg;
+        const float mean = s_sum[0] / n;
+        const float var = s_sq[0] / n - mean * mean;
+        mr[((size_t)b * groups + g) * 2] = mean;
+        mr[((size_t)b * groups + g) * 2 + 1] = rsqrtf(var + eps);
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_apply_generic_kernel(const float *__restrict__ x0, int C0, const float *__restrict__ x1,
+                                                                int C1, const float *__restrict__ mr,
+                                                                const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                                float *__restrict__ out, int HW, int groups, int act,
+                                                                long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int C = C0 + C1, cpg = C / groups;
+    const int c = (int)(i % C);
+    const long long bp = i / C;
+    const int b = (int)(bp / HW);
+    const float v = c < C0 ? x0[(size_t)bp * C0 + c] : x1[(size_t)bp * C1 + (c - C0)];
+    const float *m = mr + ((size_t)b * groups + c / cpg) * 2;
+    const float y = (v - m[0]) * m[1] * gamma[c] + beta[c];
+    out[i] = act ? swish_e(y) : y;
+}
+
+int launch_gn_generic(const float *x0, int C0, const float *x1, int C1, float *mr, const float *gamma, const float *beta,
+                      float *out, int batch, int HW, int groups, int act, float eps, hipStream_t s) {
+    const int C = C0 + C1;
+    GD_CHECK(groups >= 1 && C % groups == 0, "group_norm: %d channels do not split into %d groups", C, groups);
+    hipLaunchKernelGGL(gn_group_stats_kernel, dim3(groups, batch), dim3(256), 0, s, x0, C0, x1, C1, mr, HW, groups, eps);
+    const long long total = (long long)batch * HW * C;
+    hipLaunchKernelGGL(gn_apply_generic_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x0, C0, x1, C1, mr, gamma,
+                       beta, out, HW, groups, act, total);
+    GD_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_gn_stats(const float *x, int C, float *qs, int batch, int HW, int slices, hipStream_t s) {
     GD_CHECK(C % 4 == 0 && C / 4 <= 256, "group_norm: unsupported C=%d", C);
     hipLaunchKernelGGL(gn_stats_kernel, dim3(slices, batch), dim3(256), 0, s, x, C, qs, HW, slices);
@@ -182,6 +241,40 @@ int launch_gn_apply(const float *x0, int C0, const float *x1, int C1, const floa
     const float inv_n = 1.0f / ((float)HW * (float)(C / groups));
     hipLaunchKernelGGL(gn_apply_kernel, dim3(nblk, batch), dim3(256), 0, s, x0, C0, x1, C1, qs0, S0, qs1, S1, gamma, beta, out,
                        HW, groups, act, inv_n, eps, split_out);
+    GD_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---- naive 2x resampling of the fir=False configurations (up_or_down_sampling.py:76-86) ----
+// up: nearest neighbour (jnp.tile);  down: mean of the 2x2 block
+__global__ __launch_bounds__(256) void naive_resample2_kernel(const float *__restrict__ x, float *__restrict__ out, int H, int W,
+                                                              int C4, long long total, int up) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int f = (int)(idx % C4);
+    long long r = idx / C4;
+    const int OW = up ? 2 * W : W / 2, OH = up ? 2 * H : H / 2;
+    const int ox = (int)(r % OW);
+    r /= OW;
+    const int oy = (int)(r % OH);
+    const int b = (int)(r / OH);
+    const f32x4 *xb = reinterpret_cast<const f32x4 *>(x) + (size_t)b * H * W * C4 + f;
+    f32x4 v;
+    if (up) {
+        v = xb[((size_t)(oy >> 1) * W + (ox >> 1)) * C4];
+    } else {
+        const size_t o = ((size_t)(2 * oy) * W + 2 * ox) * C4;
+        // jnp.mean over the two block axes: the sum of the four values times 1/4
+        v = ((xb[o] + xb[o + C4]) + (xb[o + (size_t)W * C4] + xb[o + (size_t)W * C4 + C4])) * 0.25f;
+    }
+    reinterpret_cast<f32x4 *>(out)[idx] = v;
+}
+
+int launch_naive_resample2(const float *x, float *out, int batch, int H, int W, int C, int up, hipStream_t s) {
+    GD_CHECK(C % 4 == 0 && (up || (H % 2 == 0 && W % 2 == 0)), "naive resample: unsupported shape %dx%dx%d", H, W, C);
+    const int C4 = C / 4;
+    const long long total = (long long)batch * (up ? 4 * H * W : (H / 2) * (W / 2)) * C4;
+    hipLaunchKernelGGL(naive_resample2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, out, H, W, C4, total, up);
     GD_HIP(hipGetLastError());
     return 0;
 }
@@ -305,14 +398,16 @@ int launch_swish(const float *x, float *out, long long n, hipStream_t s) {
     return 0;
 }
 
+// positional = 0: GaussianFourierProjection, sin/cos(2 pi W_j log(label)) (layerspp.py:33-43)
+// positional = 1: get_timestep_embedding, sin/cos(label * W_j) with W_j = 10000^(-j / (E - 1)) (layers.py:450-464)
 __global__ void fourier_kernel(const float *__restrict__ labels, const float *__restrict__ ts_table,
                                const int *__restrict__ step, const float *__restrict__ W, float *__restrict__ out,
-                               int batch, int E) {
+                               int batch, int E, int positional) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= batch * E) return;
     const int b = i / E, j = i - b * E;
     const float label = labels ? labels[b] : 999.0f * ts_table[*step];
-    const float xp = logf(label) * W[j] * 2.0f * 3.14159265358979323846f;
+    const float xp = positional ? label * W[j] : logf(label) * W[j] * 2.0f * 3.14159265358979323846f;
     float sn, cs;
     sincosf(xp, &sn, &cs);
     out[(size_t)b * 2 * E + j] = sn;
@@ -320,9 +415,9 @@ __global__ void fourier_kernel(const float *__restrict__ labels, const float *__
 }
 
 int launch_fourier(const float *labels, const float *ts_table, const int *step, const float *W, float *out, int batch,
-                   int E, hipStream_t s) {
+                   int E, int positional, hipStream_t s) {
     hipLaunchKernelGGL(fourier_kernel, dim3((batch * E + 255) / 256), dim3(256), 0, s, labels, ts_table, step, W, out,
-                       batch, E);
+                       batch, E, positional);
     GD_HIP(hipGetLastError());
     return 0;
 }

@@ -112,6 +112,19 @@ int Plan::gn(const std::string &label, const std::string &pname, int xa, int Ca,
     int gs = new_slot(pname + "/scale", 1, C), bs = new_slot(pname + "/bias", 1, C);
     add_param(pname + "/scale", {C}, P_VEC, gs, 0);
     add_param(pname + "/bias", {C}, P_VEC, bs, 0);
+    if ((C / G) % 4 != 0 || Ca % 4 != 0) {
+        // groups that cut through a float4 column (nf = 64: 192 channels -> 32 groups of 6): the quad statistics do not apply;
+        // a direct (mean, rstd) pass over the sources and an element-wise apply (rare configurations, not tuned)
+        int mr = new_tensor(label + ".mean_rstd", 1, 1, 2 * G);
+        int out = new_tensor(label + ".out", H, W, C);
+        Op a;
+        a.kind = OP_GN_GENERIC; a.label = label + ".generic";
+        a.a0 = {xa, 0}; a.C0 = Ca; a.a1 = {xb, 0}; a.C1 = Cb; a.H = H; a.W = W; a.groups = G;
+        a.stats = {mr, 0}; a.act = act; a.gamma_slot = gs; a.beta_slot = bs; a.out = {out, 0};
+        ops.push_back(a);
+        release(mr);
+        return out;
+    }
     // quad statistics of each source: emitted by its producer, or computed here by the stand-alone kernel
     int qs[2] = {-1, -1}, S[2] = {0, 0}, tmp[2] = {-1, -1};
     const int src[2] = {xa, xb}, Cs[2] = {Ca, Cb};
@@ -187,6 +200,7 @@ int Plan::resblock(int idx, int xa, int Ca, int xb, int Cb, int H, int W, int O,
         int h0r = new_tensor(n + ".h_resampled", H2, W2, C);
         Op f;
         f.kind = up ? OP_FIR_UP : OP_FIR_DOWN; f.label = n + (up ? ".fir_up_h" : ".fir_down_h");
+        f.act = desc.no_fir ? 1 : 0;  // 1: naive_upsample_2d / naive_downsample_2d instead of the FIR (layerspp.py:203-211)
         f.a0 = {h0, 0}; f.C0 = C; f.H = H; f.W = W; f.out = {h0r, 0};
         ops.push_back(f);
         release(h0);
@@ -324,6 +338,8 @@ int Plan::build(const gd_model_desc &d) {
     GD_CHECK(d.nf >= 16 && d.nf % 16 == 0, "nf must be a multiple of 16 (GroupNorm groups of >= 4 channels), got %d", d.nf);
     GD_CHECK(d.in_channels >= 1 && d.image_size >= (1 << (d.num_levels - 1)), "bad in_channels / image_size");
     GD_CHECK(d.image_size % (1 << (d.num_levels - 1)) == 0, "image_size must be divisible by 2^(levels-1)");
+    GD_CHECK(!(d.no_fir && d.progressive_input_residual), "fir=False with progressive_input='residual' is not built (no reference "
+             "config uses it)");
     GD_CHECK(d.max_batch >= 1, "max_batch must be >= 1");
     const int nf = d.nf, nres = d.num_levels, nrb = d.num_res_blocks;
     CP = (d.in_channels + 3) / 4 * 4;
@@ -357,11 +373,23 @@ int Plan::build(const gd_model_desc &d) {
 
     // ---- time embedding (ncsnpp.py:71-91) ----
     if (d.conditional) {
-        int wf = new_slot("GaussianFourierProjection_0/W", 1, nf);
-        add_param("GaussianFourierProjection_0/W", {nf}, P_VEC, wf, 0);
-        int t0 = new_tensor("temb.fourier", 1, 1, 2 * nf);
+        // Gaussian Fourier features of log(label) (2 nf wide, learned-free W is a checkpoint parameter), or the sinusoidal
+        // positional embedding of the label itself (nf wide, fixed frequencies 10000^(-j/(nf/2-1)), layers.py:450-464)
+        const int E = d.positional_embedding ? nf / 2 : nf;
+        int wf;
+        if (d.positional_embedding) {
+            GD_CHECK(nf % 2 == 0 && nf >= 4, "positional embedding needs an even nf >= 4");
+            wf = new_slot("positional_frequencies", 1, E);
+            const double c = std::log(10000.0) / (double)(E - 1);
+            for (int j = 0; j < E; ++j) slots[wf].host[j] = (float)std::exp(-(double)(float)((float)j * (float)c));
+        } else {
+            wf = new_slot("GaussianFourierProjection_0/W", 1, nf);
+            add_param("GaussianFourierProjection_0/W", {nf}, P_VEC, wf, 0);
+        }
+        int t0 = new_tensor("temb.fourier", 1, 1, 2 * E);
         Op f;
-        f.kind = OP_FOURIER; f.label = "temb.fourier"; f.a0 = {t_labels, 0}; f.w_slot = wf; f.N = nf; f.out = {t0, 0};
+        f.kind = OP_FOURIER; f.label = "temb.fourier"; f.a0 = {t_labels, 0}; f.w_slot = wf; f.N = E; f.out = {t0, 0};
+        f.act = d.positional_embedding ? 1 : 0;
         ops.push_back(f);
         auto dense = [&](const std::string &label, const std::string &pname, int in_t, int in_c, int out_c, int act_in) {
             int ws = new_slot(pname + "/kernel", out_c, in_c), bs = new_slot(pname + "/bias", 1, out_c);
@@ -375,7 +403,7 @@ int Plan::build(const gd_model_desc &d) {
             ops.push_back(g);
             return o;
         };
-        int t1 = dense("temb.dense0", "Dense_0", t0, 2 * nf, 4 * nf, 0);
+        int t1 = dense("temb.dense0", "Dense_0", t0, 2 * E, 4 * nf, 0);
         release(t0);
         temb_t_ = dense("temb.dense1", "Dense_1", t1, 4 * nf, 4 * nf, 1);
         release(t1);

@@ -21,6 +21,7 @@ enum OpKind {
     OP_SOFTMAX,
     OP_AFFINE_PAD,
     OP_SCALE_ROWS,
+    OP_GN_GENERIC,  // GroupNorm whose groups are not whole float4 columns (e.g. 192 channels in 32 groups of 6): direct two-kernel path
 };
 
 // external tensors are bound to caller pointers at run time

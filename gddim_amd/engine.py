@@ -18,10 +18,10 @@ def model_desc_from_config(config, in_channels, max_batch):
     m = config.model
     if m.name != 'ncsnpp':
         raise GddimError("only model.name == 'ncsnpp' is built (got %r)" % (m.name,))
-    if m.resblock_type.lower() != 'biggan' or not m.fir or list(m.fir_kernel) != [1, 3, 3, 1]:
-        raise GddimError("only resblock_type='biggan' with fir=True, fir_kernel=[1,3,3,1] is built")
-    if m.embedding_type.lower() != 'fourier' or m.progressive.lower() != 'none':
-        raise GddimError("only embedding_type='fourier', progressive='none' are built")
+    if m.resblock_type.lower() != 'biggan' or (m.fir and list(m.fir_kernel) != [1, 3, 3, 1]):
+        raise GddimError("only resblock_type='biggan' (fir=False, or fir=True with fir_kernel=[1,3,3,1]) is built")
+    if m.embedding_type.lower() not in ('fourier', 'positional') or m.progressive.lower() != 'none':
+        raise GddimError("only embedding_type in {'fourier','positional'} with progressive='none' is built")
     if m.progressive_input.lower() not in ('none', 'residual') or m.nonlinearity.lower() != 'swish':
         raise GddimError("only progressive_input in {'none','residual'} and nonlinearity='swish' are built")
     if not m.resamp_with_conv:
@@ -43,6 +43,8 @@ def model_desc_from_config(config, in_channels, max_batch):
     d.scale_by_sigma = int(bool(m.scale_by_sigma))
     d.centered = int(bool(config.data.centered))
     d.max_batch = int(max_batch)
+    d.positional_embedding = int(m.embedding_type.lower() == 'positional')
+    d.no_fir = int(not m.fir)
     return d
 
 

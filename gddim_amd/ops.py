@@ -116,15 +116,16 @@ def group_norm(x, scale, bias, groups, act=False):
     return out
 
 
-def fir_resample(x, up):
-    """upsample_2d / downsample_2d with k=[1,3,3,1] (up_or_down_sampling.py:333-411)."""
+def fir_resample(x, up, naive=False):
+    """upsample_2d / downsample_2d with k=[1,3,3,1] (up_or_down_sampling.py:333-411); naive=True: naive_upsample_2d /
+    naive_downsample_2d (:76-86), the fir=False configurations."""
     import torch
     _need_gpu(x)
     x = _f32c(x)
     B, H, W, C = x.shape
     shp = (B, 2 * H, 2 * W, C) if up else (B, H // 2, W // 2, C)
     out = torch.empty(shp, dtype=torch.float32, device=x.device)
-    check(_abi.lib().gd_fir_resample(_ptr(x), _ptr(out), B, H, W, C, int(up), _stream(x)))
+    check(_abi.lib().gd_fir_resample(_ptr(x), _ptr(out), B, H, W, C, int(bool(up)) + (2 if naive else 0), _stream(x)))
     return out
 
 

@@ -53,6 +53,9 @@ typedef struct gd_model_desc {
     int scale_by_sigma;                   /* config.model.scale_by_sigma                          */
     int centered;                         /* config.data.centered (False: x <- 2x-1, ncsnpp.py:136-138) */
     int max_batch;                        /* largest per-GPU batch this engine will be asked for  */
+    int positional_embedding;             /* config.model.embedding_type == 'positional' (else 'fourier'), ncsnpp.py:71-86 */
+    int no_fir;                           /* config.model.fir == False: nearest-neighbour / 2x2-mean resampling in the BigGAN
+                                             blocks (up_or_down_sampling.py:76-86) instead of the [1,3,3,1] FIR          */
 } gd_model_desc;
 
 /* ---- diagnostics ---------------------------------------------------------------------- */
@@ -237,6 +240,7 @@ int gd_group_norm(const float *x_dev, const float *scale_dev, const float *bias_
                   int HW, int C, int groups, int act, void *stream);
 /* FIR [1,3,3,1] 2x resampling of NHWC tensors.  Replaces: upsample_2d / downsample_2d
  * (cld_jax/models/up_or_down_sampling.py:333-411). */
+/* up: 0 FIR down, 1 FIR up, 2 naive (2x2 mean) down, 3 naive (nearest) up */
 int gd_fir_resample(const float *x_dev, float *out_dev, int batch, int H, int W, int C, int up, void *stream);
 /* Single-head self-attention core on projected q,k,v packed as qkv_dev (B,N,3C):
  * out (B,N,C) = softmax(q k^T C^-1/2) v; scratch_dev must hold B*N*N floats.

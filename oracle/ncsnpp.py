@@ -124,19 +124,54 @@ def conv_downsample_2d(x, w, k, factor=2, gain=1):
     return y.permute(0, 2, 3, 1)
 
 
+def naive_upsample_2d(x, factor=2):
+    # up_or_down_sampling.py:76-80
+    N, H, W, C = x.shape
+    x = x.reshape(-1, H, 1, W, 1, C)
+    x = x.repeat(1, 1, factor, 1, factor, 1)  # jnp.tile on the two singleton axes
+    return x.reshape(-1, H * factor, W * factor, C)
+
+
+def naive_downsample_2d(x, factor=2):
+    # up_or_down_sampling.py:83-86
+    N, H, W, C = x.shape
+    x = x.reshape(-1, H // factor, factor, W // factor, factor, C)
+    return x.mean(dim=(2, 4))
+
+
+def get_timestep_embedding(timesteps, embedding_dim, max_positions=10000):
+    # layers.py:450-464
+    half_dim = embedding_dim // 2
+    emb = math.log(max_positions) / (half_dim - 1)
+    emb = torch.exp(torch.arange(half_dim, dtype=torch.float32) * -emb).to(timesteps.dtype)
+    emb = timesteps[:, None] * emb[None, :]
+    emb = torch.cat([torch.sin(emb), torch.cos(emb)], dim=1)
+    if embedding_dim % 2 == 1:
+        emb = torch.nn.functional.pad(emb, (0, 1))
+    return emb
+
+
 # ---- blocks ----
 def resnet_block_biggan(x, temb, p, cfg, out_ch=None, up=False, down=False):
-    """layerspp.py:180-227 (fir=True, dropout = identity at inference)."""
+    """layerspp.py:180-227 (dropout = identity at inference)."""
     B, H, W, C = x.shape
     out_ch = out_ch if out_ch else C
     fir_kernel = cfg.model.fir_kernel
     h = swish(group_norm(x, p["GroupNorm_0"]))
     if up:
-        h = upsample_2d(h, fir_kernel, factor=2)
-        x = upsample_2d(x, fir_kernel, factor=2)
+        if cfg.model.fir:
+            h = upsample_2d(h, fir_kernel, factor=2)
+            x = upsample_2d(x, fir_kernel, factor=2)
+        else:
+            h = naive_upsample_2d(h, factor=2)
+            x = naive_upsample_2d(x, factor=2)
     elif down:
-        h = downsample_2d(h, fir_kernel, factor=2)
-        x = downsample_2d(x, fir_kernel, factor=2)
+        if cfg.model.fir:
+            h = downsample_2d(h, fir_kernel, factor=2)
+            x = downsample_2d(x, fir_kernel, factor=2)
+        else:
+            h = naive_downsample_2d(h, factor=2)
+            x = naive_downsample_2d(x, factor=2)
     h = conv_same(h, p["Conv_0"])
     if temb is not None:
         h = h + dense(swish(temb), p["Dense_0"])[:, None, None, :]
@@ -180,8 +215,9 @@ def ncsnpp_forward(params, x, time_cond, cfg, taps=None):
     nf, ch_mult, nrb = m.nf, tuple(m.ch_mult), m.num_res_blocks
     attn_res = tuple(m.attn_resolutions)
     nres = len(ch_mult)
-    assert m.resblock_type.lower() == "biggan" and m.fir and m.embedding_type.lower() == "fourier"
+    assert m.resblock_type.lower() == "biggan" and m.embedding_type.lower() in ("fourier", "positional")
     assert m.progressive.lower() == "none" and m.progressive_input.lower() in ("none", "residual")
+    assert m.fir or m.progressive_input.lower() == "none"  # the pyramid downsample is restated for fir=True only
     idx = {"res": 0, "attn": 0, "down": 0}
 
     def RB(h, temb, **kw):
@@ -195,9 +231,12 @@ def ncsnpp_forward(params, x, time_cond, cfg, taps=None):
         return attn_block(h, p, cfg)
 
     # :71-78 Fourier embedding of log(time_cond)
-    Wf = _t(params["GaussianFourierProjection_0"]["W"], x)
-    x_proj = torch.log(time_cond.to(x.dtype))[:, None] * Wf[None, :] * 2 * math.pi
-    temb = torch.cat([torch.sin(x_proj), torch.cos(x_proj)], dim=-1)
+    if m.embedding_type.lower() == "fourier":
+        Wf = _t(params["GaussianFourierProjection_0"]["W"], x)
+        x_proj = torch.log(time_cond.to(x.dtype))[:, None] * Wf[None, :] * 2 * math.pi
+        temb = torch.cat([torch.sin(x_proj), torch.cos(x_proj)], dim=-1)
+    else:  # :80-84 sinusoidal positional embedding of the (continuous) labels
+        temb = get_timestep_embedding(time_cond.to(x.dtype), nf)
     if m.conditional:  # :87-91
         temb = dense(temb, params["Dense_0"])
         temb = dense(swish(temb), params["Dense_1"])
@@ -311,8 +350,11 @@ def param_shapes(cfg, in_ch):
             shapes[n + "/NIN_%d/W" % i] = (c, c)
             shapes[n + "/NIN_%d/b" % i] = (c,)
 
-    shapes["GaussianFourierProjection_0/W"] = (nf,)
-    shapes["Dense_0/kernel"] = (2 * nf, 4 * nf)
+    if m.embedding_type.lower() == "fourier":
+        shapes["GaussianFourierProjection_0/W"] = (nf,)
+        shapes["Dense_0/kernel"] = (2 * nf, 4 * nf)
+    else:  # positional: no parameters in the embedding, nf features
+        shapes["Dense_0/kernel"] = (nf, 4 * nf)
     shapes["Dense_0/bias"] = (4 * nf,)
     shapes["Dense_1/kernel"] = (4 * nf, 4 * nf)
     shapes["Dense_1/bias"] = (4 * nf,)

@@ -12,7 +12,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-OP_FOURIER, OP_GEMM, OP_GN_STATS, OP_GN_APPLY, OP_FIR_UP, OP_FIR_DOWN, OP_SOFTMAX, OP_AFFINE_PAD, OP_SCALE_ROWS = range(9)
+OP_FOURIER, OP_GEMM, OP_GN_STATS, OP_GN_APPLY, OP_FIR_UP, OP_FIR_DOWN, OP_SOFTMAX, OP_AFFINE_PAD, OP_SCALE_ROWS, OP_GN_GENERIC = range(10)
 EXT_NONE, EXT_X_IN, EXT_LABELS, EXT_EPS_OUT = range(4)
 
 
@@ -80,7 +80,10 @@ class PlanInterp(object):
         labels = self._flat(op["a0"], B)[:B]
         W = self.slots[op["w_slot"]].reshape(-1)
         E = op["N"]
-        xp = torch.log(labels)[:, None] * W[None, :] * 2 * math.pi
+        if op["act"]:  # positional embedding: sin / cos(label * frequency)
+            xp = labels[:, None] * W[None, :]
+        else:
+            xp = torch.log(labels)[:, None] * W[None, :] * 2 * math.pi
         o = self._rows(self._flat(op["out"], B), B, 2 * E, 2 * E)
         o[:, :E] = torch.sin(xp)
         o[:, E:] = torch.cos(xp)
@@ -180,11 +183,31 @@ class PlanInterp(object):
             y = y * torch.sigmoid(y)
         self._rows(self._flat(op["out"], B), B * HW, C, C)[:] = y.reshape(B * HW, C)
 
+    def _op9(self, op, B):  # generic GroupNorm (groups that are not whole float4 columns)
+        x = self._gn_src(op, B)
+        G = op["groups"]
+        Bn, HW, C = x.shape
+        xg = x.reshape(Bn, HW, G, C // G)
+        mean = xg.mean(dim=(1, 3), keepdim=True)
+        var = (xg * xg).mean(dim=(1, 3), keepdim=True) - mean * mean
+        y = ((xg - mean) * torch.rsqrt(var + 1e-6)).reshape(Bn, HW, C)
+        y = y * self.slots[op["gamma_slot"]].reshape(-1) + self.slots[op["beta_slot"]].reshape(-1)
+        if op["act"]:
+            y = y * torch.sigmoid(y)
+        self._rows(self._flat(op["out"], B), B * HW, C, C)[:] = y.reshape(B * HW, C)
+
     def _fir(self, op, B, up):
         H, W, C = op["H"], op["W"], op["C0"]
         x = self._rows(self._flat(op["a0"], B), B * H * W, C, C).reshape(B, H, W, C)
         k = torch.tensor([1.0, 3.0, 3.0, 1.0], dtype=self.dtype)
-        if up:
+        if op["act"]:  # fir=False: nearest-neighbour up / 2x2 mean down
+            if up:
+                y = x.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)
+                OH, OW = 2 * H, 2 * W
+            else:
+                y = x.reshape(B, H // 2, 2, W // 2, 2, C).mean(dim=(2, 4))
+                OH, OW = H // 2, W // 2
+        elif up:
             # y[2m] = (x[m-1] + 3 x[m]) / 4 ; y[2m+1] = (3 x[m] + x[m+1]) / 4, per axis
             def up1(t, dim):
                 n = t.shape[dim]

@@ -134,7 +134,8 @@ def test_conv2d_transpose_detecting(dev):
 
 
 # ---- GroupNorm / FIR / attention -----------------------------------------------------------------------------
-@pytest.mark.parametrize("B,HW,C,act", [(3, 1024, 128, 1), (2, 256, 256, 1), (2, 64, 384, 1), (5, 16, 512, 0), (2, 256, 16, 1)])
+@pytest.mark.parametrize("B,HW,C,act", [(3, 1024, 128, 1), (2, 256, 256, 1), (2, 64, 384, 1), (5, 16, 512, 0), (2, 256, 16, 1),
+                                        (2, 64, 192, 1)])  # 192 channels: 32 groups of 6 -> the generic path
 def test_group_norm_matches_oracle(dev, B, HW, C, act):
     from gddim_amd import ops
     from oracle import ncsnpp as onet
@@ -203,3 +204,17 @@ def test_conv2d_shape_fuzz(dev):
         assert err < 2e-5, (B, H, W, Cin, Cout, k, stride, bias, res, err)
 
     run()
+
+
+@pytest.mark.parametrize("up", [True, False])
+def test_naive_resample_matches_oracle(dev, up):
+    from gddim_amd import ops
+    from oracle import ncsnpp as onet
+    rng = np.random.default_rng(12)
+    x = rng.standard_normal((3, 8, 6, 20)).astype(np.float32)
+    xt = torch.as_tensor(x, dtype=torch.float64)
+    want = onet.naive_upsample_2d(xt) if up else onet.naive_downsample_2d(xt)
+    got = ops.fir_resample(torch.as_tensor(x, device=dev), up, naive=True).cpu().numpy()
+    assert got.shape == tuple(want.shape) and np.abs(got - want.numpy()).max() < 1e-6
+    if up:
+        assert np.array_equal(got, np.repeat(np.repeat(x, 2, axis=1), 2, axis=2))  # exact: pure replication

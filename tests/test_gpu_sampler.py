@@ -384,3 +384,25 @@ def test_sdeis_sampler_matches_oracle_with_the_same_noise(cld_setup, order, use_
     ex, ev = np.abs(x.cpu().numpy() - wx).max(), np.abs(v.cpu().numpy() - wv).max()
     print("sdeis order=%d: max|dx| %.3e max|dv| %.3e (|x| %.3e |v| %.3e)" % (order, ex, ev, np.abs(wx).max(), np.abs(wv).max()))
     assert n == nfe and np.isfinite(wx).all() and ex < _tol(wx) and ev < _tol(wv)
+
+
+def test_deis_sampler_on_a_ddpmpp_style_network(native_lib):
+    """The sampler is architecture agnostic: the reference's smaller U-Net flavour (positional embedding, fir=False) in the loop."""
+    from gddim_amd.cld import sampling, sde_lib
+    from gddim_amd.datasets import get_data_inverse_scaler
+    from gddim_amd.models import utils as mutils
+    cfg = tiny_config("cld", nf=32, num_res_blocks=2, image_size=16, ch_mult=(1, 2, 2), attn=(8,), progressive_input='none')
+    cfg.model.fir = False
+    cfg.model.embedding_type = 'positional'
+    params = onet.random_params(cfg, 6, seed=8)
+    sde = sde_lib.from_config(cfg)
+    osde = ocld.CLD(is_R_rk=cfg.model.is_R_rk, R_dt=cfg.model.R_dt, dtype=np.float64)
+    model = mutils.get_model(cfg.model.name)(config=cfg)
+    state = mutils.State(params_ema=params, model_state={})
+    rng = np.random.default_rng(3)
+    u = np.stack([rng.standard_normal((2, 16, 16, 3)), rng.standard_normal((2, 16, 16, 3)) / 2], axis=-1).astype(np.float32)
+    fn = sampling.get_deis_sampler(sde, model, (16, 16, 3), 6, get_data_inverse_scaler(cfg), deis_order=2, denoising=True)
+    x, v, _ = fn(0, state, 2, torch.as_tensor(u, device="cuda:0"))
+    wx, wv, _ = ocld.deis_sampler(osde, onet.cld_eps_fn(params, cfg, dtype=torch.float64), u.astype(np.float64), 6, 2, denoising=True,
+                                  inverse_scaler=ocld.inverse_scaler_centered)
+    assert np.abs(x.cpu().numpy() - wx).max() < _tol(wx) and np.abs(v.cpu().numpy() - wv).max() < _tol(wv)

@@ -92,3 +92,19 @@ def test_compute_fails_loudly_without_params(native_lib):
     with pytest.raises(GddimError):
         eng.unet(torch.zeros(1, 16, 16, 6, device="cuda:0"), torch.ones(1, device="cuda:0"))
     eng.close()
+
+
+@pytest.mark.parametrize("nf,nrb,size", [(64, 4, 32), (32, 2, 16)])
+def test_unet_ddpmpp_style_matches_oracle(native_lib, nf, nrb, size):
+    """configs/ddpmpp_cifar10_config.py / debug_ / simple_: positional embedding, fir=False, progressive_input='none',
+    num_res_blocks=4 (first case: the reference's debug config at full depth, nf=64)."""
+    cfg = tiny_config("cld", nf=nf, num_res_blocks=nrb, image_size=size, ch_mult=(1, 2, 2, 2) if size == 32 else (1, 2, 2),
+                      attn=(16,) if size == 32 else (8,), progressive_input='none')
+    cfg.model.fir = False
+    cfg.model.embedding_type = 'positional'
+    eng, params, x, t, got, want = _forward_pair(cfg, 6, B=3, seed=21)
+    assert np.isfinite(got).all() and np.abs(got - want).max() < 1e-4 * max(1.0, np.abs(want).max()), np.abs(got - want).max()
+    eng.set_precision("bf16x3")
+    got3 = eng.unet(torch.as_tensor(x, device="cuda:0"), torch.as_tensor((t * 999).astype(np.float32), device="cuda:0")).cpu().numpy()
+    assert np.abs(got3 - want).max() < 1e-4 * max(1.0, np.abs(want).max())
+    eng.close()

@@ -91,3 +91,63 @@ def test_flops_match_survey(native_lib):
     e = Engine(blur_ddpm_deep_cifar10.get_config(), 3, 1, plan_only=True)
     assert abs(e.flops_per_image(True) / 1e9 - 33.688) < 1e-3
     e.close()
+
+
+def test_plan_matches_oracle_ddpmpp_style(native_lib):
+    """The reference's smaller configurations (configs/ddpmpp_cifar10_config.py, simple_, debug_): sinusoidal positional
+    embedding (layers.py:450-464), fir=False (nearest-neighbour / 2x2-mean resampling, up_or_down_sampling.py:76-86), no input
+    pyramid, 4 res blocks per level in the originals (2 here)."""
+    cfg = tiny_config("cld", nf=32, num_res_blocks=2, image_size=16, ch_mult=(1, 2, 2), attn=(8,), progressive_input='none')
+    cfg.model.fir = False
+    cfg.model.embedding_type = 'positional'
+    got, want = _run(cfg, 6, B=2, seed=5)
+    err = (got - want).abs().max().item()
+    assert torch.isfinite(got).all() and err < 2e-5 * max(1.0, want.abs().max().item()), err
+    # blur flavour: 3 channels
+    bcfg = tiny_config("blur", nf=16, num_res_blocks=1, image_size=32, ch_mult=(1, 2), attn=(16,), progressive_input='none')
+    bcfg.model.fir = False
+    bcfg.model.embedding_type = 'positional'
+    got, want = _run(bcfg, 3, B=1, seed=6)
+    assert (got - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item())
+    # fir=False together with the input pyramid is not a configuration of the reference: refused loudly
+    from gddim_amd._abi import GddimError
+    from gddim_amd.engine import Engine
+    bad = tiny_config("cld")
+    bad.model.fir = False
+    with pytest.raises(GddimError):
+        Engine(bad, 6, max_batch=1, plan_only=True)
+
+
+def test_plan_groups_that_cut_float4_columns(native_lib):
+    """nf = 64 (configs/debug_cifar10_config.py): the up path normalises 128 + 64 = 192 concatenated channels in 32 groups of 6,
+    which the quad statistics cannot express -> the planner's generic GroupNorm op."""
+    from gddim_amd.engine import Engine
+    cfg = tiny_config("cld", nf=64, num_res_blocks=1, image_size=8, ch_mult=(1, 2), attn=(4,), progressive_input='none')
+    cfg.model.fir = False
+    cfg.model.embedding_type = 'positional'
+    eng = Engine(cfg, 6, max_batch=1, plan_only=True)
+    assert [op["kind"] for op in eng.plan()["ops"]].count(9) >= 1
+    eng.close()
+    got, want = _run(cfg, 6, B=2, seed=9)
+    assert (got - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item())
+
+
+def test_every_shipped_configuration_plans(native_lib):
+    """gddim_amd.configs.variants: every model configuration of the reference (CIFAR-10) lowers to a plan whose parameter tree
+    has the flax names / shapes the oracle derives for it, with the expected size."""
+    from gddim_amd.configs import variants
+    from gddim_amd.engine import Engine
+    sizes = {}
+    for name in variants.names():
+        cfg = variants.get_config(name)
+        in_ch = 6 if name.startswith("cld") else 3
+        eng = Engine(cfg, in_ch, max_batch=1, plan_only=True)
+        specs = eng.param_specs()
+        want = oracle_net.param_shapes(cfg, in_ch)
+        assert set(specs) == set(want) and all(tuple(want[k]) == specs[k] for k in specs), name
+        sizes[name] = sum(int(np.prod(s)) for s in specs.values())
+        eng.close()
+    assert 107e6 < sizes['cld_accr_dcifar10'] < 108e6 and sizes['cld_deep_cifar10'] == sizes['cld_accr_dcifar10']
+    assert 61e6 < sizes['cld_ddpmpp_cifar10'] < 62.5e6  # the DDPM++ of Song et al. (61.8 M at 3 channels)
+    assert sizes['cld_simple_cifar10'] < sizes['blur_debug_cifar10'] < sizes['blur_ddpmpp_cifar10']
+    assert variants.get_config('cld_ndeep_cifar10').model.mixed_score is True
