@@ -69,3 +69,44 @@ def test_bf16x3_sampler_matches_oracle(native_lib):
     print("bf16x3 sampler: rel err x %.3e v %.3e (fp32 mode %.3e)" % (ex, ev, e32))
     assert not torch.equal(x, x32)
     assert ex < 1e-4 and ev < 1e-4
+
+
+def test_production_batch_kernels_match_oracle(native_lib):
+    """At the benchmark's batch (256) the planner picks other kernels than at the small batches of the tests above: fp32
+    128x128 / 128x64 tiles, the split-precision 256x128 kernel on pre-split activations and the halo-staged 3x3 kernel.  Every image
+    is an independent unit, so the first three images of a 256-image batch are checked against the float64 oracle of those three
+    images (same bars as the small-batch tests), in both precision modes; the profile must show that those kernels really ran."""
+    from gddim_amd.configs import cld_accr_dcifar10
+    from gddim_amd.engine import Engine
+    cfg = cld_accr_dcifar10.get_config()
+    params = onet.random_params(cfg, 6, seed=0)
+    rng = np.random.default_rng(1)
+    B, n_ref = 256, 3
+    x = rng.standard_normal((B, 32, 32, 6)).astype(np.float32)
+    t = rng.uniform(1e-3, 1.0, size=B).astype(np.float32)
+    labels = (t * 999).astype(np.float32)
+    with torch.no_grad():
+        want64 = onet.ncsnpp_forward(params, torch.as_tensor(x[:n_ref], dtype=torch.float64),
+                                     torch.as_tensor(labels[:n_ref], dtype=torch.float64), cfg).numpy()
+        want32 = onet.ncsnpp_forward(params, torch.as_tensor(x[:n_ref]), torch.as_tensor(labels[:n_ref]), cfg).numpy()
+    scale = max(1.0, np.abs(want64).max())
+    e_f32 = np.abs(want32 - want64).max() / scale
+    eng = Engine(cfg, 6, max_batch=B, device=0).load_params(params)
+    xt, lt = torch.as_tensor(x, device="cuda:0"), torch.as_tensor(labels, device="cuda:0")
+    seen = {}
+    for mode in ("fp32", "bf16x3"):
+        eng.set_precision(mode)
+        eng.profile(True)
+        got = eng.unet(xt, lt).cpu().numpy()
+        seen[mode] = {p["name"] for p in eng.profile_read()}
+        eng.profile(False)
+        err = np.abs(got[:n_ref] - want64).max() / scale
+        print("B=256 %s: |hip-f64| %.3e (float32 oracle %.3e)" % (mode, err, e_f32))
+        assert np.isfinite(got).all() and err < max(4 * e_f32, 2e-5), (mode, err, e_f32)
+        # the same three images alone (small-batch kernels) agree with their slots in the big batch
+        small = eng.unet(xt[:n_ref], lt[:n_ref]).cpu().numpy()
+        assert np.abs(small - got[:n_ref]).max() / scale < 2e-5
+    eng.close()
+    assert "igemm_f32_fast_kernel<128,128,2,4,false>" in seen["fp32"] and "igemm_f32_fast_kernel<128,64,4,2,false>" in seen["fp32"]
+    assert "conv3x3_halo_bf16x3_kernel" in seen["bf16x3"] and "igemm_bf16x3_kernel<256,128,4,2>" in seen["bf16x3"]
+    assert any(n.startswith("igemm_bf16x3_kernel<128,128,2,4,pre") for n in seen["bf16x3"])

@@ -406,3 +406,28 @@ def test_deis_sampler_on_a_ddpmpp_style_network(native_lib):
     wx, wv, _ = ocld.deis_sampler(osde, onet.cld_eps_fn(params, cfg, dtype=torch.float64), u.astype(np.float64), 6, 2, denoising=True,
                                   inverse_scaler=ocld.inverse_scaler_centered)
     assert np.abs(x.cpu().numpy() - wx).max() < _tol(wx) and np.abs(v.cpu().numpy() - wv).max() < _tol(wv)
+
+
+def test_production_batch_sampler_matches_oracle(native_lib):
+    """The benchmark's shapes (accr_dcifar10 U-Net, 256 images per call, hipGraph replay): the first two images of the batch
+    against the float64 oracle loop on those two images (images are independent units), NFE 4 to keep the CPU side short."""
+    from gddim_amd.cld import sampling, sde_lib
+    from gddim_amd.configs import cld_accr_dcifar10
+    from gddim_amd.datasets import get_data_inverse_scaler
+    from gddim_amd.models import utils as mutils
+    cfg = cld_accr_dcifar10.get_config()
+    params = onet.random_params(cfg, 6, seed=0)
+    sde = sde_lib.from_config(cfg)
+    osde = ocld.CLD(is_R_rk=cfg.model.is_R_rk, R_dt=cfg.model.R_dt, dtype=np.float64)
+    model = mutils.get_model(cfg.model.name)(config=cfg)
+    state = mutils.State(params_ema=params, model_state={})
+    rng = np.random.default_rng(2)
+    B, n_ref, nfe = 256, 2, 4
+    u = np.stack([rng.standard_normal((B, 32, 32, 3)), rng.standard_normal((B, 32, 32, 3)) / 2], axis=-1).astype(np.float32)
+    fn = sampling.get_deis_sampler(sde, model, (32, 32, 3), nfe, get_data_inverse_scaler(cfg), deis_order=2, ts_order=2, denoising=True)
+    x, v, _ = fn(0, state, B, torch.as_tensor(u, device="cuda:0"))
+    wx, wv, _ = ocld.deis_sampler(osde, onet.cld_eps_fn(params, cfg, dtype=torch.float64), u[:n_ref].astype(np.float64), nfe, 2, ts_order=2,
+                                  denoising=True, inverse_scaler=ocld.inverse_scaler_centered)
+    ex, ev = np.abs(x[:n_ref].cpu().numpy() - wx).max(), np.abs(v[:n_ref].cpu().numpy() - wv).max()
+    print("B=256 sampler: max|dx| %.3e max|dv| %.3e (|x| %.3e |v| %.3e)" % (ex, ev, np.abs(wx).max(), np.abs(wv).max()))
+    assert torch.isfinite(x).all() and ex < _tol(wx) and ev < _tol(wv)
