@@ -76,6 +76,10 @@ struct GemmParams {
     // bf16x3 path: 1 = a0 already holds split activations, row m = [lda0 bf16 hi | lda0 bf16 lo] (same bytes per row as fp32),
     // written by the producing GroupNorm-apply / FIR kernel
     int a_presplit;
+    // conv3x3_halo_bf16x3 with a fused GroupNorm: a0 is the RAW fp32 input of the normalisation, gn_table[img] = [C scale | C shift]
+    // (gn_apply_kernel in table mode), gn_act = 1 applies swish; the kernel normalises, activates and splits while staging
+    const float *gn_table;
+    int gn_act;
     // fused GroupNorm statistics of the OUTPUT: qstats[img][slice][n/4] = (sum, sum of squares) over the slice's rows of
     // columns 4*(n/4)..+3; slice = 32 output rows (qs_slices = rows_per_image/32 per image), or one image when
     // rows_per_image == 16 (qs_slices = 1).  Unique writer per entry: deterministic.  null = not requested.
@@ -92,7 +96,9 @@ int launch_igemm_bf16x3(const GemmParams &p, hipStream_t s);
 // 3x3 stride-1 convolutions on pre-split activations with the input halo staged once per channel slab
 // (kernels/conv3x3_halo_bf16x3.hip); GDDIM_X3_NOHALO=1 routes them back to igemm_bf16x3_kernel
 bool conv3x3_halo_ok(const GemmParams &p);
+bool conv3x3_halo_fused_ok(const GemmParams &p);  // shape test of the fused-GroupNorm variant (p.a0 raw fp32, p.gn_table set)
 const char *conv3x3_halo_name();
+const char *conv3x3_halo_fused_name();
 int launch_conv3x3_halo(const GemmParams &p, hipStream_t s);
 // per-device zero buffer used by the staging loads; allocates on first use (call once outside graph capture)
 const float *igemm_zero_buffer();
@@ -106,9 +112,10 @@ int launch_gn_stats(const float *x, int C, float *qs, int batch, int HW, int sli
 // normalise (+ swish); (mean, rstd) per (b, group) are reduced in the kernel's prologue from the quad partial sums of up to
 // two channel-concatenated sources (S0 / S1 slices per image)
 // split_out = 1: out rows are written as [C bf16 hi | C bf16 lo] (the A operand layout of the pre-split bf16x3 GEMM)
+// table != null: nothing is normalised; table[b] = [C scale | C shift] is written for a consumer that applies the map itself
 int launch_gn_apply(const float *x0, int C0, const float *x1, int C1, const float *qs0, int S0, const float *qs1, int S1,
                     const float *gamma, const float *beta, float *out, int batch, int HW, int groups, int act, float eps,
-                    int split_out, hipStream_t s);
+                    int split_out, float *table, hipStream_t s);
 // GroupNorm for group sizes that are not a multiple of 4 channels: direct statistics + element-wise apply
 int launch_gn_generic(const float *x0, int C0, const float *x1, int C1, float *mr, const float *gamma, const float *beta,
                       float *out, int batch, int HW, int groups, int act, float eps, hipStream_t s);

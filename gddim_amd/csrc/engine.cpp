@@ -55,6 +55,7 @@ struct gd_engine {
     int precision = 0;
     unsigned short *wsplit_hi = nullptr, *wsplit_lo = nullptr;  // bf16 hi / lo of wbuf, same element offsets
     bool wsplit_valid = false;
+    std::map<int, std::vector<char>> fuse_ok;      // batch size -> per GEMM op: the fused-GroupNorm halo kernel takes it
     std::map<int, std::vector<char>> presplit_ok;  // batch size -> per tensor: may be stored pre-split (see presplit_allowed)
     std::vector<long long> slot_off;  // floats into wbuf
     long long wbuf_floats = 0;
@@ -195,7 +196,31 @@ static bool presplit_allowed(gd_engine *e, const Bind &b, int batch, int tensor)
     return tensor >= 0 && it->second[tensor] != 0;
 }
 
-static int run_op(gd_engine *e, const Op &op, const Bind &b, int batch, hipStream_t s) {
+// Fused GroupNorm (plan.h: Op::fuse_peer): taken when, at this batch size, the halo kernel accepts the convolution and the
+// tensor between the two ops would otherwise be stored pre-split.  gemm_index: the convolution's op index.  Decided once per batch.
+static bool gn_fused(gd_engine *e, const Bind &b, int batch, int gemm_index) {
+    if (e->precision != 1 || !e->wsplit_valid) return false;
+    auto it = e->fuse_ok.find(batch);
+    if (it == e->fuse_ok.end()) {
+        std::vector<char> ok(e->plan.ops.size(), 0);
+        for (size_t i = 0; i < e->plan.ops.size(); ++i) {
+            const Op &op = e->plan.ops[i];
+            if (op.kind != OP_GEMM || op.fuse_peer < 0 || !op.a_split) continue;
+            if (!presplit_allowed(e, b, batch, op.a0.t)) continue;
+            GemmParams g{};
+            const int z = fill_gemm(e, op, b, batch, g);
+            g.b_hi = e->wsplit_hi + e->slot_off[op.w_slot];
+            g.b_lo = e->wsplit_lo + e->slot_off[op.w_slot];
+            g.a0 = tptr(e, b, op.gn_src, batch);
+            ok[i] = (z == 1 && conv3x3_halo_fused_ok(g)) ? 1 : 0;
+        }
+        it = e->fuse_ok.emplace(batch, std::move(ok)).first;
+    }
+    return it->second[gemm_index] != 0;
+}
+
+static int run_op(gd_engine *e, int op_index, const Bind &b, int batch, hipStream_t s) {
+    const Op &op = e->plan.ops[op_index];
     const Plan &P = e->plan;
     static const bool by_label = getenv("GD_PROF_BY_LABEL") != nullptr;
     switch (op.kind) {
@@ -212,6 +237,14 @@ static int run_op(gd_engine *e, const Op &op, const Bind &b, int batch, hipStrea
                 g.b_lo = e->wsplit_lo + e->slot_off[op.w_slot];
                 g.a_presplit = op.a_split && presplit_allowed(e, b, batch, op.a0.t);
                 GD_CHECK(!g.a_presplit || igemm_bf16x3_ok(g, z), "%s: pre-split input but the GEMM is not eligible for bf16x3", op.label.c_str());
+                if (op.fuse_peer >= 0 && gn_fused(e, b, batch, op_index)) {
+                    g.a0 = tptr(e, b, op.gn_src, batch);  // the raw input of the GroupNorm
+                    g.a_presplit = 0;
+                    g.gn_table = tptr(e, b, op.gn_table, batch);
+                    g.gn_act = e->plan.ops[op.fuse_peer].act;
+                    ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(conv3x3_halo_fused_name()), op.flops_per_image * batch, 0);
+                    return launch_conv3x3_halo(g, s);
+                }
                 if (z == 1 && conv3x3_halo_ok(g)) {
                     ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(conv3x3_halo_name()), op.flops_per_image * batch, 0);
                     return launch_conv3x3_halo(g, s);
@@ -235,12 +268,14 @@ static int run_op(gd_engine *e, const Op &op, const Bind &b, int batch, hipStrea
         case OP_GN_APPLY: {
             const int HW = op.H * op.W;
             const int rt = gn_slices(batch, HW);
-            ProfScope ps(e, s, "gn_apply", 0, 8.0 * batch * HW * (op.C0 + op.C1));
+            const bool table_only = op.fuse_peer >= 0 && gn_fused(e, b, batch, op.fuse_peer);
+            ProfScope ps(e, s, table_only ? "gn_table" : "gn_apply", 0, table_only ? 0.0 : 8.0 * batch * HW * (op.C0 + op.C1));
             return launch_gn_apply(tptr(e, b, op.a0, batch), op.C0, tptr(e, b, op.a1, batch), op.C1, tptr(e, b, op.stats, batch),
                                    op.S0 > 0 ? op.S0 : rt, tptr(e, b, op.stats1, batch), op.S1 > 0 ? op.S1 : rt,
                                    slot_ptr(e, op.gamma_slot), slot_ptr(e, op.beta_slot), tptr(e, b, op.out, batch), batch, HW,
                                    op.groups, op.act, 1e-6f,
-                                   (e->precision == 1 && e->wsplit_valid && op.split_out && presplit_allowed(e, b, batch, op.out.t)) ? 1 : 0, s);
+                                   (e->precision == 1 && e->wsplit_valid && op.split_out && presplit_allowed(e, b, batch, op.out.t)) ? 1 : 0,
+                                   table_only ? tptr(e, b, op.gn_table, batch) : nullptr, s);
         }
         case OP_GN_GENERIC: {
             ProfScope ps(e, s, "gn_generic", 0, 12.0 * batch * op.H * op.W * (op.C0 + op.C1));
@@ -277,7 +312,7 @@ static int run_op(gd_engine *e, const Op &op, const Bind &b, int batch, hipStrea
 }
 
 static int run_unet(gd_engine *e, const Bind &b, int batch, hipStream_t s) {
-    for (const Op &op : e->plan.ops) GD_TRY(run_op(e, op, b, batch, s));
+    for (int i = 0; i < (int)e->plan.ops.size(); ++i) GD_TRY(run_op(e, i, b, batch, s));
     return 0;
 }
 
@@ -943,7 +978,7 @@ int gd_group_norm(const float *x_dev, const float *scale_dev, const float *bias_
     float *qs = nullptr;
     GD_HIP(hipMalloc((void **)&qs, (size_t)batch * sl * (C / 4) * 2 * sizeof(float)));
     int r = launch_gn_stats(x_dev, C, qs, batch, HW, sl, s);
-    if (!r) r = launch_gn_apply(x_dev, C, nullptr, 0, qs, sl, nullptr, 0, scale_dev, bias_dev, out_dev, batch, HW, groups, act, 1e-6f, 0, s);
+    if (!r) r = launch_gn_apply(x_dev, C, nullptr, 0, qs, sl, nullptr, 0, scale_dev, bias_dev, out_dev, batch, HW, groups, act, 1e-6f, 0, nullptr, s);
     (void)hipStreamSynchronize(s);
     (void)hipFree(qs);
     return r;

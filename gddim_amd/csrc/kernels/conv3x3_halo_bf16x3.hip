@@ -17,6 +17,7 @@
 #include <cstdlib>
 
 #include "../common.h"
+#include "act.h"
 #include "epilogue.h"
 
 namespace gd {
@@ -34,6 +35,11 @@ constexpr int HB_PLANE = HBN_ * HREC;      // one plane of the weight chunk
 constexpr int HSTAGE = 2 * HA_PLANE + 2 * HB_PLANE;  // elements per stage: A_hi | A_lo | B_hi | B_lo
 constexpr int HAJ = (HP_MAX * 8 + 511) / 512;        // 16-byte halo pieces per thread per slab (8 per pixel: 4 hi + 4 lo)
 
+// FUSE: the input is the RAW fp32 tensor of a GroupNorm(+swish) whose per-(image, channel) affine map comes in p.gn_table; the
+// normalisation, the activation and the bf16 hi/lo split are applied to the halo values in registers between the global load and
+// the LDS store, once per halo element (x 1.33 of the tile) -- the separate gn_apply pass over the tensor (4 B read + 4 B write per
+// element) disappears.  A thread's pieces are float4 columns (4 channels) of one fixed 4-channel slot of every slab.
+template <bool FUSE>
 __global__ __launch_bounds__(512) void conv3x3_halo_bf16x3_kernel(const GemmParams p) {
     constexpr int NT = 512, WN = 2, RM = 2, RN = 2;
     constexpr int OOB = (int)0x80000000u;
@@ -81,17 +87,20 @@ __global__ __launch_bounds__(512) void conv3x3_halo_bf16x3_kernel(const GemmPara
 #pragma unroll
     for (int j = 0; j < HAJ; ++j) {
         const int q = tid + NT * j;
-        const int plane = q >= HP * 4 ? 1 : 0;
+        // pre-split source: piece -> (plane, pixel, 16-byte slot of 8 bf16); raw fp32 source: piece -> (pixel, float4 slot), the
+        // slot (q & 7 = tid & 7) is the same for all pieces of a thread
+        const int plane = FUSE ? 0 : (q >= HP * 4 ? 1 : 0);
         const int r = q - plane * HP * 4;
-        const int pix = r >> 2, slot = r & 3;
+        const int pix = FUSE ? q >> 3 : r >> 2, slot = FUSE ? q & 7 : r & 3;
         avo[j] = OOB;
         alds[j] = 0;
         if (q < HP * 8) {
             const int hy = pix / HW2, hx = pix - hy * HW2;
             const int y = y0 + hy - 1, x = hx - 1;
-            alds[j] = plane * HA_PLANE + pix * HREC + slot * 8;
+            alds[j] = FUSE ? pix * HREC + slot * 4 : plane * HA_PLANE + pix * HREC + slot * 8;
             if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W && img < a_imgs)
-                avo[j] = ((img * H + y) * W + x) * p.lda0 * 4 + plane * p.lda0 * 2 + slot * 16;
+                avo[j] = FUSE ? ((img * H + y) * W + x) * p.lda0 * 4 + slot * 16
+                              : ((img * H + y) * W + x) * p.lda0 * 4 + plane * p.lda0 * 2 + slot * 16;
             else
                 avo[j] = OOB;  // inside the halo but outside the image: the load returns zero and the zero is stored
         }
@@ -103,12 +112,39 @@ __global__ __launch_bounds__(512) void conv3x3_halo_bf16x3_kernel(const GemmPara
 
     hu32x4 ra[HAJ], rbh, rbl;
     const int nslab = C / 32;
+    // fused GroupNorm: scale / shift of the thread's four channels in the slab being staged (tab) and the next one (tab_n)
+    const float *tab_base = FUSE ? p.gn_table + (size_t)(img < a_imgs ? img : 0) * 2 * C + (tid & 7) * 4 : nullptr;
+    hf32x4 sc4 = {0.f, 0.f, 0.f, 0.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
+    auto load_tab = [&](int slab) {
+        if (FUSE && slab < nslab) {
+            sc4 = *reinterpret_cast<const hf32x4 *>(tab_base + slab * 32);
+            sh4 = *reinterpret_cast<const hf32x4 *>(tab_base + C + slab * 32);
+        }
+    };
     auto load_halo = [&](int j, int slab) {
         const bool ok = slab < nslab;
-        ra[j] = __builtin_amdgcn_raw_buffer_load_b128(srd_a, ok ? avo[j] : OOB, slab * 64, 0);
+        ra[j] = __builtin_amdgcn_raw_buffer_load_b128(srd_a, ok ? avo[j] : OOB, slab * (FUSE ? 128 : 64), 0);
     };
     auto store_halo = [&](int j, __bf16 *st) {
-        if (tid + NT * j < HP * 8) *reinterpret_cast<hu32x4 *>(st + alds[j]) = ra[j];
+        if (tid + NT * j >= HP * 8) return;
+        if (!FUSE) {
+            *reinterpret_cast<hu32x4 *>(st + alds[j]) = ra[j];
+            return;
+        }
+        typedef __bf16 hbf16x4 __attribute__((ext_vector_type(4)));
+        const hf32x4 v = __builtin_bit_cast(hf32x4, ra[j]);
+        hbf16x4 h, l;
+        const bool inside = avo[j] != OOB;  // zero padding applies to the ACTIVATED tensor: outside pixels stay exactly zero
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float y = v[i] * sc4[i] + sh4[i];
+            y = p.gn_act ? swish_e(y) : y;
+            y = inside ? y : 0.f;
+            h[i] = (__bf16)y;
+            l[i] = (__bf16)(y - (float)h[i]);
+        }
+        *reinterpret_cast<hbf16x4 *>(st + alds[j]) = h;
+        *reinterpret_cast<hbf16x4 *>(st + HA_PLANE + alds[j]) = l;
     };
     auto load_b = [&](int tap, int slab) {
         const int soff = (tap * C + slab * 32) * 2;
@@ -144,6 +180,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_bf16x3_kernel(const GemmPara
     const int b_off = 2 * HA_PLANE + (wn * 64 + li) * HREC + lh * 8;
 
     // ---- prologue: halo of slab 0 and weight chunk (tap 0, slab 0) into stage 0; prefetch chunk (tap 1, slab 0) ----
+    load_tab(0);
 #pragma unroll
     for (int j = 0; j < HAJ; ++j) load_halo(j, 0);
     load_b(0, 0);
@@ -196,6 +233,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_bf16x3_kernel(const GemmPara
                         store_b(nxtB);
                         load_b(tap2, slab2);
                     } else if (gap == 1) {
+                        if (tap == 0) load_tab(slab + 1);  // first in the queue: the map of the slab whose pieces follow
                         if (tap < HAJ) load_halo(tap, slab + 1);
                     } else if (gap == 2) {
                         if (tap >= 9 - HAJ) store_halo(tap - (9 - HAJ), nxtA);
@@ -211,9 +249,25 @@ __global__ __launch_bounds__(512) void conv3x3_halo_bf16x3_kernel(const GemmPara
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------------
+static bool halo_shape_ok(const GemmParams &p);
+
+// fused-GroupNorm variant: same shapes, raw fp32 input (GDDIM_X3_NOFUSE=1 keeps the separate gn_apply pass)
+bool conv3x3_halo_fused_ok(const GemmParams &p) {
+    static const int off = (getenv("GDDIM_X3_NOHALO") ? atoi(getenv("GDDIM_X3_NOHALO")) : 0) |
+                           (getenv("GDDIM_X3_NOFUSE") ? atoi(getenv("GDDIM_X3_NOFUSE")) : 0);
+    if (off || !p.b_hi || !p.b_lo) return false;
+    GemmParams q = p;
+    q.a_presplit = 1;  // the addressing limits of the shared eligibility test are those of a 4-byte-per-element source
+    return halo_shape_ok(q);
+}
+
 bool conv3x3_halo_ok(const GemmParams &p) {
     static const int off = getenv("GDDIM_X3_NOHALO") ? atoi(getenv("GDDIM_X3_NOHALO")) : 0;
     if (off || !p.a_presplit || !p.b_hi || !p.b_lo) return false;
+    return halo_shape_ok(p);
+}
+
+static bool halo_shape_ok(const GemmParams &p) {
     if (p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1 || p.C1 != 0 || p.C0 % 32 != 0 || p.lda0 != p.C0) return false;
     if (p.H != p.W || p.OH != p.H || p.OW != p.W || (p.W != 32 && p.W != 16)) return false;
     if ((p.H * p.W) % HBM_ != 0 || p.M % HBM_ != 0 || p.N <= 64) return false;
@@ -222,6 +276,7 @@ bool conv3x3_halo_ok(const GemmParams &p) {
 }
 
 const char *conv3x3_halo_name() { return "conv3x3_halo_bf16x3_kernel"; }
+const char *conv3x3_halo_fused_name() { return "conv3x3_halo_bf16x3_kernel<gn>"; }
 
 static void hfill_div(unsigned d, unsigned &magic, unsigned &shift) {
     unsigned s = 0;
@@ -232,13 +287,14 @@ static void hfill_div(unsigned d, unsigned &magic, unsigned &shift) {
 
 int launch_conv3x3_halo(const GemmParams &p_in, hipStream_t s) {
     GemmParams p = p_in;
-    GD_CHECK(conv3x3_halo_ok(p), "conv3x3_halo: problem not eligible");
+    GD_CHECK(p.gn_table ? conv3x3_halo_fused_ok(p) : conv3x3_halo_ok(p), "conv3x3_halo: problem not eligible");
     hfill_div((unsigned)(p.rows_per_image > 0 ? p.rows_per_image : 1), p.mg_rpi, p.sh_rpi);
     p.m_tiles = p.M / HBM_;
     p.n_tiles = (p.N + HBN_ - 1) / HBN_;
     p.flat_tiles = p.m_tiles < 16;
     const int gx = p.flat_tiles ? p.m_tiles * p.n_tiles : ((p.m_tiles + 7) / 8) * 8 * p.n_tiles;
-    hipLaunchKernelGGL(conv3x3_halo_bf16x3_kernel, dim3(gx), dim3(512), 0, s, p);
+    if (p.gn_table) hipLaunchKernelGGL(conv3x3_halo_bf16x3_kernel<true>, dim3(gx), dim3(512), 0, s, p);
+    else hipLaunchKernelGGL(conv3x3_halo_bf16x3_kernel<false>, dim3(gx), dim3(512), 0, s, p);
     GD_HIP(hipGetLastError());
     return 0;
 }

@@ -12,12 +12,12 @@
 //   softmax    jax.nn.softmax over the key axis               (layerspp.py:76)
 //   Fourier    [sin, cos](2 pi W log(labels))                 (layerspp.py:33-43, ncsnpp.py:74-77)
 #include "../common.h"
+#include "act.h"
 
 namespace gd {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ float swish_e(float x) { return x * __frcp_rn(1.0f + __expf(-x)); }
 
 int gn_slices(int batch, int HW) {
     // enough blocks to fill 256 CUs several times over, but at least 64 pixels per slice
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float *__restrict__
                                                         const float *__restrict__ qs1, int S1,
                                                         const float *__restrict__ gamma, const float *__restrict__ beta,
                                                         float *__restrict__ out, int HW, int groups, int act, float inv_n,
-                                                        float eps, int split_out) {
+                                                        float eps, int split_out, float *__restrict__ table) {
     __shared__ float s_sum[256], s_sq[256];
     const int C = C0 + C1, C4 = C >> 2;
     const int Q0 = C0 >> 2, Q1 = C1 >> 2;
@@ -126,6 +126,14 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float *__restrict__
     f32x4 sc, sh;
 #pragma unroll
     for (int i = 0; i < 4; ++i) { sc[i] = rstd * ga[i]; sh[i] = be[i] - mean * rstd * ga[i]; }
+    if (table) {  // table mode: only the per-channel affine map of this image, table[b] = [C scale | C shift]; the consumer
+                  // GEMM applies it (and the activation) while it stages its input (conv3x3_halo_bf16x3.hip)
+        if (blockIdx.x == 0 && rp == 0) {
+            *reinterpret_cast<f32x4 *>(table + (size_t)b * 2 * C + c) = sc;
+            *reinterpret_cast<f32x4 *>(table + (size_t)b * 2 * C + C + c) = sh;
+        }
+        return;
+    }
     const float *src;
     int ld, cc;
     if (c < C0) { src = x0; ld = C0; cc = c; } else { src = x1; ld = C1; cc = c - C0; }
@@ -232,15 +240,15 @@ int launch_gn_stats(const float *x, int C, float *qs, int batch, int HW, int sli
 
 int launch_gn_apply(const float *x0, int C0, const float *x1, int C1, const float *qs0, int S0, const float *qs1, int S1,
                     const float *gamma, const float *beta, float *out, int batch, int HW, int groups, int act, float eps,
-                    int split_out, hipStream_t s) {
+                    int split_out, float *table, hipStream_t s) {
     const int C = C0 + C1;
     GD_CHECK(C % 4 == 0 && C0 % 4 == 0 && C / 4 <= 256 && (C / 4) % groups == 0 && groups <= 256 && groups >= 1,
              "group_norm: unsupported C=%d (C0=%d) groups=%d", C, C0, groups);
     int nblk = 1;
-    while (nblk < 64 && (long long)batch * nblk < 4096 && HW / (nblk * 2) >= 16) nblk *= 2;
+    while (!table && nblk < 64 && (long long)batch * nblk < 4096 && HW / (nblk * 2) >= 16) nblk *= 2;
     const float inv_n = 1.0f / ((float)HW * (float)(C / groups));
     hipLaunchKernelGGL(gn_apply_kernel, dim3(nblk, batch), dim3(256), 0, s, x0, C0, x1, C1, qs0, S0, qs1, S1, gamma, beta, out,
-                       HW, groups, act, inv_n, eps, split_out);
+                       HW, groups, act, inv_n, eps, split_out, table);
     GD_HIP(hipGetLastError());
     return 0;
 }

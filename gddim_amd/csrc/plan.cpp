@@ -73,6 +73,7 @@ void Plan::release(int t) {
     if (--T.refs == 0 && T.ext == EXT_NONE) {
         arena_free(T.offset, T.per_image);
         if (T.stats_t >= 0) release(T.stats_t);
+        if (T.table_t >= 0) release(T.table_t);
     }
 }
 
@@ -144,11 +145,13 @@ int Plan::gn(const std::string &label, const std::string &pname, int xa, int Ca,
         }
     }
     int out = new_tensor(label + ".out", H, W, C);
+    if (Cb == 0) tensors[out].table_t = new_tensor(label + ".affine", 1, 1, 2 * C);  // lives as long as the output
     Op a;
     a.kind = OP_GN_APPLY; a.label = label + ".apply";
     a.a0 = {xa, 0}; a.C0 = Ca; a.a1 = {xb, 0}; a.C1 = Cb; a.H = H; a.W = W; a.groups = G;
     a.stats = {qs[0], 0}; a.S0 = S[0]; a.stats1 = {qs[1], 0}; a.S1 = S[1];
     a.act = act; a.gamma_slot = gs; a.beta_slot = bs; a.out = {out, 0};
+    a.gn_table = {tensors[out].table_t, 0};
     ops.push_back(a);
     release(tmp[0]);
     release(tmp[1]);
@@ -214,14 +217,14 @@ int Plan::resblock(int idx, int xa, int Ca, int xb, int Cb, int H, int W, int O,
     // h = Conv_0(h) + Dense_0(act(temb))[:, None, None, :]
     const int tcol = tproj_t_ >= 0 ? rb_tproj_off_[idx] : 0;
     int h1 = conv(n + ".conv0", n + "/Conv_0", h0, C, -1, 0, H2, W2, 3, O, -1, 1.f, tproj_t_, tcol, -1, true);
+    if (!up && !down) link_fused_gn(h0);  // the source of GroupNorm_0 is the block input, alive until the end of the block
     release(h0);
     if (tproj_t_ >= 0) {
         add_param(n + "/Dense_0/kernel", {desc.nf * 4, O}, P_DENSE, tproj_slot_w_, tcol);
         add_param(n + "/Dense_0/bias", {O}, P_VEC, tproj_slot_b_, tcol);
     }
     // h = act(GroupNorm_1(h)); Dropout is the identity at inference
-    int h2 = gn(n + ".gn1", n + "/GroupNorm_1", h1, O, -1, 0, H2, W2, 1);
-    release(h1);
+    int h2 = gn(n + ".gn1", n + "/GroupNorm_1", h1, O, -1, 0, H2, W2, 1);  // h1 stays alive until Conv_1 is out (fused GroupNorm)
     // shortcut: conv1x1 iff C != out_ch or up or down (layerspp.py:221-222)
     int res_t;
     int xs = -1;
@@ -234,6 +237,8 @@ int Plan::resblock(int idx, int xa, int Ca, int xb, int Cb, int H, int W, int O,
     }
     // (x + Conv_1(h)) / sqrt(2)
     int out = conv(n + ".conv1", n + "/Conv_1", h2, O, -1, 0, H2, W2, 3, O, res_t, scale, -1, 0, -1, true);
+    link_fused_gn(h2);
+    release(h1);
     release(h2);
     release(xs);
     release(xr);
@@ -554,6 +559,31 @@ int Plan::build(const gd_model_desc &d) {
     return 0;
 }
 
+// Called right after the convolution that reads GroupNorm output `t` has been emitted (it is the last op): if the apply op that
+// produced `t` has a single source and the convolution has the halo kernel's static shape (3x3, stride 1, 16x16 or 32x32 images,
+// 32-channel slabs, more than 64 outputs), the two ops are linked for the run-time fusion.  The caller keeps the apply op's source
+// tensor alive until the convolution has been emitted.
+void Plan::link_fused_gn(int t) {
+    if (t < 0 || tensors[t].table_t < 0 || ops.empty()) return;
+    const int gi = (int)ops.size() - 1;
+    Op &g = ops[gi];
+    if (g.kind != OP_GEMM || g.a0.t != t || g.a1.t >= 0 || g.KH != 3 || g.KW != 3 || g.stride != 1 || g.pad != 1) return;
+    if (g.H != g.W || (g.W != 32 && g.W != 16) || g.C0 % 32 != 0 || g.N <= 64 || g.N % 4 != 0 || g.w_slot < 0) return;
+    for (int i = gi - 1; i >= 0; --i) {
+        Op &a = ops[i];
+        if (a.kind == OP_GN_APPLY && a.out.t == t) {
+            if (a.C1 != 0 || a.a1.t >= 0 || a.gn_table.t < 0 || a.fuse_peer >= 0) return;
+            for (int j = i + 1; j < gi; ++j)  // the convolution must be the only reader
+                if (ops[j].a0.t == t || ops[j].a1.t == t || ops[j].bten.t == t || ops[j].res.t == t) return;
+            a.fuse_peer = gi;
+            g.fuse_peer = i;
+            g.gn_src = a.a0;
+            g.gn_table = a.gn_table;
+            return;
+        }
+    }
+}
+
 // A GroupNorm-apply output may be stored split (bf16 hi|lo rows) in bf16x3 mode when all of its readers are weight GEMMs the
 // split-precision kernel accepts with a pre-split A operand: whole tensor as the single source, 32-channel slabs.
 void Plan::mark_split() {
@@ -664,7 +694,7 @@ std::string Plan::json() const {
         o << (i ? "," : "") << "{\"kind\":" << p.kind << ",\"label\":\"" << p.label << "\",";
         jref(o, "a0", p.a0); jref(o, "a1", p.a1); jref(o, "bten", p.bten); jref(o, "rowbias", p.rowbias);
         jref(o, "res", p.res); jref(o, "out", p.out); jref(o, "stats", p.stats); jref(o, "stats1", p.stats1); jref(o, "qstats", p.qstats);
-        o << "\"split_out\":" << p.split_out << ",\"a_split\":" << p.a_split << ",";
+        o << "\"split_out\":" << p.split_out << ",\"a_split\":" << p.a_split << ",\"fuse_peer\":" << p.fuse_peer << ",";
         o << "\"C0\":" << p.C0 << ",\"C1\":" << p.C1 << ",\"lda0\":" << p.lda0 << ",\"lda1\":" << p.lda1 << ",\"H\":" << p.H
           << ",\"W\":" << p.W << ",\"OH\":" << p.OH << ",\"OW\":" << p.OW << ",\"KH\":" << p.KH << ",\"KW\":" << p.KW
           << ",\"stride\":" << p.stride << ",\"pad\":" << p.pad << ",\"m_per_image\":" << p.m_per_image

@@ -38,6 +38,7 @@ struct Tensor {
     // its slices per image; -1 when the producer does not emit them
     int stats_t = -1;
     int qs_slices = 0;
+    int table_t = -1;  // companion holding the affine map of the GroupNorm that produced this tensor (see Op::gn_table)
 };
 
 struct TRef {
@@ -74,6 +75,11 @@ struct Op {
     // split precision (bf16x3 mode only): GN_APPLY writes its output as bf16 hi|lo rows (split_out) when every consumer is
     // a weight GEMM that can read them (a_split); decided by Plan::mark_split at build time
     int split_out = 0, a_split = 0;
+    // fused GroupNorm (bf16x3 mode, run-time decision): a GN_APPLY op and the 3x3 convolution that is its only reader point at each
+    // other (fuse_peer = op index).  When the halo kernel takes the convolution at the current batch size the apply op only
+    // writes gn_table (per image [C scale | C shift]) and the convolution reads gn_src, the apply op's raw input.
+    int fuse_peer = -1;
+    TRef gn_table, gn_src;
     TRef qstats;          // GEMM: quad statistics of the output (fused GroupNorm statistics), t = -1: none
     int qs_slices = 0;
     // ---- GroupNorm ----
@@ -130,6 +136,7 @@ struct Plan {
 
     int build(const gd_model_desc &d);  // 0 ok
     void mark_split();
+    void link_fused_gn(int gn_out_tensor);
     int load_param(const std::string &name, const float *data, const int64_t *shape, int ndim);
     std::string json() const;
 
