@@ -211,7 +211,8 @@ static bool gn_fused(gd_engine *e, const Bind &b, int batch, int gemm_index) {
             const int z = fill_gemm(e, op, b, batch, g);
             g.b_hi = e->wsplit_hi + e->slot_off[op.w_slot];
             g.b_lo = e->wsplit_lo + e->slot_off[op.w_slot];
-            g.a0 = tptr(e, b, op.gn_src, batch);
+            g.a0 = tptr(e, b, op.gn_src, batch); g.a1 = tptr(e, b, op.gn_src1, batch);
+            g.C0 = op.gn_C0; g.C1 = op.gn_C1; g.lda0 = op.gn_C0; g.lda1 = op.gn_C1 ? op.gn_C1 : 4;
             ok[i] = (z == 1 && conv3x3_halo_fused_ok(g)) ? 1 : 0;
         }
         it = e->fuse_ok.emplace(batch, std::move(ok)).first;
@@ -238,7 +239,9 @@ static int run_op(gd_engine *e, int op_index, const Bind &b, int batch, hipStrea
                 g.a_presplit = op.a_split && presplit_allowed(e, b, batch, op.a0.t);
                 GD_CHECK(!g.a_presplit || igemm_bf16x3_ok(g, z), "%s: pre-split input but the GEMM is not eligible for bf16x3", op.label.c_str());
                 if (op.fuse_peer >= 0 && gn_fused(e, b, batch, op_index)) {
-                    g.a0 = tptr(e, b, op.gn_src, batch);  // the raw input of the GroupNorm
+                    g.a0 = tptr(e, b, op.gn_src, batch);  // the raw input(s) of the GroupNorm
+                    g.a1 = tptr(e, b, op.gn_src1, batch);
+                    g.C0 = op.gn_C0; g.C1 = op.gn_C1; g.lda0 = op.gn_C0; g.lda1 = op.gn_C1 ? op.gn_C1 : 4;
                     g.a_presplit = 0;
                     g.gn_table = tptr(e, b, op.gn_table, batch);
                     g.gn_act = e->plan.ops[op.fuse_peer].act;

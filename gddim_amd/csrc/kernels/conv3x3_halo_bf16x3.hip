@@ -65,7 +65,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_bf16x3_kernel(const GemmPara
     if (mtile >= p.m_tiles) return;
     const int m0 = mtile * HBM_, n0 = ntile * HBN_;
 
-    const int W = p.W, H = p.H, C = p.C0;
+    const int W = p.W, H = p.H, C = p.C0 + p.C1;  // C1 > 0 only with FUSE: the GroupNorm ran on a channel concat of two tensors
     const int HW2 = W + 2;
     const int rows = HBM_ / W;                 // complete image rows per tile (H*W is a multiple of 256)
     const int HP = (rows + 2) * HW2;           // halo pixels
@@ -76,6 +76,9 @@ __global__ __launch_bounds__(512) void conv3x3_halo_bf16x3_kernel(const GemmPara
     const int a_imgs = (p.M + H * W - 1) / (H * W);
     const __amdgpu_buffer_rsrc_t srd_a =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(ac), 0, a_imgs * H * W * p.lda0 * 4, 0x00020000);
+    const char *a1c = reinterpret_cast<const char *>((FUSE && p.C1) ? p.a1 : p.a0);
+    const __amdgpu_buffer_rsrc_t srd_a1 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(a1c), 0, a_imgs * H * W * p.lda1 * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t srd_bh = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char *>(reinterpret_cast<const char *>(p.b_hi)), 0, p.N * p.ldb * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t srd_bl = __builtin_amdgcn_make_buffer_rsrc(
@@ -83,6 +86,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_bf16x3_kernel(const GemmPara
 
     // ---- halo pieces of this thread (loop invariant): piece q = tid + 512 j -> (plane, pixel, 16-byte slot) ----
     int avo[HAJ];   // global voffset (bytes, without the channel slab), OOB for out-of-image / unused pieces
+    int avo1[FUSE ? HAJ : 1];  // the same for the second source of a fused concat GroupNorm
     int alds[HAJ];  // LDS element offset inside a stage
 #pragma unroll
     for (int j = 0; j < HAJ; ++j) {
@@ -93,15 +97,17 @@ __global__ __launch_bounds__(512) void conv3x3_halo_bf16x3_kernel(const GemmPara
         const int r = q - plane * HP * 4;
         const int pix = FUSE ? q >> 3 : r >> 2, slot = FUSE ? q & 7 : r & 3;
         avo[j] = OOB;
+        if (FUSE) avo1[j] = OOB;
         alds[j] = 0;
         if (q < HP * 8) {
             const int hy = pix / HW2, hx = pix - hy * HW2;
             const int y = y0 + hy - 1, x = hx - 1;
             alds[j] = FUSE ? pix * HREC + slot * 4 : plane * HA_PLANE + pix * HREC + slot * 8;
-            if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W && img < a_imgs)
+            if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W && img < a_imgs) {
                 avo[j] = FUSE ? ((img * H + y) * W + x) * p.lda0 * 4 + slot * 16
                               : ((img * H + y) * W + x) * p.lda0 * 4 + plane * p.lda0 * 2 + slot * 16;
-            else
+                if (FUSE) avo1[j] = ((img * H + y) * W + x) * p.lda1 * 4 + slot * 16;
+            } else
                 avo[j] = OOB;  // inside the halo but outside the image: the load returns zero and the zero is stored
         }
     }
@@ -123,7 +129,10 @@ __global__ __launch_bounds__(512) void conv3x3_halo_bf16x3_kernel(const GemmPara
     };
     auto load_halo = [&](int j, int slab) {
         const bool ok = slab < nslab;
-        ra[j] = __builtin_amdgcn_raw_buffer_load_b128(srd_a, ok ? avo[j] : OOB, slab * (FUSE ? 128 : 64), 0);
+        if (FUSE && slab * 32 >= p.C0)  // second source of the concat (wave-uniform branch)
+            ra[j] = __builtin_amdgcn_raw_buffer_load_b128(srd_a1, ok ? avo1[j] : OOB, (slab * 32 - p.C0) * 4, 0);
+        else
+            ra[j] = __builtin_amdgcn_raw_buffer_load_b128(srd_a, ok ? avo[j] : OOB, slab * (FUSE ? 128 : 64), 0);
     };
     auto store_halo = [&](int j, __bf16 *st) {
         if (tid + NT * j >= HP * 8) return;
@@ -255,9 +264,13 @@ static bool halo_shape_ok(const GemmParams &p);
 bool conv3x3_halo_fused_ok(const GemmParams &p) {
     static const int off = (getenv("GDDIM_X3_NOHALO") ? atoi(getenv("GDDIM_X3_NOHALO")) : 0) |
                            (getenv("GDDIM_X3_NOFUSE") ? atoi(getenv("GDDIM_X3_NOFUSE")) : 0);
-    if (off || !p.b_hi || !p.b_lo) return false;
+    // every N tile of a row block stages (and therefore normalises) the halo again; measured (tools/variants_x3.sh): fusing the
+    // 256-output layers too still wins (+3.2 % all fused, +2.7 % only N <= 128), so there is no limit by default
+    static const int max_n = getenv("GDDIM_X3_FUSE_MAXN") ? atoi(getenv("GDDIM_X3_FUSE_MAXN")) : (1 << 30);
+    if (off || !p.b_hi || !p.b_lo || p.N > max_n) return false;
     GemmParams q = p;
-    q.a_presplit = 1;  // the addressing limits of the shared eligibility test are those of a 4-byte-per-element source
+    q.a_presplit = 0;  // igemm_bf16x3_ok then applies the concat-aware addressing limits of a 4-byte-per-element source
+    if (!q.gn_table) q.gn_table = reinterpret_cast<const float *>(&q);  // shape test only: any non-null marker
     return halo_shape_ok(q);
 }
 
@@ -268,7 +281,9 @@ bool conv3x3_halo_ok(const GemmParams &p) {
 }
 
 static bool halo_shape_ok(const GemmParams &p) {
-    if (p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1 || p.C1 != 0 || p.C0 % 32 != 0 || p.lda0 != p.C0) return false;
+    const bool two = p.gn_table && p.C1 > 0;  // the fused variant may read a concat of two raw tensors
+    if (p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1 || p.C0 % 32 != 0 || p.lda0 != p.C0) return false;
+    if (two ? (p.C1 % 32 != 0 || p.lda1 != p.C1 || !p.a1) : p.C1 != 0) return false;
     if (p.H != p.W || p.OH != p.H || p.OW != p.W || (p.W != 32 && p.W != 16)) return false;
     if ((p.H * p.W) % HBM_ != 0 || p.M % HBM_ != 0 || p.N <= 64) return false;
     const long long blocks = (long long)(p.M / HBM_) * ((p.N + HBN_ - 1) / HBN_);

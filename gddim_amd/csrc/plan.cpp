@@ -145,7 +145,7 @@ int Plan::gn(const std::string &label, const std::string &pname, int xa, int Ca,
         }
     }
     int out = new_tensor(label + ".out", H, W, C);
-    if (Cb == 0) tensors[out].table_t = new_tensor(label + ".affine", 1, 1, 2 * C);  // lives as long as the output
+    tensors[out].table_t = new_tensor(label + ".affine", 1, 1, 2 * C);  // lives as long as the output
     Op a;
     a.kind = OP_GN_APPLY; a.label = label + ".apply";
     a.a0 = {xa, 0}; a.C0 = Ca; a.a1 = {xb, 0}; a.C1 = Cb; a.H = H; a.W = W; a.groups = G;
@@ -560,7 +560,7 @@ int Plan::build(const gd_model_desc &d) {
 }
 
 // Called right after the convolution that reads GroupNorm output `t` has been emitted (it is the last op): if the apply op that
-// produced `t` has a single source and the convolution has the halo kernel's static shape (3x3, stride 1, 16x16 or 32x32 images,
+// produced `t` (one source, or a channel concat of two) and the convolution have the halo kernel's static shape (3x3, stride 1, 16x16 or 32x32 images,
 // 32-channel slabs, more than 64 outputs), the two ops are linked for the run-time fusion.  The caller keeps the apply op's source
 // tensor alive until the convolution has been emitted.
 void Plan::link_fused_gn(int t) {
@@ -572,12 +572,15 @@ void Plan::link_fused_gn(int t) {
     for (int i = gi - 1; i >= 0; --i) {
         Op &a = ops[i];
         if (a.kind == OP_GN_APPLY && a.out.t == t) {
-            if (a.C1 != 0 || a.a1.t >= 0 || a.gn_table.t < 0 || a.fuse_peer >= 0) return;
+            if (a.gn_table.t < 0 || a.fuse_peer >= 0 || a.C0 % 32 != 0 || a.C1 % 32 != 0) return;
             for (int j = i + 1; j < gi; ++j)  // the convolution must be the only reader
                 if (ops[j].a0.t == t || ops[j].a1.t == t || ops[j].bten.t == t || ops[j].res.t == t) return;
             a.fuse_peer = gi;
             g.fuse_peer = i;
             g.gn_src = a.a0;
+            g.gn_src1 = a.a1;
+            g.gn_C0 = a.C0;
+            g.gn_C1 = a.C1;
             g.gn_table = a.gn_table;
             return;
         }

@@ -79,7 +79,8 @@ struct Op {
     // other (fuse_peer = op index).  When the halo kernel takes the convolution at the current batch size the apply op only
     // writes gn_table (per image [C scale | C shift]) and the convolution reads gn_src, the apply op's raw input.
     int fuse_peer = -1;
-    TRef gn_table, gn_src;
+    TRef gn_table, gn_src, gn_src1;
+    int gn_C0 = 0, gn_C1 = 0;
     TRef qstats;          // GEMM: quad statistics of the output (fused GroupNorm statistics), t = -1: none
     int qs_slices = 0;
     // ---- GroupNorm ----
