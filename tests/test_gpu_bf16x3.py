@@ -111,3 +111,40 @@ def test_production_batch_kernels_match_oracle(native_lib):
     assert "igemm_bf16x3_kernel<256,128,4,2>" in seen["bf16x3"]
     assert "conv3x3_halo_bf16x3_kernel<gn>" in seen["bf16x3"] and "gn_table" in seen["bf16x3"]  # the fused-GroupNorm variant
     assert any(n.startswith("igemm_bf16x3_kernel<128,128,2,4,pre") for n in seen["bf16x3"])
+
+
+def test_unfused_halo_path_agrees_with_fused(native_lib, tmp_path):
+    """GDDIM_X3_NOFUSE=1 (read once per process) keeps the separate GroupNorm-apply pass in front of the halo kernel: the fallback
+    of the fused variant.  Both paths apply the same arithmetic to the same values, so their outputs must agree to roundoff."""
+    import os
+    import subprocess
+    import sys
+    script = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from gddim_amd.configs import cld_accr_dcifar10
+from gddim_amd.engine import Engine
+from oracle import ncsnpp as onet
+cfg = cld_accr_dcifar10.get_config()
+params = onet.random_params(cfg, 6, seed=0)
+rng = np.random.default_rng(1)
+B = 256
+x = rng.standard_normal((B, 32, 32, 6)).astype(np.float32)
+labels = (rng.uniform(1e-3, 1.0, size=B) * 999).astype(np.float32)
+eng = Engine(cfg, 6, max_batch=B, device=0).load_params(params)
+eng.set_precision("bf16x3")
+eng.profile(True)
+out = eng.unet(torch.as_tensor(x, device="cuda:0"), torch.as_tensor(labels, device="cuda:0")).cpu().numpy()
+names = sorted(p["name"] for p in eng.profile_read())
+np.savez(sys.argv[1], out=out[:8], names=np.array(names))
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for tag, env in (("fused", {}), ("unfused", {"GDDIM_X3_NOFUSE": "1"})):
+        f = str(tmp_path / (tag + ".npz"))
+        subprocess.run([sys.executable, "-c", script, f], check=True, env=dict(os.environ, **env))
+        outs[tag] = np.load(f)
+    fused_names, unfused_names = set(outs["fused"]["names"]), set(outs["unfused"]["names"])
+    assert "conv3x3_halo_bf16x3_kernel<gn>" in fused_names and "conv3x3_halo_bf16x3_kernel<gn>" not in unfused_names
+    assert "conv3x3_halo_bf16x3_kernel" in unfused_names
+    a, b = outs["fused"]["out"], outs["unfused"]["out"]
+    assert np.abs(a - b).max() <= 1e-6 * max(1.0, np.abs(b).max())
