@@ -31,6 +31,7 @@
 #include <cstdlib>
 
 #include "../common.h"
+#include "act.h"
 #include "qstats.h"
 
 namespace gd {
@@ -41,7 +42,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int KC = 32;   // K chunk
 constexpr int LDT = 36;  // LDS row stride (floats): 32 + 4 pad -> 144 B, odd multiple of 16 B
 
-__device__ __forceinline__ float swish_f(float x) { return x * __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float swish_f(float x) { return swish_e(x); }
 
 // BM x BN block tile, WM x WN wave grid (64*WM*WN threads), DB: double-buffered LDS (one barrier per K chunk)
 // BM x BN block tile, WM x WN wave grid (64*WM*WN threads).
