@@ -93,6 +93,9 @@ const char *igemm_variant_name(const GemmParams &p, int batch_z);
 bool igemm_bf16x3_ok(const GemmParams &p, int batch_z);
 const char *igemm_bf16x3_name(const GemmParams &p);
 int launch_igemm_bf16x3(const GemmParams &p, hipStream_t s);
+// batched products of two fp32 activation matrices (attention) on the same kernel, both operands split while staging
+bool igemm_bf16x3_act_ok(const GemmParams &p, int batch_z);
+int launch_igemm_bf16x3_act(const GemmParams &p, int batch_z, hipStream_t s);
 // 3x3 stride-1 convolutions on pre-split activations with the input halo staged once per channel slab
 // (kernels/conv3x3_halo_bf16x3.hip); GDDIM_X3_NOHALO=1 routes them back to igemm_bf16x3_kernel
 bool conv3x3_halo_ok(const GemmParams &p);

@@ -259,6 +259,10 @@ static int run_op(gd_engine *e, int op_index, const Bind &b, int batch, hipStrea
                 g.b_hi = g.b_lo = nullptr;
             }
             GD_CHECK(!g.a_presplit, "%s: pre-split input without a split-precision kernel", op.label.c_str());
+            if (e->precision == 1 && op.w_slot < 0 && igemm_bf16x3_act_ok(g, z)) {  // attention products: activation x activation
+                ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string("igemm_bf16x3_kernel<256,128,4,2,act>"), op.flops_per_image * batch, 0);
+                return launch_igemm_bf16x3_act(g, z, s);
+            }
             ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(igemm_variant_name(g, z)), op.flops_per_image * batch, 0);
             return launch_igemm(g, z, s);
         }

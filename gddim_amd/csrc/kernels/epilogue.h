@@ -19,9 +19,9 @@ __device__ __forceinline__ unsigned epi_div(unsigned n, unsigned d, unsigned mag
 // mbase / nbase: first row / column of the wave's (RM x RN) x 32 tile block (wave-uniform)
 template <int RM, int RN>
 __device__ __forceinline__ void epilogue_rows(const GemmParams &p, const epi_f32x16 (&acc)[RM][RN], int mbase, int nbase, int li,
-                                              int lh, bool no_store) {
+                                              int lh, bool no_store, float *out_base = nullptr) {
     constexpr int OOB = (int)0x80000000u;
-    char *outc = reinterpret_cast<char *>(p.out);
+    char *outc = reinterpret_cast<char *>(out_base ? out_base : p.out);  // out_base: the z slice of a batched product
     const __amdgpu_buffer_rsrc_t srd_o = __builtin_amdgcn_make_buffer_rsrc(outc, 0, p.M * p.ldc * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t srd_r =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(reinterpret_cast<const char *>(p.res ? p.res : p.out)), 0,

@@ -47,13 +47,15 @@ __device__ __forceinline__ unsigned xfast_div(unsigned n, unsigned d, unsigned m
 //   1 no output stores, 2 one K chunk only, 8 no MFMAs, 16 no split / LDS stores, 32 no global loads, 64 no fragment reads
 // PRE: the A operand is already split (rows of [lda0 bf16 hi | lda0 bf16 lo], written by gn_apply_kernel): staging is a plain
 // 16-byte copy per thread -- no conversion work in the K loop.
-template <int BM, int BN, int WM, int WN, bool PRE = false, bool DIAG = false>
+// BACT: the B operand is an fp32 ACTIVATION matrix [N][ldb] (attention: K^T rows, V^T rows) instead of pre-split weights: it is
+// split while staging exactly like A, and blockIdx.z walks the per-image slices (sA / sB / sC strides) of a batched product.
+template <int BM, int BN, int WM, int WN, bool PRE = false, bool DIAG = false, bool BACT = false>
 __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16x3_kernel(const GemmParams p) {
     constexpr int NT = 64 * WM * WN;
     constexpr int RM = BM / (32 * WM), RN = BN / (32 * WN);
     constexpr int RPP = NT / 8;          // A rows staged per pass (8 threads x 16 B of fp32 per row)
     constexpr int AJ = BM / RPP;         // fp32 float4 staged per thread for A
-    constexpr int BRP = NT / 4;          // B rows staged per pass (4 threads x 16 B of bf16 per row)
+    constexpr int BRP = BACT ? NT / 8 : NT / 4;  // B rows staged per pass (4 threads x 16 B of bf16, or 8 x 16 B of fp32, per row)
     constexpr int BJ = (BN + BRP - 1) / BRP;
     constexpr int NP = AJ + BJ;          // staging pieces per chunk (a B piece carries hi and lo)
     constexpr int NG = 6;                // MFMA groups per chunk: 2 k16 steps x 3 product terms
@@ -91,7 +93,8 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16x3_kernel(const GemmPa
     const int a_imgs = (p.M + p.OH * p.OW - 1) / (p.OH * p.OW);
     const int bias0 = (p.pad * p.W + p.pad) * p.lda0 * 4;
     const int bias1 = (p.pad * p.W + p.pad) * p.lda1 * 4;
-    const char *a0c = reinterpret_cast<const char *>(p.a0);
+    const int z = BACT ? blockIdx.z : 0;
+    const char *a0c = reinterpret_cast<const char *>(p.a0 + (size_t)z * p.sA);
     const __amdgpu_buffer_rsrc_t srd_a0 =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(a0c - bias0), 0, a_imgs * p.H * p.W * p.lda0 * 4 + bias0, 0x00020000);
     const char *a1c = reinterpret_cast<const char *>(p.C1 ? p.a1 : p.a0);
@@ -101,6 +104,8 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16x3_kernel(const GemmPa
         const_cast<char *>(reinterpret_cast<const char *>(p.b_hi)), 0, p.N * p.ldb * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t srd_bl = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char *>(reinterpret_cast<const char *>(p.b_lo)), 0, p.N * p.ldb * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srd_bf = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(reinterpret_cast<const char *>(BACT ? p.b + (size_t)z * p.sB : p.b)), 0, p.N * p.ldb * 4, 0x00020000);
 
     // ---- per-thread, loop-invariant row data (identical to igemm_f32_fast_kernel) ----
     // fp32 source: 8 threads x float4 per row.  Pre-split source: the first half of the workgroup copies the hi halves of the
@@ -137,14 +142,14 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16x3_kernel(const GemmPa
             }
         }
     }
-    const int brow = tid >> 2;        // B row inside a pass
+    const int brow = BACT ? tid >> 3 : tid >> 2;  // B row inside a pass
     const int bq = (tid & 3) * 8;     // bf16 offset inside the 32-wide chunk (16 B)
     int bvo[BJ];
 #pragma unroll
     for (int j = 0; j < BJ; ++j) {
         const int nl = brow + BRP * j;
         const int n = n0 + nl;
-        bvo[j] = (nl < BN && n < p.N) ? (n * p.ldb + bq) * 2 : OOB;
+        bvo[j] = (nl < BN && n < p.N) ? (BACT ? (n * p.ldb + kcol) * 4 : (n * p.ldb + bq) * 2) : OOB;
     }
 
     int s_tap = 0, s_ty = 0, s_tx = 0, s_c0 = 0, s_kc = 0;
@@ -177,10 +182,14 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16x3_kernel(const GemmPa
             }
         } else {
             const int j = pc - AJ;
-            const int soff = (s_tap * Cin + s_c0) * 2;
             const int vo = s_kc < nk ? bvo[j] : OOB;
-            rbh[j] = __builtin_amdgcn_raw_buffer_load_b128(srd_bh, vo, soff, 0);
-            rbl[j] = __builtin_amdgcn_raw_buffer_load_b128(srd_bl, vo, soff, 0);
+            if (BACT) {
+                rbh[j] = __builtin_amdgcn_raw_buffer_load_b128(srd_bf, vo, (s_tap * Cin + s_c0) * 4, 0);  // four fp32 of row n
+            } else {
+                const int soff = (s_tap * Cin + s_c0) * 2;
+                rbh[j] = __builtin_amdgcn_raw_buffer_load_b128(srd_bh, vo, soff, 0);
+                rbl[j] = __builtin_amdgcn_raw_buffer_load_b128(srd_bl, vo, soff, 0);
+            }
         }
     };
     // stage layout (bf16 elements): A_hi [BM][XLD] | A_lo [BM][XLD] | B_hi [BN][XLD] | B_lo [BN][XLD]
@@ -203,7 +212,18 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16x3_kernel(const GemmPa
         } else {
             const int j = pc - AJ;
             const int nl = brow + BRP * j;
-            if (nl < BN) {
+            if (nl < BN && BACT) {
+                const f32x4 v = __builtin_bit_cast(f32x4, rbh[j]);
+                bf16x4 h, l;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    h[i] = (__bf16)v[i];
+                    l[i] = (__bf16)(v[i] - (float)h[i]);
+                }
+                const int o = BBASE + nl * XLD + kcol;
+                *reinterpret_cast<bf16x4 *>(st + o) = h;
+                *reinterpret_cast<bf16x4 *>(st + BN * XLD + o) = l;
+            } else if (nl < BN) {
                 const int o = BBASE + nl * XLD + bq;
                 *reinterpret_cast<u32x4 *>(st + o) = rbh[j];
                 *reinterpret_cast<u32x4 *>(st + BN * XLD + o) = rbl[j];
@@ -296,7 +316,8 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16x3_kernel(const GemmPa
                 for (int v = 0; v < 16; ++v) sink += acc[r][c][v];
         if (sink == 1.2345e-30f) p.out[0] = sink;
     } else {
-        epilogue_rows<RM, RN>(p, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), li, lh, DIAG && (dg & 1));
+        epilogue_rows<RM, RN>(p, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), li, lh, DIAG && (dg & 1),
+                              BACT ? p.out + (size_t)z * p.sC : nullptr);
     }
 }
 
@@ -315,6 +336,39 @@ bool igemm_bf16x3_ok(const GemmParams &p, int batch_z) {
     if (a_bytes + soff_max >= (1LL << 31) || (long long)p.N * p.ldb * 2 + (long long)p.K * 2 >= (1LL << 31)) return false;
     if ((long long)p.M * p.ldc * 4 + 64 >= (1LL << 31) || (p.res && (long long)p.M * p.ldres * 4 + 64 >= (1LL << 31))) return false;
     return true;
+}
+
+// batched activation x activation products (attention QK^T, PV, V^T): both operands fp32, split in the kernel
+bool igemm_bf16x3_act_ok(const GemmParams &p, int batch_z) {
+    static const int off = getenv("GDDIM_X3_NOATTN") ? atoi(getenv("GDDIM_X3_NOATTN")) : 0;
+    if (off || batch_z < 1 || p.b_kmajor || p.in_act || !p.b || p.a_presplit || p.C1 != 0 || p.KH != 1 || p.KW != 1) return false;
+    if (p.C0 % 32 != 0 || p.K != p.C0 || p.ldb % 4 != 0 || p.lda0 % 4 != 0 || p.rowbias || p.res || p.qstats) return false;
+    if ((long long)((p.M + 255) / 256) * ((p.N + 127) / 128) * batch_z < 256) return false;  // only the 256x128 tile is instantiated
+    const long long a_bytes = (long long)p.M * p.lda0 * 4 + 64, b_bytes = (long long)p.N * p.ldb * 4 + 64;
+    return a_bytes + (long long)p.K * 4 < (1LL << 31) && b_bytes + (long long)p.K * 4 < (1LL << 31) &&
+           (long long)p.M * p.ldc * 4 + 64 < (1LL << 31);
+}
+
+int launch_igemm_bf16x3_act(const GemmParams &p_in, int batch_z, hipStream_t s) {
+    GemmParams p = p_in;
+    GD_CHECK(igemm_bf16x3_act_ok(p, batch_z), "igemm_bf16x3 (activation B): problem not eligible");
+    unsigned mg, sh;
+    auto fill = [](unsigned d, unsigned &magic, unsigned &shift) {
+        unsigned q = 0;
+        while ((1ull << q) < d) ++q;
+        shift = q;
+        magic = (unsigned)((((1ull << 32) * ((1ull << q) - d)) / d) + 1);
+    };
+    fill((unsigned)(p.OH * p.OW), p.mg_ohw, p.sh_ohw);
+    fill((unsigned)p.OW, p.mg_ow, p.sh_ow);
+    fill((unsigned)(p.rows_per_image > 0 ? p.rows_per_image : 1), p.mg_rpi, p.sh_rpi);
+    (void)mg; (void)sh;
+    p.m_tiles = (p.M + 255) / 256;
+    p.n_tiles = (p.N + 127) / 128;
+    p.flat_tiles = 1;
+    hipLaunchKernelGGL((igemm_bf16x3_kernel<256, 128, 4, 2, false, false, true>), dim3(p.m_tiles * p.n_tiles, 1, batch_z), dim3(512), 0, s, p);
+    GD_HIP(hipGetLastError());
+    return 0;
 }
 
 static void xpick(const GemmParams &p, int &bm, int &bn) {
