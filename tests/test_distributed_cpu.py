@@ -54,3 +54,51 @@ def test_shard_batch_and_seeds():
     seeds = {distributed.rank_seed(42, rnd, r) for rnd in range(50) for r in range(8)}
     assert len(seeds) == 400
     assert np.array_equal(distributed.to_uint8(np.array([-0.1, 0.0, 0.999, 0.5, 1.2])), np.array([0, 0, 254, 127, 255], np.uint8))
+
+
+def _round_worker(rank, world, port, out_dir):
+    """run_lib.sample_data under two gloo ranks with the sampler factory replaced by a CPU stand-in: what is exercised is the
+    round loop itself -- per-rank batch, per-(round, rank) seeds, the three all-gathers, rank 0 writing the files."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from gddim_amd import distributed, run_lib
+    from gddim_amd.cld import sampling
+    from gddim_amd.configs import cld_accr_dcifar10
+    from gddim_amd.models.utils import State
+    distributed.init_from_env(backend="gloo")
+    cfg = cld_accr_dcifar10.get_config()
+    cfg.data.image_size = 4
+    cfg.eval.num_samples, cfg.eval.batch_size = 10, 6  # 2 rounds of 6 images, 3 per rank
+    calls = []
+
+    def fake_factory(config, sde, model, shape, inverse_scaler):
+        def fn(rng, state, batch_size, u=None):
+            calls.append((int(rng[0]), batch_size))
+            g = torch.Generator().manual_seed(int(rng[0]) % (2 ** 31))
+            x = torch.rand((1, batch_size, 4, 4, 3), generator=g)
+            return x, -x, 50
+        return fn
+
+    sampling.get_sampling_fn = fake_factory
+    written = run_lib.sample_data(cfg, "unused", out_dir, state=State(params_ema={}))
+    seeds = [distributed.rank_seed(cfg.seed + 1, r, rank) for r in range(2)]
+    assert calls == [(seeds[0], 3), (seeds[1], 3)]
+    assert (len(written) == 2) == (rank == 0)
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_sample_data_rounds_two_ranks_gloo(tmp_path):
+    from gddim_amd import distributed
+    mp.spawn(_round_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        info = np.load(os.path.join(str(tmp_path), "samples_%d.npz" % r))
+        assert info["samples"].shape == (6, 4, 4, 3) and info["samples"].dtype == np.uint8 and int(info["nfe_cnt"]) == 50
+        # rank order inside the round, each rank's three images drawn from its own (round, rank) seed
+        want = []
+        for rank in range(2):
+            g = torch.Generator().manual_seed(distributed.rank_seed(42 + 1, r, rank) % (2 ** 31))
+            want.append(torch.rand((1, 3, 4, 4, 3), generator=g)[0])
+        want = torch.cat(want).numpy()
+        assert np.array_equal(info["samples_x"][0], want) and np.array_equal(info["samples_v"][0], -want)
+        assert np.array_equal(info["samples"], np.clip(want * 255.0, 0, 255).astype(np.uint8))
