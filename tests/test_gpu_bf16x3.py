@@ -149,3 +149,28 @@ np.savez(sys.argv[1], out=out[:8], names=np.array(names))
     assert "conv3x3_halo_bf16x3_kernel" in unfused_names
     a, b = outs["fused"]["out"], outs["unfused"]["out"]
     assert np.abs(a - b).max() <= 1e-6 * max(1.0, np.abs(b).max())
+
+
+@pytest.mark.parametrize("B", [17, 48, 100])
+def test_kernel_selection_boundaries(native_lib, B):
+    """The planner's tile choice depends on the batch (workgroup-count thresholds, ragged M tiles at the 4x4 level, the halo kernel
+    needing >= 256 workgroups, ...).  Images are independent units: the first two images of a batch of B must agree with the same two
+    images evaluated alone (kernel set checked against the oracle above), in both precision modes."""
+    from gddim_amd.configs import cld_accr_dcifar10
+    from gddim_amd.engine import Engine
+    cfg = cld_accr_dcifar10.get_config()
+    params = onet.random_params(cfg, 6, seed=0)
+    rng = np.random.default_rng(B)
+    x = torch.as_tensor(rng.standard_normal((B, 32, 32, 6)).astype(np.float32), device="cuda:0")
+    labels = torch.as_tensor((rng.uniform(1e-3, 1.0, size=B) * 999).astype(np.float32), device="cuda:0")
+    eng = Engine(cfg, 6, max_batch=B, device=0).load_params(params)
+    for mode in ("fp32", "bf16x3"):
+        eng.set_precision(mode)
+        big = eng.unet(x, labels)
+        small = eng.unet(x[:2], labels[:2])
+        scale = max(1.0, small.abs().max().item())
+        assert torch.isfinite(big).all()
+        assert (big[:2] - small).abs().max().item() < 3e-5 * scale, (mode, B)
+        one = eng.unet(x[B - 1:], labels[B - 1:])  # the last image too (tail tiles)
+        assert (big[B - 1:] - one).abs().max().item() < 3e-5 * scale, (mode, B)
+    eng.close()
