@@ -38,11 +38,12 @@ def hbm_traffic(kernel_name):
         return None
     key = kernel_name.replace(" ", "")
     # the engine's profile names abbreviate the template tail of the split-precision kernel (<..., pre> = <..., true, false>)
-    keys = {key, key.replace(",pre>", ",true,false>"), key.replace("kernel<gn>", "kernel<true>")}
+    keys = {key, key.replace(",pre>", ",true,false,false>"), key.replace(",act>", ",false,false,true>"),
+            key.replace("kernel<gn>", "kernel<true>")}
     if key == "conv3x3_halo_bf16x3_kernel":
         keys.add("conv3x3_halo_bf16x3_kernel<false>")
     if key.startswith("igemm_bf16x3_kernel<") and key.count(",") == 3:
-        keys.add(key[:-1] + ",false,false>")
+        keys.add(key[:-1] + ",false,false,false>")
     for k, v in table.items():
         if k.replace(" ", "") in keys:
             return v["hbm_bytes_per_launch"]
