@@ -1,7 +1,2 @@
-"""blur_jax/utils.py: get_data_shape (:172-177 of the CLD twin)."""
-
-
-def get_data_shape(config):
-    if "ps" in config.data.dataset:
-        return (config.data.dim,)
-    return (config.data.image_size, config.data.image_size, config.data.num_channels)
+"""blur_jax/utils.py: get_data_shape (the same helper as the CLD package's, cld_jax/utils.py:172-177)."""
+from ..cld.utils import get_data_shape  # noqa: F401

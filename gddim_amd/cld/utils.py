@@ -1,16 +1,9 @@
-"""Tiny tensor helpers of cld_jax/utils.py:172-185 (device versions run the HIP 2x2 kernel)."""
-from .. import ops
+"""Tiny helpers of cld_jax/utils.py:172-185: the sample shape of a config and the two 2x2 einsums (HIP kernel behind both)."""
+from ..ops import bmm, sbmm  # noqa: F401  einsum('bij,b...dj->b...di') / einsum('ij,b...dj->b...di')
 
 
 def get_data_shape(config):
-    if "ps" in config.data.dataset:
-        return (config.data.dim,)
-    return (config.data.image_size, config.data.image_size, config.data.num_channels)
-
-
-def bmm(b1, b2):
-    return ops.bmm(b1, b2)
-
-
-def sbmm(b1, b2):
-    return ops.sbmm(b1, b2)
+    """(H, W, C) of one sample; the 2-D point-set datasets ("ps" in their name) are flat vectors of config.data.dim."""
+    data = config.data
+    side = data.image_size
+    return (data.dim,) if "ps" in data.dataset else (side, side, data.num_channels)

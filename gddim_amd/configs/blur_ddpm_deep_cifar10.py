@@ -1,21 +1,12 @@
-"""Field names / values of blur_jax/configs/ddpm_deep_cifar10_config.py:4-48 (the blur gDDIM config)."""
+"""blur_jax/configs/ddpm_deep_cifar10_config.py:4-48, the blur gDDIM config: the same deep NCSN++ on 3 channels."""
 from .blur_default_cifar10 import get_default_configs
-from .cld_accr_dcifar10 import _ncsnpp_deep
+from .cld_accr_dcifar10 import _long_run, _ncsnpp_deep
 
 
 def get_config():
     config = get_default_configs()
-    training = config.training
-    training.n_iters = 1000001
-    training.continuous = True
-    training.reduce_mean = True
-    training.log_freq = 100
-    training.eval_freq = 2000
-    training.snapshot_freq_for_sampling = 10000
+    _long_run(config.training, 1000001)
     data = config.data
-    data.centered = True
-    data.num_channels = 3
-    data.is_partial = False
-    data.random_flip = True
+    data.centered, data.num_channels, data.is_partial, data.random_flip = True, 3, False, True
     _ncsnpp_deep(config.model)
     return config
