@@ -3,6 +3,9 @@
   get_sampling_fn(config, sde, model, shape, inverse_scaler, is_p=True)     :11-40 (only 'order0' exists)
   get_rev_ts(sde, ts_order, num_step)                                       :42-51
   get_order0_sampler(sde, model, data_shape, ts_order, nfe, inverse_scaler, is_p=False)   :53-89
+  get_deis_sampler(sde, model, data_shape, ts_order, nfe, deis_order, inverse_scaler, is_p=False)   -- not in the reference: the
+      multistep sampler blur_jax/multistep.py was started for, with per-frequency coefficients (SURVEY.md section 8f, N2);
+      `sampling.method = 'deis'` selects it, everything else raises RuntimeError as in the reference
 
 `sampling_fn(rng, state, batch_size, u=None) -> (x, nfe)` (2-tuple, unlike CLD).  The NFE loop
 [IDCT -> U-Net -> DCT -> per-frequency DDIM update] runs entirely in `gd_sample_blur`."""
@@ -20,6 +23,47 @@ _TOKENS = itertools.count(1)
 def get_rev_ts(sde, ts_order, num_step):
     return np.power(np.linspace(np.power(sde.sampling_T, 1.0 / ts_order), np.power(sde.sampling_eps, 1.0 / ts_order),
                                 num_step + 1), ts_order)
+
+
+def _scale_mode(inverse_scaler):
+    probe = np.array([-1.0, 0.0, 1.0])
+    scaled = np.asarray(inverse_scaler(probe), dtype=np.float64)
+    fuse_scale = bool(np.allclose(scaled, (probe + 1.0) / 2.0))
+    return fuse_scale, (None if fuse_scale or np.allclose(scaled, probe) else inverse_scaler)
+
+
+def get_deis_sampler(sde, model, data_shape, ts_order, nfe, deis_order, inverse_scaler, is_p=False):
+    """Adams-Bashforth exponential integrator of order `deis_order` in DCT space: y' = psi_i y + sum_o c_{i,o} eps_o per frequency
+    (multistep.get_ab_eps_coef_freq); deis_order = 0 is the order0 sampler."""
+    from . import multistep
+    rev_ts = get_rev_ts(sde, ts_order=ts_order, num_step=nfe)
+    eps_coef, psi = multistep.get_ab_eps_coef_freq(sde, deis_order, rev_ts, deis_order)
+    coef = np.concatenate([psi[:, None], eps_coef], axis=1)  # (nfe, deis_order + 2, 32, 32)
+    fuse_scale, post_scale = _scale_mode(inverse_scaler)
+    token = ("blur_deis", next(_TOKENS))
+
+    def sampler(rng, state, batch_size, u=None, use_graph=True):
+        import torch
+        if u is None:
+            u = sde.prior_sampling(_seed_of(rng), (batch_size,) + tuple(data_shape))
+        if not hasattr(u, 'is_cuda'):
+            u = torch.as_tensor(np.asarray(u), dtype=torch.float32)
+        if not u.is_cuda:
+            u = u.to(torch.device('cuda', torch.cuda.current_device()))
+        eng = model.engine_for(state.params_ema, data_shape[-1], batch_size, u.device.index)
+        eng.set_schedule_blur_deis(rev_ts[:nfe], coef, token=token)
+        x = eng.sample_blur(u.to(torch.float32), inverse_scale=fuse_scale, use_graph=use_graph)
+        return (post_scale(x) if post_scale is not None else x), nfe
+
+    def psampler(prng, pstate, batch_size, u=None, use_graph=True):
+        rng = _unreplicate_rng(prng)
+        if u is None:
+            u = sde.prior_sampling(_seed_of(rng), (_LOCAL_DEVICE_COUNT, batch_size,) + tuple(data_shape))
+        assert u.shape[0] == _LOCAL_DEVICE_COUNT, "one process drives one GPU: leading device axis must be 1"
+        x, n = sampler(rng, pstate, batch_size, u[0], use_graph)
+        return x[None], n
+
+    return psampler if is_p else sampler
 
 
 def get_order0_sampler(sde, model, data_shape, ts_order, nfe, inverse_scaler, is_p=False):
@@ -65,4 +109,8 @@ def get_sampling_fn(config, sde, model, shape, inverse_scaler, is_p=True):
     if sampler_name.lower() == 'order0':
         return get_order0_sampler(sde=sde, model=model, data_shape=data_shape, ts_order=config.sampling.ts_order,
                                   nfe=config.sampling.nfe, inverse_scaler=inverse_scaler, is_p=is_p)
+    if sampler_name.lower() == 'deis':  # extension, see get_deis_sampler
+        return get_deis_sampler(sde=sde, model=model, data_shape=data_shape, ts_order=config.sampling.ts_order,
+                                nfe=config.sampling.nfe, deis_order=config.sampling.get('deis_order', 1),
+                                inverse_scaler=inverse_scaler, is_p=is_p)
     raise RuntimeError

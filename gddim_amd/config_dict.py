@@ -31,6 +31,10 @@ class ConfigDict(object):
     def __contains__(self, name):
         return name in self._fields
 
+    def get(self, name, default=None):
+        """dict-style access with a default, as ml_collections.ConfigDict offers."""
+        return self._fields.get(name, default)
+
     def keys(self):
         return self._fields.keys()
 

@@ -164,6 +164,9 @@ int launch_advance_step(int *step, hipStream_t s);
 int launch_blur_idct_pad(const float *y, float *x8, int batch, int C, hipStream_t s);
 int launch_blur_step(float *y, const float *eps_x, const float *mean_coef, const float *std_coef, const int *step,
                      int batch, int C, hipStream_t s);
+// y' = c0 y + c1 DCT(eps_x) + sum_j c_{2+j} hist_j with per-frequency coefficient planes coef[step][n_slots][32*32]
+int launch_blur_ab_step(float *y, const float *eps_x, float *ring, int ring_slots, const float *coef, int n_slots, const int *step,
+                        int batch, int C, long long slot_stride, hipStream_t s);
 int launch_blur_finish(const float *y, float *x_out, int batch, int C, int inverse_scale, hipStream_t s);
 
 }  // namespace gd

@@ -73,7 +73,7 @@ struct gd_engine {
     unsigned long long seed = 0;
     unsigned seed_words[2] = {0, 0};  // host staging of seed_dev (must outlive the async copy)
     int *step_dev = nullptr;  // GD_MAX_LANES counters (one per concurrent sub-batch)
-    int sched_kind = 0;  // 1 cld, 2 blur
+    int sched_kind = 0;  // 1 cld, 2 blur order0, 3 blur multistep (per-frequency DEIS)
     int num_step = 0, n_slots = 0, denoise = 0;
     float t_denoise = 0;
     // the sampler loop runs on the engine's own stream (graph capture is illegal on the null stream); it is
@@ -821,10 +821,35 @@ int gd_engine_set_schedule_blur(gd_engine *e, int nfe, const float *ts_host, con
     return 0;
 }
 
+int gd_engine_set_schedule_blur_deis(gd_engine *e, int nfe, int n_slots, const float *ts_host, const float *coef_host) {
+    GD_CHECK(e && !e->plan_only, "engine has no GPU");
+    GD_CHECK(nfe >= 1 && n_slots >= 2 && ts_host && coef_host, "bad schedule");
+    GD_CHECK(e->plan.desc.image_size == 32, "the blur SDE is hard-wired to 32x32 (blur_jax/sde_lib.py:24)");
+    GD_HIP(hipSetDevice(e->device));
+    GD_HIP(hipDeviceSynchronize());
+    drop_graphs(e);
+    GD_TRY(upload(&e->ts_dev, ts_host, nfe));
+    GD_TRY(upload(&e->coef_dev, coef_host, (size_t)nfe * n_slots * 1024));
+    const int ring_slots = n_slots - 2;
+    const gd_model_desc &d = e->plan.desc;
+    const long long need = (long long)ring_slots * d.max_batch * 1024 * d.in_channels;
+    if (need > e->ring_cap) {
+        if (e->ring) (void)hipFree(e->ring);
+        e->ring = nullptr;
+        GD_HIP(hipMalloc((void **)&e->ring, (size_t)need * sizeof(float)));
+        e->ring_cap = need;
+    }
+    e->sched_kind = 3; e->num_step = nfe; e->n_slots = n_slots;
+    return 0;
+}
+
 int gd_sample_blur(gd_engine *e, int batch, const float *y_in_dev, float *x_out_dev, int inverse_scale, int use_graph,
                    void *stream) {
     GD_TRY(check_compute(e, batch));
-    GD_CHECK(e->sched_kind == 2, "no blur schedule installed (gd_engine_set_schedule_blur)");
+    GD_CHECK(e->sched_kind == 2 || e->sched_kind == 3, "no blur schedule installed (gd_engine_set_schedule_blur[_deis])");
+    const bool multistep = e->sched_kind == 3;
+    const int ring_slots = multistep ? e->n_slots - 2 : 0;
+    const long long slot_stride = (long long)e->plan.desc.max_batch * 1024 * e->plan.desc.in_channels;
     GD_CHECK(y_in_dev && x_out_dev, "null device pointer");
     GD_CHECK(!e->plan.desc.scale_by_sigma, "scale_by_sigma is not supported inside the fused sampler");
     hipStream_t caller = (hipStream_t)stream;
@@ -837,7 +862,7 @@ int gd_sample_blur(gd_engine *e, int batch, const float *y_in_dev, float *x_out_
     struct Lane {
         hipStream_t s;
         int b;
-        float *y, *xin, *eps;
+        float *y, *xin, *eps, *ring;
         int *step;
         Bind bind;
         gd_engine::Graphs *g;
@@ -855,12 +880,19 @@ int gd_sample_blur(gd_engine *e, int batch, const float *y_in_dev, float *x_out_
         l.g = graph ? &e->graphs[((long long)size[i] << 40) | ((long long)start[i] << 8) | i] : nullptr;
         GD_HIP(hipStreamWaitEvent(l.s, e->ev_in, 0));
         GD_HIP(hipMemcpyAsync(l.y, y_in_dev + p0 * C, (size_t)l.b * 1024 * C * sizeof(float), hipMemcpyDeviceToDevice, l.s));
+        l.ring = (multistep && e->ring) ? e->ring + p0 * C : nullptr;
+        for (int j = 0; j < ring_slots; ++j)  // the reference's loops start their epsilon history from the state itself
+            GD_HIP(hipMemcpyAsync(l.ring + (size_t)j * slot_stride, y_in_dev + p0 * C, (size_t)l.b * 1024 * C * sizeof(float),
+                                  hipMemcpyDeviceToDevice, l.s));
         GD_HIP(hipMemsetAsync(l.step, 0, sizeof(int), l.s));
     }
     auto step_body = [&](Lane &l) -> int {
         GD_TRY(launch_blur_idct_pad(l.y, l.xin, l.b, C, l.s));
         GD_TRY(run_unet(e, l.bind, l.b, l.s));
-        GD_TRY(launch_blur_step(l.y, l.eps, e->mean_dev, e->std_dev, l.step, l.b, C, l.s));
+        if (multistep)
+            GD_TRY(launch_blur_ab_step(l.y, l.eps, l.ring, ring_slots, e->coef_dev, e->n_slots, l.step, l.b, C, slot_stride, l.s));
+        else
+            GD_TRY(launch_blur_step(l.y, l.eps, e->mean_dev, e->std_dev, l.step, l.b, C, l.s));
         return launch_advance_step(l.step, l.s);
     };
     if (graph) {

@@ -440,6 +440,46 @@ int launch_blur_step(float *y, const float *eps_x, const float *mean_coef, const
     return 0;
 }
 
+// Multistep (DEIS) blur update with per-frequency coefficients: y' = c[step][0] y + c[step][1] e_y + sum_j c[step][2+j] hist_j, all
+// (32 x 32) planes; e_y = DCT(eps_x) of this step becomes the newest history entry.  The history ring works like the CLD one
+// (logical slot j = physical (head + j) % slots, head = (-step) mod slots).
+__global__ __launch_bounds__(256) void blur_ab_step_kernel(float *__restrict__ y, const float *__restrict__ eps_x,
+                                                            float *__restrict__ ring, int ring_slots,
+                                                            const float *__restrict__ coef, int n_slots,
+                                                            const int *__restrict__ step_ptr, int C, long long slot_stride) {
+    __shared__ float D[DN * DL], X[DN * DL], T[DN * DL];
+    const int b = blockIdx.x / C, c = blockIdx.x - b * C;
+    const int step = *step_ptr;
+    dct_fill_basis(D);
+    const size_t plane = (size_t)b * DN * DN * C + c;
+    const float *src = eps_x + plane;
+    for (int i = threadIdx.x; i < DN * DN; i += 256) X[(i / DN) * DL + (i % DN)] = src[(size_t)i * C];
+    __syncthreads();
+    dct_plane(D, X, T, 0);
+    const float *cf = coef + (size_t)step * n_slots * DN * DN;
+    const int head = ring_slots > 0 ? (ring_slots - step % ring_slots) % ring_slots : 0;
+    float *yy = y + plane;
+    for (int i = threadIdx.x; i < DN * DN; i += 256) {
+        const float ey = X[(i / DN) * DL + (i % DN)];
+        float acc = cf[i] * yy[(size_t)i * C] + cf[DN * DN + i] * ey;
+        int phys = head;
+        for (int j = 0; j < ring_slots; ++j) {
+            acc += cf[(size_t)(2 + j) * DN * DN + i] * ring[(size_t)phys * slot_stride + plane + (size_t)i * C];
+            if (++phys == ring_slots) phys = 0;
+        }
+        if (ring_slots > 0) ring[(size_t)((head + ring_slots - 1) % ring_slots) * slot_stride + plane + (size_t)i * C] = ey;
+        yy[(size_t)i * C] = acc;
+    }
+}
+
+int launch_blur_ab_step(float *y, const float *eps_x, float *ring, int ring_slots, const float *coef, int n_slots, const int *step,
+                        int batch, int C, long long slot_stride, hipStream_t s) {
+    hipLaunchKernelGGL(blur_ab_step_kernel, dim3(batch * C), dim3(256), 0, s, y, eps_x, ring, ring_slots, coef, n_slots, step, C,
+                       slot_stride);
+    GD_HIP(hipGetLastError());
+    return 0;
+}
+
 __global__ __launch_bounds__(256) void blur_finish_kernel(const float *__restrict__ y, float *__restrict__ x_out, int C,
                                                            int inverse_scale) {
     __shared__ float D[DN * DL], X[DN * DL], T[DN * DL];

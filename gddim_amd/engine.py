@@ -231,6 +231,17 @@ class Engine(object):
         check(self._lib.gd_engine_set_schedule_blur(self._h, nfe, ts_p, m_p, s_p))
         self._schedule_token = token
 
+    def set_schedule_blur_deis(self, ts, coef, token=None):
+        """coef (nfe, n_slots, 32, 32): slot 0 the transition, slots 1.. the eps coefficients (newest first)."""
+        if token is not None and token == self._schedule_token:
+            return
+        co_a, co_p = _host_f32(coef)
+        ts_a, ts_p = _host_f32(ts)
+        nfe, n_slots = co_a.shape[0], co_a.shape[1]
+        assert ts_a.shape[0] == nfe and co_a.shape[2:] == (32, 32)
+        check(self._lib.gd_engine_set_schedule_blur_deis(self._h, nfe, n_slots, ts_p, co_p))
+        self._schedule_token = token
+
     def sample_blur(self, y, inverse_scale=True, use_graph=True):
         import torch
         y = y.contiguous()

@@ -190,6 +190,11 @@ int gd_sample_cld(gd_engine *e, int batch, const float *u_in_dev, float *x_out_d
  * y_std_coef (blur_jax/sde_lib.py:90-97). */
 int gd_engine_set_schedule_blur(gd_engine *e, int nfe, const float *ts_host, const float *mean_coef_host,
                                 const float *std_coef_host);
+/* Multistep (DEIS) schedule of the blur sampler with per-frequency coefficients -- the completion of blur_jax/multistep.py for
+ * the blur SDE's per-frequency transition (the reference never runs it, there is no behaviour to match):
+ *   coef_host[nfe][n_slots][32*32]: slot 0 = psi_i = m(t_{i+1}) / m(t_i), slot 1 = coefficient of the new eps_y, slots 2.. of the
+ *   history (newest first); n_slots = order + 2.  gd_sample_blur then runs y' = c0 y + c1 e_y + sum_j c_{2+j} hist_j per step. */
+int gd_engine_set_schedule_blur_deis(gd_engine *e, int nfe, int n_slots, const float *ts_host, const float *coef_host);
 /* y_in_dev (B,32,32,C) -> x_out_dev (B,32,32,C) = inverse_scaler(IDCT(y_nfe)).
  * Replaces: sampler(rng, state, batch_size, u) (blur_jax/sampling.py:55-80). */
 int gd_sample_blur(gd_engine *e, int batch, const float *y_in_dev, float *x_out_dev, int inverse_scale,

@@ -431,3 +431,35 @@ def test_production_batch_sampler_matches_oracle(native_lib):
     ex, ev = np.abs(x[:n_ref].cpu().numpy() - wx).max(), np.abs(v[:n_ref].cpu().numpy() - wv).max()
     print("B=256 sampler: max|dx| %.3e max|dv| %.3e (|x| %.3e |v| %.3e)" % (ex, ev, np.abs(wx).max(), np.abs(wv).max()))
     assert torch.isfinite(x).all() and ex < _tol(wx) and ev < _tol(wv)
+
+
+@pytest.mark.parametrize("order", [0, 1, 2])
+def test_blur_deis_sampler_matches_float64_loop(blur_setup, order):
+    """The multistep blur sampler (extension: per-frequency DEIS) against an independent float64 loop with
+    the same coefficient tables; order 0 must reproduce the reference's order0 sampler."""
+    from gddim_amd.blur import multistep, sampling
+    from gddim_amd.datasets import get_data_inverse_scaler
+    cfg, params, sde, osde, model, state, y = blur_setup
+    nfe = 6
+    inv = get_data_inverse_scaler(cfg)
+    fn = sampling.get_deis_sampler(sde, model, (32, 32, 3), ts_order=2, nfe=nfe, deis_order=order, inverse_scaler=inv)
+    yt = torch.as_tensor(y, device="cuda:0")
+    x, n = fn(0, state, y.shape[0], yt)
+    rev = sampling.get_rev_ts(sde, 2, nfe)
+    coef, psi = multistep.get_ab_eps_coef_freq(sde, order, rev, order)
+    eps64 = onet.blur_eps_fn(params, cfg, dtype=torch.float64)
+    wx, _ = oblur.freq_deis_sampler(osde, eps64, y.astype(np.float64), nfe, order, ts_order=2, inverse_scaler=lambda a: (a + 1) / 2,
+                                    coef=coef, psi=psi)
+    err = np.abs(x.cpu().numpy() - wx).max()
+    print("blur deis order=%d: max|dx| %.3e (|x| %.2f)" % (order, err, np.abs(wx).max()))
+    assert n == nfe and np.isfinite(wx).all() and err < _tol(wx)
+    x2, _ = fn(0, state, y.shape[0], yt, use_graph=False)
+    assert torch.equal(x, x2)
+    if order == 0:
+        x0, _ = sampling.get_order0_sampler(sde, model, (32, 32, 3), ts_order=2, nfe=nfe, inverse_scaler=inv)(0, state, y.shape[0], yt)
+        assert (x - x0).abs().max().item() < 1e-4 * max(1.0, x0.abs().max().item())
+    else:
+        cfg2 = cfg.copy_and_resolve_references()
+        cfg2.sampling.method, cfg2.sampling.nfe, cfg2.sampling.deis_order = 'deis', nfe, order
+        xs, _ = sampling.get_sampling_fn(cfg2, sde, model, None, inv)([0], state, y.shape[0], yt[None])
+        assert torch.equal(xs[0], x)
