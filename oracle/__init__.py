@@ -17,4 +17,11 @@ conv/GroupNorm/softmax vs independent numpy loops, and the Dirac-data closed-for
 trajectory.  Third-party arithmetic the reference delegates to (flax ``nn.Conv`` /
 ``nn.GroupNorm(epsilon=1e-6)`` / ``nn.Dense``, ``jax.nn.softmax``, ``lax.conv_general_dilated``)
 is restated from its published semantics.
+
+Modules: ``cld`` (CLD SDE algebra, DEIS tables, deis / order0 samplers), ``cld_ext`` (LSDE, MLCLD, LambdaSDE and the ldeis /
+mldeis / sdeis / em / sscs / ode samplers, mixed score), ``ncsnpp`` (the U-Net incl. the fir=False / positional-embedding
+configurations), ``blur`` (blur SDE, DCT, order0 sampler, scalar DEIS; plus an independent float64 formulation of the package's
+per-frequency multistep extension, marked as not being reference code), ``rng`` (restatement of the ENGINE's Philox / Box-Muller
+noise source -- jax's threefry stream cannot be reproduced -- pinned by the Random123 known-answer vectors), ``rscan.c`` (R(t) scan
+in float32 / float64).
 """
