@@ -463,3 +463,27 @@ def test_blur_deis_sampler_matches_float64_loop(blur_setup, order):
         cfg2.sampling.method, cfg2.sampling.nfe, cfg2.sampling.deis_order = 'deis', nfe, order
         xs, _ = sampling.get_sampling_fn(cfg2, sde, model, None, inv)([0], state, y.shape[0], yt[None])
         assert torch.equal(xs[0], x)
+
+
+def test_production_batch_blur_sampler_matches_oracle(native_lib):
+    """BASELINE config 3 shapes (blur gDDIM, ddpm_deep U-Net on 3 channels, 256 images per call): first two images against the
+    float64 oracle loop on those two images, NFE 3."""
+    from gddim_amd.blur import sampling, sde_lib
+    from gddim_amd.configs import blur_ddpm_deep_cifar10
+    from gddim_amd.datasets import get_data_inverse_scaler
+    from gddim_amd.models import utils as mutils
+    cfg = blur_ddpm_deep_cifar10.get_config()
+    params = onet.random_params(cfg, 3, seed=0)
+    sde = sde_lib.from_config(cfg)
+    osde = oblur.SDE(sigma_blur_max=cfg.model.sigma_blur_max, sampling_eps=cfg.sampling.t0)
+    model = mutils.get_model(cfg.model.name)(config=cfg)
+    state = mutils.State(params_ema=params, model_state={})
+    B, n_ref, nfe = 256, 2, 3
+    y = np.random.default_rng(4).standard_normal((B, 32, 32, 3)).astype(np.float32)
+    fn = sampling.get_order0_sampler(sde, model, (32, 32, 3), ts_order=2, nfe=nfe, inverse_scaler=get_data_inverse_scaler(cfg))
+    x, _ = fn(0, state, B, torch.as_tensor(y, device="cuda:0"))
+    wx, _ = oblur.order0_sampler(osde, onet.blur_eps_fn(params, cfg, dtype=torch.float64), y[:n_ref].astype(np.float64), nfe, ts_order=2,
+                                 inverse_scaler=lambda a: (a + 1) / 2)
+    err = np.abs(x[:n_ref].cpu().numpy() - wx).max()
+    print("B=256 blur: max|dx| %.3e (|x| %.3e)" % (err, np.abs(wx).max()))
+    assert torch.isfinite(x).all() and err < _tol(wx)
