@@ -51,26 +51,27 @@ __global__ __launch_bounds__(512) void conv3x3_halo_bf16x3_kernel(const GemmPara
     const int wm = wave / WN, wn = wave % WN;
 
     const int nt = p.n_tiles;
-    const int id = blockIdx.x;
-    int ntile, mtile;
-    if (p.flat_tiles) {
-        mtile = id / nt;
-        ntile = id - mtile * nt;
-    } else {
-        const int grp = id / (8 * nt);
-        const int rem = id - grp * 8 * nt;
-        ntile = rem >> 3;
-        mtile = grp * 8 + (rem & 7);
-    }
-    if (mtile >= p.m_tiles) return;
-    const int m0 = mtile * HBM_, n0 = ntile * HBN_;
-
     const int W = p.W, H = p.H, C = p.C0 + p.C1;  // C1 > 0 only with FUSE: the GroupNorm ran on a channel concat of two tensors
     const int HW2 = W + 2;
     const int rows = HBM_ / W;                 // complete image rows per tile (H*W is a multiple of 256)
     const int HP = (rows + 2) * HW2;           // halo pixels
-    const int img = m0 / (H * W);
-    const int y0 = (m0 - img * H * W) / W;     // first output row of the tile inside its image
+    // The kernel is PERSISTENT: a workgroup walks tile ids blockIdx.x, blockIdx.x + gridDim.x, ... (gridDim.x a multiple of 8, so
+    // the XCD of an id is preserved) and requests the first loads of its next tile BEFORE the epilogue of the current one, so that
+    // their latency hides behind the epilogue instead of opening every tile.  p.diag == 1 (A/B) launches one workgroup per tile.
+    const int total_ids = p.flat_tiles ? p.m_tiles * nt : ((p.m_tiles + 7) / 8) * 8 * nt;
+    auto tile_of = [&](int id, int &mtile, int &ntile) {
+        if (p.flat_tiles) {
+            mtile = id / nt;
+            ntile = id - mtile * nt;
+        } else {
+            const int grp = id / (8 * nt);
+            const int rem = id - grp * 8 * nt;
+            ntile = rem >> 3;
+            mtile = grp * 8 + (rem & 7);
+        }
+        return mtile < p.m_tiles;
+    };
+    int m0 = 0, n0 = 0, img = 0, y0 = 0;       // coordinates of the tile whose loads are being issued
 
     const char *ac = reinterpret_cast<const char *>(p.a0);
     const int a_imgs = (p.M + H * W - 1) / (H * W);
@@ -84,7 +85,8 @@ __global__ __launch_bounds__(512) void conv3x3_halo_bf16x3_kernel(const GemmPara
     const __amdgpu_buffer_rsrc_t srd_bl = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char *>(reinterpret_cast<const char *>(p.b_lo)), 0, p.N * p.ldb * 2, 0x00020000);
 
-    // ---- halo pieces of this thread (loop invariant): piece q = tid + 512 j -> (plane, pixel, 16-byte slot) ----
+    // ---- halo pieces of this thread: piece q = tid + 512 j -> (plane, pixel, 16-byte slot).  The LDS side (alds) does not depend
+    // on the tile; the global side (avo, avo1, bvo, tab_base) is recomputed by setup() for every tile ----
     int avo[HAJ];   // global voffset (bytes, without the channel slab), OOB for out-of-image / unused pieces
     int avo1[FUSE ? HAJ : 1];  // the same for the second source of a fused concat GroupNorm
     int alds[HAJ];  // LDS element offset inside a stage
@@ -96,30 +98,43 @@ __global__ __launch_bounds__(512) void conv3x3_halo_bf16x3_kernel(const GemmPara
         const int plane = FUSE ? 0 : (q >= HP * 4 ? 1 : 0);
         const int r = q - plane * HP * 4;
         const int pix = FUSE ? q >> 3 : r >> 2, slot = FUSE ? q & 7 : r & 3;
-        avo[j] = OOB;
-        if (FUSE) avo1[j] = OOB;
-        alds[j] = 0;
-        if (q < HP * 8) {
-            const int hy = pix / HW2, hx = pix - hy * HW2;
-            const int y = y0 + hy - 1, x = hx - 1;
-            alds[j] = FUSE ? pix * HREC + slot * 4 : plane * HA_PLANE + pix * HREC + slot * 8;
-            if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W && img < a_imgs) {
-                avo[j] = FUSE ? ((img * H + y) * W + x) * p.lda0 * 4 + slot * 16
-                              : ((img * H + y) * W + x) * p.lda0 * 4 + plane * p.lda0 * 2 + slot * 16;
-                if (FUSE) avo1[j] = ((img * H + y) * W + x) * p.lda1 * 4 + slot * 16;
-            } else
-                avo[j] = OOB;  // inside the halo but outside the image: the load returns zero and the zero is stored
-        }
+        alds[j] = q < HP * 8 ? (FUSE ? pix * HREC + slot * 4 : plane * HA_PLANE + pix * HREC + slot * 8) : 0;
     }
     const int brow = tid >> 2;        // weight row inside the chunk (128 rows x 4 threads)
     const int bq = (tid & 3) * 8;
-    const int bn = n0 + brow;
-    const int bvo = (brow < HBN_ && bn < p.N) ? (bn * p.ldb + bq) * 2 : OOB;
+    int bvo = OOB;
+    const float *tab_base = nullptr;  // fused GroupNorm: [C scale | C shift] of the tile's image, at the thread's 4-channel slot
+    auto setup = [&](int id) {
+        int mtile, ntile;
+        tile_of(id, mtile, ntile);
+        m0 = mtile * HBM_;
+        n0 = ntile * HBN_;
+        img = m0 / (H * W);
+        y0 = (m0 - img * H * W) / W;  // first output row of the tile inside its image
+#pragma unroll
+        for (int j = 0; j < HAJ; ++j) {
+            const int q = tid + NT * j;
+            const int plane = FUSE ? 0 : (q >= HP * 4 ? 1 : 0);
+            const int r = q - plane * HP * 4;
+            const int pix = FUSE ? q >> 3 : r >> 2, slot = FUSE ? q & 7 : r & 3;
+            avo[j] = OOB;  // outside the image (the load returns zero and the zero is stored) or an unused piece
+            if (FUSE) avo1[j] = OOB;
+            const int hy = pix / HW2, hx = pix - hy * HW2;
+            const int y = y0 + hy - 1, x = hx - 1;
+            if (q < HP * 8 && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W && img < a_imgs) {
+                avo[j] = FUSE ? ((img * H + y) * W + x) * p.lda0 * 4 + slot * 16
+                              : ((img * H + y) * W + x) * p.lda0 * 4 + plane * p.lda0 * 2 + slot * 16;
+                if (FUSE) avo1[j] = ((img * H + y) * W + x) * p.lda1 * 4 + slot * 16;
+            }
+        }
+        const int bn = n0 + brow;
+        bvo = (brow < HBN_ && bn < p.N) ? (bn * p.ldb + bq) * 2 : OOB;
+        if (FUSE) tab_base = p.gn_table + (size_t)(img < a_imgs ? img : 0) * 2 * C + (tid & 7) * 4;
+    };
 
     hu32x4 ra[HAJ], rbh, rbl;
     const int nslab = C / 32;
-    // fused GroupNorm: scale / shift of the thread's four channels in the slab being staged (tab) and the next one (tab_n)
-    const float *tab_base = FUSE ? p.gn_table + (size_t)(img < a_imgs ? img : 0) * 2 * C + (tid & 7) * 4 : nullptr;
+    // fused GroupNorm: scale / shift of the thread's four channels in the slab whose pieces are stored next
     hf32x4 sc4 = {0.f, 0.f, 0.f, 0.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
     auto load_tab = [&](int slab) {
         if (FUSE && slab < nslab) {
@@ -170,13 +185,6 @@ __global__ __launch_bounds__(512) void conv3x3_halo_bf16x3_kernel(const GemmPara
     };
 
     hf32x16 acc[RM][RN];
-#pragma unroll
-    for (int r = 0; r < RM; ++r)
-#pragma unroll
-        for (int c = 0; c < RN; ++c)
-#pragma unroll
-            for (int v = 0; v < 16; ++v) acc[r][c][v] = 0.f;
-
     const int li = lane & 31, lh = lane >> 5;
     // A fragment base per r tile: output pixel m_local = wm*64 + r*32 + li -> (ly, x) -> halo pixel (ly, x) for tap (0, 0)
     int a_off[RM];
@@ -188,73 +196,107 @@ __global__ __launch_bounds__(512) void conv3x3_halo_bf16x3_kernel(const GemmPara
     }
     const int b_off = 2 * HA_PLANE + (wn * 64 + li) * HREC + lh * 8;
 
-    // ---- prologue: halo of slab 0 and weight chunk (tap 0, slab 0) into stage 0; prefetch chunk (tap 1, slab 0) ----
-    load_tab(0);
+    auto issue_prologue = [&]() {  // first loads of the tile set up by setup(): affine map, halo of slab 0, weight chunk (0, 0)
+        load_tab(0);
 #pragma unroll
-    for (int j = 0; j < HAJ; ++j) load_halo(j, 0);
-    load_b(0, 0);
-#pragma unroll
-    for (int j = 0; j < HAJ; ++j) store_halo(j, smem);
-    store_b(smem);
-    load_b(1, 0);
-    __syncthreads();
+        for (int j = 0; j < HAJ; ++j) load_halo(j, 0);
+        load_b(0, 0);
+    };
 
-    // Iteration (slab, tap) reads A from halo stage (slab & 1) and B from weight stage ((slab + tap) & 1) (9 taps: the parity of
-    // slab*9 + tap); during it the weight chunk of the next iteration (already in registers) is stored to the other B stage and the
-    // one after that is requested; the halo of slab + 1 is requested during taps 0..HAJ-1 (one piece per tap) and stored into the
-    // other halo stage during taps 9-HAJ..8.  The tap loop is unrolled so that every register-array index is a constant.
-    for (int slab = 0; slab < nslab; ++slab) {
-        const __bf16 *curA = smem + (slab & 1) * HSTAGE;
-        __bf16 *nxtA = smem + ((slab + 1) & 1) * HSTAGE;
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const __bf16 *curB = smem + ((slab + tap) & 1) * HSTAGE;
-            __bf16 *nxtB = smem + ((slab + tap + 1) & 1) * HSTAGE;
-            const int ty = tap / 3, tx = tap - ty * 3;
-            const int tap_off = (ty * HW2 + tx) * HREC;
-            const int tap2 = (tap + 2) % 9, slab2 = slab + (tap + 2) / 9;  // the chunk two iterations ahead
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                hbf16x8 ah[RM], al[RM], bh[RN], bl[RN];
-#pragma unroll
-                for (int r = 0; r < RM; ++r) {
-                    ah[r] = *reinterpret_cast<const hbf16x8 *>(curA + a_off[r] + tap_off + s * 16);
-                    al[r] = *reinterpret_cast<const hbf16x8 *>(curA + HA_PLANE + a_off[r] + tap_off + s * 16);
-                }
-#pragma unroll
-                for (int c = 0; c < RN; ++c) {
-                    bh[c] = *reinterpret_cast<const hbf16x8 *>(curB + b_off + c * 32 * HREC + s * 16);
-                    bl[c] = *reinterpret_cast<const hbf16x8 *>(curB + HB_PLANE + b_off + c * 32 * HREC + s * 16);
-                }
-#pragma unroll
-                for (int term = 0; term < 3; ++term) {
-#pragma unroll
-                    for (int r = 0; r < RM; ++r)
-#pragma unroll
-                        for (int c = 0; c < RN; ++c) {
-                            const hbf16x8 a = term == 2 ? al[r] : ah[r];
-                            const hbf16x8 b = term == 1 ? bl[c] : bh[c];
-                            acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[r][c], 0, 0, 0);
-                        }
-                    __builtin_amdgcn_sched_barrier(0);
-                    const int gap = s * 3 + term;
-                    if (gap == 0) {
-                        store_b(nxtB);
-                        load_b(tap2, slab2);
-                    } else if (gap == 1) {
-                        if (tap == 0) load_tab(slab + 1);  // first in the queue: the map of the slab whose pieces follow
-                        if (tap < HAJ) load_halo(tap, slab + 1);
-                    } else if (gap == 2) {
-                        if (tap >= 9 - HAJ) store_halo(tap - (9 - HAJ), nxtA);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            __syncthreads();
-        }
+    int id = blockIdx.x;
+    {
+        int mt, ntl;
+        if (id >= total_ids || !tile_of(id, mt, ntl)) return;  // (padded ids of the XCD-aware mapping)
     }
+    setup(id);
+    issue_prologue();
+    for (;;) {
+        // ---- halo of slab 0 and weight chunk (tap 0, slab 0) into stage 0; request chunk (tap 1, slab 0) ----
+#pragma unroll
+        for (int j = 0; j < HAJ; ++j) store_halo(j, smem);
+        store_b(smem);
+        load_b(1, 0);
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < RM; ++r)
+#pragma unroll
+            for (int c = 0; c < RN; ++c)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) acc[r][c][v] = 0.f;
 
-    epilogue_rows<RM, RN>(p, acc, m0 + wm * 64, n0 + wn * 64, li, lh, false);
+        // Iteration (slab, tap) reads A from halo stage (slab & 1) and B from weight stage ((slab + tap) & 1) (9 taps: the parity of
+        // slab*9 + tap); during it the weight chunk of the next iteration (already in registers) is stored to the other B stage and the
+        // one after that is requested; the halo of slab + 1 is requested during taps 0..HAJ-1 (one piece per tap) and stored into the
+        // other halo stage during taps 9-HAJ..8.  The tap loop is unrolled so that every register-array index is a constant.
+        for (int slab = 0; slab < nslab; ++slab) {
+            const __bf16 *curA = smem + (slab & 1) * HSTAGE;
+            __bf16 *nxtA = smem + ((slab + 1) & 1) * HSTAGE;
+    #pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const __bf16 *curB = smem + ((slab + tap) & 1) * HSTAGE;
+                __bf16 *nxtB = smem + ((slab + tap + 1) & 1) * HSTAGE;
+                const int ty = tap / 3, tx = tap - ty * 3;
+                const int tap_off = (ty * HW2 + tx) * HREC;
+                const int tap2 = (tap + 2) % 9, slab2 = slab + (tap + 2) / 9;  // the chunk two iterations ahead
+    #pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    hbf16x8 ah[RM], al[RM], bh[RN], bl[RN];
+    #pragma unroll
+                    for (int r = 0; r < RM; ++r) {
+                        ah[r] = *reinterpret_cast<const hbf16x8 *>(curA + a_off[r] + tap_off + s * 16);
+                        al[r] = *reinterpret_cast<const hbf16x8 *>(curA + HA_PLANE + a_off[r] + tap_off + s * 16);
+                    }
+    #pragma unroll
+                    for (int c = 0; c < RN; ++c) {
+                        bh[c] = *reinterpret_cast<const hbf16x8 *>(curB + b_off + c * 32 * HREC + s * 16);
+                        bl[c] = *reinterpret_cast<const hbf16x8 *>(curB + HB_PLANE + b_off + c * 32 * HREC + s * 16);
+                    }
+    #pragma unroll
+                    for (int term = 0; term < 3; ++term) {
+    #pragma unroll
+                        for (int r = 0; r < RM; ++r)
+    #pragma unroll
+                            for (int c = 0; c < RN; ++c) {
+                                const hbf16x8 a = term == 2 ? al[r] : ah[r];
+                                const hbf16x8 b = term == 1 ? bl[c] : bh[c];
+                                acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[r][c], 0, 0, 0);
+                            }
+                        __builtin_amdgcn_sched_barrier(0);
+                        const int gap = s * 3 + term;
+                        if (gap == 0) {
+                            store_b(nxtB);
+                            load_b(tap2, slab2);
+                        } else if (gap == 1) {
+                            if (tap == 0) load_tab(slab + 1);  // first in the queue: the map of the slab whose pieces follow
+                            if (tap < HAJ) load_halo(tap, slab + 1);
+                        } else if (gap == 2) {
+                            if (tap >= 9 - HAJ) store_halo(tap - (9 - HAJ), nxtA);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                __syncthreads();
+            }
+        }
+
+
+        // ---- next tile: its first loads go out now, the epilogue below covers their latency ----
+        const int done_m0 = m0, done_n0 = n0;
+        int next = id + (int)gridDim.x;
+        bool more = false;
+        if (p.diag != 1) {
+            int mt, ntl;
+            while (next < total_ids && !tile_of(next, mt, ntl)) next += (int)gridDim.x;
+            more = next < total_ids;
+        }
+        if (more) {
+            setup(next);
+            issue_prologue();
+        }
+        epilogue_rows<RM, RN>(p, acc, done_m0 + wm * 64, done_n0 + wn * 64, li, lh, false);
+        if (!more) break;
+        id = next;
+    }
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------------
@@ -307,7 +349,17 @@ int launch_conv3x3_halo(const GemmParams &p_in, hipStream_t s) {
     p.m_tiles = p.M / HBM_;
     p.n_tiles = (p.N + HBN_ - 1) / HBN_;
     p.flat_tiles = p.m_tiles < 16;
-    const int gx = p.flat_tiles ? p.m_tiles * p.n_tiles : ((p.m_tiles + 7) / 8) * 8 * p.n_tiles;
+    const int total = p.flat_tiles ? p.m_tiles * p.n_tiles : ((p.m_tiles + 7) / 8) * 8 * p.n_tiles;
+    static const int one_per_tile = getenv("GDDIM_X3_NOPERSIST") ? atoi(getenv("GDDIM_X3_NOPERSIST")) : 0;  // A/B only
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        cus = (cus / 8) * 8;  // one workgroup per CU (150 KB of LDS each); a multiple of 8 keeps a tile id on its XCD
+    }
+    p.diag = one_per_tile ? 1 : 0;
+    const int gx = one_per_tile ? total : (total < cus ? total : cus);
     if (p.gn_table) hipLaunchKernelGGL(conv3x3_halo_bf16x3_kernel<true>, dim3(gx), dim3(512), 0, s, p);
     else hipLaunchKernelGGL(conv3x3_halo_bf16x3_kernel<false>, dim3(gx), dim3(512), 0, s, p);
     GD_HIP(hipGetLastError());
