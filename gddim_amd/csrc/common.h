@@ -85,6 +85,10 @@ struct GemmParams {
     // rows_per_image == 16 (qs_slices = 1).  Unique writer per entry: deterministic.  null = not requested.
     float *qstats;
     int qs_slices;
+    // fp32 Winograd F(2,3) path (kernels/conv3x3_wino_f32.hip): the 3x3 weights pre-transformed to
+    // U[n][ky][Cin/8][component][8] by launch_wino_weights (row stride ldb_wino = 12 Cin); null = direct kernel
+    const float *b_wino;
+    int ldb_wino;
 };
 
 int launch_igemm(const GemmParams &p, int batch_z, hipStream_t s);
@@ -103,6 +107,12 @@ bool conv3x3_halo_fused_ok(const GemmParams &p);  // shape test of the fused-Gro
 const char *conv3x3_halo_name();
 const char *conv3x3_halo_fused_name();
 int launch_conv3x3_halo(const GemmParams &p, hipStream_t s);
+// fp32 3x3 stride-1 convolutions through the 1-D Winograd transform F(2,3) (x 1.5 fewer matrix-core flops);
+// GDDIM_NOWINO=1 routes them back to igemm_f32_fast_kernel
+bool conv3x3_wino_ok(const GemmParams &p);
+const char *conv3x3_wino_name();
+int launch_conv3x3_wino(const GemmParams &p, hipStream_t s);
+int launch_wino_weights(const float *w, float *u, int N, int Cin, hipStream_t s);
 // per-device zero buffer used by the staging loads; allocates on first use (call once outside graph capture)
 const float *igemm_zero_buffer();
 

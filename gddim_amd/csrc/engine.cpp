@@ -1000,6 +1000,23 @@ int gd_conv2d(const float *x_dev, const float *w_dev, const float *bias_dev, con
     return launch_igemm(g, 1, (hipStream_t)stream);
 }
 
+int gd_conv3x3_winograd(const float *x_dev, const float *w_dev, float *u_scratch_dev, const float *bias_dev, const float *res_dev,
+                        float *out_dev, int batch, int H, int W, int Cin, int Cout, float alpha, float out_scale, void *stream) {
+    GD_CHECK(x_dev && w_dev && u_scratch_dev && out_dev, "null pointer");
+    GemmParams g{};
+    g.a0 = x_dev; g.C0 = Cin; g.lda0 = Cin; g.lda1 = 4;
+    g.H = H; g.W = W; g.KH = 3; g.KW = 3; g.stride = 1; g.pad = 1; g.OH = H; g.OW = W;
+    g.M = batch * H * W; g.N = Cout; g.K = 9 * Cin;
+    g.b = w_dev; g.ldb = g.K;
+    g.out = out_dev; g.ldc = Cout; g.bias = bias_dev; g.res = res_dev; g.ldres = Cout;
+    g.rows_per_image = H * W;
+    g.alpha = alpha; g.out_scale = out_scale;
+    GD_CHECK(conv3x3_wino_ok(g), "conv3x3_winograd: shape not eligible (B=%d H=%d W=%d Cin=%d Cout=%d)", batch, H, W, Cin, Cout);
+    GD_TRY(launch_wino_weights(w_dev, u_scratch_dev, Cout, Cin, (hipStream_t)stream));
+    g.b_wino = u_scratch_dev;
+    return launch_conv3x3_wino(g, (hipStream_t)stream);
+}
+
 int gd_group_norm(const float *x_dev, const float *scale_dev, const float *bias_dev, float *out_dev, int batch, int HW, int C,
                   int groups, int act, void *stream) {
     GD_CHECK(x_dev && scale_dev && bias_dev && out_dev, "null pointer");

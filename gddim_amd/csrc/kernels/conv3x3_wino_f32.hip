@@ -1,0 +1,423 @@
+// 3x3 / stride 1 / pad 1 convolution in fp32 with the one-dimensional Winograd transform F(2,3) along x.
+//
+// The fp32 matrix core is the roofline of this path (157 TFLOP/s; igemm_f32_fast_kernel sits at 86 % of it), so the only
+// way past it is to issue fewer multiplications.  For an output pixel pair (x = 2p, 2p+1) of one row, the three taps
+// g0 g1 g2 of a kernel row ky and the four inputs d0..d3 = in[y+ky-1][2p-1 .. 2p+2]:
+//     M0 = (d0 - d2) g0,   M1 = (d1 + d2)(g0 + g1 + g2)/2,   M2 = (d2 - d1)(g0 - g1 + g2)/2,   M3 = (d1 - d3) g2
+//     out[2p] = M0 + M1 + M2,   out[2p+1] = M1 - M2 - M3
+// The sums over (ky, c) commute with the output transform, so each component t is a plain GEMM
+//     M_t[pair][n] = sum_{ky,c} V_t[pair][ky,c] * U_t[n][ky,c]          (4 components x (M/2) x N x 3 Cin)
+// = 12 M N Cin flops instead of 18 M N Cin: x 1.5 fewer matrix-core cycles.  Both transforms are additions only (the 1/2
+// lives in the pre-transformed weights, which are computed in double and rounded once), so the result differs from the
+// direct fp32 sum by a few more roundings, not by a conditioning problem (F(2,3) is the benign Winograd size).
+//
+// Kernel: 256 threads = 4 wave64 as 2 x 2; workgroup tile BP pixel pairs x BN output channels x 4 components, each wave
+// (BP/2) x (BN/2) x 4 as v_mfma_f32_32x32x2_f32 accumulators (64 x 128: 8 accumulators = 128 VGPRs); two workgroups per CU
+// (55 KB of LDS each) so one computes while the other runs its output transform and epilogue.  K is consumed in chunks of
+// 8 channels of one kernel row: one ds_read_b128 per (fragment, component) feeds four MFMAs, 32 MFMAs per wave between
+// barriers.  The input transform runs in the staging path (raw float4 loads of the four pixels of a pair -> 16 VALU -> four
+// float4 LDS stores) on half of the waves, the other half stage more of the (pre-transformed) weights, so every wave issues
+// six global loads and six LDS stores per chunk.  Addressing follows igemm_f32_fast_kernel: chunk state in SGPRs, the row
+// part of an address precomputed per thread, out-of-image pixels pushed out of the buffer bounds (hardware zero fill).
+// K order: 32-channel slab outermost, then kernel row, then the four 8-channel chunks of the slab, so the 128-byte lines of
+// a pixel are touched by consecutive chunks.  Weights arrive as U[n][ky][Cin/8][component][8] (launch_wino_weights).
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+
+#include "../common.h"
+#include "epilogue.h"
+
+namespace gd {
+
+typedef float wf32x16 __attribute__((ext_vector_type(16)));
+typedef float wf32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int wu32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int WKC = 8;    // channels per chunk
+constexpr int WLD = 36;   // LDS row stride (floats): a row = 4 components x 8 channels + 4 pad -> 144 B, an odd number of 16-byte
+                          // units, so the ds_read_b128 of 8 consecutive rows and the 8 stores of one weight row cover all banks
+
+__device__ __forceinline__ wf32x4 wbuf_load16(__amdgpu_buffer_rsrc_t rsrc, int voffset, int soffset) {
+    wu32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voffset, soffset, 0);
+    return __builtin_bit_cast(wf32x4, v);
+}
+
+template <int BP, int BN>
+__global__ __launch_bounds__(256, 2) void conv3x3_wino_f32_kernel(const GemmParams p) {
+    constexpr int NT = 256;
+    constexpr int RM = BP / 64, RN = BN / 64;        // 32x32 accumulators per wave and component
+    constexpr int STAGE = (BP + BN) * WLD;           // floats per LDS stage: V[BP][4][8] | U[BN][4][8] (rows padded to 36)
+    constexpr int NA = BP * 2;                       // threads that stage activations: (pair, 4-channel half of the chunk)
+    constexpr int NBP = BN * 8;                      // 16-byte weight pieces per chunk: (n, component, half)
+    constexpr int BA = NA == NT ? NBP / NT : (NBP / 128 - 4) / 2;  // weight pieces of an activation thread ...
+    constexpr int BO = NA == NT ? 0 : BA + 4;                       // ... and of the other threads
+    constexpr int NG = 4 + BA > BO ? 4 + BA : BO;    // MFMA gaps that carry staging work
+    constexpr int OOB = (int)0x80000000u;
+    static_assert(NA % 64 == 0 && NA <= NT && NA * BA + (NT - NA) * BO == NBP && NG <= 16 && RM >= 1 && RN >= 1, "bad tile geometry");
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const bool is_a = wave < NA / 64;  // wave-uniform role
+
+    const int nt = p.n_tiles;
+    const int id = blockIdx.x;
+    int ntile, mtile;
+    if (p.flat_tiles) {
+        mtile = id / nt;
+        ntile = id - mtile * nt;
+    } else {
+        const int grp = id / (8 * nt);
+        const int rem = id - grp * 8 * nt;
+        ntile = rem >> 3;
+        mtile = grp * 8 + (rem & 7);
+    }
+    if (mtile >= p.m_tiles) return;
+    const int pair0 = mtile * BP, n0 = ntile * BN;
+
+    const int W = p.W, H = p.H, HW = H * W;
+    const int Cin = p.C0 + p.C1;
+    const int a_imgs = (p.M + HW - 1) / HW;
+    const int bias0 = (W + 1) * p.lda0 * 4, bias1 = (W + 1) * p.lda1 * 4;
+    const char *a0c = reinterpret_cast<const char *>(p.a0);
+    const __amdgpu_buffer_rsrc_t srd_a0 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(a0c - bias0), 0, a_imgs * HW * p.lda0 * 4 + bias0, 0x00020000);
+    const char *a1c = reinterpret_cast<const char *>(p.C1 ? p.a1 : p.a0);
+    const __amdgpu_buffer_rsrc_t srd_a1 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(a1c - bias1), 0, a_imgs * HW * p.lda1 * 4 + bias1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srd_b = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(reinterpret_cast<const char *>(p.b_wino)), 0, p.N * p.ldb_wino * 4, 0x00020000);
+
+    // ---- loop-invariant per-thread staging data.  Every thread owns NS = 6 staging slots (one float4 register each, one MFMA gap
+    // each).  Activation thread: slots 0..3 are the raw pixels d0..d3 of its pair, slots 4.. weight pieces; weight thread: all
+    // slots are weight pieces.  sv[] / sl[] hold the global voffset / LDS offset of a weight slot; an activation thread keeps
+    // (rb0, rb1, inv) in sv[0..2] and its LDS offset in sl[0]. ----
+    constexpr int NS = NG;
+    int sv[NS], sl[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        // weight piece of slot i: activation threads use slots 4..4+BA-1, weight threads slots 0..BO-1
+        const bool used = is_a ? (i >= 4 && i < 4 + BA) : i < BO;
+        const int q = is_a ? tid + NA * (i - 4) : NA * BA + (tid - NA) + (NT - NA) * i;
+        const int nl = (q >> 3) & (BN - 1), j = q & 7;
+        const int n = n0 + nl;
+        sv[i] = (used && n < p.N) ? (n * p.ldb_wino + j * 4) * 4 : OOB;
+        sl[i] = (BP + nl) * WLD + j * 4;
+    }
+    if (is_a) {
+        const int pl = tid >> 1, cq = tid & 1;
+        const int pair = pair0 + pl;
+        sl[0] = pl * WLD + cq * 4;
+        sv[0] = 0; sv[1] = 0; sv[2] = -1;  // rb0, rb1, inv (all taps invalid)
+        if (2 * pair < p.M) {
+            const int m = 2 * pair;
+            const int img = (int)epi_div((unsigned)m, (unsigned)HW, p.mg_ohw, p.sh_ohw);
+            const int r = m - img * HW;
+            const int y = (int)epi_div((unsigned)r, (unsigned)W, p.mg_ow, p.sh_ow);
+            const int x0 = r - y * W;
+            const int pix = (img * H + y - 1) * W + x0 - 1;
+            sv[0] = pix * p.lda0 * 4 + bias0 + cq * 16;
+            sv[1] = pix * p.lda1 * 4 + bias1 + cq * 16;
+            unsigned xb = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xb |= ((unsigned)(x0 - 1 + j) < (unsigned)W ? 0u : 1u) << j;
+            unsigned mk = 0;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) mk |= ((unsigned)(y + ky - 1) < (unsigned)H ? xb : 15u) << (4 * ky);
+            sv[2] = (int)mk;
+        }
+    }
+
+    // ---- wave-uniform state of the chunk whose loads are issued next ----
+    int s_kc = 0, s_sub = 0, s_ky = 0, s_c = 0;
+    const int nk = 3 * (Cin / WKC);
+    const int c8n = Cin / WKC;
+    auto advance = [&]() {
+        ++s_kc;
+        ++s_sub;
+        s_c += WKC;
+        if (s_sub == 4) {
+            s_sub = 0;
+            ++s_ky;
+            s_c -= 32;
+            if (s_ky == 3) { s_ky = 0; s_c += 32; }
+        }
+    };
+
+    wf32x4 rs[NS];
+    auto load_a = [&](int j) {  // raw pixel j of the pair -> rs[j]
+        const int bad = __builtin_amdgcn_sbfe(sv[2], s_ky * 4 + j, 1);
+        if (s_c < p.C0) {
+            const int soff = ((s_ky * W + j) * p.lda0 + s_c) * 4;
+            rs[j] = wbuf_load16(srd_a0, sv[0] | (bad & OOB), soff);
+        } else {
+            const int soff = ((s_ky * W + j) * p.lda1 + (s_c - p.C0)) * 4;
+            rs[j] = wbuf_load16(srd_a1, sv[1] | (bad & OOB), soff);
+        }
+    };
+    auto load_b = [&](int i) {
+        const int soff = ((s_ky * c8n + (s_c >> 3)) * 32) * 4;
+        rs[i] = wbuf_load16(srd_b, sv[i], soff);
+    };
+    auto store_b = [&](int i, float *st) { *reinterpret_cast<wf32x4 *>(&st[sl[i]]) = rs[i]; };
+    auto store_v = [&](int t, wf32x4 v, float *st) { *reinterpret_cast<wf32x4 *>(&st[t * 8 + sl[0]]) = v; };
+    // Staging work of MFMA gap g: write slot g's piece of chunk kc+1 to the other LDS stage, then request slot g for chunk
+    // kc+2.  The input transform is arranged so that an activation thread frees its raw pixels in slot order:
+    //   gap 0: V0 = d0 - d2 stored;                       gap 1: V1 = d1 + d2 stored, d2 <- d2 - d1 (= V2), d3 <- d1 - d3 (= V3);
+    //   gap 2: V2 stored;                                 gap 3: V3 stored.
+    // ROLE / LOADS are compile-time tags (std::integral_constant): the two roles run two separate copies of the K loop (no
+    // control-flow joins between them inside the loop -- joins made the compiler copy the staging registers and wait for
+    // vmcnt(0) in every gap), and the last two iterations, which have nothing left to request, are peeled without loads.
+    auto stage_gap = [&](int g, float *st, auto role_a, auto loads) {
+        if constexpr (decltype(role_a)::value) {
+            if (g == 0) store_v(0, rs[0] - rs[2], st);
+            else if (g == 1) {
+                store_v(1, rs[1] + rs[2], st);
+                rs[2] = rs[2] - rs[1];
+                rs[3] = rs[1] - rs[3];
+            } else if (g == 2) store_v(2, rs[2], st);
+            else if (g == 3) store_v(3, rs[3], st);
+            else if (g < 4 + BA) store_b(g, st);
+            if constexpr (decltype(loads)::value) {
+                if (g < 4) load_a(g);
+                else if (g < 4 + BA) load_b(g);
+            }
+        } else {
+            if (g < BO) {
+                store_b(g, st);
+                if constexpr (decltype(loads)::value) load_b(g);
+            }
+        }
+    };
+    auto load_all = [&](auto role_a) {
+#pragma unroll
+        for (int g = 0; g < NS; ++g) {
+            if constexpr (decltype(role_a)::value) {
+                if (g < 4) load_a(g);
+                else if (g < 4 + BA) load_b(g);
+            } else if (g < BO) load_b(g);
+        }
+    };
+
+    wf32x16 acc[4][RM][RN];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < RM; ++r)
+#pragma unroll
+            for (int c = 0; c < RN; ++c)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) acc[t][r][c][v] = 0.f;
+
+    const int li = lane & 31, lh = lane >> 5;
+    const int a_off = (wm * (BP / 2) + li) * WLD + lh * 4;
+    const int b_off = (BP + wn * (BN / 2) + li) * WLD + lh * 4;
+
+    wf32x4 af[2][RM], bf[2][RN];  // fragments of the component being multiplied and of the next one
+    auto load_frags = [&](int t, const float *st, int set) {
+#pragma unroll
+        for (int r = 0; r < RM; ++r) af[set][r] = *reinterpret_cast<const wf32x4 *>(st + t * 8 + a_off + r * 32 * WLD);
+#pragma unroll
+        for (int c = 0; c < RN; ++c) bf[set][c] = *reinterpret_cast<const wf32x4 *>(st + t * 8 + b_off + c * 32 * WLD);
+    };
+    auto chunk = [&](int kc, auto role_a, auto loads) {
+        const float *cur = smem + (kc & 1) * STAGE;
+        float *nxt = smem + ((kc + 1) & 1) * STAGE;
+        load_frags(0, cur, 0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+#pragma unroll
+                for (int r = 0; r < RM; ++r)
+#pragma unroll
+                    for (int c = 0; c < RN; ++c)
+                        acc[t][r][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[t & 1][r][jj], bf[t & 1][c][jj], acc[t][r][c], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                const int gap = t * 4 + jj;
+                if (jj == 0 && t < 3) load_frags(t + 1, cur, (t + 1) & 1);
+                if (gap < NG) stage_gap(gap, nxt, role_a, loads);
+                else if (gap == NG) advance();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (NG == 16) advance();
+        __syncthreads();
+    };
+    // prologue (chunk 0 -> stage 0, chunk 1 in registers) and K loop of one role
+    auto run = [&](auto role_a) {
+        load_all(role_a);
+        advance();
+        if constexpr (decltype(role_a)::value) {
+            store_v(0, rs[0] - rs[2], smem);
+            store_v(1, rs[1] + rs[2], smem);
+            store_v(2, rs[2] - rs[1], smem);
+            store_v(3, rs[1] - rs[3], smem);
+#pragma unroll
+            for (int i = 4; i < 4 + BA; ++i) store_b(i, smem);
+        } else {
+#pragma unroll
+            for (int i = 0; i < BO; ++i) store_b(i, smem);
+        }
+        load_all(role_a);
+        advance();
+        __syncthreads();
+        for (int kc = 0; kc < nk - 2; ++kc) chunk(kc, role_a, std::true_type{});
+        chunk(nk - 2, role_a, std::false_type{});
+        chunk(nk - 1, role_a, std::false_type{});
+    };
+    if (is_a) run(std::true_type{});
+    else run(std::false_type{});
+
+    // ---- output transform + epilogue.  Accumulator row (v&3) + 8 (v>>2) + 4 lh of tile r is pixel pair
+    // prow + that; its two pixels are rows 2*pair and 2*pair + 1 of the output matrix.  Column = lane & 31. ----
+    {
+        char *outc = reinterpret_cast<char *>(p.out);
+        const __amdgpu_buffer_rsrc_t srd_o = __builtin_amdgcn_make_buffer_rsrc(outc, 0, p.M * p.ldc * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t srd_r =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(reinterpret_cast<const char *>(p.res ? p.res : p.out)), 0,
+                                              p.M * p.ldres * 4, 0x00020000);
+        const unsigned rpi = p.rows_per_image;
+#pragma unroll
+        for (int c = 0; c < RN; ++c) {
+            const int n = n0 + wn * (BN / 2) + c * 32 + li;
+            const bool nok = n < p.N;
+            const float bias = (p.bias && nok) ? p.bias[n] : 0.f;
+            const int vo_o = nok ? (8 * lh * p.ldc + n) * 4 : OOB;
+            const int vo_r = nok ? (8 * lh * p.ldres + n) * 4 : OOB;
+#pragma unroll
+            for (int r = 0; r < RM; ++r) {
+                const int prow = pair0 + wm * (BP / 2) + r * 32;  // wave-uniform
+                const int mrow = 2 * prow;
+                float res_e[16], res_o[16];
+                if (p.res) {
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) {
+                        const int so = (mrow + 2 * ((v & 3) + 8 * (v >> 2))) * p.ldres * 4;
+                        res_e[v] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_r, vo_r, so, 0));
+                        res_o[v] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_r, vo_r, so + p.ldres * 4, 0));
+                    }
+                }
+                float addv[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) addv[g] = bias;
+                if (p.rowbias) {
+                    // rows_per_image is a multiple of 16: the 8 pairs (v & 3) + 4 lh of a group v >> 2 belong to one image
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const unsigned mr = (unsigned)(mrow + 16 * g);
+                        const unsigned img = mr < (unsigned)p.M ? epi_div(mr, rpi, p.mg_rpi, p.sh_rpi) : 0u;
+                        addv[g] += nok ? p.rowbias[(size_t)img * p.ld_rowbias + n] : 0.f;
+                    }
+                }
+                float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const float m0 = acc[0][r][c][v], m1 = acc[1][r][c][v], m2 = acc[2][r][c][v], m3 = acc[3][r][c][v];
+                    float ye = m0 + m1 + m2, yo = m1 - m2 - m3;
+                    float ae = addv[v >> 2], ao = addv[v >> 2];
+                    if (p.res) { ae += res_e[v]; ao += res_o[v]; }
+                    ye = (p.alpha * ye + ae) * p.out_scale;
+                    yo = (p.alpha * yo + ao) * p.out_scale;
+                    const int so = (mrow + 2 * ((v & 3) + 8 * (v >> 2))) * p.ldc * 4;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ye), srd_o, vo_o, so, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, yo), srd_o, vo_o, so + p.ldc * 4, 0);
+                    if (v < 8) { s0 += ye + yo; q0 += ye * ye + yo * yo; }
+                    else { s1 += ye + yo; q1 += ye * ye + yo * yo; }
+                }
+                if (p.qstats) {
+                    // pairs 0..15 of the tile (v < 8) are output rows mrow .. mrow+31 = one 32-row slice, pairs 16..31 the next one
+                    // (rows_per_image % 64 == 0 and M % 64 == 0: a tile is inside one image and either whole or absent)
+                    if (!nok) { s0 = q0 = s1 = q1 = 0.f; }
+                    s0 += __shfl_xor(s0, 1); q0 += __shfl_xor(q0, 1); s1 += __shfl_xor(s1, 1); q1 += __shfl_xor(q1, 1);
+                    s0 += __shfl_xor(s0, 2); q0 += __shfl_xor(q0, 2); s1 += __shfl_xor(s1, 2); q1 += __shfl_xor(q1, 2);
+                    s0 += __shfl_xor(s0, 32); q0 += __shfl_xor(q0, 32); s1 += __shfl_xor(s1, 32); q1 += __shfl_xor(q1, 32);
+                    if ((li & 3) == 0 && lh == 0 && nok && mrow < p.M) {
+                        const int Q = p.N >> 2;
+                        const int img = mrow / (int)rpi;
+                        const int sl = (mrow - img * (int)rpi) >> 5;
+                        float2 *o = reinterpret_cast<float2 *>(p.qstats) + ((size_t)img * p.qs_slices + sl) * Q + (n >> 2);
+                        o[0] = make_float2(s0, q0);
+                        o[Q] = make_float2(s1, q1);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// U[n][ky][c/8][t][c%8] from the packed direct weights w[n][(ky*3 + kx)*Cin + c]; sums in double, one rounding
+__global__ void wino_weights_kernel(const float *__restrict__ w, float *__restrict__ u, int N, int Cin) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)N * 3 * Cin;
+    if (idx >= total) return;
+    const int c = (int)(idx % Cin);
+    const int ky = (int)((idx / Cin) % 3);
+    const long long n = idx / (3LL * Cin);
+    const float *wr = w + n * 9 * Cin + (long long)ky * 3 * Cin + c;
+    const double g0 = wr[0], g1 = wr[Cin], g2 = wr[2 * Cin];
+    float *ur = u + n * 12 * Cin + ((long long)(ky * (Cin / 8) + c / 8) * 4) * 8 + (c & 7);
+    ur[0] = (float)g0;
+    ur[8] = (float)(0.5 * (g0 + g1 + g2));
+    ur[16] = (float)(0.5 * (g0 - g1 + g2));
+    ur[24] = (float)g2;
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------------------
+int launch_wino_weights(const float *w, float *u, int N, int Cin, hipStream_t s) {
+    GD_CHECK(w && u && N > 0 && Cin > 0 && Cin % 8 == 0, "wino_weights: bad argument (N=%d Cin=%d)", N, Cin);
+    const long long total = (long long)N * 3 * Cin;
+    hipLaunchKernelGGL(wino_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, u, N, Cin);
+    GD_HIP(hipGetLastError());
+    return 0;
+}
+
+static void wfill_div(unsigned d, unsigned &magic, unsigned &shift) {
+    unsigned s = 0;
+    while ((1ull << s) < d) ++s;
+    shift = s;
+    magic = (unsigned)((((1ull << 32) * ((1ull << s) - d)) / d) + 1);
+}
+
+// shape test (p.b_wino is not looked at); GDDIM_NOWINO=1 routes everything back to the direct kernel
+bool conv3x3_wino_ok(const GemmParams &p) {
+    static const int off = getenv("GDDIM_NOWINO") ? atoi(getenv("GDDIM_NOWINO")) : 0;
+    static const int min_blocks = getenv("GDDIM_WINO_MINBLOCKS") ? atoi(getenv("GDDIM_WINO_MINBLOCKS")) : 512;
+    if (off || p.in_act || p.b_kmajor || p.a_presplit || p.gn_table) return false;
+    if (p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1 || p.OH != p.H || p.OW != p.W) return false;
+    const int Cin = p.C0 + p.C1;
+    if (Cin % 32 != 0 || (p.C1 > 0 && (p.C0 % 32 != 0 || !p.a1)) || p.K != 9 * Cin) return false;
+    if (p.W % 2 != 0 || (p.H * p.W) % 64 != 0 || p.M % 64 != 0 || p.rows_per_image != p.H * p.W || p.N % 4 != 0 || p.N < 64) return false;
+    if (p.qstats && p.qs_slices != p.rows_per_image / 32) return false;
+    if ((long long)p.M * p.ldc * 4 + 64 >= (1LL << 31) || (p.res && (long long)p.M * p.ldres * 4 + 64 >= (1LL << 31))) return false;
+    const long long ldmax = p.lda0 > p.lda1 ? p.lda0 : p.lda1;
+    const long long a_bytes = ((long long)p.M + 2 * p.W + 8) * ldmax * 4 + Cin * 4 + 64;
+    if (a_bytes >= (1LL << 31) || (long long)p.N * 12 * Cin * 4 + 64 >= (1LL << 31)) return false;
+    const long long blocks = (long long)((p.M / 2 + 63) / 64) * ((p.N + 127) / 128);
+    return blocks >= min_blocks;
+}
+
+const char *conv3x3_wino_name() { return "conv3x3_wino_f32_kernel<64,128>"; }
+
+int launch_conv3x3_wino(const GemmParams &p_in, hipStream_t s) {
+    GemmParams p = p_in;
+    GD_CHECK(conv3x3_wino_ok(p) && p.b_wino, "conv3x3_wino: problem not eligible");
+    p.ldb_wino = 12 * (p.C0 + p.C1);
+    if (p.C1 == 0) p.lda1 = 4;
+    wfill_div((unsigned)(p.H * p.W), p.mg_ohw, p.sh_ohw);
+    wfill_div((unsigned)p.W, p.mg_ow, p.sh_ow);
+    wfill_div((unsigned)(p.rows_per_image > 0 ? p.rows_per_image : 1), p.mg_rpi, p.sh_rpi);
+    constexpr int BP = 64, BN = 128;
+    p.m_tiles = (p.M / 2 + BP - 1) / BP;
+    p.n_tiles = (p.N + BN - 1) / BN;
+    p.flat_tiles = p.m_tiles < 16;
+    const int gx = p.flat_tiles ? p.m_tiles * p.n_tiles : ((p.m_tiles + 7) / 8) * 8 * p.n_tiles;
+    hipLaunchKernelGGL((conv3x3_wino_f32_kernel<BP, BN>), dim3(gx), dim3(256), 0, s, p);
+    GD_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace gd

@@ -239,6 +239,13 @@ int gd_dct2d_32(const float *in_dev, float *out_dev, int batch, int channels, in
 int gd_conv2d(const float *x_dev, const float *w_dev, const float *bias_dev, const float *res_dev, float *out_dev,
               int batch, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, float alpha,
               float out_scale, void *stream);
+/* The same 3x3 / stride 1 / pad 1 convolution through the fp32 Winograd F(2,3) kernel (what the engine runs for the
+ * 32x32 / 16x16 levels in fp32 mode).  u_scratch_dev: Cout * 12 * Cin floats, filled with the transformed weights by
+ * the call.  Fails (non-zero) when the shape is not eligible (Cin % 32, even W, H*W % 64, Cout % 4, ...).
+ * Replaces: the same nn.Conv call sites (cld_jax/models/layers.py:66-107). */
+int gd_conv3x3_winograd(const float *x_dev, const float *w_dev, float *u_scratch_dev, const float *bias_dev,
+                        const float *res_dev, float *out_dev, int batch, int H, int W, int Cin, int Cout, float alpha,
+                        float out_scale, void *stream);
 /* flax GroupNorm(num_groups, eps=1e-6) (+ swish when act != 0) on NHWC (B,H,W,C).
  * Replaces: nn.GroupNorm + nn.swish call sites (cld_jax/models/layerspp.py:69,196,218). */
 int gd_group_norm(const float *x_dev, const float *scale_dev, const float *bias_dev, float *out_dev, int batch,

@@ -21,7 +21,7 @@ python - <<PY
 import json
 d=json.load(open("$OUT/summary.json"))
 for k,v in d["kernels"].items():
-    if "igemm" in k:
+    if "igemm" in k or "wino" in k:
         print(k, "avg_us", v.get("avg_us"))
         for c,x in sorted(v.get("counters_mean_per_dispatch",{}).items()): print("   %-34s %.4g"%(c,x))
 PY
