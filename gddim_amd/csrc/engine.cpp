@@ -55,6 +55,10 @@ struct gd_engine {
     int precision = 0;
     unsigned short *wsplit_hi = nullptr, *wsplit_lo = nullptr;  // bf16 hi / lo of wbuf, same element offsets
     bool wsplit_valid = false;
+    // fp32 mode: Winograd F(2,3) copies of the 3x3 stride-1 convolution weights (kernels/conv3x3_wino_f32.hip), one region per
+    // eligible weight slot (float offset into wwino, -1 = none); built on the device from wbuf when the parameters are uploaded
+    float *wwino = nullptr;
+    std::vector<long long> wino_off;
     std::map<int, std::vector<char>> fuse_ok;      // batch size -> per GEMM op: the fused-GroupNorm halo kernel takes it
     std::map<int, std::vector<char>> presplit_ok;  // batch size -> per tensor: may be stored pre-split (see presplit_allowed)
     std::vector<long long> slot_off;  // floats into wbuf
@@ -263,6 +267,11 @@ static int run_op(gd_engine *e, int op_index, const Bind &b, int batch, hipStrea
                 ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string("igemm_bf16x3_kernel<256,128,4,2,act>"), op.flops_per_image * batch, 0);
                 return launch_igemm_bf16x3_act(g, z, s);
             }
+            if (e->precision == 0 && z == 1 && op.w_slot >= 0 && e->wwino && e->wino_off[op.w_slot] >= 0 && conv3x3_wino_ok(g)) {
+                g.b_wino = e->wwino + e->wino_off[op.w_slot];
+                ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(conv3x3_wino_name()), op.flops_per_image * batch, 0);
+                return launch_conv3x3_wino(g, s);
+            }
             ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(igemm_variant_name(g, z)), op.flops_per_image * batch, 0);
             return launch_igemm(g, z, s);
         }
@@ -404,6 +413,7 @@ int gd_engine_destroy(gd_engine *e) {
         (void)hipDeviceSynchronize();
         drop_graphs(e);
         for (auto &p : e->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+        if (e->wwino) (void)hipFree(e->wwino);
         if (e->wsplit_hi) (void)hipFree(e->wsplit_hi);
         if (e->wsplit_lo) (void)hipFree(e->wsplit_lo);
         float *bufs[] = {e->arena, e->wbuf, e->xin, e->epsb, e->eps_planar, e->labels, e->u8, e->ring, e->ystate,
@@ -490,6 +500,33 @@ static int upload_split_weights(gd_engine *e) {
     return 0;
 }
 
+// U = G g for every weight slot read by a 3x3 / stride 1 / pad 1 convolution whose channel counts fit the Winograd kernel
+// (the per-launch shape test conv3x3_wino_ok decides whether a given batch size actually uses it)
+static int build_wino_weights(gd_engine *e) {
+    const Plan &P = e->plan;
+    e->wino_off.assign(P.slots.size(), -1);
+    long long total = 0;
+    std::vector<std::pair<int, int>> dims(P.slots.size(), {0, 0});  // (N, Cin) per slot
+    for (const Op &op : P.ops) {
+        if (op.kind != OP_GEMM || op.w_slot < 0 || op.a_slot >= 0 || op.z_per_image) continue;
+        const int Cin = op.C0 + op.C1;
+        if (op.KH != 3 || op.KW != 3 || op.stride != 1 || op.pad != 1 || Cin % 32 != 0 || op.K != 9 * Cin || op.ldb != op.K) continue;
+        if (op.N % 4 != 0 || op.N < 64 || e->wino_off[op.w_slot] >= 0) continue;
+        if (P.slots[op.w_slot].rows != op.N || P.slots[op.w_slot].cols != op.K) continue;
+        e->wino_off[op.w_slot] = total;
+        dims[op.w_slot] = {op.N, Cin};
+        total += (long long)op.N * 12 * Cin;
+    }
+    if (e->wwino) { (void)hipFree(e->wwino); e->wwino = nullptr; }
+    if (total == 0) return 0;
+    GD_HIP(hipMalloc((void **)&e->wwino, (size_t)total * sizeof(float)));
+    for (size_t i = 0; i < P.slots.size(); ++i)
+        if (e->wino_off[i] >= 0)
+            GD_TRY(launch_wino_weights(e->wbuf + e->slot_off[i], e->wwino + e->wino_off[i], dims[i].first, dims[i].second, nullptr));
+    GD_HIP(hipDeviceSynchronize());
+    return 0;
+}
+
 int gd_engine_set_precision(gd_engine *e, int mode) {
     GD_CHECK(e, "null engine");
     GD_CHECK(mode == 0 || mode == 1, "unknown precision mode %d (0 = fp32, 1 = bf16x3)", mode);
@@ -521,6 +558,7 @@ int gd_engine_params_ready(gd_engine *e) {
         }
         e->params_uploaded = true;
         e->wsplit_valid = false;
+        GD_TRY(build_wino_weights(e));
         if (e->precision == 1) GD_TRY(upload_split_weights(e));
     }
     return 0;
