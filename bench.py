@@ -206,6 +206,12 @@ def main():
                               "launches": dom["launches"], "avg_launch_ms": dom["ms"] / max(1, dom["launches"]),
                               "flops_per_launch": dom["flops"] / max(1, dom["launches"]),
                               "share_of_gpu_time": dom["ms"] / tot_ms if tot_ms else None}
+        if "wino" in dom["name"]:
+            # Winograd F(2,3): `achieved` counts the ALGORITHMIC flops of the direct convolution (18 M N Cin); the kernel issues
+            # 12 M N Cin on the fp32 matrix core, so the fraction of the pipe it keeps busy is 2/3 of `frac` (which may exceed 1)
+            result["roofline"]["frac_of_issued_mfma"] = achieved / 1.5 / peak
+            result["roofline"]["note"] = ("Winograd F(2,3) along x: algorithmic flops / time, peak = dense fp32 MFMA; "
+                                          "issued MFMA flops are 2/3 of algorithmic")
         result["kernel_breakdown"] = [
             {"name": p["name"], "ms": round(p["ms"], 3), "launches": p["launches"],
              "tflops": (p["flops"] / (p["ms"] * 1e-3) / 1e12) if p["flops"] and p["ms"] else None,

@@ -269,7 +269,7 @@ static int run_op(gd_engine *e, int op_index, const Bind &b, int batch, hipStrea
             }
             if (e->precision == 0 && z == 1 && op.w_slot >= 0 && e->wwino && e->wino_off[op.w_slot] >= 0 && conv3x3_wino_ok(g)) {
                 g.b_wino = e->wwino + e->wino_off[op.w_slot];
-                ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(conv3x3_wino_name()), op.flops_per_image * batch, 0);
+                ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(conv3x3_wino_name(g)), op.flops_per_image * batch, 0);
                 return launch_conv3x3_wino(g, s);
             }
             ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(igemm_variant_name(g, z)), op.flops_per_image * batch, 0);

@@ -38,13 +38,21 @@ constexpr int WKC = 8;    // channels per chunk
 constexpr int WLD = 36;   // LDS row stride (floats): a row = 4 components x 8 channels + 4 pad -> 144 B, an odd number of 16-byte
                           // units, so the ds_read_b128 of 8 consecutive rows and the 8 stores of one weight row cover all banks
 
+#ifndef WINO_B_AUX
+#define WINO_B_AUX 0  // cache policy of the weight loads (A/B builds: 2 = nt)
+#endif
+#ifndef WINO_A_MAP
+#define WINO_A_MAP 0  // A/B builds: 1 = activation lanes (pair = tid & 63, half = tid >> 6) instead of (tid >> 1, tid & 1)
+#endif
+
+template <int AUX = 0>
 __device__ __forceinline__ wf32x4 wbuf_load16(__amdgpu_buffer_rsrc_t rsrc, int voffset, int soffset) {
-    wu32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voffset, soffset, 0);
+    wu32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voffset, soffset, AUX);
     return __builtin_bit_cast(wf32x4, v);
 }
 
 template <int BP, int BN>
-__global__ __launch_bounds__(256, 2) void conv3x3_wino_f32_kernel(const GemmParams p) {
+__global__ __launch_bounds__(256, BN >= 128 ? 2 : 4) void conv3x3_wino_f32_kernel(const GemmParams p) {
     constexpr int NT = 256;
     constexpr int RM = BP / 64, RN = BN / 64;        // 32x32 accumulators per wave and component
     constexpr int STAGE = (BP + BN) * WLD;           // floats per LDS stage: V[BP][4][8] | U[BN][4][8] (rows padded to 36)
@@ -108,7 +116,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_f32_kernel(const GemmPara
         sl[i] = (BP + nl) * WLD + j * 4;
     }
     if (is_a) {
-        const int pl = tid >> 1, cq = tid & 1;
+        const int pl = WINO_A_MAP ? (tid & (BP - 1)) : tid >> 1, cq = WINO_A_MAP ? tid / BP : tid & 1;
         const int pair = pair0 + pl;
         sl[0] = pl * WLD + cq * 4;
         sv[0] = 0; sv[1] = 0; sv[2] = -1;  // rb0, rb1, inv (all taps invalid)
@@ -135,7 +143,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_f32_kernel(const GemmPara
     int s_kc = 0, s_sub = 0, s_ky = 0, s_c = 0;
     const int nk = 3 * (Cin / WKC);
     const int c8n = Cin / WKC;
-    auto advance = [&]() {
+    // Activation thread: voffsets of its four pixels for the current (source, kernel row), out-of-image pixels already pushed out
+    // of bounds.  They change every fourth chunk only, so the K loop spends 3 VALU per chunk on addresses instead of 16.
+    int vo[4] = {OOB, OOB, OOB, OOB};
+    auto refresh_vo = [&]() {
+        const int rb = s_c < p.C0 ? sv[0] : sv[1];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vo[j] = rb | (__builtin_amdgcn_sbfe(sv[2], s_ky * 4 + j, 1) & OOB);
+    };
+    auto advance = [&](auto role_a) {
         ++s_kc;
         ++s_sub;
         s_c += WKC;
@@ -144,23 +160,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_f32_kernel(const GemmPara
             ++s_ky;
             s_c -= 32;
             if (s_ky == 3) { s_ky = 0; s_c += 32; }
+            if constexpr (decltype(role_a)::value) refresh_vo();
         }
     };
 
     wf32x4 rs[NS];
     auto load_a = [&](int j) {  // raw pixel j of the pair -> rs[j]
-        const int bad = __builtin_amdgcn_sbfe(sv[2], s_ky * 4 + j, 1);
         if (s_c < p.C0) {
             const int soff = ((s_ky * W + j) * p.lda0 + s_c) * 4;
-            rs[j] = wbuf_load16(srd_a0, sv[0] | (bad & OOB), soff);
+            rs[j] = wbuf_load16(srd_a0, vo[j], soff);
         } else {
             const int soff = ((s_ky * W + j) * p.lda1 + (s_c - p.C0)) * 4;
-            rs[j] = wbuf_load16(srd_a1, sv[1] | (bad & OOB), soff);
+            rs[j] = wbuf_load16(srd_a1, vo[j], soff);
         }
     };
     auto load_b = [&](int i) {
         const int soff = ((s_ky * c8n + (s_c >> 3)) * 32) * 4;
-        rs[i] = wbuf_load16(srd_b, sv[i], soff);
+        rs[i] = wbuf_load16<WINO_B_AUX>(srd_b, sv[i], soff);
     };
     auto store_b = [&](int i, float *st) { *reinterpret_cast<wf32x4 *>(&st[sl[i]]) = rs[i]; };
     auto store_v = [&](int t, wf32x4 v, float *st) { *reinterpret_cast<wf32x4 *>(&st[t * 8 + sl[0]]) = v; };
@@ -240,17 +256,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_f32_kernel(const GemmPara
                 const int gap = t * 4 + jj;
                 if (jj == 0 && t < 3) load_frags(t + 1, cur, (t + 1) & 1);
                 if (gap < NG) stage_gap(gap, nxt, role_a, loads);
-                else if (gap == NG) advance();
+                else if (gap == NG) advance(role_a);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (NG == 16) advance();
+        if (NG == 16) advance(role_a);
         __syncthreads();
     };
     // prologue (chunk 0 -> stage 0, chunk 1 in registers) and K loop of one role
     auto run = [&](auto role_a) {
+        if constexpr (decltype(role_a)::value) refresh_vo();
         load_all(role_a);
-        advance();
+        advance(role_a);
         if constexpr (decltype(role_a)::value) {
             store_v(0, rs[0] - rs[2], smem);
             store_v(1, rs[1] + rs[2], smem);
@@ -263,7 +280,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_f32_kernel(const GemmPara
             for (int i = 0; i < BO; ++i) store_b(i, smem);
         }
         load_all(role_a);
-        advance();
+        advance(role_a);
         __syncthreads();
         for (int kc = 0; kc < nk - 2; ++kc) chunk(kc, role_a, std::true_type{});
         chunk(nk - 2, role_a, std::false_type{});
@@ -382,10 +399,20 @@ static void wfill_div(unsigned d, unsigned &magic, unsigned &shift) {
     magic = (unsigned)((((1ull << 32) * ((1ull << s) - d)) / d) + 1);
 }
 
+// Tile choice: 64 pairs x 128 outputs when that gives every CU two workgroups, 64 x 64 (half the accumulators, up to four
+// workgroups per CU) for the 8x8 level; 0 = neither fills the chip (the direct kernel's smaller tiles take the problem).
+static int wino_bn(const GemmParams &p) {
+    static const int min_blocks = getenv("GDDIM_WINO_MINBLOCKS") ? atoi(getenv("GDDIM_WINO_MINBLOCKS")) : 512;
+    static const int no_small = getenv("GDDIM_WINO_NOSMALL") ? atoi(getenv("GDDIM_WINO_NOSMALL")) : 0;  // A/B only
+    const long long mt = (p.M / 2 + 63) / 64;
+    if (mt * ((p.N + 127) / 128) >= min_blocks) return 128;
+    if (!no_small && mt * ((p.N + 63) / 64) >= min_blocks) return 64;
+    return 0;
+}
+
 // shape test (p.b_wino is not looked at); GDDIM_NOWINO=1 routes everything back to the direct kernel
 bool conv3x3_wino_ok(const GemmParams &p) {
     static const int off = getenv("GDDIM_NOWINO") ? atoi(getenv("GDDIM_NOWINO")) : 0;
-    static const int min_blocks = getenv("GDDIM_WINO_MINBLOCKS") ? atoi(getenv("GDDIM_WINO_MINBLOCKS")) : 512;
     if (off || p.in_act || p.b_kmajor || p.a_presplit || p.gn_table) return false;
     if (p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1 || p.OH != p.H || p.OW != p.W) return false;
     const int Cin = p.C0 + p.C1;
@@ -396,11 +423,12 @@ bool conv3x3_wino_ok(const GemmParams &p) {
     const long long ldmax = p.lda0 > p.lda1 ? p.lda0 : p.lda1;
     const long long a_bytes = ((long long)p.M + 2 * p.W + 8) * ldmax * 4 + Cin * 4 + 64;
     if (a_bytes >= (1LL << 31) || (long long)p.N * 12 * Cin * 4 + 64 >= (1LL << 31)) return false;
-    const long long blocks = (long long)((p.M / 2 + 63) / 64) * ((p.N + 127) / 128);
-    return blocks >= min_blocks;
+    return wino_bn(p) != 0;
 }
 
-const char *conv3x3_wino_name() { return "conv3x3_wino_f32_kernel<64,128>"; }
+const char *conv3x3_wino_name(const GemmParams &p) {
+    return wino_bn(p) == 64 ? "conv3x3_wino_f32_kernel<64,64>" : "conv3x3_wino_f32_kernel<64,128>";
+}
 
 int launch_conv3x3_wino(const GemmParams &p_in, hipStream_t s) {
     GemmParams p = p_in;
@@ -410,12 +438,14 @@ int launch_conv3x3_wino(const GemmParams &p_in, hipStream_t s) {
     wfill_div((unsigned)(p.H * p.W), p.mg_ohw, p.sh_ohw);
     wfill_div((unsigned)p.W, p.mg_ow, p.sh_ow);
     wfill_div((unsigned)(p.rows_per_image > 0 ? p.rows_per_image : 1), p.mg_rpi, p.sh_rpi);
-    constexpr int BP = 64, BN = 128;
+    constexpr int BP = 64;
+    const int bn = wino_bn(p);
     p.m_tiles = (p.M / 2 + BP - 1) / BP;
-    p.n_tiles = (p.N + BN - 1) / BN;
+    p.n_tiles = (p.N + bn - 1) / bn;
     p.flat_tiles = p.m_tiles < 16;
     const int gx = p.flat_tiles ? p.m_tiles * p.n_tiles : ((p.m_tiles + 7) / 8) * 8 * p.n_tiles;
-    hipLaunchKernelGGL((conv3x3_wino_f32_kernel<BP, BN>), dim3(gx), dim3(256), 0, s, p);
+    if (bn == 128) hipLaunchKernelGGL((conv3x3_wino_f32_kernel<BP, 128>), dim3(gx), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((conv3x3_wino_f32_kernel<BP, 64>), dim3(gx), dim3(256), 0, s, p);
     GD_HIP(hipGetLastError());
     return 0;
 }
