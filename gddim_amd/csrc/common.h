@@ -110,6 +110,7 @@ int launch_conv3x3_halo(const GemmParams &p, hipStream_t s);
 // fp32 3x3 stride-1 convolutions through the 1-D Winograd transform F(2,3) (x 1.5 fewer matrix-core flops);
 // GDDIM_NOWINO=1 routes them back to igemm_f32_fast_kernel
 bool conv3x3_wino_ok(const GemmParams &p);
+bool conv3x3_wino_shape_ok(const GemmParams &p);  // without the fill-the-chip criterion (stand-alone entry)
 const char *conv3x3_wino_name(const GemmParams &p);
 int launch_conv3x3_wino(const GemmParams &p, hipStream_t s);
 int launch_wino_weights(const float *w, float *u, int N, int Cin, hipStream_t s);

@@ -1049,7 +1049,7 @@ int gd_conv3x3_winograd(const float *x_dev, const float *w_dev, float *u_scratch
     g.out = out_dev; g.ldc = Cout; g.bias = bias_dev; g.res = res_dev; g.ldres = Cout;
     g.rows_per_image = H * W;
     g.alpha = alpha; g.out_scale = out_scale;
-    GD_CHECK(conv3x3_wino_ok(g), "conv3x3_winograd: shape not eligible (B=%d H=%d W=%d Cin=%d Cout=%d)", batch, H, W, Cin, Cout);
+    GD_CHECK(conv3x3_wino_shape_ok(g), "conv3x3_winograd: shape not eligible (B=%d H=%d W=%d Cin=%d Cout=%d)", batch, H, W, Cin, Cout);
     GD_TRY(launch_wino_weights(w_dev, u_scratch_dev, Cout, Cin, (hipStream_t)stream));
     g.b_wino = u_scratch_dev;
     return launch_conv3x3_wino(g, (hipStream_t)stream);

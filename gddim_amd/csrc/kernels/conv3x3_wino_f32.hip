@@ -410,10 +410,9 @@ static int wino_bn(const GemmParams &p) {
     return 0;
 }
 
-// shape test (p.b_wino is not looked at); GDDIM_NOWINO=1 routes everything back to the direct kernel
-bool conv3x3_wino_ok(const GemmParams &p) {
-    static const int off = getenv("GDDIM_NOWINO") ? atoi(getenv("GDDIM_NOWINO")) : 0;
-    if (off || p.in_act || p.b_kmajor || p.a_presplit || p.gn_table) return false;
+// what the kernel can compute at all (p.b_wino is not looked at)
+bool conv3x3_wino_shape_ok(const GemmParams &p) {
+    if (p.in_act || p.b_kmajor || p.a_presplit || p.gn_table) return false;
     if (p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1 || p.OH != p.H || p.OW != p.W) return false;
     const int Cin = p.C0 + p.C1;
     if (Cin % 32 != 0 || (p.C1 > 0 && (p.C0 % 32 != 0 || !p.a1)) || p.K != 9 * Cin) return false;
@@ -422,8 +421,13 @@ bool conv3x3_wino_ok(const GemmParams &p) {
     if ((long long)p.M * p.ldc * 4 + 64 >= (1LL << 31) || (p.res && (long long)p.M * p.ldres * 4 + 64 >= (1LL << 31))) return false;
     const long long ldmax = p.lda0 > p.lda1 ? p.lda0 : p.lda1;
     const long long a_bytes = ((long long)p.M + 2 * p.W + 8) * ldmax * 4 + Cin * 4 + 64;
-    if (a_bytes >= (1LL << 31) || (long long)p.N * 12 * Cin * 4 + 64 >= (1LL << 31)) return false;
-    return wino_bn(p) != 0;
+    return a_bytes < (1LL << 31) && (long long)p.N * 12 * Cin * 4 + 64 < (1LL << 31);
+}
+
+// what the engine sends to it: an eligible shape that fills the chip; GDDIM_NOWINO=1 routes everything back to the direct kernel
+bool conv3x3_wino_ok(const GemmParams &p) {
+    static const int off = getenv("GDDIM_NOWINO") ? atoi(getenv("GDDIM_NOWINO")) : 0;
+    return !off && conv3x3_wino_shape_ok(p) && wino_bn(p) != 0;
 }
 
 const char *conv3x3_wino_name(const GemmParams &p) {
@@ -432,14 +436,15 @@ const char *conv3x3_wino_name(const GemmParams &p) {
 
 int launch_conv3x3_wino(const GemmParams &p_in, hipStream_t s) {
     GemmParams p = p_in;
-    GD_CHECK(conv3x3_wino_ok(p) && p.b_wino, "conv3x3_wino: problem not eligible");
+    GD_CHECK(conv3x3_wino_shape_ok(p) && p.b_wino, "conv3x3_wino: problem not eligible");
     p.ldb_wino = 12 * (p.C0 + p.C1);
     if (p.C1 == 0) p.lda1 = 4;
     wfill_div((unsigned)(p.H * p.W), p.mg_ohw, p.sh_ohw);
     wfill_div((unsigned)p.W, p.mg_ow, p.sh_ow);
     wfill_div((unsigned)(p.rows_per_image > 0 ? p.rows_per_image : 1), p.mg_rpi, p.sh_rpi);
     constexpr int BP = 64;
-    const int bn = wino_bn(p);
+    int bn = wino_bn(p);
+    if (!bn) bn = p.N > 64 ? 128 : 64;  // small stand-alone problems (gd_conv3x3_winograd)
     p.m_tiles = (p.M / 2 + BP - 1) / BP;
     p.n_tiles = (p.N + bn - 1) / bn;
     p.flat_tiles = p.m_tiles < 16;

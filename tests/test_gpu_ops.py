@@ -133,6 +133,64 @@ def test_conv2d_transpose_detecting(dev):
     assert (got.double() - want).abs().max() < 1e-5
 
 
+# ---- fp32 Winograd F(2,3) kernel (what the engine runs for the 3x3 stride-1 convolutions at production batch sizes) --------
+WINO_CASES = [
+    # B, H, W, Cin, Cout, bias, res
+    (2, 32, 32, 128, 128, True, True),    # 64 x 128 tile, the dominant layer shape
+    (3, 16, 16, 256, 256, True, True),    # two N tiles
+    (2, 8, 8, 64, 64, True, False),       # 64 x 64 tile variant (N <= 64)
+    (1, 32, 32, 32, 68, False, True),     # ragged N tile (68 = 64 + 4), K of one slab
+    (5, 8, 16, 96, 132, True, True),      # non-square image, Cin = 3 slabs, ragged N, ragged M tile (5 * 64 pairs)
+    (4, 4, 16, 32, 64, False, False),     # H*W = 64: one wave tile per image
+]
+
+
+@pytest.mark.parametrize("case", WINO_CASES)
+def test_conv3x3_winograd_matches_torch_fp64(dev, case):
+    """gd_conv3x3_winograd against the float64 direct convolution; the bar is the direct fp32 kernel's (2e-5): F(2,3) adds a few
+    roundings (transforms are additions, the 1/2 of the weight transform is exact), not a conditioning problem."""
+    from gddim_amd import ops
+    B, H, W, Cin, Cout, use_bias, use_res = case
+    g = torch.Generator().manual_seed(sum(case[:5]))
+    x = torch.randn(B, H, W, Cin, generator=g)
+    w = torch.randn(3, 3, Cin, Cout, generator=g) / math.sqrt(9 * Cin)
+    bias = torch.randn(Cout, generator=g) if use_bias else None
+    res = torch.randn(B, H, W, Cout, generator=g) if use_res else None
+    wp = w.permute(3, 0, 1, 2).reshape(Cout, 9 * Cin).contiguous()
+    got = ops.conv3x3_winograd(x.to(dev), wp.to(dev), None if bias is None else bias.to(dev), None if res is None else res.to(dev),
+                               alpha=1.25, out_scale=0.7).cpu().double()
+    want = 1.25 * F.conv2d(x.permute(0, 3, 1, 2).double(), w.permute(3, 2, 0, 1).double(), padding=1).permute(0, 2, 3, 1)
+    if bias is not None:
+        want = want + bias.double()
+    if res is not None:
+        want = want + res.double()
+    want = want * 0.7
+    direct = ops.conv2d(x.to(dev), wp.to(dev), None if bias is None else bias.to(dev), None if res is None else res.to(dev),
+                        alpha=1.25, out_scale=0.7).cpu().double()
+    err, err_direct = (got - want).abs().max().item(), (direct - want).abs().max().item()
+    assert err < 2e-5 and err < 4 * err_direct + 1e-6, (case, err, err_direct)
+
+
+def test_conv3x3_winograd_impulse_and_rejects(dev):
+    """An impulse input with an asymmetric kernel (catches a swapped tap, pixel-parity or component order), at an image corner and
+    at an odd column; shapes the kernel cannot take (odd W, Cin % 32 != 0) are refused loudly."""
+    from gddim_amd import ops
+    from gddim_amd._abi import GddimError
+    B, H, W, Cin, Cout = 1, 8, 8, 32, 64
+    w = torch.arange(3 * 3 * Cin * Cout, dtype=torch.float32).reshape(3, 3, Cin, Cout) / 1000.0
+    wp = w.permute(3, 0, 1, 2).reshape(Cout, 9 * Cin).contiguous()
+    for (y, xx, c) in [(0, 0, 5), (3, 5, 17), (7, 7, 31), (4, 2, 0)]:
+        x = torch.zeros(B, H, W, Cin)
+        x[0, y, xx, c] = 1.0
+        got = ops.conv3x3_winograd(x.to(dev), wp.to(dev)).cpu().double()
+        want = F.conv2d(x.permute(0, 3, 1, 2).double(), w.permute(3, 2, 0, 1).double(), padding=1).permute(0, 2, 3, 1)
+        assert (got - want).abs().max() < 1e-4 * want.abs().max(), (y, xx, c)
+    with pytest.raises(GddimError):
+        ops.conv3x3_winograd(torch.zeros(1, 8, 7, 32, device=dev), wp.to(dev))
+    with pytest.raises(GddimError):
+        ops.conv3x3_winograd(torch.zeros(1, 8, 8, 16, device=dev), torch.zeros(64, 9 * 16, device=dev))
+
+
 # ---- GroupNorm / FIR / attention -----------------------------------------------------------------------------
 @pytest.mark.parametrize("B,HW,C,act", [(3, 1024, 128, 1), (2, 256, 256, 1), (2, 64, 384, 1), (5, 16, 512, 0), (2, 256, 16, 1),
                                         (2, 64, 192, 1)])  # 192 channels: 32 groups of 6 -> the generic path
