@@ -108,3 +108,34 @@ def test_unet_ddpmpp_style_matches_oracle(native_lib, nf, nrb, size):
     got3 = eng.unet(torch.as_tensor(x, device="cuda:0"), torch.as_tensor((t * 999).astype(np.float32), device="cuda:0")).cpu().numpy()
     assert np.abs(got3 - want).max() < 1e-4 * max(1.0, np.abs(want).max())
     eng.close()
+
+
+def test_unet_64x64_winograd_levels_match_oracle(native_lib):
+    """BASELINE config 5 geometry (64x64 input, nf = 128): at batch 16 the 64x64 level runs the 64x128 Winograd tile and the 32x32
+    level the 64x64 one (asserted from the engine profile).  Images are independent units: the first image of the batch against the
+    float64 oracle of that image (bar: 4x the float32 oracle's own error), and against the same image evaluated alone (direct kernels)."""
+    from gddim_amd.engine import Engine
+    cfg = tiny_config("cld", nf=128, num_res_blocks=1, image_size=64, ch_mult=(1, 2, 2, 2), attn=(16,))
+    params = onet.random_params(cfg, 6, seed=3)
+    rng = np.random.default_rng(5)
+    B = 16
+    x = rng.standard_normal((B, 64, 64, 6)).astype(np.float32)
+    labels = (rng.uniform(1e-3, 1.0, size=B) * 999).astype(np.float32)
+    with torch.no_grad():
+        want64 = onet.ncsnpp_forward(params, torch.as_tensor(x[:1], dtype=torch.float64), torch.as_tensor(labels[:1], dtype=torch.float64), cfg).numpy()
+        want32 = onet.ncsnpp_forward(params, torch.as_tensor(x[:1]), torch.as_tensor(labels[:1]), cfg).numpy()
+    scale = max(1.0, np.abs(want64).max())
+    e_f32 = np.abs(want32 - want64).max() / scale
+    eng = Engine(cfg, 6, max_batch=B, device=0).load_params(params)
+    xt, lt = torch.as_tensor(x, device="cuda:0"), torch.as_tensor(labels, device="cuda:0")
+    eng.profile(True)
+    got = eng.unet(xt, lt).cpu().numpy()
+    seen = {p["name"] for p in eng.profile_read()}
+    eng.profile(False)
+    alone = eng.unet(xt[:1], lt[:1]).cpu().numpy()
+    eng.close()
+    err = np.abs(got[:1] - want64).max() / scale
+    print("64x64 B=16: |hip-f64| %.3e (float32 oracle %.3e), batch vs alone %.3e" % (err, e_f32, np.abs(got[:1] - alone).max() / scale))
+    assert "conv3x3_wino_f32_kernel<64,128>" in seen and "conv3x3_wino_f32_kernel<64,64>" in seen, seen
+    assert np.isfinite(got).all() and err < max(4 * e_f32, 2e-5), (err, e_f32)
+    assert np.abs(got[:1] - alone).max() / scale < 2e-5
