@@ -517,9 +517,9 @@ static int build_wino_weights(gd_engine *e) {
         dims[op.w_slot] = {op.N, Cin};
         total += (long long)op.N * 12 * Cin;
     }
-    if (e->wwino) { (void)hipFree(e->wwino); e->wwino = nullptr; }
     if (total == 0) return 0;
-    GD_HIP(hipMalloc((void **)&e->wwino, (size_t)total * sizeof(float)));
+    // allocated once (the plan fixes its size): captured graphs keep pointing into it when parameters are loaded again
+    if (!e->wwino) GD_HIP(hipMalloc((void **)&e->wwino, (size_t)total * sizeof(float)));
     for (size_t i = 0; i < P.slots.size(); ++i)
         if (e->wino_off[i] >= 0)
             GD_TRY(launch_wino_weights(e->wbuf + e->slot_off[i], e->wwino + e->wino_off[i], dims[i].first, dims[i].second, nullptr));

@@ -18,6 +18,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--no-res", action="store_true", help="no residual / bias in the epilogue")
     args = ap.parse_args()
     import torch
     from gddim_amd import ops
@@ -30,6 +31,8 @@ def main():
         b = torch.randn(Cout, device=dev)
         r = torch.randn(args.batch, H, H, Cout, device=dev)
         u = torch.empty(Cout * 12 * Cin, device=dev)
+        if args.no_res:
+            b, r = None, None
         fl = 2.0 * args.batch * H * H * Cout * 9 * Cin
         ref = ops.conv2d(x, w, b, r, out_scale=0.7)
         try:
