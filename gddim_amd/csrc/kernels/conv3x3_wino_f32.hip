@@ -41,6 +41,10 @@ constexpr int WLD = 36;   // LDS row stride (floats): a row = 4 components x 8 c
 #ifndef WINO_B_AUX
 #define WINO_B_AUX 0  // cache policy of the weight loads (A/B builds: 2 = nt)
 #endif
+#ifndef WINO_ABL
+#define WINO_ABL 0  // timing ablations (results wrong): 1 no global loads in the K loop, 2 no LDS stores, 4 no fragment reads,
+                    // 8 no barrier, 16 no transform arithmetic
+#endif
 #ifndef WINO_A_MAP
 #define WINO_A_MAP 0  // A/B builds: 1 = activation lanes (pair = tid & 63, half = tid >> 6) instead of (tid >> 1, tid & 1)
 #endif
@@ -52,7 +56,7 @@ __device__ __forceinline__ wf32x4 wbuf_load16(__amdgpu_buffer_rsrc_t rsrc, int v
 }
 
 template <int BP, int BN>
-__global__ __launch_bounds__(256, BN >= 128 ? 2 : 4) void conv3x3_wino_f32_kernel(const GemmParams p) {
+__global__ __launch_bounds__(256, BN >= 128 ? 2 : 3) void conv3x3_wino_f32_kernel(const GemmParams p) {
     constexpr int NT = 256;
     constexpr int RM = BP / 64, RN = BN / 64;        // 32x32 accumulators per wave and component
     constexpr int STAGE = (BP + BN) * WLD;           // floats per LDS stage: V[BP][4][8] | U[BN][4][8] (rows padded to 36)
@@ -164,57 +168,70 @@ __global__ __launch_bounds__(256, BN >= 128 ? 2 : 4) void conv3x3_wino_f32_kerne
         }
     };
 
-    wf32x4 rs[NS];
-    auto load_a = [&](int j) {  // raw pixel j of the pair -> rs[j]
+    // Two sets of staging registers: the loads issued in iteration kc fetch chunk kc+3 and are written to LDS in iteration kc+2,
+    // so a global load has two chunks (4-8 thousand cycles) to return instead of one.  Set (kc+1)&1 is the one iteration kc
+    // stores and re-requests; the set index is a compile-time constant (the K loop is unrolled by two).
+    wf32x4 rs2[2][NS];
+    auto load_a = [&](auto set, int j) {  // raw pixel j of the pair
+        constexpr int S = decltype(set)::value;
         if (s_c < p.C0) {
             const int soff = ((s_ky * W + j) * p.lda0 + s_c) * 4;
-            rs[j] = wbuf_load16(srd_a0, vo[j], soff);
+            rs2[S][j] = wbuf_load16(srd_a0, vo[j], soff);
         } else {
             const int soff = ((s_ky * W + j) * p.lda1 + (s_c - p.C0)) * 4;
-            rs[j] = wbuf_load16(srd_a1, vo[j], soff);
+            rs2[S][j] = wbuf_load16(srd_a1, vo[j], soff);
         }
     };
-    auto load_b = [&](int i) {
+    auto load_b = [&](auto set, int i) {
+        constexpr int S = decltype(set)::value;
         const int soff = ((s_ky * c8n + (s_c >> 3)) * 32) * 4;
-        rs[i] = wbuf_load16<WINO_B_AUX>(srd_b, sv[i], soff);
+        rs2[S][i] = wbuf_load16<WINO_B_AUX>(srd_b, sv[i], soff);
     };
-    auto store_b = [&](int i, float *st) { *reinterpret_cast<wf32x4 *>(&st[sl[i]]) = rs[i]; };
-    auto store_v = [&](int t, wf32x4 v, float *st) { *reinterpret_cast<wf32x4 *>(&st[t * 8 + sl[0]]) = v; };
+    auto store_x = [&](wf32x4 v, float *dst) {
+        if (!(WINO_ABL & 2)) *reinterpret_cast<wf32x4 *>(dst) = v;
+        else asm volatile("" ::"v"(v));
+    };
+    auto store_b = [&](auto set, int i, float *st) { store_x(rs2[decltype(set)::value][i], &st[sl[i]]); };
+    auto store_v = [&](int t, wf32x4 v, float *st) { store_x(v, &st[t * 8 + sl[0]]); };
     // Staging work of MFMA gap g: write slot g's piece of chunk kc+1 to the other LDS stage, then request slot g for chunk
-    // kc+2.  The input transform is arranged so that an activation thread frees its raw pixels in slot order:
+    // kc+3.  The input transform is arranged so that an activation thread frees its raw pixels in slot order:
     //   gap 0: V0 = d0 - d2 stored;                       gap 1: V1 = d1 + d2 stored, d2 <- d2 - d1 (= V2), d3 <- d1 - d3 (= V3);
     //   gap 2: V2 stored;                                 gap 3: V3 stored.
     // ROLE / LOADS are compile-time tags (std::integral_constant): the two roles run two separate copies of the K loop (no
     // control-flow joins between them inside the loop -- joins made the compiler copy the staging registers and wait for
-    // vmcnt(0) in every gap), and the last two iterations, which have nothing left to request, are peeled without loads.
-    auto stage_gap = [&](int g, float *st, auto role_a, auto loads) {
+    // vmcnt(0) in every gap), and the last three iterations, which have nothing left to request, are peeled without loads.
+    auto stage_gap = [&](int g, float *st, auto set, auto role_a, auto loads) {
+        constexpr int S = decltype(set)::value;
+        wf32x4 (&rs)[NS] = rs2[S];
         if constexpr (decltype(role_a)::value) {
-            if (g == 0) store_v(0, rs[0] - rs[2], st);
+            if (g == 0) store_v(0, (WINO_ABL & 16) ? rs[0] : rs[0] - rs[2], st);
             else if (g == 1) {
-                store_v(1, rs[1] + rs[2], st);
-                rs[2] = rs[2] - rs[1];
-                rs[3] = rs[1] - rs[3];
+                store_v(1, (WINO_ABL & 16) ? rs[1] : rs[1] + rs[2], st);
+                if (!(WINO_ABL & 16)) {
+                    rs[2] = rs[2] - rs[1];
+                    rs[3] = rs[1] - rs[3];
+                }
             } else if (g == 2) store_v(2, rs[2], st);
             else if (g == 3) store_v(3, rs[3], st);
-            else if (g < 4 + BA) store_b(g, st);
-            if constexpr (decltype(loads)::value) {
-                if (g < 4) load_a(g);
-                else if (g < 4 + BA) load_b(g);
+            else if (g < 4 + BA) store_b(set, g, st);
+            if constexpr (decltype(loads)::value && !(WINO_ABL & 1)) {
+                if (g < 4) load_a(set, g);
+                else if (g < 4 + BA) load_b(set, g);
             }
         } else {
             if (g < BO) {
-                store_b(g, st);
-                if constexpr (decltype(loads)::value) load_b(g);
+                store_b(set, g, st);
+                if constexpr (decltype(loads)::value && !(WINO_ABL & 1)) load_b(set, g);
             }
         }
     };
-    auto load_all = [&](auto role_a) {
+    auto load_all = [&](auto set, auto role_a) {
 #pragma unroll
         for (int g = 0; g < NS; ++g) {
             if constexpr (decltype(role_a)::value) {
-                if (g < 4) load_a(g);
-                else if (g < 4 + BA) load_b(g);
-            } else if (g < BO) load_b(g);
+                if (g < 4) load_a(set, g);
+                else if (g < 4 + BA) load_b(set, g);
+            } else if (g < BO) load_b(set, g);
         }
     };
 
@@ -239,10 +256,10 @@ __global__ __launch_bounds__(256, BN >= 128 ? 2 : 4) void conv3x3_wino_f32_kerne
 #pragma unroll
         for (int c = 0; c < RN; ++c) bf[set][c] = *reinterpret_cast<const wf32x4 *>(st + t * 8 + b_off + c * 32 * WLD);
     };
-    auto chunk = [&](int kc, auto role_a, auto loads) {
+    auto chunk = [&](int kc, auto set, auto role_a, auto loads) {
         const float *cur = smem + (kc & 1) * STAGE;
         float *nxt = smem + ((kc + 1) & 1) * STAGE;
-        load_frags(0, cur, 0);
+        if (!(WINO_ABL & 4) || kc == 0) load_frags(0, cur, 0);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
 #pragma unroll
@@ -254,37 +271,49 @@ __global__ __launch_bounds__(256, BN >= 128 ? 2 : 4) void conv3x3_wino_f32_kerne
                         acc[t][r][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[t & 1][r][jj], bf[t & 1][c][jj], acc[t][r][c], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 const int gap = t * 4 + jj;
-                if (jj == 0 && t < 3) load_frags(t + 1, cur, (t + 1) & 1);
-                if (gap < NG) stage_gap(gap, nxt, role_a, loads);
+                if (jj == 0 && t < 3 && !(WINO_ABL & 4)) load_frags(t + 1, cur, (t + 1) & 1);
+                if (gap < NG) stage_gap(gap, nxt, set, role_a, loads);
                 else if (gap == NG) advance(role_a);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
         if (NG == 16) advance(role_a);
-        __syncthreads();
+        if (!(WINO_ABL & 8)) __syncthreads();
     };
-    // prologue (chunk 0 -> stage 0, chunk 1 in registers) and K loop of one role
+    // Prologue and K loop of one role.  At the top of iteration kc: LDS stage kc&1 holds chunk kc, register set (kc+1)&1 chunk
+    // kc+1 (raw), set kc&1 chunk kc+2 (possibly still in flight).  nk is a multiple of 12.
     auto run = [&](auto role_a) {
+        constexpr std::integral_constant<int, 0> S0{};
+        constexpr std::integral_constant<int, 1> S1{};
         if constexpr (decltype(role_a)::value) refresh_vo();
-        load_all(role_a);
+        load_all(S0, role_a);  // chunk 0
+        advance(role_a);
+        load_all(S1, role_a);  // chunk 1
         advance(role_a);
         if constexpr (decltype(role_a)::value) {
+            wf32x4 (&rs)[NS] = rs2[0];
             store_v(0, rs[0] - rs[2], smem);
             store_v(1, rs[1] + rs[2], smem);
             store_v(2, rs[2] - rs[1], smem);
             store_v(3, rs[1] - rs[3], smem);
 #pragma unroll
-            for (int i = 4; i < 4 + BA; ++i) store_b(i, smem);
+            for (int i = 4; i < 4 + BA; ++i) store_b(S0, i, smem);
         } else {
 #pragma unroll
-            for (int i = 0; i < BO; ++i) store_b(i, smem);
+            for (int i = 0; i < BO; ++i) store_b(S0, i, smem);
         }
-        load_all(role_a);
+        load_all(S0, role_a);  // chunk 2
         advance(role_a);
         __syncthreads();
-        for (int kc = 0; kc < nk - 2; ++kc) chunk(kc, role_a, std::true_type{});
-        chunk(nk - 2, role_a, std::false_type{});
-        chunk(nk - 1, role_a, std::false_type{});
+        int kc = 0;
+        for (; kc < nk - 4; kc += 2) {  // iterations 0 .. nk-5 request chunks 3 .. nk-2
+            chunk(kc, S1, role_a, std::true_type{});
+            chunk(kc + 1, S0, role_a, std::true_type{});
+        }
+        chunk(nk - 4, S1, role_a, std::true_type{});   // requests chunk nk-1
+        chunk(nk - 3, S0, role_a, std::false_type{});
+        chunk(nk - 2, S1, role_a, std::false_type{});
+        chunk(nk - 1, S0, role_a, std::false_type{});  // (what it stores is never read)
     };
     if (is_a) run(std::true_type{});
     else run(std::false_type{});
