@@ -330,7 +330,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_kernel(const GemmParam
 //     rides in the scalar soffset of a raw buffer load, and the buffer's bounds check returns the zero padding;
 //   * B (weights / K matrix) rows need no VALU at all: voffset is constant, soffset = chunk offset.
 // Same tiling, LDS layout, software pipeline and epilogue as the generic kernel above.
-// Requirements (checked by launch_igemm): (C0+C1) % 32 == 0, C0 % 32 == 0 when C1 > 0, KH*KW <= 32, every operand
+// Requirements (checked by launch_igemm): (C0+C1) % 32 == 0, C0 % 32 == 0 when C1 > 0, KH*KW <= 32 (<= 64: the T64 instances), every operand
 // smaller than 2 GiB, no input activation.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -346,7 +346,8 @@ __device__ __forceinline__ f32x4 buf_load16(__amdgpu_buffer_rsrc_t rsrc, int vof
     return __builtin_bit_cast(f32x4, v);
 }
 
-template <int BM, int BN, int WM, int WN, bool B_KMAJOR>
+// T64: kernels with 33..64 taps (the 6x6 stride-2 pyramid convolutions) keep a second mask word per row
+template <int BM, int BN, int WM, int WN, bool B_KMAJOR, bool T64 = false>
 __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_fast_kernel(const GemmParams p) {
     constexpr int NT = 64 * WM * WN;
     constexpr int RM = BM / (32 * WM), RN = BN / (32 * WN);
@@ -401,6 +402,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_fast_kernel(const Gemm
     const int kcol = (tid & 7) * 4;
     int rb0[AJ], rb1[AJ];      // byte offset of (row's tap (0,0) pixel, channel kcol) in source 0 / 1, + bias
     unsigned inv[AJ];          // bit t set: tap t of this row lies outside the image (or the row is >= M)
+    unsigned inv_hi[T64 ? AJ : 1];  // taps 32..63
     {
         const unsigned OHW = p.OH * p.OW;
         const unsigned rowbits = (1u << p.KW) - 1u;
@@ -408,6 +410,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_fast_kernel(const Gemm
         for (int j = 0; j < AJ; ++j) {
             const int m = m0 + arow + RPP * j;
             rb0[j] = 0; rb1[j] = 0; inv[j] = 0xFFFFFFFFu;
+            if (T64) inv_hi[j] = 0xFFFFFFFFu;
             if (m < p.M) {
                 const int img = (int)fast_div((unsigned)m, OHW, p.mg_ohw, p.sh_ohw);
                 const int r = m - img * (int)OHW;
@@ -419,10 +422,11 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_fast_kernel(const Gemm
                 rb1[j] = pix * p.lda1 * 4 + bias1 + kcol * 4;
                 unsigned xb = 0;  // columns of the window outside the image
                 for (int tx = 0; tx < p.KW; ++tx) xb |= ((unsigned)(ix0 + tx) < (unsigned)p.W ? 0u : 1u) << tx;
-                unsigned mk = 0;
+                unsigned long long mk = 0;
                 for (int ty = 0; ty < p.KH; ++ty)
-                    mk |= ((unsigned)(iy0 + ty) < (unsigned)p.H ? xb : rowbits) << (ty * p.KW);
-                inv[j] = mk;
+                    mk |= (unsigned long long)((unsigned)(iy0 + ty) < (unsigned)p.H ? xb : rowbits) << (ty * p.KW);
+                inv[j] = (unsigned)mk;
+                if (T64) inv_hi[j] = (unsigned)(mk >> 32);
             }
         }
     }
@@ -458,7 +462,8 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_fast_kernel(const Gemm
         if (pc < AJ) {
             const int j = pc;
             // sign-extended "invalid" bit of the current tap: -1 pushes the offset out of bounds -> hardware returns 0
-            const int bad = __builtin_amdgcn_sbfe(inv[j], s_tap < 32 ? s_tap : 31, 1) | (s_kc < nk ? 0 : -1);
+            const unsigned word = (T64 && s_tap >= 32) ? inv_hi[j] : inv[j];
+            const int bad = __builtin_amdgcn_sbfe(word, T64 ? (s_tap & 31) : (s_tap < 32 ? s_tap : 31), 1) | (s_kc < nk ? 0 : -1);
             if (s_c0 < p.C0) {
                 const int soff = ((s_ty * p.W + s_tx) * p.lda0 + s_c0) * 4;
                 ra[j] = buf_load16(srd_a0, rb0[j] | (bad & OOB), soff);
@@ -681,7 +686,7 @@ static bool fast_ok(const GemmParams &p) {
     static const int off = getenv("GDDIM_IGEMM_NOFAST") ? atoi(getenv("GDDIM_IGEMM_NOFAST")) : 0;
     if (off || p.in_act) return false;
     const int Cin = p.C0 + p.C1;
-    if (Cin % 32 != 0 || (p.C1 > 0 && p.C0 % 32 != 0) || p.KH * p.KW > 32 || p.K % 32 != 0) return false;
+    if (Cin % 32 != 0 || (p.C1 > 0 && p.C0 % 32 != 0) || p.KH * p.KW > 64 || (p.KH * p.KW > 32 && p.b_kmajor) || p.K % 32 != 0) return false;
     if (p.rowbias && p.rows_per_image % 8 != 0) return false;
     if ((long long)p.M * p.ldc * 4 + 64 >= (1LL << 31) || (p.res && (long long)p.M * p.ldres * 4 + 64 >= (1LL << 31))) return false;
     const long long ldmax = p.lda0 > p.lda1 ? p.lda0 : p.lda1;
@@ -698,6 +703,7 @@ static void launch_variant(const GemmParams &p, dim3 grid, hipStream_t s) {
     dim3 block(64 * WM * WN);
     if (fast_ok(p)) {
         if (p.b_kmajor) hipLaunchKernelGGL((igemm_f32_fast_kernel<BM, BN, WM, WN, true>), grid, block, 0, s, p);
+        else if (p.KH * p.KW > 32) hipLaunchKernelGGL((igemm_f32_fast_kernel<BM, BN, WM, WN, false, true>), grid, block, 0, s, p);
         else hipLaunchKernelGGL((igemm_f32_fast_kernel<BM, BN, WM, WN, false>), grid, block, 0, s, p);
         return;
     }

@@ -110,6 +110,8 @@ def _conv_case(dev, B, H, W, Cin, Cout, k, stride, pad, bias, res, seed, alpha=1
     (2, 32, 32, 128, 6, 3, 1, 1, True, False),       # head: N = 6 (masked columns)
     (2, 16, 16, 384, 256, 1, 1, 0, True, False),     # 1x1 shortcut
     (2, 32, 32, 8, 128, 6, 2, 2, True, True),        # pyramid 6x6 stride 2 pad 2
+    (3, 16, 16, 128, 256, 6, 2, 2, True, True),      # pyramid 6x6 stride 2 with Cin % 32 == 0: the 36-tap (two mask words) fast path
+    (2, 8, 10, 64, 64, 6, 2, 2, False, False),       # the same on a non-square image, borders on all sides
     (5, 4, 4, 512, 256, 3, 1, 1, False, False),      # rows of several images in one tile, M = 80 (ragged)
     (1, 1, 1, 256, 512, 1, 1, 0, True, False),       # dense layer, M = 1
     (48, 32, 32, 128, 128, 3, 1, 1, True, True),     # 49152 rows -> 128x128 tiles
