@@ -42,6 +42,8 @@ def hbm_traffic(kernel_name):
             key.replace("kernel<gn>", "kernel<true>")}
     if key == "conv3x3_halo_bf16x3_kernel":
         keys.add("conv3x3_halo_bf16x3_kernel<false>")
+    if key.startswith("igemm_f32_fast_kernel<") and key.count(",") == 4:
+        keys.add(key[:-1] + ",false>")  # the default T64 = false template argument rocprofv3 prints
     if key.startswith("igemm_bf16x3_kernel<") and key.count(",") == 3:
         keys.add(key[:-1] + ",false,false,false>")
     for k, v in table.items():
