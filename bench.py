@@ -91,7 +91,7 @@ def main():
     ap.add_argument("--image-size", type=int, default=32)
     ap.add_argument("--workload", choices=["cld", "blur"], default="cld", help="cld = BASELINE configs 2/4/5, blur = config 3")
     ap.add_argument("--precision", choices=["fp32", "bf16x3"], default="fp32",
-                    help="fp32 = exact fp32 MFMA (headline); bf16x3 = split-precision weight contractions on the bf16 matrix core")
+                    help="fp32 = fp32 operands on the fp32 matrix core, 3x3 convolutions through Winograd F(2,3) (headline); bf16x3 = split-precision weight contractions on the bf16 matrix core")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")

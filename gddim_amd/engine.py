@@ -155,7 +155,7 @@ class Engine(object):
         return self
 
     def set_precision(self, mode):
-        """'fp32' (exact fp32 MFMA, default) or 'bf16x3' (split-precision weight contractions on the bf16 matrix core)."""
+        """'fp32' (fp32 MFMA, 3x3 convolutions through Winograd F(2,3) at production batch sizes; default) or 'bf16x3' (split-precision weight contractions on the bf16 matrix core)."""
         code = {"fp32": 0, "f32": 0, 0: 0, "bf16x3": 1, 1: 1}[mode]
         check(self._lib.gd_engine_set_precision(self._h, code))
         self._schedule_token = None

@@ -120,7 +120,9 @@ int gd_engine_params_ready(gd_engine *e);
 int gd_engine_packed_weight(gd_engine *e, const char *slot, float *host_out, size_t cap_floats, size_t *n_floats);
 
 /* Arithmetic of the weight contractions (convolutions, NIN, dense):
- *   0  exact fp32 (v_mfma_f32_32x32x2_f32), the default and the mode every parity claim refers to;
+ *   0  fp32 operands and accumulation on the fp32 matrix core (v_mfma_f32_32x32x2_f32), the default and the mode every
+ *      parity claim refers to; 3x3 stride-1 convolutions large enough to fill the chip go through the Winograd F(2,3)
+ *      transform along x (additions in fp32, weights transformed in double; GDDIM_NOWINO=1 keeps the direct sum);
  *   1  "bf16x3": fp32 operands split into bf16 hi + lo, a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on the bf16 matrix
  *      core with fp32 accumulation (per-product error ~2^-16, measured as close to float64 as mode 0 on this network).
  * Also selectable with GDDIM_PRECISION=bf16x3 at engine creation.  The reference has one arithmetic only (XLA fp32);
