@@ -56,13 +56,13 @@ __device__ __forceinline__ wf32x4 wbuf_load16(__amdgpu_buffer_rsrc_t rsrc, int v
 }
 
 template <int BP, int BN>
-__global__ __launch_bounds__(256, BN >= 128 ? 2 : 3) void conv3x3_wino_f32_kernel(const GemmParams p) {
-    constexpr int NT = 256;
-    constexpr int RM = BP / 64, RN = BN / 64;        // 32x32 accumulators per wave and component
+__global__ __launch_bounds__(BP * 4, BP == 128 ? 2 : BN >= 128 ? 2 : 3) void conv3x3_wino_f32_kernel(const GemmParams p) {
+    constexpr int NT = BP * 4;                       // BP/32 x 2 waves: every wave owns 32 pairs x BN/2 outputs x 4 components
+    constexpr int RM = 1, RN = BN / 64;              // 32x32 accumulators per wave and component
     constexpr int STAGE = (BP + BN) * WLD;           // floats per LDS stage: V[BP][4][8] | U[BN][4][8] (rows padded to 36)
     constexpr int NA = BP * 2;                       // threads that stage activations: (pair, 4-channel half of the chunk)
     constexpr int NBP = BN * 8;                      // 16-byte weight pieces per chunk: (n, component, half)
-    constexpr int BA = NA == NT ? NBP / NT : (NBP / 128 - 4) / 2;  // weight pieces of an activation thread ...
+    constexpr int BA = NA == NT ? NBP / NT : (NBP / NA - 4) / 2;  // weight pieces of an activation thread ...
     constexpr int BO = NA == NT ? 0 : BA + 4;                       // ... and of the other threads
     constexpr int NG = 4 + BA > BO ? 4 + BA : BO;    // MFMA gaps that carry staging work
     constexpr int OOB = (int)0x80000000u;
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256, BN >= 128 ? 2 : 3) void conv3x3_wino_f32_kerne
                 for (int v = 0; v < 16; ++v) acc[t][r][c][v] = 0.f;
 
     const int li = lane & 31, lh = lane >> 5;
-    const int a_off = (wm * (BP / 2) + li) * WLD + lh * 4;
+    const int a_off = (wm * 32 + li) * WLD + lh * 4;
     const int b_off = (BP + wn * (BN / 2) + li) * WLD + lh * 4;
 
     wf32x4 af[2][RM], bf[2][RN];  // fragments of the component being multiplied and of the next one
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256, BN >= 128 ? 2 : 3) void conv3x3_wino_f32_kerne
             const int vo_r = nok ? (8 * lh * p.ldres + n) * 4 : OOB;
 #pragma unroll
             for (int r = 0; r < RM; ++r) {
-                const int prow = pair0 + wm * (BP / 2) + r * 32;  // wave-uniform
+                const int prow = pair0 + wm * 32 + r * 32;  // wave-uniform
                 const int mrow = 2 * prow;
                 float res_e[16], res_o[16];
                 if (p.res) {
@@ -459,7 +459,15 @@ bool conv3x3_wino_ok(const GemmParams &p) {
     return !off && conv3x3_wino_shape_ok(p) && wino_bn(p) != 0;
 }
 
+// 128 pairs x 128 outputs, eight waves, ONE workgroup per CU: a third less staging traffic per MAC (the weight chunk is shared by
+// twice as many pairs); taken when it still gives every CU two tiles.  GDDIM_WINO_NOBIG=1 (A/B) keeps the 64-pair tiles.
+static bool wino_big(const GemmParams &p) {
+    static const int nobig = getenv("GDDIM_WINO_NOBIG") ? atoi(getenv("GDDIM_WINO_NOBIG")) : 0;
+    return !nobig && wino_bn(p) == 128 && (long long)((p.M / 2 + 127) / 128) * ((p.N + 127) / 128) >= 512;
+}
+
 const char *conv3x3_wino_name(const GemmParams &p) {
+    if (wino_big(p)) return "conv3x3_wino_f32_kernel<128,128>";
     return wino_bn(p) == 64 ? "conv3x3_wino_f32_kernel<64,64>" : "conv3x3_wino_f32_kernel<64,128>";
 }
 
@@ -471,15 +479,17 @@ int launch_conv3x3_wino(const GemmParams &p_in, hipStream_t s) {
     wfill_div((unsigned)(p.H * p.W), p.mg_ohw, p.sh_ohw);
     wfill_div((unsigned)p.W, p.mg_ow, p.sh_ow);
     wfill_div((unsigned)(p.rows_per_image > 0 ? p.rows_per_image : 1), p.mg_rpi, p.sh_rpi);
-    constexpr int BP = 64;
     int bn = wino_bn(p);
     if (!bn) bn = p.N > 64 ? 128 : 64;  // small stand-alone problems (gd_conv3x3_winograd)
+    const bool use_big = wino_big(p);
+    const int BP = use_big ? 128 : 64;
     p.m_tiles = (p.M / 2 + BP - 1) / BP;
     p.n_tiles = (p.N + bn - 1) / bn;
     p.flat_tiles = p.m_tiles < 16;
     const int gx = p.flat_tiles ? p.m_tiles * p.n_tiles : ((p.m_tiles + 7) / 8) * 8 * p.n_tiles;
-    if (bn == 128) hipLaunchKernelGGL((conv3x3_wino_f32_kernel<BP, 128>), dim3(gx), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((conv3x3_wino_f32_kernel<BP, 64>), dim3(gx), dim3(256), 0, s, p);
+    if (use_big) hipLaunchKernelGGL((conv3x3_wino_f32_kernel<128, 128>), dim3(gx), dim3(512), 0, s, p);
+    else if (bn == 128) hipLaunchKernelGGL((conv3x3_wino_f32_kernel<64, 128>), dim3(gx), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((conv3x3_wino_f32_kernel<64, 64>), dim3(gx), dim3(256), 0, s, p);
     GD_HIP(hipGetLastError());
     return 0;
 }

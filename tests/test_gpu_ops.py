@@ -173,6 +173,26 @@ def test_conv3x3_winograd_matches_torch_fp64(dev, case):
     assert err < 2e-5 and err < 4 * err_direct + 1e-6, (case, err, err_direct)
 
 
+def test_conv3x3_winograd_big_tile(dev):
+    """Problems with >= 512 tiles of 128 pairs x 128 outputs take the eight-wave 128 x 128 tile (one workgroup per CU): batch 128 of
+    the dominant layer shape, and a 256-output layer whose last N tile is ragged.  Whole output against the direct fp32 kernel, the
+    first two images against float64."""
+    from gddim_amd import ops
+    for (B, H, Cin, Cout) in [(128, 32, 128, 128), (128, 16, 64, 260)]:
+        g = torch.Generator().manual_seed(B + Cout)
+        x = torch.randn(B, H, H, Cin, generator=g)
+        w = torch.randn(3, 3, Cin, Cout, generator=g) / math.sqrt(9 * Cin)
+        bias = torch.randn(Cout, generator=g)
+        res = torch.randn(B, H, H, Cout, generator=g)
+        wp = w.permute(3, 0, 1, 2).reshape(Cout, 9 * Cin).contiguous()
+        got = ops.conv3x3_winograd(x.to(dev), wp.to(dev), bias.to(dev), res.to(dev), out_scale=0.7).cpu()
+        direct = ops.conv2d(x.to(dev), wp.to(dev), bias.to(dev), res.to(dev), out_scale=0.7).cpu()
+        want = (F.conv2d(x[:2].permute(0, 3, 1, 2).double(), w.permute(3, 2, 0, 1).double(), padding=1).permute(0, 2, 3, 1)
+                + bias.double() + res[:2].double()) * 0.7
+        assert (got - direct).abs().max().item() < 2e-5, (B, H, Cin, Cout)
+        assert (got[:2].double() - want).abs().max().item() < 2e-5, (B, H, Cin, Cout)
+
+
 def test_conv3x3_winograd_impulse_and_rejects(dev):
     """An impulse input with an asymmetric kernel (catches a swapped tap, pixel-parity or component order), at an image corner and
     at an odd column; shapes the kernel cannot take (odd W, Cin % 32 != 0) are refused loudly."""
