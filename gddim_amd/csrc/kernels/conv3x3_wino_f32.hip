@@ -75,20 +75,30 @@ __global__ __launch_bounds__(BP * 4, BP == 128 ? 2 : BN >= 128 ? 2 : 3) void con
     const int wm = wave >> 1, wn = wave & 1;
     const bool is_a = wave < NA / 64;  // wave-uniform role
 
+    // PERSIST (the 128 x 128 tile, one workgroup per CU): the workgroup walks tile ids blockIdx.x, blockIdx.x + gridDim.x, ...;
+    // gridDim.x is a multiple of 8 * n_tiles, so the N tile (and with it the weight addresses) and the XCD of a workgroup never
+    // change.  The software pipeline of the K loop runs ACROSS tiles: the last three iterations of a tile already request chunks
+    // 0..2 of the next one, so a tile has no prologue of its own and its epilogue runs with the next tile's first loads in flight.
+    constexpr bool PERSIST = BP == 128;
     const int nt = p.n_tiles;
-    const int id = blockIdx.x;
-    int ntile, mtile;
-    if (p.flat_tiles) {
-        mtile = id / nt;
-        ntile = id - mtile * nt;
-    } else {
-        const int grp = id / (8 * nt);
-        const int rem = id - grp * 8 * nt;
-        ntile = rem >> 3;
-        mtile = grp * 8 + (rem & 7);
-    }
-    if (mtile >= p.m_tiles) return;
-    const int pair0 = mtile * BP, n0 = ntile * BN;
+    const int total_ids = p.flat_tiles ? p.m_tiles * nt : ((p.m_tiles + 7) / 8) * 8 * nt;
+    auto tile_of = [&](int tid_, int &mtile_, int &ntile_) __attribute__((always_inline)) {
+        if (p.flat_tiles) {
+            mtile_ = tid_ / nt;
+            ntile_ = tid_ - mtile_ * nt;
+        } else {
+            const int grp = tid_ / (8 * nt);
+            const int rem = tid_ - grp * 8 * nt;
+            ntile_ = rem >> 3;
+            mtile_ = grp * 8 + (rem & 7);
+        }
+        return mtile_ < p.m_tiles;
+    };
+    int id = blockIdx.x;
+    int mtile, ntile;
+    if (!tile_of(id, mtile, ntile)) return;
+    int pair0 = mtile * BP;  // first pixel pair of the tile whose loads are being issued
+    const int n0 = ntile * BN;
 
     const int W = p.W, H = p.H, HW = H * W;
     const int Cin = p.C0 + p.C1;
@@ -119,10 +129,10 @@ __global__ __launch_bounds__(BP * 4, BP == 128 ? 2 : BN >= 128 ? 2 : 3) void con
         sv[i] = (used && n < p.N) ? (n * p.ldb_wino + j * 4) * 4 : OOB;
         sl[i] = (BP + nl) * WLD + j * 4;
     }
-    if (is_a) {
-        const int pl = WINO_A_MAP ? (tid & (BP - 1)) : tid >> 1, cq = WINO_A_MAP ? tid / BP : tid & 1;
-        const int pair = pair0 + pl;
-        sl[0] = pl * WLD + cq * 4;
+    const int a_pl = WINO_A_MAP ? (tid & (BP - 1)) : tid >> 1, a_cq = WINO_A_MAP ? tid / BP : tid & 1;
+    if (is_a) sl[0] = a_pl * WLD + a_cq * 4;
+    auto setup_a = [&]() __attribute__((always_inline)) {  // activation thread: addresses of its pair in the tile starting at pair0
+        const int pair = pair0 + a_pl;
         sv[0] = 0; sv[1] = 0; sv[2] = -1;  // rb0, rb1, inv (all taps invalid)
         if (2 * pair < p.M) {
             const int m = 2 * pair;
@@ -131,8 +141,8 @@ __global__ __launch_bounds__(BP * 4, BP == 128 ? 2 : BN >= 128 ? 2 : 3) void con
             const int y = (int)epi_div((unsigned)r, (unsigned)W, p.mg_ow, p.sh_ow);
             const int x0 = r - y * W;
             const int pix = (img * H + y - 1) * W + x0 - 1;
-            sv[0] = pix * p.lda0 * 4 + bias0 + cq * 16;
-            sv[1] = pix * p.lda1 * 4 + bias1 + cq * 16;
+            sv[0] = pix * p.lda0 * 4 + bias0 + a_cq * 16;
+            sv[1] = pix * p.lda1 * 4 + bias1 + a_cq * 16;
             unsigned xb = 0;
 #pragma unroll
             for (int j = 0; j < 4; ++j) xb |= ((unsigned)(x0 - 1 + j) < (unsigned)W ? 0u : 1u) << j;
@@ -141,7 +151,8 @@ __global__ __launch_bounds__(BP * 4, BP == 128 ? 2 : BN >= 128 ? 2 : 3) void con
             for (int ky = 0; ky < 3; ++ky) mk |= ((unsigned)(y + ky - 1) < (unsigned)H ? xb : 15u) << (4 * ky);
             sv[2] = (int)mk;
         }
-    }
+    };
+    if (is_a) setup_a();
 
     // ---- wave-uniform state of the chunk whose loads are issued next ----
     int s_kc = 0, s_sub = 0, s_ky = 0, s_c = 0;
@@ -150,12 +161,12 @@ __global__ __launch_bounds__(BP * 4, BP == 128 ? 2 : BN >= 128 ? 2 : 3) void con
     // Activation thread: voffsets of its four pixels for the current (source, kernel row), out-of-image pixels already pushed out
     // of bounds.  They change every fourth chunk only, so the K loop spends 3 VALU per chunk on addresses instead of 16.
     int vo[4] = {OOB, OOB, OOB, OOB};
-    auto refresh_vo = [&]() {
+    auto refresh_vo = [&]() __attribute__((always_inline)) {
         const int rb = s_c < p.C0 ? sv[0] : sv[1];
 #pragma unroll
         for (int j = 0; j < 4; ++j) vo[j] = rb | (__builtin_amdgcn_sbfe(sv[2], s_ky * 4 + j, 1) & OOB);
     };
-    auto advance = [&](auto role_a) {
+    auto advance = [&](auto role_a) __attribute__((always_inline)) {
         ++s_kc;
         ++s_sub;
         s_c += WKC;
@@ -172,7 +183,7 @@ __global__ __launch_bounds__(BP * 4, BP == 128 ? 2 : BN >= 128 ? 2 : 3) void con
     // so a global load has two chunks (4-8 thousand cycles) to return instead of one.  Set (kc+1)&1 is the one iteration kc
     // stores and re-requests; the set index is a compile-time constant (the K loop is unrolled by two).
     wf32x4 rs2[2][NS];
-    auto load_a = [&](auto set, int j) {  // raw pixel j of the pair
+    auto load_a = [&](auto set, int j) __attribute__((always_inline)) {  // raw pixel j of the pair
         constexpr int S = decltype(set)::value;
         if (s_c < p.C0) {
             const int soff = ((s_ky * W + j) * p.lda0 + s_c) * 4;
@@ -182,17 +193,17 @@ __global__ __launch_bounds__(BP * 4, BP == 128 ? 2 : BN >= 128 ? 2 : 3) void con
             rs2[S][j] = wbuf_load16(srd_a1, vo[j], soff);
         }
     };
-    auto load_b = [&](auto set, int i) {
+    auto load_b = [&](auto set, int i) __attribute__((always_inline)) {
         constexpr int S = decltype(set)::value;
         const int soff = ((s_ky * c8n + (s_c >> 3)) * 32) * 4;
         rs2[S][i] = wbuf_load16<WINO_B_AUX>(srd_b, sv[i], soff);
     };
-    auto store_x = [&](wf32x4 v, float *dst) {
+    auto store_x = [&](wf32x4 v, float *dst) __attribute__((always_inline)) {
         if (!(WINO_ABL & 2)) *reinterpret_cast<wf32x4 *>(dst) = v;
         else asm volatile("" ::"v"(v));
     };
-    auto store_b = [&](auto set, int i, float *st) { store_x(rs2[decltype(set)::value][i], &st[sl[i]]); };
-    auto store_v = [&](int t, wf32x4 v, float *st) { store_x(v, &st[t * 8 + sl[0]]); };
+    auto store_b = [&](auto set, int i, float *st) __attribute__((always_inline)) { store_x(rs2[decltype(set)::value][i], &st[sl[i]]); };
+    auto store_v = [&](int t, wf32x4 v, float *st) __attribute__((always_inline)) { store_x(v, &st[t * 8 + sl[0]]); };
     // Staging work of MFMA gap g: write slot g's piece of chunk kc+1 to the other LDS stage, then request slot g for chunk
     // kc+3.  The input transform is arranged so that an activation thread frees its raw pixels in slot order:
     //   gap 0: V0 = d0 - d2 stored;                       gap 1: V1 = d1 + d2 stored, d2 <- d2 - d1 (= V2), d3 <- d1 - d3 (= V3);
@@ -200,7 +211,7 @@ __global__ __launch_bounds__(BP * 4, BP == 128 ? 2 : BN >= 128 ? 2 : 3) void con
     // ROLE / LOADS are compile-time tags (std::integral_constant): the two roles run two separate copies of the K loop (no
     // control-flow joins between them inside the loop -- joins made the compiler copy the staging registers and wait for
     // vmcnt(0) in every gap), and the last three iterations, which have nothing left to request, are peeled without loads.
-    auto stage_gap = [&](int g, float *st, auto set, auto role_a, auto loads) {
+    auto stage_gap = [&](int g, float *st, auto set, auto role_a, auto loads) __attribute__((always_inline)) {
         constexpr int S = decltype(set)::value;
         wf32x4 (&rs)[NS] = rs2[S];
         if constexpr (decltype(role_a)::value) {
@@ -225,7 +236,7 @@ __global__ __launch_bounds__(BP * 4, BP == 128 ? 2 : BN >= 128 ? 2 : 3) void con
             }
         }
     };
-    auto load_all = [&](auto set, auto role_a) {
+    auto load_all = [&](auto set, auto role_a) __attribute__((always_inline)) {
 #pragma unroll
         for (int g = 0; g < NS; ++g) {
             if constexpr (decltype(role_a)::value) {
@@ -236,27 +247,29 @@ __global__ __launch_bounds__(BP * 4, BP == 128 ? 2 : BN >= 128 ? 2 : 3) void con
     };
 
     wf32x16 acc[4][RM][RN];
+    auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int r = 0; r < RM; ++r)
+            for (int r = 0; r < RM; ++r)
 #pragma unroll
-            for (int c = 0; c < RN; ++c)
+                for (int c = 0; c < RN; ++c)
 #pragma unroll
-                for (int v = 0; v < 16; ++v) acc[t][r][c][v] = 0.f;
+                    for (int v = 0; v < 16; ++v) acc[t][r][c][v] = 0.f;
+    };
 
     const int li = lane & 31, lh = lane >> 5;
     const int a_off = (wm * 32 + li) * WLD + lh * 4;
     const int b_off = (BP + wn * (BN / 2) + li) * WLD + lh * 4;
 
     wf32x4 af[2][RM], bf[2][RN];  // fragments of the component being multiplied and of the next one
-    auto load_frags = [&](int t, const float *st, int set) {
+    auto load_frags = [&](int t, const float *st, int set) __attribute__((always_inline)) {
 #pragma unroll
         for (int r = 0; r < RM; ++r) af[set][r] = *reinterpret_cast<const wf32x4 *>(st + t * 8 + a_off + r * 32 * WLD);
 #pragma unroll
         for (int c = 0; c < RN; ++c) bf[set][c] = *reinterpret_cast<const wf32x4 *>(st + t * 8 + b_off + c * 32 * WLD);
     };
-    auto chunk = [&](int kc, auto set, auto role_a, auto loads) {
+    auto chunk = [&](int kc, auto set, auto role_a, auto loads) __attribute__((always_inline)) {
         const float *cur = smem + (kc & 1) * STAGE;
         float *nxt = smem + ((kc + 1) & 1) * STAGE;
         if (!(WINO_ABL & 4) || kc == 0) load_frags(0, cur, 0);
@@ -280,47 +293,9 @@ __global__ __launch_bounds__(BP * 4, BP == 128 ? 2 : BN >= 128 ? 2 : 3) void con
         if (NG == 16) advance(role_a);
         if (!(WINO_ABL & 8)) __syncthreads();
     };
-    // Prologue and K loop of one role.  At the top of iteration kc: LDS stage kc&1 holds chunk kc, register set (kc+1)&1 chunk
-    // kc+1 (raw), set kc&1 chunk kc+2 (possibly still in flight).  nk is a multiple of 12.
-    auto run = [&](auto role_a) {
-        constexpr std::integral_constant<int, 0> S0{};
-        constexpr std::integral_constant<int, 1> S1{};
-        if constexpr (decltype(role_a)::value) refresh_vo();
-        load_all(S0, role_a);  // chunk 0
-        advance(role_a);
-        load_all(S1, role_a);  // chunk 1
-        advance(role_a);
-        if constexpr (decltype(role_a)::value) {
-            wf32x4 (&rs)[NS] = rs2[0];
-            store_v(0, rs[0] - rs[2], smem);
-            store_v(1, rs[1] + rs[2], smem);
-            store_v(2, rs[2] - rs[1], smem);
-            store_v(3, rs[1] - rs[3], smem);
-#pragma unroll
-            for (int i = 4; i < 4 + BA; ++i) store_b(S0, i, smem);
-        } else {
-#pragma unroll
-            for (int i = 0; i < BO; ++i) store_b(S0, i, smem);
-        }
-        load_all(S0, role_a);  // chunk 2
-        advance(role_a);
-        __syncthreads();
-        int kc = 0;
-        for (; kc < nk - 4; kc += 2) {  // iterations 0 .. nk-5 request chunks 3 .. nk-2
-            chunk(kc, S1, role_a, std::true_type{});
-            chunk(kc + 1, S0, role_a, std::true_type{});
-        }
-        chunk(nk - 4, S1, role_a, std::true_type{});   // requests chunk nk-1
-        chunk(nk - 3, S0, role_a, std::false_type{});
-        chunk(nk - 2, S1, role_a, std::false_type{});
-        chunk(nk - 1, S0, role_a, std::false_type{});  // (what it stores is never read)
-    };
-    if (is_a) run(std::true_type{});
-    else run(std::false_type{});
-
     // ---- output transform + epilogue.  Accumulator row (v&3) + 8 (v>>2) + 4 lh of tile r is pixel pair
     // prow + that; its two pixels are rows 2*pair and 2*pair + 1 of the output matrix.  Column = lane & 31. ----
-    {
+    auto epilogue = [&](int pair0_done) __attribute__((always_inline)) {
         char *outc = reinterpret_cast<char *>(p.out);
         const __amdgpu_buffer_rsrc_t srd_o = __builtin_amdgcn_make_buffer_rsrc(outc, 0, p.M * p.ldc * 4, 0x00020000);
         const __amdgpu_buffer_rsrc_t srd_r =
@@ -336,7 +311,7 @@ __global__ __launch_bounds__(BP * 4, BP == 128 ? 2 : BN >= 128 ? 2 : 3) void con
             const int vo_r = nok ? (8 * lh * p.ldres + n) * 4 : OOB;
 #pragma unroll
             for (int r = 0; r < RM; ++r) {
-                const int prow = pair0 + wm * 32 + r * 32;  // wave-uniform
+                const int prow = pair0_done + wm * 32 + r * 32;  // wave-uniform
                 const int mrow = 2 * prow;
                 float res_e[16], res_o[16];
                 if (p.res) {
@@ -392,7 +367,77 @@ __global__ __launch_bounds__(BP * 4, BP == 128 ? 2 : BN >= 128 ? 2 : 3) void con
                 }
             }
         }
-    }
+    };
+
+    // Prologue of the first tile and the tile loop of one role.  At the top of iteration kc: LDS stage kc&1 holds chunk kc,
+    // register set (kc+1)&1 chunk kc+1 (raw), set kc&1 chunk kc+2 (possibly still in flight).  nk is a multiple of 12.
+    auto run = [&](auto role_a) __attribute__((always_inline)) {
+        constexpr std::integral_constant<int, 0> S0{};
+        constexpr std::integral_constant<int, 1> S1{};
+        if constexpr (decltype(role_a)::value) refresh_vo();
+        load_all(S0, role_a);  // chunk 0
+        advance(role_a);
+        load_all(S1, role_a);  // chunk 1
+        advance(role_a);
+        if constexpr (decltype(role_a)::value) {
+            wf32x4 (&rs)[NS] = rs2[0];
+            store_v(0, rs[0] - rs[2], smem);
+            store_v(1, rs[1] + rs[2], smem);
+            store_v(2, rs[2] - rs[1], smem);
+            store_v(3, rs[1] - rs[3], smem);
+#pragma unroll
+            for (int i = 4; i < 4 + BA; ++i) store_b(S0, i, smem);
+        } else {
+#pragma unroll
+            for (int i = 0; i < BO; ++i) store_b(S0, i, smem);
+        }
+        load_all(S0, role_a);  // chunk 2
+        advance(role_a);
+        __syncthreads();
+        for (;;) {
+            zero_acc();
+            int kc = 0;
+            for (; kc < nk - 4; kc += 2) {  // iterations 0 .. nk-5 request chunks 3 .. nk-2
+                chunk(kc, S1, role_a, std::true_type{});
+                chunk(kc + 1, S0, role_a, std::true_type{});
+            }
+            chunk(nk - 4, S1, role_a, std::true_type{});  // requests chunk nk-1; the state now points past the tile
+            if constexpr (!PERSIST) {
+                chunk(nk - 3, S0, role_a, std::false_type{});
+                chunk(nk - 2, S1, role_a, std::false_type{});
+                chunk(nk - 1, S0, role_a, std::false_type{});  // (what it stores is never read)
+                epilogue(pair0);
+                break;
+            } else {
+                // roll over to the next tile of this workgroup: iterations nk-3 .. nk-1 request ITS chunks 0 .. 2 (and the last one
+                // writes its chunk 0 to stage 0), so the loop simply continues after the epilogue.  Without a next tile the
+                // addresses are pushed out of bounds: the loads fetch nothing and what is stored is never read.
+                const int pair0_done = pair0;
+                int next = id + (int)gridDim.x, mt = 0, ntl = 0;
+                while (next < total_ids && !tile_of(next, mt, ntl)) next += (int)gridDim.x;
+                const bool more = next < total_ids;
+                s_kc = 0; s_sub = 0; s_ky = 0; s_c = 0;
+                if (more) {
+                    id = next;
+                    pair0 = mt * BP;
+                    if constexpr (decltype(role_a)::value) setup_a();
+                } else {
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) sv[i] = OOB;
+                    if constexpr (decltype(role_a)::value) { sv[0] = 0; sv[1] = 0; sv[2] = -1; }
+                }
+                if constexpr (decltype(role_a)::value) refresh_vo();
+                chunk(nk - 3, S0, role_a, std::true_type{});
+                chunk(nk - 2, S1, role_a, std::true_type{});
+                chunk(nk - 1, S0, role_a, std::true_type{});
+                epilogue(pair0_done);
+                if (!more) break;
+            }
+        }
+    };
+    if (is_a) run(std::true_type{});
+    else run(std::false_type{});
+
 }
 
 // U[n][ky][c/8][t][c%8] from the packed direct weights w[n][(ky*3 + kx)*Cin + c]; sums in double, one rounding
@@ -487,7 +532,20 @@ int launch_conv3x3_wino(const GemmParams &p_in, hipStream_t s) {
     p.n_tiles = (p.N + bn - 1) / bn;
     p.flat_tiles = p.m_tiles < 16;
     const int gx = p.flat_tiles ? p.m_tiles * p.n_tiles : ((p.m_tiles + 7) / 8) * 8 * p.n_tiles;
-    if (use_big) hipLaunchKernelGGL((conv3x3_wino_f32_kernel<128, 128>), dim3(gx), dim3(512), 0, s, p);
+    if (use_big) {
+        // persistent: one workgroup per CU walks tile ids with a stride that is a multiple of 8 * n_tiles (same N tile, same XCD)
+        static const int one_per_tile = getenv("GDDIM_WINO_NOPERSIST") ? atoi(getenv("GDDIM_WINO_NOPERSIST")) : 0;  // A/B only
+        static int cus = 0;
+        if (!cus) {
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        }
+        const int unit = p.flat_tiles ? p.n_tiles : 8 * p.n_tiles;
+        int g = (cus / unit) * unit;
+        if (g <= 0 || g > gx || one_per_tile) g = gx;
+        hipLaunchKernelGGL((conv3x3_wino_f32_kernel<128, 128>), dim3(g), dim3(512), 0, s, p);
+    }
     else if (bn == 128) hipLaunchKernelGGL((conv3x3_wino_f32_kernel<64, 128>), dim3(gx), dim3(256), 0, s, p);
     else hipLaunchKernelGGL((conv3x3_wino_f32_kernel<64, 64>), dim3(gx), dim3(256), 0, s, p);
     GD_HIP(hipGetLastError());
