@@ -314,7 +314,7 @@ __global__ __launch_bounds__(BP * 4, BP == 128 ? 2 : BN >= 128 ? 2 : 3) void con
                 const int prow = pair0_done + wm * 32 + r * 32;  // wave-uniform
                 const int mrow = 2 * prow;
                 float res_e[16], res_o[16];
-                if (p.res) {
+                if (p.res && !(WINO_ABL & 64)) {
 #pragma unroll
                     for (int v = 0; v < 16; ++v) {
                         const int so = (mrow + 2 * ((v & 3) + 8 * (v >> 2))) * p.ldres * 4;
@@ -340,12 +340,15 @@ __global__ __launch_bounds__(BP * 4, BP == 128 ? 2 : BN >= 128 ? 2 : 3) void con
                     const float m0 = acc[0][r][c][v], m1 = acc[1][r][c][v], m2 = acc[2][r][c][v], m3 = acc[3][r][c][v];
                     float ye = m0 + m1 + m2, yo = m1 - m2 - m3;
                     float ae = addv[v >> 2], ao = addv[v >> 2];
-                    if (p.res) { ae += res_e[v]; ao += res_o[v]; }
+                    if (p.res && !(WINO_ABL & 64)) { ae += res_e[v]; ao += res_o[v]; }
                     ye = (p.alpha * ye + ae) * p.out_scale;
                     yo = (p.alpha * yo + ao) * p.out_scale;
                     const int so = (mrow + 2 * ((v & 3) + 8 * (v >> 2))) * p.ldc * 4;
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ye), srd_o, vo_o, so, 0);
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, yo), srd_o, vo_o, so + p.ldc * 4, 0);
+                    if (WINO_ABL & 32) { asm volatile("" ::"v"(ye), "v"(yo)); }
+                    else {
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ye), srd_o, vo_o, so, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, yo), srd_o, vo_o, so + p.ldc * 4, 0);
+                    }
                     if (v < 8) { s0 += ye + yo; q0 += ye * ye + yo * yo; }
                     else { s1 += ye + yo; q1 += ye * ye + yo * yo; }
                 }
