@@ -378,6 +378,19 @@ __global__ __launch_bounds__(BP * 4, BP == 128 ? 2 : BN >= 128 ? 2 : 3) void con
         constexpr std::integral_constant<int, 0> S0{};
         constexpr std::integral_constant<int, 1> S1{};
         if constexpr (decltype(role_a)::value) refresh_vo();
+#ifdef WINO_TRACE
+        const unsigned long long tr0 = wall_clock64();
+        int trn = 0;
+        float *trbuf = const_cast<float *>(p.res) + (size_t)p.M * p.ldres - 256 + (blockIdx.x == 0 ? 0 : 128);
+        const bool trw = (blockIdx.x == 0 || blockIdx.x == 100) && tid == 0 && p.res;
+        const unsigned long long cy0 = __builtin_readcyclecounter();
+        auto trace = [&]() __attribute__((always_inline)) {
+            if (trw && trn < 60) { trbuf[2 * trn] = (float)(wall_clock64() - tr0); trbuf[2 * trn + 1] = (float)(__builtin_readcyclecounter() - cy0); }
+            ++trn;
+        };
+#else
+        auto trace = [&]() __attribute__((always_inline)) {};
+#endif
         load_all(S0, role_a);  // chunk 0
         advance(role_a);
         load_all(S1, role_a);  // chunk 1
@@ -398,13 +411,18 @@ __global__ __launch_bounds__(BP * 4, BP == 128 ? 2 : BN >= 128 ? 2 : 3) void con
         advance(role_a);
         __syncthreads();
         for (;;) {
+            trace();  // tile start
             zero_acc();
             int kc = 0;
             for (; kc < nk - 4; kc += 2) {  // iterations 0 .. nk-5 request chunks 3 .. nk-2
                 chunk(kc, S1, role_a, std::true_type{});
                 chunk(kc + 1, S0, role_a, std::true_type{});
+#ifdef WINO_TRACE
+                trace();
+#endif
             }
             chunk(nk - 4, S1, role_a, std::true_type{});  // requests chunk nk-1; the state now points past the tile
+            trace();  // main loop done
             if constexpr (!PERSIST) {
                 chunk(nk - 3, S0, role_a, std::false_type{});
                 chunk(nk - 2, S1, role_a, std::false_type{});
@@ -433,7 +451,9 @@ __global__ __launch_bounds__(BP * 4, BP == 128 ? 2 : BN >= 128 ? 2 : 3) void con
                 chunk(nk - 3, S0, role_a, std::true_type{});
                 chunk(nk - 2, S1, role_a, std::true_type{});
                 chunk(nk - 1, S0, role_a, std::true_type{});
+                trace();  // K loop done
                 epilogue(pair0_done);
+                trace();  // epilogue issued
                 if (!more) break;
             }
         }
