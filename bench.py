@@ -29,12 +29,19 @@ HBM_PEAK_GBS = 8000.0
 
 
 def hbm_traffic(kernel_name):
-    """HBM bytes per launch of `kernel_name` from the committed PMC passes (profiles/r01_hbm_traffic.json:
-    (2*FETCH_SIZE + WRITE_SIZE)*1024 with the gfx950 FETCH_SIZE correction), or None when not profiled."""
-    path = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-    try:
-        table = json.load(open(path))["kernels"]
-    except (OSError, ValueError, KeyError):
+    """HBM bytes per launch of `kernel_name` from the newest committed PMC passes (profiles/rNN_hbm_traffic.json:
+    (2*FETCH_SIZE + WRITE_SIZE)*1024 with the gfx950 FETCH_SIZE correction), or None when not profiled.  PMC counters need
+    their own rocprofv3 passes, so this figure is replayed from the committed profile of the same command, not observed
+    in this run."""
+    import glob
+    table = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")), reverse=True):
+        try:
+            table = json.load(open(path))["kernels"]
+            break
+        except (OSError, ValueError, KeyError):
+            continue
+    if table is None:
         return None
     key = kernel_name.replace(" ", "")
     # the engine's profile names abbreviate the template tail of the split-precision kernel (<..., pre> = <..., true, false>)
@@ -108,7 +115,8 @@ def main():
     from gddim_amd.datasets import get_data_inverse_scaler
     from gddim_amd.models import utils as mutils
 
-    rank, world, local_rank = distributed.init_from_env()
+    rank, world, local_rank = distributed.init_from_env(single_rank_group=True)
+    grouped = torch.distributed.is_available() and torch.distributed.is_initialized()
     assert world == args.gpus, "launch with --nproc-per-node equal to --gpus (WORLD_SIZE=%d, --gpus=%d)" % (world, args.gpus)
     if not os.path.exists(os.path.join(ROOT, "gddim_amd", "libgddim_amd.so")):
         if local_rank == 0:
@@ -157,10 +165,12 @@ def main():
     def step():
         xs, vs, nfe = sampling_fn([rank], state, B, u, use_graph=not args.no_graph)
         u8 = distributed.to_uint8(xs[0])
-        return distributed.all_gather_samples(u8)
+        # equal shards (weak scaling): one all_gather_into_tensor, no size exchange; under a launcher the collective runs
+        # through RCCL even at N = 1
+        return distributed.all_gather_samples(u8, equal_shards=True, force=grouped)
 
     def fence():
-        if world > 1:
+        if grouped:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -173,7 +183,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if grouped:
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
     dt = float(tt.item())
     assert out.shape[0] == B * world and out.dtype == torch.uint8
@@ -186,7 +196,7 @@ def main():
         "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16x3 (fp32 split into bf16 hi+lo, fp32 accumulate)", "data": "synthetic",
         "config": {"workload": "%s, batch=%d per GPU, %dx%dx3 synthetic noise, random-init NCSN++ "
                                "(nf=128, ch_mult=(1,2,2,2), 8 res blocks, attn@16)" % (desc, B, cfg.data.image_size, cfg.data.image_size),
-                   "global_batch": B * world, "parallelism": "dp%d (one process per GPU, uint8 all-gather per round)" % world,
+                   "global_batch": B * world, "parallelism": "dp%d (one process per GPU, uint8 all-gather per round%s)" % (world, ", RCCL" if grouped else ""),
                    "hipgraph": not args.no_graph, "tflop_per_image": flops_img / 1e12},
         "e2e_tflops_per_gpu": B * args.steps * flops_img / dt / 1e12,
     }
@@ -203,17 +213,21 @@ def main():
         achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
         # bf16x3 issues 3 bf16 MFMAs per algorithmic product: achieved stays ALGORITHMIC flops, the peak is the bf16 one
         peak = BF16_MFMA_PEAK_TFLOPS if "bf16x3" in dom["name"] else FP32_MFMA_PEAK_TFLOPS
+        # `achieved` = ALGORITHMIC flops of the direct algorithm / time.  `frac` = fraction of the matrix
+        # pipe the kernel keeps busy = ISSUED MFMA flops / time / peak (<= 1): Winograd F(2,3) issues 2/3 of the algorithmic
+        # products, bf16x3 issues 3 bf16 MFMAs per algorithmic product.  `algorithmic_frac` = achieved / peak (may exceed 1
+        # for Winograd: the kernel does less work than the direct algorithm).
+        issue_ratio = (2.0 / 3.0) if "wino" in dom["name"] else (3.0 if "bf16x3" in dom["name"] else 1.0)
         result["roofline"] = {"kernel": dom["name"], "bound": "mfma", "achieved": achieved, "peak": peak,
-                              "unit": "TFLOP/s", "frac": achieved / peak, "traffic": hbm_traffic(dom["name"]),
+                              "unit": "TFLOP/s", "frac": achieved * issue_ratio / peak, "traffic": hbm_traffic(dom["name"]),
+                              "algorithmic_frac": achieved / peak, "issued": achieved * issue_ratio,
                               "launches": dom["launches"], "avg_launch_ms": dom["ms"] / max(1, dom["launches"]),
                               "flops_per_launch": dom["flops"] / max(1, dom["launches"]),
-                              "share_of_gpu_time": dom["ms"] / tot_ms if tot_ms else None}
+                              "share_of_gpu_time": dom["ms"] / tot_ms if tot_ms else None,
+                              "traffic_source": "committed rocprofv3 --pmc passes of this command (profiles/), not this run"}
         if "wino" in dom["name"]:
-            # Winograd F(2,3): `achieved` counts the ALGORITHMIC flops of the direct convolution (18 M N Cin); the kernel issues
-            # 12 M N Cin on the fp32 matrix core, so the fraction of the pipe it keeps busy is 2/3 of `frac` (which may exceed 1)
-            result["roofline"]["frac_of_issued_mfma"] = achieved / 1.5 / peak
-            result["roofline"]["note"] = ("Winograd F(2,3) along x: algorithmic flops / time, peak = dense fp32 MFMA; "
-                                          "issued MFMA flops are 2/3 of algorithmic")
+            result["roofline"]["note"] = ("Winograd F(2,3) along x: achieved = algorithmic flops of the direct convolution / time; "
+                                          "issued MFMA flops are 2/3 of that; frac = issued / dense fp32 MFMA peak")
         result["kernel_breakdown"] = [
             {"name": p["name"], "ms": round(p["ms"], 3), "launches": p["launches"],
              "tflops": (p["flops"] / (p["ms"] * 1e-3) / 1e12) if p["flops"] and p["ms"] else None,
@@ -232,7 +246,7 @@ def main():
         fence()
         dta = time.perf_counter() - t0
         tta = torch.tensor([dta], dtype=torch.float64, device=dev)
-        if world > 1:
+        if grouped:
             torch.distributed.all_reduce(tta, op=torch.distributed.ReduceOp.MAX)
         dta = float(tta.item())
         alt = {"dtype": "bf16x3 (fp32 operands split into bf16 hi+lo, 3 bf16 MFMAs per product, fp32 accumulate)",
@@ -249,7 +263,7 @@ def main():
             ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
             alt["roofline"] = {"kernel": dom["name"], "bound": "mfma", "achieved": ach, "peak": BF16_MFMA_PEAK_TFLOPS,
                                "unit": "TFLOP/s (algorithmic; the kernel issues 3x this in bf16 MFMAs)",
-                               "frac": ach / BF16_MFMA_PEAK_TFLOPS, "frac_of_issued_mfma": 3 * ach / BF16_MFMA_PEAK_TFLOPS,
+                               "frac": 3 * ach / BF16_MFMA_PEAK_TFLOPS, "algorithmic_frac": ach / BF16_MFMA_PEAK_TFLOPS, "issued": 3 * ach,
                                "traffic": hbm_traffic(dom["name"]), "launches": dom["launches"],
                                "avg_launch_ms": dom["ms"] / max(1, dom["launches"])}
         eng.set_precision("fp32")
@@ -259,7 +273,7 @@ def main():
         result["cpu_baseline"] = cpu_baseline(cfg, params, args.nfe, args.cpu_batch, args.cpu_nfe)
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if grouped:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

@@ -79,6 +79,7 @@ SIGNATURES = {
     "gd_sample_cld": (_I, [_P, _I, _P, _P, _P, _I, _I, _P]),
     "gd_engine_set_schedule_blur": (_I, [_P, _I, _P, _P, _P]),
     "gd_engine_set_schedule_blur_deis": (_I, [_P, _I, _I, _P, _P]),
+    "gd_engine_set_model2eps_blur": (_I, [_P, _P]),
     "gd_sample_blur": (_I, [_P, _I, _P, _P, _I, _I, _P]),
     "gd_engine_profile": (_I, [_P, _I]),
     "gd_engine_profile_read": (_I, [_P, ctypes.POINTER(ProfEntry), _I, ctypes.POINTER(_I)]),

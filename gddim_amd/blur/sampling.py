@@ -32,6 +32,25 @@ def _scale_mode(inverse_scaler):
     return fuse_scale, (None if fuse_scale or np.allclose(scaled, probe) else inverse_scaler)
 
 
+def _model2eps_rows(sde, rev_ts, nfe):
+    """sde.model2eps (blur_jax/sde_lib.py:150-152) is the identity in the reference's SDE class.  A subclass that predicts
+    something else may expose the linear form `model2eps_affine(t) -> (a, b)`: eps_x = a * model_output + b * x for a scalar b, or,
+    for a (32, 32) plane b in DCT space, eps_y = a * DCT(model_output) + b (.) y -- which the fused loop applies per step.  Any other
+    override of model2eps cannot run inside the fused loop and is refused."""
+    aff = getattr(sde, 'model2eps_affine', None)
+    if aff is not None:
+        rows = np.empty((nfe, 1025), dtype=np.float64)
+        for i, t in enumerate(rev_ts[:nfe]):
+            a, b = aff(float(t))
+            rows[i, 0] = a
+            rows[i, 1:] = np.broadcast_to(np.asarray(b, dtype=np.float64), (32, 32)).reshape(-1)
+        return rows
+    probe = np.array([0.25, -2.0])
+    if not np.array_equal(np.asarray(sde.model2eps(probe * 3.0, 0.5, probe)), probe):
+        raise NotImplementedError("sde.model2eps is not the identity: expose it as model2eps_affine(t) -> (a, b)")
+    return None
+
+
 def get_deis_sampler(sde, model, data_shape, ts_order, nfe, deis_order, inverse_scaler, is_p=False):
     """Adams-Bashforth exponential integrator of order `deis_order` in DCT space: y' = psi_i y + sum_o c_{i,o} eps_o per frequency
     (multistep.get_ab_eps_coef_freq); deis_order = 0 is the order0 sampler."""
@@ -41,6 +60,7 @@ def get_deis_sampler(sde, model, data_shape, ts_order, nfe, deis_order, inverse_
     coef = np.concatenate([psi[:, None], eps_coef], axis=1)  # (nfe, deis_order + 2, 32, 32)
     fuse_scale, post_scale = _scale_mode(inverse_scaler)
     token = ("blur_deis", next(_TOKENS))
+    m2e = _model2eps_rows(sde, rev_ts, nfe)
 
     def sampler(rng, state, batch_size, u=None, use_graph=True):
         import torch
@@ -51,7 +71,9 @@ def get_deis_sampler(sde, model, data_shape, ts_order, nfe, deis_order, inverse_
         if not u.is_cuda:
             u = u.to(torch.device('cuda', torch.cuda.current_device()))
         eng = model.engine_for(state.params_ema, data_shape[-1], batch_size, u.device.index)
-        eng.set_schedule_blur_deis(rev_ts[:nfe], coef, token=token)
+        if eng._schedule_token != token:
+            eng.set_schedule_blur_deis(rev_ts[:nfe], coef, token=token)
+            eng.set_model2eps_blur(m2e)
         x = eng.sample_blur(u.to(torch.float32), inverse_scale=fuse_scale, use_graph=use_graph)
         return (post_scale(x) if post_scale is not None else x), nfe
 
@@ -75,6 +97,7 @@ def get_order0_sampler(sde, model, data_shape, ts_order, nfe, inverse_scaler, is
     fuse_scale = bool(np.allclose(scaled, (probe + 1.0) / 2.0))
     post_scale = None if fuse_scale or np.allclose(scaled, probe) else inverse_scaler
     token = ("blur_order0", next(_TOKENS))
+    m2e = _model2eps_rows(sde, rev_ts, nfe)
 
     def sampler(rng, state, batch_size, u=None, use_graph=True):
         import torch
@@ -85,7 +108,9 @@ def get_order0_sampler(sde, model, data_shape, ts_order, nfe, inverse_scaler, is
         if not u.is_cuda:
             u = u.to(torch.device('cuda', torch.cuda.current_device()))
         eng = model.engine_for(state.params_ema, data_shape[-1], batch_size, u.device.index)
-        eng.set_schedule_blur(rev_ts[:nfe], mean_coef, std_coef, token=token)
+        if eng._schedule_token != token:
+            eng.set_schedule_blur(rev_ts[:nfe], mean_coef, std_coef, token=token)
+            eng.set_model2eps_blur(m2e)
         x = eng.sample_blur(u.to(torch.float32), inverse_scale=fuse_scale, use_graph=use_graph)
         if post_scale is not None:
             x = post_scale(x)

@@ -165,11 +165,10 @@ def _make_sampler(sde, model, data_shape, nfe, inverse_scaler, rev_ts, coef, den
 
 
 def get_order0_sampler(sde, model, data_shape, nfe, inverse_scaler, is_em=False, denoising=False, is_p=False):
-    if is_em:
-        raise NotImplementedError("is_em=True (prepare_naive_coef) is outside this round's scope")
     num_step = nfe - 1 if denoising else nfe
     rev_ts = get_rev_ts(sde, 2, num_step)  # ts_order is hard-coded to 2 here (cld_jax/sampling.py:162)
-    mean_matrix, eps_matrix = sde.prepare_order0_coef(rev_ts)
+    # is_em: Euler step of the probability-flow ODE instead of the exponential integrator (:171-174)
+    mean_matrix, eps_matrix = sde.prepare_naive_coef(rev_ts) if is_em else sde.prepare_order0_coef(rev_ts)
     coef = np.stack([mean_matrix, eps_matrix], axis=1)  # n_slots = 2: no epsilon history
     return _make_sampler(sde, model, data_shape, nfe, inverse_scaler, rev_ts, coef, denoising, is_p, "order0")
 

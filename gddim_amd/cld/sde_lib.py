@@ -181,6 +181,19 @@ class CLD(object):
         eps = deis.get_ab_eps_coef(self, 0, ts, 0, num_item=num_item)[:, 0]
         return mean, eps
 
+    def prepare_naive_coef(self, rev_ts):
+        """sde_lib.py:276-287 (`get_order0_sampler(is_em=True)`): the Euler step of the probability-flow ODE in the
+        [mean, eps] form -- Psi_i = I + F(t_i) dt and C_i = 1/2 G(t_i) G(t_i) R(t_i)^-T dt, dt = t_{i+1} - t_i < 0."""
+        ts = np.asarray(rev_ts, dtype=np.float64)
+        n = ts.shape[0] - 1
+        mean, eps = np.empty((n, 2, 2)), np.empty((n, 2, 2))
+        for i in range(n):
+            dt = ts[i + 1] - ts[i]
+            G = self.s_G(ts[i])
+            mean[i] = np.eye(2) + self.s_F(ts[i]) * dt
+            eps[i] = 0.5 * G @ G @ self.s_invR(ts[i]).T * dt
+        return mean, eps
+
     def get_deis_coef(self, order, rev_timesteps, used_cache=True):
         """(N, order+3, 2, 2) = [Psi_i, C_i0 .. C_i(order+1)] (sde_lib.py:308-319; highest_order = order+1)."""
         ts = np.asarray(rev_timesteps, dtype=np.float64)

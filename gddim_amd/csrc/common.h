@@ -173,11 +173,12 @@ int launch_cld_finish(const float *u8, const float *eps, const float *dn, float 
 int launch_advance_step(int *step, hipStream_t s);
 // blur fused-sampler kernels
 int launch_blur_idct_pad(const float *y, float *x8, int batch, int C, hipStream_t s);
+// m2e: optional per-step rows [a, b[32*32]] of sde.model2eps in linear form, eps_y = a DCT(net) + b (.) y (null: identity)
 int launch_blur_step(float *y, const float *eps_x, const float *mean_coef, const float *std_coef, const int *step,
-                     int batch, int C, hipStream_t s);
+                     int batch, int C, const float *m2e, hipStream_t s);
 // y' = c0 y + c1 DCT(eps_x) + sum_j c_{2+j} hist_j with per-frequency coefficient planes coef[step][n_slots][32*32]
 int launch_blur_ab_step(float *y, const float *eps_x, float *ring, int ring_slots, const float *coef, int n_slots, const int *step,
-                        int batch, int C, long long slot_stride, hipStream_t s);
+                        int batch, int C, long long slot_stride, const float *m2e, hipStream_t s);
 int launch_blur_finish(const float *y, float *x_out, int batch, int C, int inverse_scale, hipStream_t s);
 
 }  // namespace gd

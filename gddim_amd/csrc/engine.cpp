@@ -68,6 +68,7 @@ struct gd_engine {
     float *u8 = nullptr, *ring = nullptr, *ystate = nullptr;
     long long ring_cap = 0;
     float *ts_dev = nullptr, *coef_dev = nullptr, *dn_dev = nullptr, *mean_dev = nullptr, *std_dev = nullptr;
+    float *m2e_dev = nullptr;     // blur: per-step [a, b[1024]] of sde.model2eps in linear form (gd_engine_set_model2eps_blur), null = identity
     float *tf_dev = nullptr;      // per-step [P, E, U] rows of the CLD sampler (gd_engine_set_transforms_cld), null = none
     bool tf_pre = false;          // the rows carry a non-identity P: the U-Net reads xin = P u instead of u
     int fin_flags = 0;            // cld_finish: 1 mixed-score term, 2 final frame change
@@ -417,7 +418,7 @@ int gd_engine_destroy(gd_engine *e) {
         if (e->wsplit_hi) (void)hipFree(e->wsplit_hi);
         if (e->wsplit_lo) (void)hipFree(e->wsplit_lo);
         float *bufs[] = {e->arena, e->wbuf, e->xin, e->epsb, e->eps_planar, e->labels, e->u8, e->ring, e->ystate,
-                         e->ts_dev, e->coef_dev, e->dn_dev, e->mean_dev, e->std_dev, e->tf_dev, e->nz_dev, (float *)e->seed_dev,
+                         e->ts_dev, e->coef_dev, e->dn_dev, e->mean_dev, e->std_dev, e->tf_dev, e->nz_dev, e->m2e_dev, (float *)e->seed_dev,
                          (float *)e->step_dev};
         for (float *b : bufs)
             if (b) (void)hipFree(b);
@@ -624,7 +625,11 @@ int gd_engine_set_schedule_cld(gd_engine *e, int num_step, int n_slots, const fl
     std::vector<float> ts(ts_host, ts_host + num_step);
     ts.push_back(t_denoise);  // ts[num_step]: the time of the denoising evaluation
     GD_TRY(upload(&e->ts_dev, ts.data(), ts.size()));
-    GD_TRY(upload(&e->coef_dev, coef_host, (size_t)std::max(1, num_step) * n_slots * 4));
+    if (num_step > 0) GD_TRY(upload(&e->coef_dev, coef_host, (size_t)num_step * n_slots * 4));
+    else {  // nfe = 1 with noise removal: no AB step runs, the caller's coef buffer is empty -- upload one zero row
+        std::vector<float> zero((size_t)n_slots * 4, 0.f);
+        GD_TRY(upload(&e->coef_dev, zero.data(), zero.size()));
+    }
     if (denoise) {
         GD_CHECK(dn_F && dn_GG && dn_RinvT, "denoise matrices missing");
         float dn[12];
@@ -856,6 +861,7 @@ int gd_engine_set_schedule_blur(gd_engine *e, int nfe, const float *ts_host, con
     GD_TRY(upload(&e->mean_dev, mean_coef_host, (size_t)(nfe + 1) * 1024));
     GD_TRY(upload(&e->std_dev, std_coef_host, (size_t)(nfe + 1)));
     e->sched_kind = 2; e->num_step = nfe;
+    if (e->m2e_dev) { (void)hipFree(e->m2e_dev); e->m2e_dev = nullptr; }
     return 0;
 }
 
@@ -878,6 +884,18 @@ int gd_engine_set_schedule_blur_deis(gd_engine *e, int nfe, int n_slots, const f
         e->ring_cap = need;
     }
     e->sched_kind = 3; e->num_step = nfe; e->n_slots = n_slots;
+    if (e->m2e_dev) { (void)hipFree(e->m2e_dev); e->m2e_dev = nullptr; }
+    return 0;
+}
+
+int gd_engine_set_model2eps_blur(gd_engine *e, const float *rows_host) {
+    GD_CHECK(e && !e->plan_only, "engine has no GPU");
+    GD_CHECK(e->sched_kind == 2 || e->sched_kind == 3, "install a blur schedule first (gd_engine_set_schedule_blur[_deis])");
+    GD_HIP(hipSetDevice(e->device));
+    GD_HIP(hipDeviceSynchronize());
+    drop_graphs(e);  // captured launches bake the table pointer
+    if (e->m2e_dev) { (void)hipFree(e->m2e_dev); e->m2e_dev = nullptr; }
+    if (rows_host) GD_TRY(upload(&e->m2e_dev, rows_host, (size_t)e->num_step * 1025));
     return 0;
 }
 
@@ -928,9 +946,9 @@ int gd_sample_blur(gd_engine *e, int batch, const float *y_in_dev, float *x_out_
         GD_TRY(launch_blur_idct_pad(l.y, l.xin, l.b, C, l.s));
         GD_TRY(run_unet(e, l.bind, l.b, l.s));
         if (multistep)
-            GD_TRY(launch_blur_ab_step(l.y, l.eps, l.ring, ring_slots, e->coef_dev, e->n_slots, l.step, l.b, C, slot_stride, l.s));
+            GD_TRY(launch_blur_ab_step(l.y, l.eps, l.ring, ring_slots, e->coef_dev, e->n_slots, l.step, l.b, C, slot_stride, e->m2e_dev, l.s));
         else
-            GD_TRY(launch_blur_step(l.y, l.eps, e->mean_dev, e->std_dev, l.step, l.b, C, l.s));
+            GD_TRY(launch_blur_step(l.y, l.eps, e->mean_dev, e->std_dev, l.step, l.b, C, e->m2e_dev, l.s));
         return launch_advance_step(l.step, l.s);
     };
     if (graph) {

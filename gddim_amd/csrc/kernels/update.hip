@@ -413,7 +413,8 @@ int launch_blur_idct_pad(const float *y, float *x8, int batch, int C, hipStream_
 __global__ __launch_bounds__(256) void blur_step_kernel(float *__restrict__ y, const float *__restrict__ eps_x,
                                                          const float *__restrict__ mean_coef,
                                                          const float *__restrict__ std_coef,
-                                                         const int *__restrict__ step_ptr, int C) {
+                                                         const int *__restrict__ step_ptr, int C,
+                                                         const float *__restrict__ m2e) {
     __shared__ float D[DN * DL], X[DN * DL], T[DN * DL];
     const int b = blockIdx.x / C, c = blockIdx.x - b * C;
     const int step = *step_ptr;
@@ -424,18 +425,22 @@ __global__ __launch_bounds__(256) void blur_step_kernel(float *__restrict__ y, c
     dct_plane(D, X, T, 0);
     const float *m0 = mean_coef + (size_t)step * DN * DN, *m1 = m0 + DN * DN;
     const float s0 = std_coef[step], s1 = std_coef[step + 1];
+    // sde.model2eps in linear form (blur_jax/models/utils.py:147): eps_y = a DCT(net) + b (.) y with a per-frequency plane b
+    const float *mrow = m2e ? m2e + (size_t)step * (1 + DN * DN) : nullptr;
+    const float ma = mrow ? mrow[0] : 1.f;
     float *yy = y + (size_t)b * DN * DN * C + c;
     for (int i = threadIdx.x; i < DN * DN; i += 256) {
-        const float ey = X[(i / DN) * DL + (i % DN)];
         const float ycur = yy[(size_t)i * C];
+        float ey = X[(i / DN) * DL + (i % DN)];
+        if (mrow) ey = ma * ey + mrow[1 + i] * ycur;
         const float y0 = 1.0f / m0[i] * (ycur - s0 * ey);  // blur_jax/sampling.py:69
         yy[(size_t)i * C] = m1[i] * y0 + s1 * ey;           // :71-74
     }
 }
 
 int launch_blur_step(float *y, const float *eps_x, const float *mean_coef, const float *std_coef, const int *step,
-                     int batch, int C, hipStream_t s) {
-    hipLaunchKernelGGL(blur_step_kernel, dim3(batch * C), dim3(256), 0, s, y, eps_x, mean_coef, std_coef, step, C);
+                     int batch, int C, const float *m2e, hipStream_t s) {
+    hipLaunchKernelGGL(blur_step_kernel, dim3(batch * C), dim3(256), 0, s, y, eps_x, mean_coef, std_coef, step, C, m2e);
     GD_HIP(hipGetLastError());
     return 0;
 }
@@ -446,7 +451,8 @@ int launch_blur_step(float *y, const float *eps_x, const float *mean_coef, const
 __global__ __launch_bounds__(256) void blur_ab_step_kernel(float *__restrict__ y, const float *__restrict__ eps_x,
                                                             float *__restrict__ ring, int ring_slots,
                                                             const float *__restrict__ coef, int n_slots,
-                                                            const int *__restrict__ step_ptr, int C, long long slot_stride) {
+                                                            const int *__restrict__ step_ptr, int C, long long slot_stride,
+                                                            const float *__restrict__ m2e) {
     __shared__ float D[DN * DL], X[DN * DL], T[DN * DL];
     const int b = blockIdx.x / C, c = blockIdx.x - b * C;
     const int step = *step_ptr;
@@ -459,8 +465,11 @@ __global__ __launch_bounds__(256) void blur_ab_step_kernel(float *__restrict__ y
     const float *cf = coef + (size_t)step * n_slots * DN * DN;
     const int head = ring_slots > 0 ? (ring_slots - step % ring_slots) % ring_slots : 0;
     float *yy = y + plane;
+    const float *mrow = m2e ? m2e + (size_t)step * (1 + DN * DN) : nullptr;
+    const float ma = mrow ? mrow[0] : 1.f;
     for (int i = threadIdx.x; i < DN * DN; i += 256) {
-        const float ey = X[(i / DN) * DL + (i % DN)];
+        float ey = X[(i / DN) * DL + (i % DN)];
+        if (mrow) ey = ma * ey + mrow[1 + i] * yy[(size_t)i * C];
         float acc = cf[i] * yy[(size_t)i * C] + cf[DN * DN + i] * ey;
         int phys = head;
         for (int j = 0; j < ring_slots; ++j) {
@@ -473,9 +482,9 @@ __global__ __launch_bounds__(256) void blur_ab_step_kernel(float *__restrict__ y
 }
 
 int launch_blur_ab_step(float *y, const float *eps_x, float *ring, int ring_slots, const float *coef, int n_slots, const int *step,
-                        int batch, int C, long long slot_stride, hipStream_t s) {
+                        int batch, int C, long long slot_stride, const float *m2e, hipStream_t s) {
     hipLaunchKernelGGL(blur_ab_step_kernel, dim3(batch * C), dim3(256), 0, s, y, eps_x, ring, ring_slots, coef, n_slots, step, C,
-                       slot_stride);
+                       slot_stride, m2e);
     GD_HIP(hipGetLastError());
     return 0;
 }

@@ -9,14 +9,17 @@ import os
 import numpy as np
 
 
-def init_from_env(backend=None):
-    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun).  Returns (rank, world, local_rank)."""
+def init_from_env(backend=None, single_rank_group=False):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun).  Returns (rank, world, local_rank).
+    single_rank_group=True also builds the (1-rank) group when the launcher set RANK with WORLD_SIZE=1, so that a
+    `torch.distributed.run --nproc-per-node 1` launch runs its end-of-round gather through RCCL like the N>1 launches do."""
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ
+    if (world > 1 or (single_rank_group and launched)) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
@@ -49,22 +52,35 @@ def to_uint8(x):
     return np.clip(np.asarray(x) * 255.0, 0, 255).astype(np.uint8)
 
 
-def all_gather_samples(local_u8, world=None):
-    """Gather every rank's uint8 images (B_r,H,W,C) into (sum B_r,H,W,C) on every rank.  Shards may differ
-    in size by one image; they are padded to the largest shard for the collective and trimmed after."""
+def all_gather_samples(local, equal_shards=None, force=False):
+    """Gather every rank's images (B_r, ...) into (sum B_r, ...) on every rank -- one collective per round, uint8 for the
+    FID images (3 072 B per image), the only data-path exchange of the sampler.
+
+    equal_shards=True (the caller split the round with `shard_batch` and the batch divides the world size): one
+    `all_gather_into_tensor` straight into the output, no size exchange, no host synchronisation.  equal_shards=None/False:
+    shard sizes (which differ by at most one image) are exchanged first, shards are padded to the largest one for the
+    collective and trimmed after.  force=True runs the collective even in a 1-rank group (used to exercise RCCL on one GPU)."""
     import torch
     import torch.distributed as dist
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
-        return local_u8
+    if not dist.is_available() or not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
+        return local
     world = dist.get_world_size()
-    n = torch.tensor([local_u8.shape[0]], dtype=torch.int64, device=local_u8.device)
+    local = local.contiguous()
+    if equal_shards:
+        out = local.new_empty((world * local.shape[0],) + tuple(local.shape[1:]))
+        if dist.get_backend() == "gloo":  # gloo has no all_gather_into_tensor
+            dist.all_gather(list(out.chunk(world)), local)
+        else:
+            dist.all_gather_into_tensor(out, local)
+        return out
+    n = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
     sizes = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(sizes, n)
-    sizes = [int(s.item()) for s in sizes]
+    sizes = [int(s) for s in torch.cat(sizes).tolist()]
     mx = max(sizes)
-    pad = local_u8
-    if local_u8.shape[0] < mx:
-        pad = torch.cat([local_u8, local_u8.new_zeros((mx - local_u8.shape[0],) + tuple(local_u8.shape[1:]))])
+    pad = local
+    if local.shape[0] < mx:
+        pad = torch.cat([local, local.new_zeros((mx - local.shape[0],) + tuple(local.shape[1:]))])
     bufs = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(bufs, pad.contiguous())
     return torch.cat([b[:s] for b, s in zip(bufs, sizes)])

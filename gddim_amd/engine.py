@@ -242,6 +242,16 @@ class Engine(object):
         check(self._lib.gd_engine_set_schedule_blur_deis(self._h, nfe, n_slots, ts_p, co_p))
         self._schedule_token = token
 
+    def set_model2eps_blur(self, rows=None):
+        """Per-step rows [a, b(32*32)] of sde.model2eps in linear form, eps_y = a * DCT(model_output) + b (.) y
+        (include/gddim_amd.h); None removes it."""
+        if rows is None:
+            check(self._lib.gd_engine_set_model2eps_blur(self._h, None))
+            return
+        a, p = _host_f32(rows)
+        assert a.ndim == 2 and a.shape[1] == 1025
+        check(self._lib.gd_engine_set_model2eps_blur(self._h, p))
+
     def sample_blur(self, y, inverse_scale=True, use_graph=True):
         import torch
         y = y.contiguous()

@@ -22,20 +22,39 @@ class NCSNpp(object):
         self.config = config
         self._engines = {}
 
-    # -- engine cache: one engine per (params identity, in_channels), grown when a larger batch arrives
+    # -- engine cache: at most ONE engine per (in_channels, device).  A different parameter tree (another checkpoint of the
+    # reference's evaluate() loop, a new EMA copy) or an in-place update of the same tree is detected by identity plus a cheap
+    # content fingerprint and re-uploaded into the existing engine, so weights are never stale and GPU memory does not grow with
+    # the number of parameter trees seen.  A larger batch replaces the engine (the arena is sized by max_batch).
     def engine_for(self, params, in_channels, batch, device=None):
         import torch
         dev = torch.cuda.current_device() if device is None else device
-        key = (id(params), int(in_channels), dev)
+        key = (int(in_channels), dev)
         ent = self._engines.get(key)
-        if ent is None or ent[1] < batch:
+        fp = _fingerprint(params)
+        if ent is None or ent['cap'] < batch:
             if ent is not None:
-                ent[0].close()
+                ent['eng'].close()
             eng = _engine.Engine(self.config, in_channels, max_batch=batch, device=dev)
             eng.load_params(params)
-            ent = (eng, batch, params)  # keep `params` alive so id() stays unique
+            ent = {'eng': eng, 'cap': batch, 'pid': id(params), 'fp': fp, 'params': params}  # `params` kept alive: id() stays unique
             self._engines[key] = ent
-        return ent[0]
+        elif ent['pid'] != id(params) or ent['fp'] != fp:
+            ent['eng'].load_params(params)
+            ent.update(pid=id(params), fp=fp, params=params)
+        return ent['eng']
+
+    def invalidate(self):
+        """Forget the uploaded weights: the next call re-uploads its parameter tree (use after an in-place edit too small for
+        the fingerprint to see, or to release the parameter tree the cache keeps alive)."""
+        for ent in self._engines.values():
+            ent.update(pid=None, fp=None, params=None)
+
+    def close(self):
+        """Destroy every native engine of this model (GPU memory is returned)."""
+        for ent in self._engines.values():
+            ent['eng'].close()
+        self._engines = {}
 
     def apply(self, variables, x, labels, train=False, mutable=False, rngs=None):
         if train:
@@ -48,6 +67,25 @@ class NCSNpp(object):
         """flax `model.init`: returns {'params': tree}.  rngs: {'params': seed-like}."""
         seed = rngs['params'] if isinstance(rngs, dict) else rngs
         return {'params': init_params(self.config, int(fake_input.shape[-1]), mutils.as_numpy_rng(seed))}
+
+
+def _fingerprint(params):
+    """Cheap content fingerprint of a parameter tree: per leaf its name, shape and 12 sampled values (first / middle / last four).
+    Catches a new checkpoint or EMA copied into the same dict; `model.invalidate()` covers anything subtler."""
+    import hashlib
+    h = hashlib.blake2b(digest_size=16)
+    for name, a in sorted(_engine.flatten_params(params).items()):
+        flat = a.reshape(-1)
+        n = int(flat.shape[0])
+        h.update(name.encode())
+        h.update(repr(tuple(a.shape)).encode())
+        if n:
+            mid = max(0, n // 2 - 2)
+            for part in (flat[:4], flat[mid:mid + 4], flat[-4:]):  # sampled before any device->host copy
+                if hasattr(part, 'detach'):
+                    part = part.detach().cpu().numpy()
+                h.update(np.ascontiguousarray(part).tobytes())
+    return h.digest()
 
 
 def param_shapes(config, in_channels):

@@ -44,8 +44,11 @@ def sample_data(config, ckpt_file, result_folder, is_continue=False, state=None)
         state = checkpoints.restore_checkpoint(ckpt_file, mutils.State(lr=config.optim.lr, ema_rate=config.model.ema_rate))
     if torch.cuda.is_available():
         torch.cuda.set_device(local_rank)
-    per_rank = config.eval.batch_size // world
-    if per_rank < 1:
+    # the reference gives every device eval.batch_size // n_dev images (cld_jax/run_lib.py:721) and silently drops the remainder;
+    # here the remainder goes to the first ranks so that a round always holds eval.batch_size images
+    _, per_rank = distributed.shard_batch(config.eval.batch_size, world, rank)
+    equal = config.eval.batch_size % world == 0
+    if config.eval.batch_size < world:
         raise GddimError("eval.batch_size %d is smaller than the number of ranks %d" % (config.eval.batch_size, world))
     written = []
     for r in range(num_sampling_rounds):
@@ -56,14 +59,19 @@ def sample_data(config, ckpt_file, result_folder, is_continue=False, state=None)
         samples_org_x, nfe_cnt = out[0], out[-1]
         samples_v = out[1] if len(out) == 3 else None
         x = samples_org_x.reshape((-1,) + tuple(samples_org_x.shape[2:]))
-        u8 = distributed.all_gather_samples(distributed.to_uint8(x))
-        xf = distributed.all_gather_samples(x)
-        vf = distributed.all_gather_samples(samples_v.reshape(x.shape)) if samples_v is not None else None
+        u8 = distributed.all_gather_samples(distributed.to_uint8(x), equal_shards=equal)
+        # the float copies the reference also stores (samples_x, samples_v): one more gather, x and v stacked
+        fl = x[..., None] if samples_v is None else torch.stack([x, samples_v.reshape(x.shape)], dim=-1)
+        fl = distributed.all_gather_samples(fl, equal_shards=equal)
+        xf = fl[..., 0]
+        vf = fl[..., 1] if samples_v is not None else None
+        # reference layout of the float arrays: (n_dev, B / n_dev, H, W, C); uneven shards (not possible there) are written as one row
+        lead = (world, config.eval.batch_size // world) if equal else (1, config.eval.batch_size)
         if rank == 0:
             keys = dict(samples=u8.cpu().numpy().reshape((-1, config.data.image_size, config.data.image_size, config.data.num_channels)),
-                        nfe_cnt=nfe_cnt, samples_x=xf.cpu().numpy()[None])
+                        nfe_cnt=nfe_cnt, samples_x=xf.cpu().numpy().reshape(lead + tuple(xf.shape[1:])))
             if vf is not None:
-                keys['samples_v'] = vf.cpu().numpy()[None]
+                keys['samples_v'] = vf.cpu().numpy().reshape(lead + tuple(vf.shape[1:]))
             tmp = f_sample + ".tmp.npz"
             np.savez_compressed(tmp, **keys)
             os.replace(tmp, f_sample)

@@ -197,6 +197,12 @@ int gd_engine_set_schedule_blur(gd_engine *e, int nfe, const float *ts_host, con
  *   coef_host[nfe][n_slots][32*32]: slot 0 = psi_i = m(t_{i+1}) / m(t_i), slot 1 = coefficient of the new eps_y, slots 2.. of the
  *   history (newest first); n_slots = order + 2.  gd_sample_blur then runs y' = c0 y + c1 e_y + sum_j c_{2+j} hist_j per step. */
 int gd_engine_set_schedule_blur_deis(gd_engine *e, int nfe, int n_slots, const float *ts_host, const float *coef_host);
+/* sde.model2eps(x, t, model_output) (blur_jax/sde_lib.py:150-152, applied in get_eps_fn, blur_jax/models/utils.py:147) in linear
+ * form, stated in DCT space where the sampler lives:
+ *   rows_host[nfe][1 + 32*32] = [a_i, b_i(h,w)]:  eps_y = a_i * DCT(model_output) + b_i (.) y  at step i
+ *   (a scalar b_i, i.e. a constant plane, is eps_x = a_i * model_output + b_i * x; identity = a 1, b 0: the reference's own SDE
+ *   class).  Pass NULL to remove it.  Call after gd_engine_set_schedule_blur[_deis]. */
+int gd_engine_set_model2eps_blur(gd_engine *e, const float *rows_host);
 /* y_in_dev (B,32,32,C) -> x_out_dev (B,32,32,C) = inverse_scaler(IDCT(y_nfe)).
  * Replaces: sampler(rng, state, batch_size, u) (blur_jax/sampling.py:55-80). */
 int gd_sample_blur(gd_engine *e, int batch, const float *y_in_dev, float *x_out_dev, int inverse_scale,

@@ -63,8 +63,8 @@ def get_interp_fn(xp, fp):
         delta = x - xp[i - 1]
         if np.ndim(x) == 0:
             return fp[i] if dx == 0 else fp[i - 1] + (delta / dx) * df
-        w = np.where(dx == 0, 0.0, delta / np.where(dx == 0, 1.0, dx)).astype(xp.dtype)
-        return fp[i - 1] + w[..., None, None] * df
+        w = (delta / np.where(dx == 0, 1.0, dx)).astype(xp.dtype)
+        return np.where((dx == 0)[..., None, None], fp[i], fp[i - 1] + w[..., None, None] * df)  # :41 fp[i] on a zero-width cell
 
     return _fn
 
@@ -175,6 +175,14 @@ class CLD:
         return mean, eps
 
     # ---- DEIS coefficients (sde_lib.py:308-319 + deis.py:19-95) ----
+    def prepare_naive_coef(self, rev_ts):
+        # sde_lib.py:276-287
+        rev_ts = np.asarray(rev_ts, dtype=self.dtype)
+        mean = np.stack([np.eye(2, dtype=self.dtype) + self.s_F(c) * (n - c) for c, n in zip(rev_ts[:-1], rev_ts[1:])])
+        eps = np.stack([self.dtype.type(0.5) * self.s_G(c) @ self.s_G(c) @ inv_2x2(self.s_R(c)).T * (n - c)
+                        for c, n in zip(rev_ts[:-1], rev_ts[1:])])
+        return mean, eps
+
     def get_deis_coef(self, order, rev_timesteps):
         rev_timesteps = np.asarray(rev_timesteps, dtype=self.dtype)
         x_coef = np.stack([self.s_psi(rev_timesteps[i], rev_timesteps[i + 1])
@@ -343,11 +351,14 @@ def deis_sampler(sde, eps_fn, u, nfe, deis_order, ts_order=2, denoising=False, i
     return x, v, nfe
 
 
-def order0_sampler(sde, eps_fn, u, nfe, denoising=False, inverse_scaler=None, coefs=None):
-    """sampling.py:156-202 (is_em=False); ts_order is hard-coded to 2 there (:162)."""
+def order0_sampler(sde, eps_fn, u, nfe, denoising=False, inverse_scaler=None, coefs=None, is_em=False):
+    """sampling.py:156-202; ts_order is hard-coded to 2 there (:162); is_em selects prepare_naive_coef (:171-174)."""
     num_step = nfe - 1 if denoising else nfe
     rev_ts = get_rev_ts(sde, 2, num_step)
-    mean_matrix, eps_matrix = coefs if coefs is not None else sde.prepare_order0_coef(rev_ts)
+    if coefs is not None:
+        mean_matrix, eps_matrix = coefs
+    else:
+        mean_matrix, eps_matrix = sde.prepare_naive_coef(rev_ts) if is_em else sde.prepare_order0_coef(rev_ts)
     ones = np.ones(u.shape[0], dtype=u.dtype)
     for i in range(num_step):
         u = sbmm(mean_matrix[i].astype(u.dtype), u) + sbmm(eps_matrix[i].astype(u.dtype),

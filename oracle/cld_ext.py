@@ -7,6 +7,7 @@ Restates, in numpy float64, deliberately literal (python loops):
   /root/reference/cld_jax/sampling.py:272-320  get_ml_psi2_fn, class MLCLD
   /root/reference/cld_jax/sampling.py:322-378  get_mldeis_sampler
   /root/reference/cld_jax/sampling.py:497-540  _impl_Ldeis_sampler, get_L_deis_sampler
+  /root/reference/cld_jax/sampling.py:255-269  get_hyd_deis_sampler (the two-phase time grid of `hybdeis`)
   /root/reference/cld_jax/models/utils.py:168-182  get_eps_fn with sde.mixed_score=True
   /root/reference/cld_jax/sampling.py:432-463  get_ode_sampler (the non-pmapped `sampler`)
   /root/reference/cld_jax/sampling.py:625-655  get_em_sampler (noise injected by the caller: jax's threefry stream is not
@@ -175,6 +176,28 @@ class MLCLD:
         x_coef = np.stack([self.s_psi(rev_timesteps[i], rev_timesteps[i + 1]) for i in range(len(rev_timesteps) - 1)])
         eps_coef = ocld.get_ab_eps_coef(self, order + 1, rev_timesteps, order)
         return np.concatenate([x_coef[:, None], eps_coef], axis=1)
+
+
+def hyd_rev_ts(sde, nfe, noise_nfe_ratio=0.3, img_t_ratio=0.3, ts_order=2.0, denoising=False):
+    """The time grid of get_hyd_deis_sampler (sampling.py:259-268): int(num_step * noise_nfe_ratio) uniform knots on
+    [T, T * img_t_ratio) followed by get_rev_ts(sde, ts_order, img_nfe) -- which starts again at T (:264), kept literally."""
+    num_step = nfe - 1 if denoising else nfe
+    mid_t = sde.T * img_t_ratio
+    noise_nfe = int(num_step * noise_nfe_ratio)
+    img_nfe = num_step - noise_nfe
+    noise_ts = np.linspace(sde.T, mid_t, noise_nfe, endpoint=False)
+    img_ts = ocld.get_rev_ts(sde, ts_order, img_nfe)
+    rev_ts = np.concatenate([noise_ts, img_ts])
+    assert rev_ts.shape[0] == num_step + 1  # :268
+    return rev_ts
+
+
+def hybdeis_sampler(sde, eps_fn, u, nfe, deis_order, noise_nfe_ratio=0.3, img_t_ratio=0.3, ts_order=2.0, denoising=False,
+                    inverse_scaler=None, deis_coef=None):
+    """get_hyd_deis_sampler (sampling.py:255-269): _impl_deis_sampler on the two-phase grid."""
+    rev_ts = hyd_rev_ts(sde, nfe, noise_nfe_ratio, img_t_ratio, ts_order, denoising)
+    return ocld.deis_sampler(sde, eps_fn, u, nfe, deis_order, denoising=denoising, inverse_scaler=inverse_scaler,
+                             deis_coef=deis_coef, rev_ts=rev_ts)
 
 
 def ldeis_sampler(sde, eps_fn, u, nfe, deis_order, ts_order=2, inverse_scaler=None, deis_coef=None):

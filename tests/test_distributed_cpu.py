@@ -31,6 +31,11 @@ def _worker(rank, world, port, global_batch, out_dir):
     u8 = distributed.to_uint8(x + 0.9 / 255.0)  # truncation, not rounding
     full = distributed.all_gather_samples(u8.contiguous())
     np.save(os.path.join(out_dir, "rank%d.npy" % r), full.numpy())
+    # equal shards: one collective, no size exchange; and the same answer as the general path
+    eq = torch.full((3, 2, 2, 3), r, dtype=torch.uint8)
+    a = distributed.all_gather_samples(eq, equal_shards=True)
+    b = distributed.all_gather_samples(eq)
+    assert torch.equal(a, b) and a.shape[0] == 3 * w and all(int(a[3 * k, 0, 0, 0]) == k for k in range(w))
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
@@ -56,7 +61,7 @@ def test_shard_batch_and_seeds():
     assert np.array_equal(distributed.to_uint8(np.array([-0.1, 0.0, 0.999, 0.5, 1.2])), np.array([0, 0, 254, 127, 255], np.uint8))
 
 
-def _round_worker(rank, world, port, out_dir):
+def _round_worker(rank, world, port, out_dir, batch=6):
     """run_lib.sample_data under two gloo ranks with the sampler factory replaced by a CPU stand-in: what is exercised is the
     round loop itself -- per-rank batch, per-(round, rank) seeds, the three all-gathers, rank 0 writing the files."""
     sys.path.insert(0, ROOT)
@@ -68,7 +73,7 @@ def _round_worker(rank, world, port, out_dir):
     distributed.init_from_env(backend="gloo")
     cfg = cld_accr_dcifar10.get_config()
     cfg.data.image_size = 4
-    cfg.eval.num_samples, cfg.eval.batch_size = 10, 6  # 2 rounds of 6 images, 3 per rank
+    cfg.eval.num_samples, cfg.eval.batch_size = 10, batch  # 2 rounds of 6 images, 3 per rank (7: 4 + 3)
     calls = []
 
     def fake_factory(config, sde, model, shape, inverse_scaler):
@@ -82,7 +87,8 @@ def _round_worker(rank, world, port, out_dir):
     sampling.get_sampling_fn = fake_factory
     written = run_lib.sample_data(cfg, "unused", out_dir, state=State(params_ema={}))
     seeds = [distributed.rank_seed(cfg.seed + 1, r, rank) for r in range(2)]
-    assert calls == [(seeds[0], 3), (seeds[1], 3)]
+    per = distributed.shard_batch(batch, world, rank)[1]
+    assert calls == [(seeds[0], per), (seeds[1], per)]
     assert (len(written) == 2) == (rank == 0)
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
@@ -100,5 +106,14 @@ def test_sample_data_rounds_two_ranks_gloo(tmp_path):
             g = torch.Generator().manual_seed(distributed.rank_seed(42 + 1, r, rank) % (2 ** 31))
             want.append(torch.rand((1, 3, 4, 4, 3), generator=g)[0])
         want = torch.cat(want).numpy()
-        assert np.array_equal(info["samples_x"][0], want) and np.array_equal(info["samples_v"][0], -want)
+        # float copies in the reference's (n_dev, B / n_dev, H, W, C) layout (cld_jax/run_lib.py:722-730)
+        assert info["samples_x"].shape == (2, 3, 4, 4, 3) and info["samples_v"].shape == (2, 3, 4, 4, 3)
+        assert np.array_equal(info["samples_x"].reshape(want.shape), want) and np.array_equal(info["samples_v"].reshape(want.shape), -want)
         assert np.array_equal(info["samples"], np.clip(want * 255.0, 0, 255).astype(np.uint8))
+
+
+def test_sample_data_uneven_round_keeps_every_image(tmp_path):
+    """eval.batch_size = 7 over two ranks: shards of 4 and 3; the round file still holds 7 images (the reference would drop one)."""
+    mp.spawn(_round_worker, args=(2, _free_port(), str(tmp_path), 7), nprocs=2, join=True)
+    info = np.load(os.path.join(str(tmp_path), "samples_0.npz"))
+    assert info["samples"].shape == (7, 4, 4, 3) and info["samples_x"].shape == (1, 7, 4, 4, 3)

@@ -1,0 +1,269 @@
+"""Full-length parity at the north-star's own bar: |x_hip - x_oracle| <= 1e-3 per pixel, ABSOLUTE, images in [0, 1] units.
+
+The other sampler tests use random weights, for which nothing cancels the reverse-time transition (|x| grows to 1e3..1e5) and the
+bar has to be read relative to the output scale.  Here the score model is a *near-denoiser*, so the trajectory stays O(1) over all
+NFE steps and the absolute bar applies, on the production configuration (BASELINE configs 2, 3, 5: full accr / ddpm_deep
+NCSN++, 256 images per call, NFE 50 / 100, hipGraph replay, the production kernels):
+
+  CLD   eps(u, t) = NCSNpp(u, t) + X(t) u with X(t) = R(t)^T S(t)^-1, S(t) = Psi(0,t) diag(s^2, 0) Psi(0,t)^T + R(t) R(t)^T: the
+        second term is the exact eps of Gaussian data x0 ~ N(0, s^2 I) (score = -S^-1 u, eps = -R^T score), whose probability
+        flow carries the prior to images of standard deviation s = 0.5 ([0, 1] units: 0.5 +- 0.25) along a bounded trajectory.
+        It enters through the reference's own `mixed_score` hook (cld_jax/models/utils.py:174-176: eps_fn adds a matrix times
+        u), here with X(t) instead of R(t)^-1 diag(0, 1).  The network (random weights, head convolution scaled by GAIN)
+        perturbs that trajectory; GAIN is chosen so that the network moves the final image by far more than the bar
+        (asserted) while |u| stays O(1..10).
+  blur  eps_y(y, t) = DCT(NCSNpp(IDCT y, t)) + b(t) (.) y, b = sigma / (m^2 s^2 + sigma^2) per frequency: the same construction
+        (y0 ~ N(0, s^2 I)) through the reference's `sde.model2eps` hook (blur_jax/sde_lib.py:150-152), exposed by the product
+        in linear form.
+
+The oracle side is the float64 restatement loop on the first images of the batch (images are independent units)."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import blur as oblur
+from oracle import cld as ocld
+from oracle import ncsnpp as onet
+
+pytestmark = pytest.mark.gpu
+
+ABS_TOL = 1e-3  # BASELINE.json north_star: "within fp32 1e-3 per pixel"
+S_DATA = 0.5    # standard deviation of the Gaussian data model of the near-denoiser
+
+
+def _gauss_eps_matrix(sde, t):
+    """X(t) = R^T (Psi(0,t) diag(s^2, 0) Psi(0,t)^T + R R^T)^-1 for either the product's or the oracle's CLD object."""
+    R = np.asarray(sde.s_R(np.float64(t)), dtype=np.float64)
+    P = np.asarray(sde.s_psi(0.0, np.float64(t)), dtype=np.float64)
+    S = P @ np.diag([S_DATA * S_DATA, 0.0]) @ P.T + R @ R.T
+    return R.T @ np.linalg.inv(S)
+
+
+def _scaled_head(params, gain):
+    p = copy.deepcopy(params)
+    p["Conv_1"]["kernel"] = (p["Conv_1"]["kernel"] * gain).astype(np.float32)
+    p["Conv_1"]["bias"] = (p["Conv_1"]["bias"] * gain).astype(np.float32)
+    return p
+
+
+def _cld_case(native_lib, cfg_mod, image_size, B, n_ref, nfe, gain, seed, method="deis", **samp):
+    from gddim_amd.cld import sampling, sde_lib
+    from gddim_amd.datasets import get_data_inverse_scaler
+    from gddim_amd.models import utils as mutils
+    cfg = cfg_mod.get_config()
+    cfg.data.image_size = image_size
+    params = _scaled_head(onet.random_params(cfg, 6, seed=seed), gain)
+
+    class NearDenoiserCLD(sde_lib.CLD):
+        def mixed_u_matrix(self, t):  # X(t) instead of the reference's R(t)^-1 diag(0, 1)
+            return _gauss_eps_matrix(self, t)
+
+    sde = sde_lib.from_config(cfg)
+    sde.__class__ = NearDenoiserCLD
+    sde.mixed_score = True
+    osde = ocld.CLD(is_R_rk=cfg.model.is_R_rk, R_dt=cfg.model.R_dt, dtype=np.float64)
+    model = mutils.get_model(cfg.model.name)(config=cfg)
+    state = mutils.State(params_ema=params, model_state={})
+    rng = np.random.default_rng(seed + 100)
+    shape = (B, image_size, image_size, 3)
+    u = np.stack([rng.standard_normal(shape), rng.standard_normal(shape) / 2], axis=-1).astype(np.float32)
+    cfg.sampling.method, cfg.sampling.nfe, cfg.sampling.deis_order, cfg.sampling.noise_removal = method, nfe, 2, True
+    for k, v in samp.items():
+        setattr(cfg.sampling, k, v)
+    fn = sampling.get_sampling_fn(cfg, sde, model, None, get_data_inverse_scaler(cfg))  # the factory: is_p=True, hipGraph replay
+    xs, vs, n = fn([0], state, B, torch.as_tensor(u[None], device="cuda:0"))
+    x, v = xs[0].cpu().numpy(), vs[0].cpu().numpy()
+    net64 = onet.cld_eps_fn(params, cfg, dtype=torch.float64)
+
+    def lin64(uu, t):  # the Gaussian-data model alone: how much of the result is the network's doing
+        return ocld.bmm(np.stack([_gauss_eps_matrix(osde, tb) for tb in t]), uu)
+
+    def eps64(uu, t):  # NCSNpp(u, t) + X(t) u
+        return net64(uu, t) + lin64(uu, t)
+
+    u_ref = u[:n_ref].astype(np.float64)
+    return cfg, osde, eps64, lin64, u_ref, x, v, n, model
+
+
+def _report(tag, x, v, wx, wv, lx, n_ref, trace=None):
+    ex = float(np.abs(x[:n_ref] - wx).max())
+    ev = float(np.abs(v[:n_ref] - wv).max())
+    moved = float(np.abs(wx - lx).max())
+    print("%s: max|dx| %.3e (abs, bar %.0e)  max|dv| %.3e  | x in [%.3f, %.3f] std %.3f, |v| <= %.2f, network moved x by %.3f%s"
+          % (tag, ex, ABS_TOL, ev, wx.min(), wx.max(), wx.std(), np.abs(wv).max(), moved,
+             "" if trace is None else ", max|u| along the trajectory %.2f" % max(float(np.abs(a).max()) for a in trace)))
+    return ex, ev, moved
+
+
+def test_cld_nfe50_b256_absolute_parity(native_lib):
+    """BASELINE config 2: CLD gDDIM deis_order=2, NFE=50 (49 AB steps + denoising), 256 images, full accr U-Net, hipGraph."""
+    from gddim_amd.configs import cld_accr_dcifar10
+    n_ref, nfe, gain = 2, 50, 0.3
+    cfg, osde, eps64, lin64, u_ref, x, v, n, model = _cld_case(native_lib, cld_accr_dcifar10, 32, 256, n_ref, nfe, gain, seed=0)
+    trace = []
+    wx, wv, _ = ocld.deis_sampler(osde, eps64, u_ref, nfe, 2, ts_order=2, denoising=True, inverse_scaler=ocld.inverse_scaler_centered, trace=trace)
+    lx, _, _ = ocld.deis_sampler(osde, lin64, u_ref, nfe, 2, ts_order=2, denoising=True, inverse_scaler=ocld.inverse_scaler_centered)
+    ex, ev, moved = _report("CLD NFE=50 B=256", x, v, wx, wv, lx, n_ref, trace)
+    # the kernels of the benchmark ran (persistent 128x128 Winograd tile), not a small-batch fallback
+    names = _profile_names(model, 6, 256)
+    assert any("conv3x3_wino_f32_kernel<128,128>" in k for k in names), names
+    assert n == nfe and np.isfinite(x).all() and np.isfinite(v).all()
+    assert moved > 20 * ABS_TOL, "the network must matter for the test to mean anything (moved x by %.3e)" % moved
+    assert max(float(np.abs(a).max()) for a in trace) < 100.0
+    assert ex <= ABS_TOL and ev <= ABS_TOL * max(1.0, float(np.abs(wv).max()))
+
+
+def _profile_names(model, in_ch, B):
+    """Kernel names one U-Net evaluation at this batch size launches (engine profile of a single forward)."""
+    ent = model._engines[(in_ch, 0)]
+    eng = ent['eng']
+    eng.profile(True)
+    xin = torch.zeros((B, eng.image_size, eng.image_size, in_ch), device="cuda:0")
+    eng.unet(xin, torch.full((B,), 500.0, device="cuda:0"))
+    names = [p["name"] for p in eng.profile_read()]
+    eng.profile(False)
+    return names
+
+
+def test_cld_nfe100_b256_absolute_parity(native_lib):
+    """NFE = 100 (BASELINE config 5's longest schedule) on the 32x32 production batch: error growth over 99 AB steps."""
+    from gddim_amd.configs import cld_accr_dcifar10
+    n_ref, nfe, gain = 1, 100, 0.3
+    cfg, osde, eps64, lin64, u_ref, x, v, n, model = _cld_case(native_lib, cld_accr_dcifar10, 32, 256, n_ref, nfe, gain, seed=1)
+    wx, wv, _ = ocld.deis_sampler(osde, eps64, u_ref, nfe, 2, ts_order=2, denoising=True, inverse_scaler=ocld.inverse_scaler_centered)
+    lx, _, _ = ocld.deis_sampler(osde, lin64, u_ref, nfe, 2, ts_order=2, denoising=True, inverse_scaler=ocld.inverse_scaler_centered)
+    ex, ev, moved = _report("CLD NFE=100 B=256", x, v, wx, wv, lx, n_ref)
+    assert n == nfe and np.isfinite(x).all() and moved > 20 * ABS_TOL
+    assert ex <= ABS_TOL and ev <= ABS_TOL * max(1.0, float(np.abs(wv).max()))
+
+
+def test_cld_64x64_nfe10_persistent_tile_absolute_parity(native_lib):
+    """BASELINE config 5 shape (64x64x3) at a batch that selects the persistent 128x128 Winograd tile on 64-wide images
+    (32 images x 2048 pixel pairs / 128 = 512 tiles on the top level), NFE = 10."""
+    from gddim_amd.configs import cld_accr_dcifar10
+    n_ref, nfe, gain = 1, 10, 0.3
+    cfg, osde, eps64, lin64, u_ref, x, v, n, model = _cld_case(native_lib, cld_accr_dcifar10, 64, 32, n_ref, nfe, gain, seed=2)
+    wx, wv, _ = ocld.deis_sampler(osde, eps64, u_ref, nfe, 2, ts_order=2, denoising=True, inverse_scaler=ocld.inverse_scaler_centered)
+    lx, _, _ = ocld.deis_sampler(osde, lin64, u_ref, nfe, 2, ts_order=2, denoising=True, inverse_scaler=ocld.inverse_scaler_centered)
+    ex, ev, moved = _report("CLD 64x64 NFE=10 B=32", x, v, wx, wv, lx, n_ref)
+    names = _profile_names(model, 6, 32)
+    assert any("conv3x3_wino_f32_kernel<128,128>" in k for k in names), names
+    assert n == nfe and np.isfinite(x).all() and moved > 20 * ABS_TOL
+    assert ex <= ABS_TOL and ev <= ABS_TOL * max(1.0, float(np.abs(wv).max()))
+
+
+def test_hybdeis_absolute_parity(native_lib):
+    """`hybdeis` (cld_jax/sampling.py:255-269) through get_sampling_fn against the oracle's restatement of its two-phase grid,
+    on a small network, bounded trajectory."""
+    from conftest import tiny_config
+    from gddim_amd.cld import sampling, sde_lib
+    from gddim_amd.datasets import get_data_inverse_scaler
+    from gddim_amd.models import utils as mutils
+    from oracle import cld_ext as ox
+    cfg = tiny_config("cld", nf=16, num_res_blocks=1, image_size=16, ch_mult=(1, 2, 2), attn=(8,))
+    params = _scaled_head(onet.random_params(cfg, 6, seed=3), 0.3)
+    sde = sde_lib.from_config(cfg)
+    osde = ocld.CLD(is_R_rk=cfg.model.is_R_rk, R_dt=cfg.model.R_dt, dtype=np.float64)
+    model = mutils.get_model(cfg.model.name)(config=cfg)
+    state = mutils.State(params_ema=params, model_state={})
+    rng = np.random.default_rng(4)
+    B = 4
+    u = np.stack([rng.standard_normal((B, 16, 16, 3)), rng.standard_normal((B, 16, 16, 3)) / 2], axis=-1).astype(np.float32)
+    cfg = cfg.copy_and_resolve_references()
+    cfg.sampling.method, cfg.sampling.nfe, cfg.sampling.deis_order, cfg.sampling.noise_removal = 'hybdeis', 12, 2, True
+    cfg.sampling.noise_nfe_ratio, cfg.sampling.img_t_ratio = 0.3, 0.3
+    fn = sampling.get_sampling_fn(cfg, sde, model, None, get_data_inverse_scaler(cfg))
+    xs, vs, n = fn([0], state, B, torch.as_tensor(u[None], device="cuda:0"))
+    eps64 = onet.cld_eps_fn(params, cfg, dtype=torch.float64)
+    wx, wv, wn = ox.hybdeis_sampler(osde, eps64, u.astype(np.float64), 12, 2, noise_nfe_ratio=0.3, img_t_ratio=0.3,
+                                    ts_order=cfg.sampling.ts_order, denoising=True, inverse_scaler=ocld.inverse_scaler_centered)
+    # plain random-weight network on the non-monotone grid (it restarts at T after the noise phase): the output scale is large,
+    # so this comparison is relative to it like the other variant tests
+    sx, sv = max(1.0, float(np.abs(wx).max())), max(1.0, float(np.abs(wv).max()))
+    ex, ev = float(np.abs(xs[0].cpu().numpy() - wx).max()), float(np.abs(vs[0].cpu().numpy() - wv).max())
+    print("hybdeis nfe=12: max|dx| %.3e max|dv| %.3e (|x| %.3e |v| %.3e)" % (ex, ev, sx, sv))
+    assert n == wn == 12 and np.isfinite(wx).all() and ex < 1e-4 * sx and ev < 1e-4 * sv
+
+
+def test_order0_is_em_matches_oracle(native_lib):
+    """get_order0_sampler(is_em=True) -> CLD.prepare_naive_coef (cld_jax/sampling.py:171-172, sde_lib.py:276-287)."""
+    from conftest import tiny_config
+    from gddim_amd.cld import sampling, sde_lib
+    from gddim_amd.datasets import get_data_inverse_scaler
+    from gddim_amd.models import utils as mutils
+    cfg = tiny_config("cld", nf=16, num_res_blocks=1, image_size=16, ch_mult=(1, 2, 2), attn=(8,))
+    params = onet.random_params(cfg, 6, seed=5)
+    sde = sde_lib.from_config(cfg)
+    osde = ocld.CLD(is_R_rk=cfg.model.is_R_rk, R_dt=cfg.model.R_dt, dtype=np.float64)
+    model = mutils.get_model(cfg.model.name)(config=cfg)
+    state = mutils.State(params_ema=params, model_state={})
+    rng = np.random.default_rng(6)
+    B = 2
+    u = np.stack([rng.standard_normal((B, 16, 16, 3)), rng.standard_normal((B, 16, 16, 3)) / 2], axis=-1).astype(np.float32)
+    cfg = cfg.copy_and_resolve_references()
+    cfg.sampling.method, cfg.sampling.nfe, cfg.sampling.is_em, cfg.sampling.noise_removal = 'order0', 8, True, True
+    fn = sampling.get_sampling_fn(cfg, sde, model, None, get_data_inverse_scaler(cfg))
+    xs, vs, n = fn([0], state, B, torch.as_tensor(u[None], device="cuda:0"))
+    eps64 = onet.cld_eps_fn(params, cfg, dtype=torch.float64)
+    wx, wv, _ = ocld.order0_sampler(osde, eps64, u.astype(np.float64), 8, denoising=True, inverse_scaler=ocld.inverse_scaler_centered, is_em=True)
+    sx, sv = max(1.0, float(np.abs(wx).max())), max(1.0, float(np.abs(wv).max()))
+    ex, ev = float(np.abs(xs[0].cpu().numpy() - wx).max()), float(np.abs(vs[0].cpu().numpy() - wv).max())
+    print("order0 is_em: max|dx| %.3e max|dv| %.3e (|x| %.3e |v| %.3e)" % (ex, ev, sx, sv))
+    assert n == 8 and np.isfinite(wx).all() and ex < 1e-4 * sx and ev < 1e-4 * sv
+    # and it is not the exponential-integrator sampler
+    cfg.sampling.is_em = False
+    x0, _, _ = sampling.get_sampling_fn(cfg, sde, model, None, get_data_inverse_scaler(cfg))([0], state, B, torch.as_tensor(u[None], device="cuda:0"))
+    assert (x0 - xs).abs().max().item() > 1e-3 * sx
+
+
+def test_blur_nfe50_b256_absolute_parity(native_lib):
+    """BASELINE config 3: blur gDDIM order0, NFE=50, 256 images, ddpm_deep U-Net on 3 channels, hipGraph; near-denoiser through
+    sde.model2eps: eps_y = DCT(NCSNpp(IDCT y, t)) + b(t) (.) y."""
+    from gddim_amd.blur import sampling, sde_lib
+    from gddim_amd.configs import blur_ddpm_deep_cifar10
+    from gddim_amd.datasets import get_data_inverse_scaler
+    from gddim_amd.models import utils as mutils
+    cfg = blur_ddpm_deep_cifar10.get_config()
+    gain, B, n_ref, nfe = 0.3, 256, 2, 50
+    params = _scaled_head(onet.random_params(cfg, 3, seed=0), gain)
+
+    def b_plane(s_, t):  # sigma / (m^2 s^2 + sigma^2), (32, 32), for the product's or the oracle's SDE object
+        tt = np.asarray([t], dtype=np.float64)
+        m = np.asarray(s_.y_mean_coef(tt), dtype=np.float64).reshape(32, 32)
+        sig = float(np.asarray(s_.y_std_coef(tt)).reshape(-1)[0])
+        return sig / (m * m * S_DATA * S_DATA + sig * sig)
+
+    class NearDenoiserSDE(sde_lib.SDE):
+        def model2eps_affine(self, t):
+            return 1.0, b_plane(self, t)
+
+    sde = sde_lib.from_config(cfg)
+    sde.__class__ = NearDenoiserSDE
+    osde = oblur.SDE(sigma_blur_max=cfg.model.sigma_blur_max, sampling_eps=cfg.sampling.t0)
+    model = mutils.get_model(cfg.model.name)(config=cfg)
+    state = mutils.State(params_ema=params, model_state={})
+    y = np.random.default_rng(7).standard_normal((B, 32, 32, 3)).astype(np.float32)
+    cfg.sampling.nfe = nfe
+    fn = sampling.get_sampling_fn(cfg, sde, model, None, get_data_inverse_scaler(cfg))
+    xs, n = fn([0], state, B, torch.as_tensor(y[None], device="cuda:0"))
+    x = xs[0].cpu().numpy()
+    net64 = onet.blur_eps_fn(params, cfg, dtype=torch.float64)
+
+    def lin64(xx, t):  # IDCT(b (.) DCT x): t is batch-uniform in the sampler
+        return osde.y2x(b_plane(osde, float(t[0]))[None, :, :, None] * osde.x2y(xx))
+
+    def eps64(xx, t):
+        return net64(xx, t) + lin64(xx, t)
+
+    inv = lambda a: (a + 1) / 2
+    trace = []
+    wx, wn = oblur.order0_sampler(osde, eps64, y[:n_ref].astype(np.float64), nfe, ts_order=cfg.sampling.ts_order, inverse_scaler=inv, trace=trace)
+    lx, _ = oblur.order0_sampler(osde, lin64, y[:n_ref].astype(np.float64), nfe, ts_order=cfg.sampling.ts_order, inverse_scaler=inv)
+    err = float(np.abs(x[:n_ref] - wx).max())
+    moved = float(np.abs(wx - lx).max())
+    print("blur NFE=50 B=256: max|dx| %.3e (abs, bar %.0e) | x in [%.3f, %.3f] std %.3f, network moved x by %.3f, max|y| along the trajectory %.2f"
+          % (err, ABS_TOL, wx.min(), wx.max(), wx.std(), moved, max(float(np.abs(a).max()) for a in trace)))
+    assert n == wn == nfe and np.isfinite(x).all() and moved > 20 * ABS_TOL
+    assert err <= ABS_TOL

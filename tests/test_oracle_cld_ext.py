@@ -210,3 +210,40 @@ def test_product_lambda_sde_matches_oracle(native_lib, osde, olam):
     f = sampling.svd_noise_factor(np.array([[2.0, 0.3], [0.3, 1.0]]))
     assert np.abs(f @ f.T - np.array([[2.0, 0.3], [0.3, 1.0]])).max() < 1e-12  # a root when the matrix is a covariance
     assert np.abs(f - ox.svd_factor(np.array([[2.0, 0.3], [0.3, 1.0]]))).max() == 0
+
+
+def test_hybdeis_grid_and_table(native_lib, osde):
+    """`hybdeis` (cld_jax/sampling.py:255-269): the grid is int(num_step * 0.3) uniform knots from T towards 0.3 T, then the
+    power-law grid -- which restarts at T (kept literally).  The product's table on that non-monotone grid equals the oracle's."""
+    from gddim_amd.cld import sampling, sde_lib
+    rev = ox.hyd_rev_ts(osde, 11, 0.3, 0.3, 2.0, denoising=True)  # num_step 10: 3 noise knots + 8 image knots
+    assert rev.shape == (11,) and np.allclose(rev[:3], [1.0, 1.0 - 0.7 / 3, 1.0 - 1.4 / 3]) and rev[3] == 1.0 and abs(rev[-1] - 1e-3) < 1e-15
+    assert np.all(np.diff(rev[3:]) < 0) and rev[2] < rev[3]  # the restart
+    sde = sde_lib.CLD(is_R_rk=True, R_dt=1e-5)
+    seen = {}
+    orig = sampling._impl_deis_sampler
+    try:
+        sampling._impl_deis_sampler = lambda sde_, model, shape, nfe, inv, order, rev_ts, denoising, is_p: seen.update(rev=np.asarray(rev_ts), order=order)
+        sampling.get_hyd_deis_sampler(sde, None, (8, 8, 3), 11, None, 2, noise_nfe_ratio=0.3, img_t_ratio=0.3, ts_order=2.0, denoising=True)
+    finally:
+        sampling._impl_deis_sampler = orig
+    assert np.abs(seen["rev"] - rev).max() < 1e-15 and seen["order"] == 2
+    got, want = sde.get_deis_coef(1, rev[:6]), osde.get_deis_coef(1, rev[:6])
+    assert np.abs(got - want).max() < 1e-9 * np.abs(want).max()
+
+
+def test_naive_coef_is_the_euler_step(native_lib, osde):
+    """prepare_naive_coef (cld_jax/sde_lib.py:276-287, `order0` with is_em=True): product == oracle, and both are the first-order
+    expansion of the exponential-integrator coefficients (gap O(dt^2))."""
+    from gddim_amd.cld import sde_lib
+    sde = sde_lib.CLD(is_R_rk=True, R_dt=1e-5)
+    rev = ocld.get_rev_ts(osde, 2, 200)
+    pm, pe = sde.prepare_naive_coef(rev)
+    om, oe = osde.prepare_naive_coef(rev)
+    assert pm.shape == (200, 2, 2) and np.abs(pm - om).max() < 1e-12 and np.abs(pe - oe).max() < 1e-9 * np.abs(oe).max()
+    dt = rev[1] - rev[0]
+    assert np.abs(pm[0] - (np.eye(2) + np.array([[0.0, 16.0], [-4.0, -16.0]]) * dt)).max() < 1e-14
+    em, ee = sde.prepare_order0_coef(rev)
+    i = 150  # a short step
+    h = abs(rev[i + 1] - rev[i])
+    assert np.abs(pm[i] - em[i]).max() < 200 * h * h and np.abs(pe[i] - ee[i]).max() < 0.1 * np.abs(ee[i]).max()
