@@ -100,6 +100,8 @@ def main():
     ap.add_argument("--precision", choices=["fp32", "bf16x3"], default="fp32",
                     help="fp32 = fp32 operands on the fp32 matrix core, 3x3 convolutions through Winograd F(2,3) (headline); bf16x3 = split-precision weight contractions on the bf16 matrix core")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--graph", choices=["step", "loop", "none"], default="step",
+                    help="step: one captured hipGraph per NFE step, replayed (default); loop: ONE graph for the whole sampler call; none: eager launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the secondary bf16x3 measurement")
@@ -162,8 +164,14 @@ def main():
             xs, n = blur_fn(rng, st, bs, uu, use_graph=use_graph)
             return xs, None, n
 
+    if args.no_graph:
+        args.graph = "none"
+    graph_mode = {"step": True, "loop": "loop", "none": False}[args.graph]
+    if args.workload == "blur" and graph_mode == "loop":
+        graph_mode = True  # the blur loop has the per-step graph only
+
     def step():
-        xs, vs, nfe = sampling_fn([rank], state, B, u, use_graph=not args.no_graph)
+        xs, vs, nfe = sampling_fn([rank], state, B, u, use_graph=graph_mode)
         u8 = distributed.to_uint8(xs[0])
         # equal shards (weak scaling): one all_gather_into_tensor, no size exchange; under a launcher the collective runs
         # through RCCL even at N = 1
@@ -197,7 +205,7 @@ def main():
         "config": {"workload": "%s, batch=%d per GPU, %dx%dx3 synthetic noise, random-init NCSN++ "
                                "(nf=128, ch_mult=(1,2,2,2), 8 res blocks, attn@16)" % (desc, B, cfg.data.image_size, cfg.data.image_size),
                    "global_batch": B * world, "parallelism": "dp%d (one process per GPU, uint8 all-gather per round%s)" % (world, ", RCCL" if grouped else ""),
-                   "hipgraph": not args.no_graph, "tflop_per_image": flops_img / 1e12},
+                   "hipgraph": {True: "per-step graph replayed NFE-1 times + denoise graph", "loop": "one graph per sampler call", False: False}[graph_mode], "tflop_per_image": flops_img / 1e12},
         "e2e_tflops_per_gpu": B * args.steps * flops_img / dt / 1e12,
     }
 

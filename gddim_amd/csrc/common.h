@@ -66,6 +66,7 @@ struct GemmParams {
     int in_act;  // 1: swish applied to A elements on load
     int m_tiles, n_tiles;
     int flat_tiles;  // 1: block id -> (mtile, ntile) row-major; 0: XCD-aware grouping (set by the launchers)
+    int z_count;     // persistent kernel: number of z slices (the other kernels read gridDim.z / blockIdx.z)
     const float *zeros;  // >= 16 B of device zeros (filled in by launch_igemm when null)
     // magic numbers for division by OH*OW, OW and rows_per_image (filled in by launch_igemm)
     unsigned mg_ohw, sh_ohw, mg_ow, sh_ow, mg_rpi, sh_rpi;

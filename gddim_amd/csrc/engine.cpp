@@ -91,7 +91,9 @@ struct gd_engine {
     hipEvent_t ev_in = nullptr, ev_out[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
     int lanes = 1;  // measured on MI355X (B=256): 2 lanes overlap in the trace but change throughput by < 1 %
     // graphs keyed by (sub-batch size, first image, lane)
-    struct Graphs { hipGraphExec_t step = nullptr, fin = nullptr; };
+    struct Graphs { hipGraphExec_t step = nullptr, fin = nullptr, loop = nullptr; };
+    // whole-loop graphs (use_graph = 2) bake every address, so the call's input / outputs pass through engine-owned staging buffers
+    float *uin_stage = nullptr, *xout_stage = nullptr, *vout_stage = nullptr;
     std::map<long long, Graphs> graphs;
     // profiling
     bool prof = false;
@@ -105,6 +107,7 @@ static void drop_graphs(gd_engine *e) {
     for (auto &kv : e->graphs) {
         if (kv.second.step) (void)hipGraphExecDestroy(kv.second.step);
         if (kv.second.fin) (void)hipGraphExecDestroy(kv.second.fin);
+        if (kv.second.loop) (void)hipGraphExecDestroy(kv.second.loop);
     }
     e->graphs.clear();
 }
@@ -389,6 +392,9 @@ int gd_engine_create(const gd_model_desc *desc, int device, gd_engine **out) {
         GD_ALLOC(e->labels, B);
         GD_ALLOC(e->u8, pix * CP);
         GD_ALLOC(e->ystate, pix * desc->in_channels);
+        GD_ALLOC(e->uin_stage, pix * desc->in_channels);
+        GD_ALLOC(e->xout_stage, pix * desc->in_channels);
+        GD_ALLOC(e->vout_stage, pix * desc->in_channels);
         GD_ALLOC(e->dn_dev, 20);
         GD_HIP(hipMalloc((void **)&e->seed_dev, 2 * sizeof(unsigned)));
         GD_ALLOC(e->step_dev, gd_engine::MAX_LANES);
@@ -417,7 +423,8 @@ int gd_engine_destroy(gd_engine *e) {
         if (e->wwino) (void)hipFree(e->wwino);
         if (e->wsplit_hi) (void)hipFree(e->wsplit_hi);
         if (e->wsplit_lo) (void)hipFree(e->wsplit_lo);
-        float *bufs[] = {e->arena, e->wbuf, e->xin, e->epsb, e->eps_planar, e->labels, e->u8, e->ring, e->ystate,
+        float *bufs[] = {e->arena, e->wbuf, e->xin, e->epsb, e->eps_planar, e->labels, e->u8, e->ring, e->ystate, e->uin_stage,
+                         e->xout_stage, e->vout_stage,
                          e->ts_dev, e->coef_dev, e->dn_dev, e->mean_dev, e->std_dev, e->tf_dev, e->nz_dev, e->m2e_dev, (float *)e->seed_dev,
                          (float *)e->step_dev};
         for (float *b : bufs)
@@ -765,8 +772,9 @@ int gd_sample_cld(gd_engine *e, int batch, const float *u_in_dev, float *x_out_d
     const size_t HW = (size_t)d.image_size * d.image_size;
     const int ring_slots = e->n_slots - 2;
     const bool graph = use_graph && !e->prof;
+    const bool whole = graph && use_graph == 2;  // one graph for the whole call (single lane)
     int start[gd_engine::MAX_LANES], size[gd_engine::MAX_LANES];
-    const int nl = split_lanes(e, batch, !e->prof, start, size);
+    const int nl = split_lanes(e, batch, !e->prof && !whole, start, size);
     if (e->nz_dev) {  // the seed of this call, in device memory so that captured graphs read the current one
         e->seed_words[0] = (unsigned)e->seed;
         e->seed_words[1] = (unsigned)(e->seed >> 32);
@@ -799,8 +807,10 @@ int gd_sample_cld(gd_engine *e, int batch, const float *u_in_dev, float *x_out_d
         l.bind_u = Bind{l.u8, nullptr, l.eps, e->arena + (size_t)e->plan.arena_per_image * start[i], l.step};
         l.bind = l.bind_u;
         if (e->tf_pre) l.bind.x_in = l.xin;
-        l.g = graph ? &e->graphs[((long long)size[i] << 40) | ((long long)start[i] << 8) | i] : nullptr;
+        l.g = graph ? &e->graphs[((long long)size[i] << 40) | ((long long)start[i] << 8) | i | (whole ? (1LL << 62) : 0) |
+                                 (whole && inverse_scale ? (1LL << 61) : 0)] : nullptr;
         GD_HIP(hipStreamWaitEvent(l.s, e->ev_in, 0));
+        if (whole) continue;  // pack and the counter reset are nodes of the whole-loop graph
         GD_TRY(launch_cld_pack(u_in_dev + p0 * C * 2, l.u8, l.ring, ring_slots, l.pix, C, l.s));
         GD_HIP(hipMemsetAsync(l.step, 0, sizeof(int), l.s));
     }
@@ -812,6 +822,30 @@ int gd_sample_cld(gd_engine *e, int batch, const float *u_in_dev, float *x_out_d
                                   e->seed_dev, l.elem0, l.s));
         return launch_advance_step(l.step, l.s);
     };
+    if (whole) {
+        // ONE graph for the whole call: pack -> num_step x [U-Net, AB step, step++] -> denoising U-Net -> finish.  Every address is
+        // baked, so the caller's buffers are copied to / from engine-owned staging buffers around the single hipGraphLaunch.
+        Lane &l = L[0];
+        const size_t n_in = (size_t)l.pix * C * 2, n_out = (size_t)l.pix * C;
+        GD_HIP(hipMemcpyAsync(e->uin_stage, u_in_dev, n_in * sizeof(float), hipMemcpyDeviceToDevice, l.s));
+        if (!l.g->loop) {
+            GD_TRY(capture_begin(l.s));
+            int r = launch_cld_pack(e->uin_stage, l.u8, l.ring, ring_slots, l.pix, C, l.s);
+            if (!r && hipMemsetAsync(l.step, 0, sizeof(int), l.s) != hipSuccess) r = 1;
+            for (int k = 0; k < e->num_step && !r; ++k) r = step_body(l);
+            if (!r && e->denoise) r = run_unet(e, l.bind_u, l.b, l.s);
+            if (!r) r = launch_cld_finish(l.u8, l.eps, e->dn_dev, -e->t_denoise, e->denoise, inverse_scale, e->xout_stage, e->vout_stage,
+                                          l.pix, C, e->fin_flags, l.s);
+            int r2 = capture_end(l.s, &l.g->loop);
+            if (r || r2) return 1;
+        }
+        GD_HIP(hipGraphLaunch(l.g->loop, l.s));
+        GD_HIP(hipMemcpyAsync(x_out_dev, e->xout_stage, n_out * sizeof(float), hipMemcpyDeviceToDevice, l.s));
+        GD_HIP(hipMemcpyAsync(v_out_dev, e->vout_stage, n_out * sizeof(float), hipMemcpyDeviceToDevice, l.s));
+        GD_HIP(hipEventRecord(e->ev_out[0], l.s));
+        GD_HIP(hipStreamWaitEvent(caller, e->ev_out[0], 0));
+        return 0;
+    }
     if (graph) {
         for (int i = 0; i < nl; ++i) {
             Lane &l = L[i];

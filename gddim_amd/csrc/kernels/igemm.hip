@@ -347,9 +347,14 @@ __device__ __forceinline__ f32x4 buf_load16(__amdgpu_buffer_rsrc_t rsrc, int vof
 }
 
 // T64: kernels with 33..64 taps (the 6x6 stride-2 pyramid convolutions) keep a second mask word per row
-template <int BM, int BN, int WM, int WN, bool B_KMAJOR, bool T64 = false>
-__global__ __launch_bounds__(64 * WM * WN) void igemm_f32_fast_kernel(const GemmParams p) {
-    constexpr int NT = 64 * WM * WN;
+// KS > 1: intra-workgroup split-K.  KS wave groups of WM x WN waves each own every KS-th K chunk (their own LDS stages, their
+// own accumulators over the SAME output tile); after the loop groups 1..KS-1 hand their accumulators to group 0 through LDS
+// and group 0 runs the epilogue.  For launches with too few tiles to give every SIMD two waves (the 4x4 level of the U-Net:
+// 256 tiles of K = 2304..4608) this doubles the resident waves without a second pass or atomics; summation order over the
+// chunks changes (even/odd partial sums), results stay deterministic.
+template <int BM, int BN, int WM, int WN, bool B_KMAJOR, bool T64 = false, int KS = 1>
+__global__ __launch_bounds__(64 * WM * WN * KS) void igemm_f32_fast_kernel(const GemmParams p) {
+    constexpr int NT = 64 * WM * WN;  // threads of one wave group
     constexpr int RM = BM / (32 * WM), RN = BN / (32 * WN);
     constexpr int RPP = NT / 8;
     constexpr int AJ = BM / RPP, BJ = BN / RPP;
@@ -357,11 +362,14 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_fast_kernel(const Gemm
     constexpr int BUF = (BM + BN) * LDT;
     constexpr int OOB = (int)0x80000000u;  // voffset that fails the bounds check of every (< 2 GiB) buffer
     static_assert(BM % RPP == 0 && BN % RPP == 0 && RM >= 1 && RN >= 1 && NP <= 14, "bad tile geometry");
-    __shared__ __attribute__((aligned(16))) float smem[2 * BUF];
+    static_assert(KS == 1 || (KS - 1) * RM * RN * 16 * NT <= 2 * KS * BUF, "split-K reduction buffer does not fit the stages");
+    __shared__ __attribute__((aligned(16))) float smem[2 * KS * BUF];
 
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keeps the epilogue row offsets in SGPRs
+    const int lane = threadIdx.x & 63;
+    const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keeps the epilogue row offsets in SGPRs
+    const int ks = KS == 1 ? 0 : wave_all / (WM * WN);                       // K-split group of this wave
+    const int wave = KS == 1 ? wave_all : wave_all - ks * (WM * WN);
+    const int tid = wave * 64 + lane;                                       // thread index inside the wave group
     const int wm = wave / WN, wn = wave % WN;
 
     const int nt = p.n_tiles;
@@ -445,16 +453,22 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_fast_kernel(const Gemm
     // ---- wave-uniform state of the chunk whose loads are issued next: tap (ty, tx), channel base c0 ----
     int s_tap = 0, s_ty = 0, s_tx = 0, s_c0 = 0, s_kc = 0;
     const int nk = p.diag == 2 ? 1 : p.K / KC;  // diag: diagnostic only (GDDIM_IGEMM_DIAG), results wrong
+    const int nit = (nk + KS - 1) / KS;         // loop iterations: group ks owns chunks ks, ks + KS, ... (chunks >= nk read zeros)
     // K order: 32-channel slab outermost, the KH*KW taps of that slab innermost.  The taps re-read (shifted) the same
     // activation lines, so keeping them adjacent in time turns 8 of 9 tap loads into L1/L2 hits (with taps outermost
     // the lines are evicted between taps: ~4x HBM over-fetch in the PMC pass).  Any K permutation is legal as long as
     // A and B agree; B is addressed through the scalar soffset, so the packed weight layout [n][tap][c] is unchanged.
-    auto advance_k = [&]() {
+    auto advance_1 = [&]() {
         ++s_kc;
         ++s_tap;
         if (++s_tx == p.KW) { s_tx = 0; ++s_ty; }
         if (s_tap == taps) { s_tap = 0; s_ty = 0; s_tx = 0; s_c0 += KC; }
     };
+    auto advance_k = [&]() {
+#pragma unroll
+        for (int i = 0; i < KS; ++i) advance_1();
+    };
+    for (int i = 0; i < ks; ++i) advance_1();  // first chunk of this group
 
     f32x4 ra[AJ], rb[BJ];
 
@@ -509,19 +523,20 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_fast_kernel(const Gemm
     const int a_off = (wm * (BM / WM) + li) * LDT + lh * 4;
     const int b_offl = BM * LDT + (wn * (BN / WN) + li) * LDT + lh * 4;
 
+    float *const stage0 = smem + ks * 2 * BUF;  // this group's two LDS stages
 #pragma unroll
     for (int pc = 0; pc < NP; ++pc) load_piece(pc);
     advance_k();
 #pragma unroll
-    for (int pc = 0; pc < NP; ++pc) store_piece(pc, smem);
+    for (int pc = 0; pc < NP; ++pc) store_piece(pc, stage0);
 #pragma unroll
     for (int pc = 0; pc < NP; ++pc) load_piece(pc);
     advance_k();
     __syncthreads();
 
-    for (int kc = 0; kc < nk; ++kc) {
-        const float *cur = smem + (kc & 1) * BUF;
-        float *nxt = smem + ((kc + 1) & 1) * BUF;
+    for (int kc = 0; kc < nit; ++kc) {
+        const float *cur = stage0 + (kc & 1) * BUF;
+        float *nxt = stage0 + ((kc + 1) & 1) * BUF;
         f32x4 af[RM], bf[RN];
 #pragma unroll
         for (int r = 0; r < RM; ++r) af[r] = *reinterpret_cast<const f32x4 *>(cur + a_off + r * 32 * LDT);
@@ -568,6 +583,29 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_fast_kernel(const Gemm
     // scalar soffset, rows >= M fall outside the descriptor (dropped by the bounds check), columns >= N are pushed out
     // of bounds once.  fast_ok() guarantees rows_per_image % 8 == 0, so the two half-waves of one store (rows r0, r0+4)
     // belong to the same image and the per-image bias row is wave-uniform.
+    if (KS > 1) {  // partial sums of groups 1..KS-1 -> LDS (lane-contiguous, conflict-free) -> group 0
+        if (ks > 0) {
+            float *dst = smem + (size_t)(ks - 1) * RM * RN * 16 * NT + tid;
+#pragma unroll
+            for (int r = 0; r < RM; ++r)
+#pragma unroll
+                for (int c = 0; c < RN; ++c)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) dst[((r * RN + c) * 16 + v) * NT] = acc[r][c][v];
+        }
+        __syncthreads();
+        if (ks > 0) return;
+#pragma unroll
+        for (int g = 1; g < KS; ++g) {
+            const float *src = smem + (size_t)(g - 1) * RM * RN * 16 * NT + tid;
+#pragma unroll
+            for (int r = 0; r < RM; ++r)
+#pragma unroll
+                for (int c = 0; c < RN; ++c)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) acc[r][c][v] += src[((r * RN + c) * 16 + v) * NT];
+        }
+    }
     {
         char *outc = reinterpret_cast<char *>(p.out + (size_t)z * p.sC);
         const __amdgpu_buffer_rsrc_t srd_o = __builtin_amdgcn_make_buffer_rsrc(outc, 0, p.M * p.ldc * 4, 0x00020000);
@@ -630,6 +668,296 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_fast_kernel(const Gemm
     }
 }
 
+// =====================================================================================================================
+// Persistent variant of the fast path for SHORT K (the 1x1 convolutions, NIN layers and attention products: K = 256..512,
+// 8..16 chunks).  With one workgroup per tile such a launch spends a third of its time outside the K loop (first loads,
+// last stores: T ~ 14 us + 0.129 us x K per pair of tiles).  Here a workgroup walks tile ids blockIdx.x, blockIdx.x + gridDim.x,
+// ... (flattened over the z slices of a batched product; the stride keeps the N tile, hence the weight rows and the XCD) and
+// the software pipeline of the K loop runs ACROSS tiles: the last two iterations of a tile request the first two chunks of the
+// next one (and the last one writes its chunk 0 to LDS), so only the first tile of a workgroup has a prologue and every epilogue
+// runs with the next tile's loads in flight.  Same tiling, LDS layout, fragment order (hence bit-identical sums) and epilogue
+// arithmetic as igemm_f32_fast_kernel.  Requirements: those of the fast path, n-major B, <= 32 taps, K >= 96.
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void igemm_f32_pers_kernel(const GemmParams p) {
+    constexpr int NT = 64 * WM * WN;
+    constexpr int RM = BM / (32 * WM), RN = BN / (32 * WN);
+    constexpr int RPP = NT / 8;
+    constexpr int AJ = BM / RPP, BJ = BN / RPP;
+    constexpr int NP = AJ + BJ;
+    constexpr int BUF = (BM + BN) * LDT;
+    constexpr int OOB = (int)0x80000000u;
+    static_assert(BM % RPP == 0 && BN % RPP == 0 && RM >= 1 && RN >= 1 && NP <= 14, "bad tile geometry");
+    __shared__ __attribute__((aligned(16))) float smem[2 * BUF];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+
+    const int nt = p.n_tiles;
+    const int ids_per_z = p.flat_tiles ? p.m_tiles * nt : ((p.m_tiles + 7) / 8) * 8 * nt;
+    const int total_ids = ids_per_z * p.z_count;
+    auto tile_of = [&](int id_, int &z_, int &mtile_, int &ntile_) __attribute__((always_inline)) {
+        z_ = id_ / ids_per_z;
+        const int r_ = id_ - z_ * ids_per_z;
+        if (p.flat_tiles) {
+            mtile_ = r_ / nt;
+            ntile_ = r_ - mtile_ * nt;
+        } else {
+            const int grp = r_ / (8 * nt);
+            const int rem = r_ - grp * 8 * nt;
+            ntile_ = rem >> 3;
+            mtile_ = grp * 8 + (rem & 7);
+        }
+        return mtile_ < p.m_tiles;
+    };
+    int id = blockIdx.x, z_ld = 0, mt_ld = 0, ntile = 0;
+    while (id < total_ids && !tile_of(id, z_ld, mt_ld, ntile)) id += (int)gridDim.x;
+    if (id >= total_ids) return;
+    const int n0 = ntile * BN;  // the same for every tile of this workgroup
+
+    const int Cin = p.C0 + p.C1;
+    const int taps = p.KH * p.KW;
+    const int a_imgs = (p.M + p.OH * p.OW - 1) / (p.OH * p.OW);
+    const int bias0 = (p.pad * p.W + p.pad) * p.lda0 * 4;
+    const int bias1 = (p.pad * p.W + p.pad) * p.lda1 * 4;
+    const int a0_bytes = a_imgs * p.H * p.W * p.lda0 * 4 + bias0;
+    const int b_bytes = p.N * p.ldb * 4;
+    auto make_a0 = [&](int z_) __attribute__((always_inline)) {
+        const char *a0c = reinterpret_cast<const char *>(p.a0 + (size_t)z_ * p.sA);
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(a0c - bias0), 0, a0_bytes, 0x00020000);
+    };
+    auto make_b = [&](int z_) __attribute__((always_inline)) {
+        const char *bc = reinterpret_cast<const char *>(p.b + (size_t)z_ * p.sB);
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(bc), 0, b_bytes, 0x00020000);
+    };
+    __amdgpu_buffer_rsrc_t srd_a0 = make_a0(z_ld);
+    const char *a1c = reinterpret_cast<const char *>(p.C1 ? p.a1 : p.a0);
+    const __amdgpu_buffer_rsrc_t srd_a1 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(a1c - bias1), 0, a_imgs * p.H * p.W * p.lda1 * 4 + bias1, 0x00020000);
+    __amdgpu_buffer_rsrc_t srd_b = make_b(z_ld);
+
+    const int arow = tid >> 3;
+    const int kcol = (tid & 7) * 4;
+    int rb0[AJ], rb1[AJ];
+    unsigned inv[AJ];
+    auto setup_rows = [&](int m0_) __attribute__((always_inline)) {  // row data of the tile whose loads are issued next
+        const unsigned OHW = p.OH * p.OW;
+        const unsigned rowbits = (1u << p.KW) - 1u;
+#pragma unroll
+        for (int j = 0; j < AJ; ++j) {
+            const int m = m0_ + arow + RPP * j;
+            rb0[j] = 0; rb1[j] = 0; inv[j] = 0xFFFFFFFFu;
+            if (m < p.M) {
+                const int img = (int)fast_div((unsigned)m, OHW, p.mg_ohw, p.sh_ohw);
+                const int r = m - img * (int)OHW;
+                const int oy = (int)fast_div((unsigned)r, (unsigned)p.OW, p.mg_ow, p.sh_ow);
+                const int ox = r - oy * p.OW;
+                const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+                const int pix = (img * p.H + iy0) * p.W + ix0;
+                rb0[j] = pix * p.lda0 * 4 + bias0 + kcol * 4;
+                rb1[j] = pix * p.lda1 * 4 + bias1 + kcol * 4;
+                unsigned xb = 0;
+                for (int tx = 0; tx < p.KW; ++tx) xb |= ((unsigned)(ix0 + tx) < (unsigned)p.W ? 0u : 1u) << tx;
+                unsigned mk = 0;
+                for (int ty = 0; ty < p.KH; ++ty) mk |= ((unsigned)(iy0 + ty) < (unsigned)p.H ? xb : rowbits) << (ty * p.KW);
+                inv[j] = mk;
+            }
+        }
+    };
+    setup_rows(mt_ld * BM);
+    int bvo[BJ];
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) {
+        const int n = n0 + arow + RPP * j;
+        bvo[j] = n < p.N ? (n * p.ldb + kcol) * 4 : OOB;
+    }
+
+    // ---- wave-uniform state of the chunk whose loads are issued next; when it runs past the tile it rolls to the next tile ----
+    int s_tap = 0, s_ty = 0, s_tx = 0, s_c0 = 0, s_kc = 0;
+    const int nk = p.K / KC;  // >= 3 (launch_igemm)
+    int z_nx = 0, m0_nx = 0;  // the tile the load side moved on to (valid when `more`)
+    bool more = false;
+    auto roll = [&]() __attribute__((always_inline)) {
+        int next = id + (int)gridDim.x, zz = 0, mt = 0, ntl = 0;
+        while (next < total_ids && !tile_of(next, zz, mt, ntl)) next += (int)gridDim.x;
+        more = next < total_ids;
+        s_kc = 0; s_tap = 0; s_ty = 0; s_tx = 0; s_c0 = 0;
+        if (more) {
+            id = next;
+            z_nx = zz; m0_nx = mt * BM;
+            if (p.z_count > 1) { srd_a0 = make_a0(zz); srd_b = make_b(zz); }
+            setup_rows(m0_nx);
+        } else {  // nothing left: the remaining requests of the pipeline fetch nothing (what they store is never read)
+#pragma unroll
+            for (int j = 0; j < AJ; ++j) inv[j] = 0xFFFFFFFFu;
+#pragma unroll
+            for (int j = 0; j < BJ; ++j) bvo[j] = OOB;
+        }
+    };
+    auto advance_k = [&]() __attribute__((always_inline)) {
+        ++s_kc;
+        ++s_tap;
+        if (++s_tx == p.KW) { s_tx = 0; ++s_ty; }
+        if (s_tap == taps) { s_tap = 0; s_ty = 0; s_tx = 0; s_c0 += KC; }
+        if (s_kc == nk) roll();
+    };
+
+    f32x4 ra[AJ], rb[BJ];
+    auto load_piece = [&](int pc) __attribute__((always_inline)) {
+        if (pc < AJ) {
+            const int j = pc;
+            const int bad = __builtin_amdgcn_sbfe(inv[j], s_tap, 1);
+            if (s_c0 < p.C0) {
+                const int soff = ((s_ty * p.W + s_tx) * p.lda0 + s_c0) * 4;
+                ra[j] = buf_load16(srd_a0, rb0[j] | (bad & OOB), soff);
+            } else {
+                const int soff = ((s_ty * p.W + s_tx) * p.lda1 + (s_c0 - p.C0)) * 4;
+                ra[j] = buf_load16(srd_a1, rb1[j] | (bad & OOB), soff);
+            }
+        } else {
+            const int j = pc - AJ;
+            rb[j] = buf_load16(srd_b, bvo[j], (s_tap * Cin + s_c0) * 4);
+        }
+    };
+    auto store_piece = [&](int pc, float *st) __attribute__((always_inline)) {
+        if (pc < AJ) *reinterpret_cast<f32x4 *>(&st[(arow + RPP * pc) * LDT + kcol]) = ra[pc];
+        else *reinterpret_cast<f32x4 *>(&st[BM * LDT + (arow + RPP * (pc - AJ)) * LDT + kcol]) = rb[pc - AJ];
+    };
+
+    f32x16 acc[RM][RN];
+    const int li = lane & 31, lh = lane >> 5;
+    const int a_off = (wm * (BM / WM) + li) * LDT + lh * 4;
+    const int b_offl = BM * LDT + (wn * (BN / WN) + li) * LDT + lh * 4;
+
+    int z_ep = z_ld, m0_ep = mt_ld * BM;  // the tile being multiplied
+#pragma unroll
+    for (int pc = 0; pc < NP; ++pc) load_piece(pc);
+    advance_k();
+#pragma unroll
+    for (int pc = 0; pc < NP; ++pc) store_piece(pc, smem);
+#pragma unroll
+    for (int pc = 0; pc < NP; ++pc) load_piece(pc);
+    advance_k();
+    __syncthreads();
+
+    int it = 0;  // chunks multiplied so far by this workgroup: LDS stage it & 1 holds the current one
+    for (;;) {
+#pragma unroll
+        for (int r = 0; r < RM; ++r)
+#pragma unroll
+            for (int c = 0; c < RN; ++c)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) acc[r][c][v] = 0.f;
+        for (int kc = 0; kc < nk; ++kc, ++it) {
+            const float *cur = smem + (it & 1) * BUF;
+            float *nxt = smem + ((it + 1) & 1) * BUF;
+            f32x4 af[RM], bf[RN];
+#pragma unroll
+            for (int r = 0; r < RM; ++r) af[r] = *reinterpret_cast<const f32x4 *>(cur + a_off + r * 32 * LDT);
+#pragma unroll
+            for (int c = 0; c < RN; ++c) bf[c] = *reinterpret_cast<const f32x4 *>(cur + b_offl + c * 32 * LDT);
+#pragma unroll
+            for (int kb = 0; kb < KC / 8; ++kb) {
+                f32x4 afn[RM], bfn[RN];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+#pragma unroll
+                    for (int r = 0; r < RM; ++r)
+#pragma unroll
+                        for (int c = 0; c < RN; ++c)
+                            acc[r][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[r][jj], bf[c][jj], acc[r][c], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int gap = kb * 4 + jj;
+                    if (gap < NP) {
+                        store_piece(gap, nxt);
+                        load_piece(gap);
+                    } else if (gap == NP) {
+                        advance_k();
+                    }
+                    if (jj == 2 && kb + 1 < KC / 8) {
+#pragma unroll
+                        for (int r = 0; r < RM; ++r) afn[r] = *reinterpret_cast<const f32x4 *>(cur + a_off + r * 32 * LDT + (kb + 1) * 8);
+#pragma unroll
+                        for (int c = 0; c < RN; ++c) bfn[c] = *reinterpret_cast<const f32x4 *>(cur + b_offl + c * 32 * LDT + (kb + 1) * 8);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (kb + 1 < KC / 8) {
+#pragma unroll
+                    for (int r = 0; r < RM; ++r) af[r] = afn[r];
+#pragma unroll
+                    for (int c = 0; c < RN; ++c) bf[c] = bfn[c];
+                }
+            }
+            __syncthreads();
+        }
+
+        // ---- epilogue of tile (z_ep, m0_ep): as in igemm_f32_fast_kernel; the next tile's first chunks are in flight ----
+        {
+            char *outc = reinterpret_cast<char *>(p.out + (size_t)z_ep * p.sC);
+            const __amdgpu_buffer_rsrc_t srd_o = __builtin_amdgcn_make_buffer_rsrc(outc, 0, p.M * p.ldc * 4, 0x00020000);
+            const __amdgpu_buffer_rsrc_t srd_r =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(reinterpret_cast<const char *>(p.res ? p.res : p.out)), 0,
+                                                  p.M * p.ldres * 4, 0x00020000);
+            const unsigned rpi = p.rows_per_image;
+#pragma unroll
+            for (int c = 0; c < RN; ++c) {
+                const int n = n0 + wn * (BN / WN) + c * 32 + li;
+                const bool nok = n < p.N;
+                const float bias = (p.bias && nok) ? p.bias[n] : 0.f;
+                const int vo_o = nok ? (4 * lh * p.ldc + n) * 4 : OOB;
+                const int vo_r = nok ? (4 * lh * p.ldres + n) * 4 : OOB;
+#pragma unroll
+                for (int r = 0; r < RM; ++r) {
+                    const int mrow = m0_ep + wm * (BM / WM) + r * 32;  // wave-uniform
+                    float addv[16];
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) addv[v] = bias;
+                    if (p.res) {
+                        float t[16];
+#pragma unroll
+                        for (int v = 0; v < 16; ++v)
+                            t[v] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_r, vo_r, (mrow + (v & 3) + 8 * (v >> 2)) * p.ldres * 4, 0));
+#pragma unroll
+                        for (int v = 0; v < 16; ++v) addv[v] += t[v];
+                    }
+                    if (p.rowbias) {
+                        float t[4];
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const unsigned mr = (unsigned)(mrow + 8 * g);
+                            const unsigned img = mr < (unsigned)p.M ? fast_div(mr, rpi, p.mg_rpi, p.sh_rpi) : 0u;
+                            t[g] = nok ? p.rowbias[(size_t)img * p.ld_rowbias + n] : 0.f;
+                        }
+#pragma unroll
+                        for (int v = 0; v < 16; ++v) addv[v] += t[v >> 2];
+                    }
+                    float vals[16];
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) {
+                        const float val = (p.alpha * acc[r][c][v] + addv[v]) * p.out_scale;
+                        vals[v] = val;
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), srd_o, vo_o,
+                                                              (mrow + (v & 3) + 8 * (v >> 2)) * p.ldc * 4, 0);
+                    }
+                    if (p.qstats) {
+                        if (!nok || mrow + 32 > p.M) {
+#pragma unroll
+                            for (int v = 0; v < 16; ++v)
+                                if (!nok || mrow + (v & 3) + 8 * (v >> 2) + 4 * lh >= p.M) vals[v] = 0.f;
+                        }
+                        emit_qstats(p, vals, mrow, n, nok, li, lh);
+                    }
+                }
+            }
+        }
+        if (!more) break;
+        z_ep = z_nx;
+        m0_ep = m0_nx;
+    }
+}
+
 // ---- variant selection ------------------------------------------------------------------------------------------
 // GDDIM_IGEMM_VARIANT (env, read once) overrides the large-tile kernel for A/B measurements:
 //   0: 128x128, 8 waves (2x4)  [default]     1: 128x128, 4 waves (2x2)     2: 256x128, 8 waves (4x2) when M is large
@@ -658,6 +986,41 @@ static void pick_tiles(const GemmParams &p, int batch_z, int &bm, int &bn) {
 
 static bool fast_ok(const GemmParams &p);
 
+// Intra-workgroup split-K factor of the 64x64 tile (igemm_f32_fast_kernel<..., KS>): when a launch has fewer than two tiles per
+// CU and K is long, KS wave groups share a tile.  GDDIM_IGEMM_KS=1/2/4 overrides (A/B).
+static int pick_ksplit(const GemmParams &p, int batch_z, int bm, int bn) {
+    static const int forced = getenv("GDDIM_IGEMM_KS") ? atoi(getenv("GDDIM_IGEMM_KS")) : 0;
+    if (bm != 64 || bn != 64 || !fast_ok(p) || p.b_kmajor || p.KH * p.KW > 32) return 1;
+    const long long blocks = (long long)((p.M + 63) / 64) * ((p.N + 63) / 64) * batch_z;
+    const int nk = p.K / KC;
+    if (forced == 1 || forced == 2 || forced == 4) return nk >= 2 * forced ? forced : 1;
+    if (blocks <= 512 && nk >= 32) return 4;
+    if (blocks <= 1024 && nk >= 16) return 2;
+    return 1;
+}
+
+// The persistent short-K kernel (igemm_f32_pers_kernel) takes a launch when it is eligible for the fast path with the 128x128
+// tile, K is short (<= GDDIM_IGEMM_PERS_MAXK, default 1024) and there are more tiles than resident workgroups (2 per CU).
+// GDDIM_IGEMM_NOPERSIST=1 routes everything back to one workgroup per tile (A/B).
+static int device_cus() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
+static bool pers_ok(const GemmParams &p, int batch_z, int bm, int bn) {
+    static const int off = getenv("GDDIM_IGEMM_NOPERSIST") ? atoi(getenv("GDDIM_IGEMM_NOPERSIST")) : 0;
+    static const int maxk = getenv("GDDIM_IGEMM_PERS_MAXK") ? atoi(getenv("GDDIM_IGEMM_PERS_MAXK")) : 1024;
+    if (off || bm != 128 || bn != 128 || big_variant() != 0 || !fast_ok(p) || p.b_kmajor || p.KH * p.KW > 32) return false;
+    if (p.K < 3 * KC || p.K > maxk || p.diag) return false;
+    const long long tiles = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) * batch_z;
+    return tiles > 2LL * device_cus() && tiles < (1LL << 24);
+}
+
 // The kernel symbol (as rocprofv3 prints it) that launch_igemm would pick for this problem.
 const char *igemm_variant_name(const GemmParams &p, int batch_z) {
     int bm, bn;
@@ -669,7 +1032,10 @@ const char *igemm_variant_name(const GemmParams &p, int batch_z) {
         else if (big_variant() != 1) { wmm = 2; wnn = 4; }
     }
     if (bm == 128 && bn == 64 && !getenv("GDDIM_IGEMM_SMALL4")) { wmm = 4; wnn = 2; }
-    if (fast_ok(p)) snprintf(buf, sizeof buf, "igemm_f32_fast_kernel<%d,%d,%d,%d,%s>", bm, bn, wmm, wnn, p.b_kmajor ? "true" : "false");
+    const int ksp = pick_ksplit(p, batch_z, bm, bn);
+    if (pers_ok(p, batch_z, bm, bn)) snprintf(buf, sizeof buf, "igemm_f32_pers_kernel<128,128,2,4>");
+    else if (ksp > 1) snprintf(buf, sizeof buf, "igemm_f32_fast_kernel<64,64,2,2,false,false,%d>", ksp);
+    else if (fast_ok(p)) snprintf(buf, sizeof buf, "igemm_f32_fast_kernel<%d,%d,%d,%d,%s>", bm, bn, wmm, wnn, p.b_kmajor ? "true" : "false");
     else snprintf(buf, sizeof buf, "igemm_f32_kernel<%d,%d,%d,%d,%s,%s>", bm, bn, wmm, wnn, p.b_kmajor ? "true" : "false", p.in_act ? "true" : "false");
     return buf;
 }
@@ -760,6 +1126,14 @@ int launch_igemm(const GemmParams &p_in, int batch_z, hipStream_t s) {
         p.flat_tiles = p.m_tiles < 16;
         gx = p.flat_tiles ? p.m_tiles * p.n_tiles : ((p.m_tiles + 7) / 8) * 8 * p.n_tiles;
         launch_variant<256, 128, 4, 2>(p, dim3(gx, 1, batch_z), s);
+    } else if (pers_ok(p, batch_z, bm, bn)) {
+        // persistent: 2 workgroups per CU walk the (z, tile) ids with a stride that keeps the N tile and the XCD
+        p.z_count = batch_z;
+        const int unit = p.flat_tiles ? p.n_tiles : 8 * p.n_tiles;
+        const long long total = (long long)gx * batch_z;
+        long long g = (2LL * device_cus() / unit) * unit;
+        if (g <= 0 || g > total) g = total;
+        hipLaunchKernelGGL((igemm_f32_pers_kernel<128, 128, 2, 4>), dim3((unsigned)g), dim3(512), 0, s, p);
     } else if (bm == 128 && bn == 128) {
         if (big_variant() == 1) launch_variant<128, 128, 2, 2>(p, dim3(gx, 1, batch_z), s);
         else launch_variant<128, 128, 2, 4>(p, dim3(gx, 1, batch_z), s);
@@ -767,7 +1141,10 @@ int launch_igemm(const GemmParams &p_in, int batch_z, hipStream_t s) {
         if (getenv("GDDIM_IGEMM_SMALL4")) launch_variant<128, 64, 2, 2>(p, dim3(gx, 1, batch_z), s);
         else launch_variant<128, 64, 4, 2>(p, dim3(gx, 1, batch_z), s);
     } else {
-        launch_variant<64, 64, 2, 2>(p, dim3(gx, 1, batch_z), s);
+        const int ksp = pick_ksplit(p, batch_z, bm, bn);
+        if (ksp == 4) hipLaunchKernelGGL((igemm_f32_fast_kernel<64, 64, 2, 2, false, false, 4>), dim3(gx, 1, batch_z), dim3(1024), 0, s, p);
+        else if (ksp == 2) hipLaunchKernelGGL((igemm_f32_fast_kernel<64, 64, 2, 2, false, false, 2>), dim3(gx, 1, batch_z), dim3(512), 0, s, p);
+        else launch_variant<64, 64, 2, 2>(p, dim3(gx, 1, batch_z), s);
     }
     GD_HIP(hipGetLastError());
     return 0;

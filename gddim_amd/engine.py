@@ -211,12 +211,15 @@ class Engine(object):
         check(self._lib.gd_engine_set_seed(self._h, int(seed) & 0xFFFFFFFFFFFFFFFF))
 
     def sample_cld(self, u, inverse_scale=True, use_graph=True):
+        """use_graph: False eager launches, True one captured graph per step replayed num_step times, 'loop' one graph for the
+        whole call (include/gddim_amd.h: gd_sample_cld)."""
         import torch
+        use_graph = 2 if use_graph == 'loop' else int(bool(use_graph))
         u = u.contiguous()
         B = u.shape[0]
         x = torch.empty(u.shape[:-1], dtype=torch.float32, device=u.device)
         v = torch.empty_like(x)
-        check(self._lib.gd_sample_cld(self._h, B, _ptr(u), _ptr(x), _ptr(v), int(bool(inverse_scale)), int(bool(use_graph)),
+        check(self._lib.gd_sample_cld(self._h, B, _ptr(u), _ptr(x), _ptr(v), int(bool(inverse_scale)), use_graph,
                                       _stream(self.device)))
         return x, v
 

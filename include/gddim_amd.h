@@ -178,7 +178,9 @@ int gd_randn_pairs(float *out_dev, long long n_pairs, unsigned long long seed, u
                    void *stream);
 /* One sampler call: u_in_dev (B,H,W,C,2) initial noise -> x_out_dev (B,H,W,C) = (u_x+1)/2 when
  * inverse_scale != 0 else u_x, v_out_dev (B,H,W,C).  use_graph: 0 eager launches, 1 replay a
- * captured hipGraph per step (captured on first use for this batch size).
+ * captured hipGraph per step (captured on first use for this batch size), 2 ONE hipGraph for the
+ * whole call (pack, every step, the denoising evaluation, finish; input / outputs pass through
+ * engine-owned staging buffers because a graph bakes its addresses).
  * Replaces: sampler(rng, state, batch_size, u) (cld_jax/sampling.py:212-230 / :178-193):
  * fori_loop(body_fn) = eps_fn + multistep_ab_step, then step_fn, inverse_scaler. */
 int gd_sample_cld(gd_engine *e, int batch, const float *u_in_dev, float *x_out_dev, float *v_out_dev,

@@ -13,6 +13,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _cap_torch_threads():
+    """The oracle's torch-CPU convolutions collapse when a 256-thread host pool (the GPU box) is thrown at 1-2 image problems
+    (measured in round 1: 658 s instead of 6 s for the same sample); cap the pool like bench.py's cpu_baseline does."""
+    try:
+        import torch
+        torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    except ImportError:
+        pass
+    yield
+
+
 @pytest.fixture(scope="session")
 def native_lib():
     """Build (if stale) and load the native library; the build is a cross-compile and needs no GPU."""

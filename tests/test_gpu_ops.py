@@ -116,6 +116,12 @@ def _conv_case(dev, B, H, W, Cin, Cout, k, stride, pad, bias, res, seed, alpha=1
     (1, 1, 1, 256, 512, 1, 1, 0, True, False),       # dense layer, M = 1
     (48, 32, 32, 128, 128, 3, 1, 1, True, True),     # 49152 rows -> 128x128 tiles
     (96, 16, 16, 64, 64, 3, 1, 1, True, False),      # 24576 rows, N = 64 -> 128x64 tiles
+    (256, 4, 4, 256, 256, 3, 1, 1, True, True),      # the 4x4 level at the production batch: 256 tiles, K = 2304 -> split-K x4 in the workgroup
+    (4, 4, 4, 512, 256, 1, 1, 0, True, True),        # K = 512 (16 chunks) on few tiles -> split-K x2
+    (3, 4, 4, 288, 64, 3, 1, 1, True, False),        # K = 2592 = 81 chunks: not a multiple of the split (zero-filled tail chunks)
+    (65, 32, 32, 256, 128, 1, 1, 0, True, True),     # 520 tiles of K = 256: the persistent short-K kernel, two tiles per workgroup + residual
+    (70, 30, 30, 128, 256, 1, 1, 0, True, False),    # persistent kernel: ragged last M tile (63000 rows), two N tiles, K = 128 (4 chunks)
+    (70, 32, 32, 96, 128, 3, 1, 1, True, True),      # persistent kernel on a 3x3 window (K = 864, 27 chunks: borders through the tap masks)
 ])
 def test_conv2d_matches_torch_fp64(dev, case):
     err = _conv_case(dev, *case, seed=hash(case) % 1000, alpha=1.0, out_scale=1.0 / math.sqrt(2.0) if case[-1] else 1.0)
@@ -245,7 +251,7 @@ def test_fir_resample_matches_oracle(dev, up):
     assert np.abs(got - want.numpy()).max() < 2e-6
 
 
-@pytest.mark.parametrize("B,N,C", [(3, 256, 256), (4, 16, 256), (2, 64, 32)])
+@pytest.mark.parametrize("B,N,C", [(3, 256, 256), (4, 16, 256), (2, 64, 32), (160, 256, 256)])  # 160 x 4 tiles: the persistent kernel over z slices
 def test_attention_matches_torch(dev, B, N, C):
     from gddim_amd import ops
     rng = np.random.default_rng(N)

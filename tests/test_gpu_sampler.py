@@ -63,6 +63,12 @@ def test_deis_sampler_matches_oracle(cld_setup, nfe, order, denoise):
     assert torch.equal(x, x2) and torch.equal(v, v2)
     x3, _, _ = fn(0, state, u.shape[0], torch.as_tensor(u, device="cuda:0"))
     assert torch.equal(x, x3)
+    # one hipGraph for the whole call (pack, every step, denoising evaluation, finish): same bits, and replayable
+    for _ in range(2):
+        x4, v4, _ = fn(0, state, u.shape[0], torch.as_tensor(u, device="cuda:0"), use_graph='loop')
+        assert torch.equal(x, x4) and torch.equal(v, v4)
+    x5, _, _ = fn(0, state, 2, torch.as_tensor(u[:2], device="cuda:0"), use_graph='loop')  # another batch size: its own graph
+    assert torch.equal(x5, x[:2])
 
 
 def test_order0_sampler_and_factory(cld_setup):
