@@ -86,6 +86,13 @@ struct GemmParams {
     // rows_per_image == 16 (qs_slices = 1).  Unique writer per entry: deterministic.  null = not requested.
     float *qstats;
     int qs_slices;
+    // GroupNorm of the OUTPUT in this GEMM's epilogue (fp32 kernels, rows_per_image 16 or 64: one wave's 32 x 32 accumulator tile
+    // holds whole images and whole groups of egn_cpg channels): egn_out[m * ldc + n] = act((y - mean) rstd gamma[n] + beta[n]) with
+    // (mean, rstd) of (image, group) reduced in registers (flax: var = E[y^2] - E[y]^2, eps 1e-6); egn_skip_raw: the raw output has
+    // no other reader and is not stored.  null = off.  (plan.h: Op::egn_peer)
+    float *egn_out;
+    const float *egn_gamma, *egn_beta;
+    int egn_cpg, egn_act, egn_skip_raw;
     // fp32 Winograd F(2,3) path (kernels/conv3x3_wino_f32.hip): the 3x3 weights pre-transformed to
     // U[n][ky][Cin/8][component][8] by launch_wino_weights (row stride ldb_wino = 12 Cin); null = direct kernel
     const float *b_wino;
@@ -93,6 +100,8 @@ struct GemmParams {
 };
 
 int launch_igemm(const GemmParams &p, int batch_z, hipStream_t s);
+// true when launch_igemm would run this problem on igemm_f32_fast_kernel (any tile, any split), whose epilogue implements egn_out
+bool igemm_egn_ok(const GemmParams &p, int batch_z);
 const char *igemm_variant_name(const GemmParams &p, int batch_z);
 // split-precision (bf16x3) variant for weight GEMMs (kernels/igemm_bf16x3.hip)
 bool igemm_bf16x3_ok(const GemmParams &p, int batch_z);
@@ -112,6 +121,7 @@ int launch_conv3x3_halo(const GemmParams &p, hipStream_t s);
 // GDDIM_NOWINO=1 routes them back to igemm_f32_fast_kernel
 bool conv3x3_wino_ok(const GemmParams &p);
 bool conv3x3_wino_shape_ok(const GemmParams &p);  // without the fill-the-chip criterion (stand-alone entry)
+bool conv3x3_wino_egn_ok(const GemmParams &p);    // ... and its tile implements the epilogue GroupNorm (p.egn_* set)
 const char *conv3x3_wino_name(const GemmParams &p);
 int launch_conv3x3_wino(const GemmParams &p, hipStream_t s);
 int launch_wino_weights(const float *w, float *u, int N, int Cin, hipStream_t s);

@@ -60,6 +60,7 @@ struct gd_engine {
     float *wwino = nullptr;
     std::vector<long long> wino_off;
     std::map<int, std::vector<char>> fuse_ok;      // batch size -> per GEMM op: the fused-GroupNorm halo kernel takes it
+    std::map<int, std::vector<char>> egn_ok;       // batch size -> per GEMM op: normalises its output in the epilogue (Op::egn_peer)
     std::map<int, std::vector<char>> presplit_ok;  // batch size -> per tensor: may be stored pre-split (see presplit_allowed)
     std::vector<long long> slot_off;  // floats into wbuf
     long long wbuf_floats = 0;
@@ -228,6 +229,39 @@ static bool gn_fused(gd_engine *e, const Bind &b, int batch, int gemm_index) {
     return it->second[gemm_index] != 0;
 }
 
+// Epilogue GroupNorm (plan.h: Op::egn_peer), fp32 mode: taken when, at this batch size, the kernel the GEMM runs on implements it
+// (a 64-pair Winograd tile on 8x8 images, igemm_f32_fast_kernel on 4x4 images).  Fills the egn_* fields of g.  Decided once per
+// batch size; GDDIM_NO_EGN=1 switches it off (A/B).
+static void fill_egn(gd_engine *e, const Op &op, const Bind &b, int batch, GemmParams &g) {
+    const Op &a = e->plan.ops[op.egn_peer];
+    g.egn_out = tptr(e, b, a.out, batch);
+    g.egn_gamma = slot_ptr(e, a.gamma_slot);
+    g.egn_beta = slot_ptr(e, a.beta_slot);
+    g.egn_cpg = a.C0 / a.groups;
+    g.egn_act = a.act;
+    g.egn_skip_raw = op.egn_sole;
+}
+
+static bool egn_fused(gd_engine *e, const Bind &b, int batch, int gemm_index) {
+    static const bool off = getenv("GDDIM_NO_EGN") != nullptr;
+    if (off || e->precision != 0 || gemm_index < 0) return false;
+    auto it = e->egn_ok.find(batch);
+    if (it == e->egn_ok.end()) {
+        std::vector<char> ok(e->plan.ops.size(), 0);
+        for (size_t i = 0; i < e->plan.ops.size(); ++i) {
+            const Op &op = e->plan.ops[i];
+            if (op.kind != OP_GEMM || op.egn_peer < 0) continue;
+            GemmParams g{};
+            const int z = fill_gemm(e, op, b, batch, g);
+            fill_egn(e, op, b, batch, g);
+            const bool wino = z == 1 && op.w_slot >= 0 && e->wwino && e->wino_off[op.w_slot] >= 0 && conv3x3_wino_ok(g);
+            ok[i] = (wino ? conv3x3_wino_egn_ok(g) : igemm_egn_ok(g, z)) ? 1 : 0;
+        }
+        it = e->egn_ok.emplace(batch, std::move(ok)).first;
+    }
+    return it->second[gemm_index] != 0;
+}
+
 static int run_op(gd_engine *e, int op_index, const Bind &b, int batch, hipStream_t s) {
     const Op &op = e->plan.ops[op_index];
     const Plan &P = e->plan;
@@ -267,6 +301,7 @@ static int run_op(gd_engine *e, int op_index, const Bind &b, int batch, hipStrea
                 g.b_hi = g.b_lo = nullptr;
             }
             GD_CHECK(!g.a_presplit, "%s: pre-split input without a split-precision kernel", op.label.c_str());
+            if (op.egn_peer >= 0 && egn_fused(e, b, batch, op_index)) fill_egn(e, op, b, batch, g);
             if (e->precision == 1 && op.w_slot < 0 && igemm_bf16x3_act_ok(g, z)) {  // attention products: activation x activation
                 ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string("igemm_bf16x3_kernel<256,128,4,2,act>"), op.flops_per_image * batch, 0);
                 return launch_igemm_bf16x3_act(g, z, s);
@@ -286,6 +321,7 @@ static int run_op(gd_engine *e, int op_index, const Bind &b, int batch, hipStrea
             return launch_gn_stats(tptr(e, b, op.a0, batch), op.C0, tptr(e, b, op.stats, batch), batch, HW, sl, s);
         }
         case OP_GN_APPLY: {
+            if (op.egn_peer >= 0 && egn_fused(e, b, batch, op.egn_peer)) return 0;  // the producer's epilogue wrote op.out
             const int HW = op.H * op.W;
             const int rt = gn_slices(batch, HW);
             const bool table_only = op.fuse_peer >= 0 && gn_fused(e, b, batch, op.fuse_peer);
@@ -542,6 +578,7 @@ int gd_engine_set_precision(gd_engine *e, int mode) {
         GD_HIP(hipSetDevice(e->device));
         GD_HIP(hipDeviceSynchronize());
         drop_graphs(e);  // captured graphs bake the kernel choice
+        e->egn_ok.clear();
         if (mode == 1 && e->params_uploaded && !e->wsplit_valid) GD_TRY(upload_split_weights(e));
     }
     e->precision = mode;

@@ -26,6 +26,7 @@
 #include <type_traits>
 
 #include "../common.h"
+#include "act.h"
 #include "epilogue.h"
 
 namespace gd {
@@ -335,6 +336,7 @@ __global__ __launch_bounds__(BP * 4, BP == 128 ? 2 : BN >= 128 ? 2 : 3) void con
                     }
                 }
                 float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+                float yev[16], yov[16];  // kept for the epilogue GroupNorm (dead otherwise)
 #pragma unroll
                 for (int v = 0; v < 16; ++v) {
                     const float m0 = acc[0][r][c][v], m1 = acc[1][r][c][v], m2 = acc[2][r][c][v], m3 = acc[3][r][c][v];
@@ -343,14 +345,37 @@ __global__ __launch_bounds__(BP * 4, BP == 128 ? 2 : BN >= 128 ? 2 : 3) void con
                     if (p.res && !(WINO_ABL & 64)) { ae += res_e[v]; ao += res_o[v]; }
                     ye = (p.alpha * ye + ae) * p.out_scale;
                     yo = (p.alpha * yo + ao) * p.out_scale;
+                    if (BP == 64) { yev[v] = ye; yov[v] = yo; }
                     const int so = (mrow + 2 * ((v & 3) + 8 * (v >> 2))) * p.ldc * 4;
                     if (WINO_ABL & 32) { asm volatile("" ::"v"(ye), "v"(yo)); }
-                    else {
+                    else if (!(BP == 64 && p.egn_skip_raw)) {
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ye), srd_o, vo_o, so, 0);
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, yo), srd_o, vo_o, so + p.ldc * 4, 0);
                     }
                     if (v < 8) { s0 += ye + yo; q0 += ye * ye + yo * yo; }
                     else { s1 += ye + yo; q1 += ye * ye + yo * yo; }
+                }
+                if (BP == 64 && p.egn_out) {  // (the 128-pair tile has no registers to spare and never sees 8x8 images at sane batches)
+                    // GroupNorm (+ swish) of the output, here: rows_per_image == 64, so the 32 pairs of this accumulator tile (both
+                    // half-waves) are exactly one image; a group is egn_cpg consecutive columns = consecutive lanes
+                    float gs = s0 + s1, gq = q0 + q1;
+                    gs += __shfl_xor(gs, 32); gq += __shfl_xor(gq, 32);
+                    for (int o = 1; o < p.egn_cpg; o <<= 1) { gs += __shfl_xor(gs, o); gq += __shfl_xor(gq, o); }
+                    const float inv_n = 1.0f / (64.0f * (float)p.egn_cpg);
+                    const float mean = gs * inv_n;
+                    const float rstd = rsqrtf(gq * inv_n - mean * mean + 1e-6f);
+                    const float ga = nok ? p.egn_gamma[n] : 0.f, be = nok ? p.egn_beta[n] : 0.f;
+                    const float sc = rstd * ga, sh = be - mean * rstd * ga;
+                    const __amdgpu_buffer_rsrc_t srd_g =
+                        __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(p.egn_out), 0, p.M * p.ldc * 4, 0x00020000);
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) {
+                        float ne = yev[v] * sc + sh, no = yov[v] * sc + sh;
+                        if (p.egn_act) { ne = swish_e(ne); no = swish_e(no); }
+                        const int so = (mrow + 2 * ((v & 3) + 8 * (v >> 2))) * p.ldc * 4;
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ne), srd_g, vo_o, so, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, no), srd_g, vo_o, so + p.ldc * 4, 0);
+                    }
                 }
                 if (p.qstats) {
                     // pairs 0..15 of the tile (v < 8) are output rows mrow .. mrow+31 = one 32-row slice, pairs 16..31 the next one
@@ -515,6 +540,8 @@ bool conv3x3_wino_shape_ok(const GemmParams &p) {
     if (Cin % 32 != 0 || (p.C1 > 0 && (p.C0 % 32 != 0 || !p.a1)) || p.K != 9 * Cin) return false;
     if (p.W % 2 != 0 || (p.H * p.W) % 64 != 0 || p.M % 64 != 0 || p.rows_per_image != p.H * p.W || p.N % 4 != 0 || p.N < 64) return false;
     if (p.qstats && p.qs_slices != p.rows_per_image / 32) return false;
+    if (p.egn_out && (p.rows_per_image != 64 || p.N % p.egn_cpg != 0 ||
+                      (p.egn_cpg != 4 && p.egn_cpg != 8 && p.egn_cpg != 16 && p.egn_cpg != 32))) return false;
     if ((long long)p.M * p.ldc * 4 + 64 >= (1LL << 31) || (p.res && (long long)p.M * p.ldres * 4 + 64 >= (1LL << 31))) return false;
     const long long ldmax = p.lda0 > p.lda1 ? p.lda0 : p.lda1;
     const long long a_bytes = ((long long)p.M + 2 * p.W + 8) * ldmax * 4 + Cin * 4 + 64;
@@ -534,6 +561,11 @@ static bool wino_big(const GemmParams &p) {
     return !nobig && wino_bn(p) == 128 && (long long)((p.M / 2 + 127) / 128) * ((p.N + 127) / 128) >= 512;
 }
 
+// the engine would send this problem to a 64-pair Winograd tile and that tile can normalise its output (p.egn_* set)
+bool conv3x3_wino_egn_ok(const GemmParams &p) {
+    return p.egn_out != nullptr && conv3x3_wino_ok(p) && !wino_big(p);
+}
+
 const char *conv3x3_wino_name(const GemmParams &p) {
     if (wino_big(p)) return "conv3x3_wino_f32_kernel<128,128>";
     return wino_bn(p) == 64 ? "conv3x3_wino_f32_kernel<64,64>" : "conv3x3_wino_f32_kernel<64,128>";
@@ -550,6 +582,7 @@ int launch_conv3x3_wino(const GemmParams &p_in, hipStream_t s) {
     int bn = wino_bn(p);
     if (!bn) bn = p.N > 64 ? 128 : 64;  // small stand-alone problems (gd_conv3x3_winograd)
     const bool use_big = wino_big(p);
+    GD_CHECK(!(use_big && p.egn_out), "conv3x3_wino: epilogue GroupNorm is not built into the 128-pair tile");
     const int BP = use_big ? 128 : 64;
     p.m_tiles = (p.M / 2 + BP - 1) / BP;
     p.n_tiles = (p.N + bn - 1) / bn;

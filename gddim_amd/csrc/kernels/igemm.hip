@@ -652,8 +652,36 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void igemm_f32_fast_kernel(const
                 for (int v = 0; v < 16; ++v) {
                     const float val = (p.alpha * acc[r][c][v] + addv[v]) * p.out_scale;
                     vals[v] = val;
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), srd_o, vo_o,
-                                                          (mrow + (v & 3) + 8 * (v >> 2)) * p.ldc * 4, 0);
+                    if (!p.egn_skip_raw)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), srd_o, vo_o,
+                                                              (mrow + (v & 3) + 8 * (v >> 2)) * p.ldc * 4, 0);
+                }
+                if (p.egn_out) {
+                    // GroupNorm (+ swish) of the output, here: rows_per_image == 16, so accumulator rows 0..15 (v < 8, both half-waves)
+                    // are one image and rows 16..31 the next; a group is egn_cpg consecutive columns = consecutive lanes
+                    float sa = 0.f, qa = 0.f, sb = 0.f, qb = 0.f;
+#pragma unroll
+                    for (int v = 0; v < 8; ++v) { sa += vals[v]; qa += vals[v] * vals[v]; }
+#pragma unroll
+                    for (int v = 8; v < 16; ++v) { sb += vals[v]; qb += vals[v] * vals[v]; }
+                    sa += __shfl_xor(sa, 32); qa += __shfl_xor(qa, 32); sb += __shfl_xor(sb, 32); qb += __shfl_xor(qb, 32);
+                    for (int o = 1; o < p.egn_cpg; o <<= 1) {
+                        sa += __shfl_xor(sa, o); qa += __shfl_xor(qa, o); sb += __shfl_xor(sb, o); qb += __shfl_xor(qb, o);
+                    }
+                    const float inv_n = 1.0f / (16.0f * (float)p.egn_cpg);
+                    const float ma = sa * inv_n, mb = sb * inv_n;
+                    const float ra_ = rsqrtf(qa * inv_n - ma * ma + 1e-6f), rb_ = rsqrtf(qb * inv_n - mb * mb + 1e-6f);
+                    const float ga = nok ? p.egn_gamma[n] : 0.f, be = nok ? p.egn_beta[n] : 0.f;
+                    const float sca = ra_ * ga, sha = be - ma * ra_ * ga, scb = rb_ * ga, shb = be - mb * rb_ * ga;
+                    const __amdgpu_buffer_rsrc_t srd_g =
+                        __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(p.egn_out), 0, p.M * p.ldc * 4, 0x00020000);
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) {
+                        float y = v < 8 ? vals[v] * sca + sha : vals[v] * scb + shb;
+                        if (p.egn_act) y = swish_e(y);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y), srd_g, vo_o,
+                                                              (mrow + (v & 3) + 8 * (v >> 2)) * p.ldc * 4, 0);
+                    }
                 }
                 if (p.qstats) {
                     if (!nok || mrow + 32 > p.M) {  // edge tile: rows >= M / columns >= N contribute nothing
@@ -1064,6 +1092,15 @@ static bool fast_ok(const GemmParams &p) {
     return a_bytes + soff_max < (1LL << 31) && b_bytes + (long long)p.K * (p.b_kmajor ? p.ldb : 1) * 4 < (1LL << 31);
 }
 
+bool igemm_egn_ok(const GemmParams &p, int batch_z) {
+    if (batch_z != 1 || p.rows_per_image != 16 || p.M % 16 != 0 || !fast_ok(p) || p.b_kmajor) return false;
+    if (p.egn_cpg != 4 && p.egn_cpg != 8 && p.egn_cpg != 16 && p.egn_cpg != 32) return false;
+    if (p.N % p.egn_cpg != 0) return false;
+    int bm, bn;
+    pick_tiles(p, batch_z, bm, bn);
+    return !pers_ok(p, batch_z, bm, bn) && !(bm == 128 && bn == 128 && big_variant() == 2);
+}
+
 template <int BM, int BN, int WM, int WN>
 static void launch_variant(const GemmParams &p, dim3 grid, hipStream_t s) {
     dim3 block(64 * WM * WN);
@@ -1110,6 +1147,7 @@ int launch_igemm(const GemmParams &p_in, int batch_z, hipStream_t s) {
     }
     static const int diag = getenv("GDDIM_IGEMM_DIAG") ? atoi(getenv("GDDIM_IGEMM_DIAG")) : 0;
     p.diag = diag;
+    GD_CHECK(!p.egn_out || igemm_egn_ok(p, batch_z), "igemm: epilogue GroupNorm requested for a launch that cannot compute it");
     fill_div((unsigned)(p.OH * p.OW), p.mg_ohw, p.sh_ohw);
     fill_div((unsigned)p.OW, p.mg_ow, p.sh_ow);
     fill_div((unsigned)(p.rows_per_image > 0 ? p.rows_per_image : 1), p.mg_rpi, p.sh_rpi);

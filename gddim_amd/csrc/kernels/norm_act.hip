@@ -75,15 +75,12 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float *__restrict__
                                                         const float *__restrict__ qs1, int S1,
                                                         const float *__restrict__ gamma, const float *__restrict__ beta,
                                                         float *__restrict__ out, int HW, int groups, int act, float inv_n,
-                                                        float eps, int split_out, float *__restrict__ table, int reverse) {
+                                                        float eps, int split_out, float *__restrict__ table) {
     __shared__ float s_sum[256], s_sq[256];
     const int C = C0 + C1, C4 = C >> 2;
     const int Q0 = C0 >> 2, Q1 = C1 >> 2;
     const int tid = threadIdx.x;
-    // reverse: images in descending order.  The producer GEMM wrote the images in ascending order, so the last ones are the
-    // ones still resident in the 256 MiB Infinity Cache; and this pass then leaves the FIRST images most recently written
-    // for the consumer GEMM, which reads in ascending order.
-    const int b = reverse ? (int)gridDim.y - 1 - (int)blockIdx.y : (int)blockIdx.y;
+    const int b = blockIdx.y;
     {
         const int phases = 256 / groups;
         const int g = tid % groups, ph = tid / groups;
@@ -252,9 +249,8 @@ int launch_gn_apply(const float *x0, int C0, const float *x1, int C1, const floa
     int nblk = 1;
     while (!table && nblk < 64 && (long long)batch * nblk < 4096 && HW / (nblk * 2) >= 16) nblk *= 2;
     const float inv_n = 1.0f / ((float)HW * (float)(C / groups));
-    static const int reverse = getenv("GDDIM_GN_FORWARD") ? 0 : 1;  // A/B switch
     hipLaunchKernelGGL(gn_apply_kernel, dim3(nblk, batch), dim3(256), 0, s, x0, C0, x1, C1, qs0, S0, qs1, S1, gamma, beta, out,
-                       HW, groups, act, inv_n, eps, split_out, table, reverse);
+                       HW, groups, act, inv_n, eps, split_out, table);
     GD_HIP(hipGetLastError());
     return 0;
 }

@@ -37,6 +37,14 @@ long long Plan::arena_alloc(long long size) {
     return off;
 }
 
+// a block above everything handed out so far: whatever is written there early cannot alias a tensor that was live before
+long long Plan::arena_alloc_fresh(long long size) {
+    size = (size + 63) / 64 * 64;
+    const long long off = arena_per_image;
+    arena_per_image = off + size;
+    return off;
+}
+
 void Plan::arena_free(long long off, long long size) {
     size = (size + 63) / 64 * 64;
     Block b{off, size};
@@ -55,14 +63,15 @@ void Plan::arena_free(long long off, long long size) {
     }
 }
 
-int Plan::new_tensor(const std::string &name, int H, int W, int C, int ext, long long per_image) {
+int Plan::new_tensor(const std::string &name, int H, int W, int C, int ext, long long per_image, bool fresh) {
     Tensor t;
     t.name = name;
     t.H = H; t.W = W; t.C = C;
     t.per_image = per_image >= 0 ? per_image : (long long)H * W * C;
     t.ext = ext;
     t.refs = 1;
-    if (ext == EXT_NONE) t.offset = arena_alloc(t.per_image);
+    if (ext == EXT_NONE) t.offset = fresh ? arena_alloc_fresh(t.per_image) : arena_alloc(t.per_image);
+    t.fresh = fresh ? 1 : 0;
     tensors.push_back(t);
     return (int)tensors.size() - 1;
 }
@@ -144,7 +153,12 @@ int Plan::gn(const std::string &label, const std::string &pname, int xa, int Ca,
             S[i] = 0;  // run-time slice count
         }
     }
-    int out = new_tensor(label + ".out", H, W, C);
+    // candidate for normalisation in the producer's epilogue (Op::egn_peer): one source that carries fused statistics, an image of
+    // 16 or 64 pixels, groups of 4..32 channels that divide a 32-column accumulator tile
+    const int cpg = C / G;
+    const bool egn_candidate = Cb == 0 && (H * W == 16 || H * W == 64) && tensors[xa].stats_t >= 0 && tensors[xa].C == C &&
+                               (cpg == 4 || cpg == 8 || cpg == 16 || cpg == 32) && C % 32 == 0;
+    int out = new_tensor(label + ".out", H, W, C, EXT_NONE, -1, egn_candidate);
     tensors[out].table_t = new_tensor(label + ".affine", 1, 1, 2 * C);  // lives as long as the output
     Op a;
     a.kind = OP_GN_APPLY; a.label = label + ".apply";
@@ -551,6 +565,7 @@ int Plan::build(const gd_model_desc &d) {
     GD_CHECK((int)rb_tproj_off_.size() == rb, "internal: resblock count mismatch (%d vs %d)", (int)rb_tproj_off_.size(), rb);
 
     mark_split();
+    link_epilogue_gn();
     flops_per_image = conv3x3_flops_per_image = 0;
     for (const Op &o : ops) {
         flops_per_image += o.flops_per_image;
@@ -584,6 +599,33 @@ void Plan::link_fused_gn(int t) {
             g.gn_table = a.gn_table;
             return;
         }
+    }
+}
+
+// Pairs every epilogue-normalisation candidate (Plan::gn: `fresh` output) with the GEMM that produces its source (Op::egn_peer).
+void Plan::link_epilogue_gn() {
+    for (int i = 0; i < (int)ops.size(); ++i) {
+        Op &a = ops[i];
+        if (a.kind != OP_GN_APPLY || a.C1 != 0 || a.a0.col != 0 || !tensors[a.out.t].fresh) continue;
+        const int t = a.a0.t;
+        int prod = -1;
+        for (int j = i - 1; j >= 0; --j)
+            if ((ops[j].kind == OP_GEMM || ops[j].kind == OP_GN_APPLY || ops[j].kind == OP_FIR_UP || ops[j].kind == OP_FIR_DOWN) &&
+                ops[j].out.t == t) { prod = j; break; }
+        if (prod < 0) continue;
+        Op &g = ops[prod];
+        if (g.kind != OP_GEMM || g.z_per_image || g.out.col != 0 || g.qstats.t < 0 || g.N != a.C0 || g.ldc != a.C0 ||
+            g.m_per_image != a.H * a.W || g.w_slot < 0 || g.egn_peer >= 0)
+            continue;
+        bool sole = true;
+        for (int k = 0; k < (int)ops.size() && sole; ++k) {
+            if (k == i) continue;
+            const Op &o = ops[k];
+            if (o.a0.t == t || o.a1.t == t || o.bten.t == t || o.res.t == t || o.rowbias.t == t || (k != prod && o.out.t == t)) sole = false;
+        }
+        a.egn_peer = prod;
+        g.egn_peer = i;
+        g.egn_sole = sole ? 1 : 0;
     }
 }
 
@@ -697,7 +739,8 @@ std::string Plan::json() const {
         o << (i ? "," : "") << "{\"kind\":" << p.kind << ",\"label\":\"" << p.label << "\",";
         jref(o, "a0", p.a0); jref(o, "a1", p.a1); jref(o, "bten", p.bten); jref(o, "rowbias", p.rowbias);
         jref(o, "res", p.res); jref(o, "out", p.out); jref(o, "stats", p.stats); jref(o, "stats1", p.stats1); jref(o, "qstats", p.qstats);
-        o << "\"split_out\":" << p.split_out << ",\"a_split\":" << p.a_split << ",\"fuse_peer\":" << p.fuse_peer << ",";
+        o << "\"split_out\":" << p.split_out << ",\"a_split\":" << p.a_split << ",\"fuse_peer\":" << p.fuse_peer << ",\"egn_peer\":" << p.egn_peer
+          << ",\"egn_sole\":" << p.egn_sole << ",";
         o << "\"C0\":" << p.C0 << ",\"C1\":" << p.C1 << ",\"lda0\":" << p.lda0 << ",\"lda1\":" << p.lda1 << ",\"H\":" << p.H
           << ",\"W\":" << p.W << ",\"OH\":" << p.OH << ",\"OW\":" << p.OW << ",\"KH\":" << p.KH << ",\"KW\":" << p.KW
           << ",\"stride\":" << p.stride << ",\"pad\":" << p.pad << ",\"m_per_image\":" << p.m_per_image

@@ -39,6 +39,7 @@ struct Tensor {
     int stats_t = -1;
     int qs_slices = 0;
     int table_t = -1;  // companion holding the affine map of the GroupNorm that produced this tensor (see Op::gn_table)
+    int fresh = 0;     // allocated above everything allocated before it (never in a recycled block): see Op::egn_peer
 };
 
 struct TRef {
@@ -81,6 +82,12 @@ struct Op {
     int fuse_peer = -1;
     TRef gn_table, gn_src, gn_src1;
     int gn_C0 = 0, gn_C1 = 0;
+    // GroupNorm in the producer's epilogue (fp32 mode, run-time decision): a single-source GN_APPLY op on an 8x8 or 4x4 tensor and
+    // the GEMM that produces that tensor point at each other (egn_peer = op index).  At those sizes one wave's 32 x 32 accumulator
+    // tile holds whole images and whole groups, so the epilogue can reduce (mean, rstd) in registers and write the normalised
+    // (+ swish) tensor itself; the apply op is then skipped.  egn_sole: the apply op is the only reader of the raw output, which
+    // is then not stored at all.  The apply op's output tensor is `fresh` so that writing it early cannot hit live data.
+    int egn_peer = -1, egn_sole = 0;
     TRef qstats;          // GEMM: quad statistics of the output (fused GroupNorm statistics), t = -1: none
     int qs_slices = 0;
     // ---- GroupNorm ----
@@ -138,6 +145,7 @@ struct Plan {
     int build(const gd_model_desc &d);  // 0 ok
     void mark_split();
     void link_fused_gn(int gn_out_tensor);
+    void link_epilogue_gn();
     int load_param(const std::string &name, const float *data, const int64_t *shape, int ndim);
     std::string json() const;
 
@@ -146,9 +154,10 @@ struct Plan {
     struct Block { long long off, size; };
     std::vector<Block> free_list_;
     long long arena_alloc(long long size);
+    long long arena_alloc_fresh(long long size);
     void arena_free(long long off, long long size);
     // builders
-    int new_tensor(const std::string &name, int H, int W, int C, int ext = EXT_NONE, long long per_image = -1);
+    int new_tensor(const std::string &name, int H, int W, int C, int ext = EXT_NONE, long long per_image = -1, bool fresh = false);
     void retain(int t) { tensors[t].refs++; }
     void release(int t);
     int new_slot(const std::string &name, long long rows, long long cols);
