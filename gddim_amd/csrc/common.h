@@ -125,6 +125,14 @@ bool conv3x3_wino_egn_ok(const GemmParams &p);    // ... and its tile implements
 const char *conv3x3_wino_name(const GemmParams &p);
 int launch_conv3x3_wino(const GemmParams &p, hipStream_t s);
 int launch_wino_weights(const float *w, float *u, int N, int Cin, hipStream_t s);
+// fp32 3x3 stride-1 convolutions through the two-dimensional Winograd transform F(2x2, 3x3) (x 2.25 fewer matrix-core flops than
+// the direct sum, kernels/conv3x3_wino2d_f32.hip); p.b_wino = U[n][Cin/8][16][8] from launch_wino2d_weights (16 N Cin floats);
+// GDDIM_NOWINO2=1 routes them back to the one-dimensional kernel
+bool conv3x3_wino2d_ok(const GemmParams &p);
+bool conv3x3_wino2d_shape_ok(const GemmParams &p);
+const char *conv3x3_wino2d_name();
+int launch_conv3x3_wino2d(const GemmParams &p, hipStream_t s);
+int launch_wino2d_weights(const float *w, float *u, int N, int Cin, hipStream_t s);
 // per-device zero buffer used by the staging loads; allocates on first use (call once outside graph capture)
 const float *igemm_zero_buffer();
 

@@ -59,6 +59,9 @@ struct gd_engine {
     // eligible weight slot (float offset into wwino, -1 = none); built on the device from wbuf when the parameters are uploaded
     float *wwino = nullptr;
     std::vector<long long> wino_off;
+    // ... and their two-dimensional F(2x2, 3x3) copies (kernels/conv3x3_wino2d_f32.hip), 16 N Cin floats per eligible slot
+    float *wwino2 = nullptr;
+    std::vector<long long> wino2_off;
     std::map<int, std::vector<char>> fuse_ok;      // batch size -> per GEMM op: the fused-GroupNorm halo kernel takes it
     std::map<int, std::vector<char>> egn_ok;       // batch size -> per GEMM op: normalises its output in the epilogue (Op::egn_peer)
     std::map<int, std::vector<char>> presplit_ok;  // batch size -> per tensor: may be stored pre-split (see presplit_allowed)
@@ -306,6 +309,11 @@ static int run_op(gd_engine *e, int op_index, const Bind &b, int batch, hipStrea
                 ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string("igemm_bf16x3_kernel<256,128,4,2,act>"), op.flops_per_image * batch, 0);
                 return launch_igemm_bf16x3_act(g, z, s);
             }
+            if (e->precision == 0 && z == 1 && op.w_slot >= 0 && e->wwino2 && e->wino2_off[op.w_slot] >= 0 && conv3x3_wino2d_ok(g)) {
+                g.b_wino = e->wwino2 + e->wino2_off[op.w_slot];
+                ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(conv3x3_wino2d_name()), op.flops_per_image * batch, 0);
+                return launch_conv3x3_wino2d(g, s);
+            }
             if (e->precision == 0 && z == 1 && op.w_slot >= 0 && e->wwino && e->wino_off[op.w_slot] >= 0 && conv3x3_wino_ok(g)) {
                 g.b_wino = e->wwino + e->wino_off[op.w_slot];
                 ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(conv3x3_wino_name(g)), op.flops_per_image * batch, 0);
@@ -457,6 +465,7 @@ int gd_engine_destroy(gd_engine *e) {
         drop_graphs(e);
         for (auto &p : e->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
         if (e->wwino) (void)hipFree(e->wwino);
+        if (e->wwino2) (void)hipFree(e->wwino2);
         if (e->wsplit_hi) (void)hipFree(e->wsplit_hi);
         if (e->wsplit_lo) (void)hipFree(e->wsplit_lo);
         float *bufs[] = {e->arena, e->wbuf, e->xin, e->epsb, e->eps_planar, e->labels, e->u8, e->ring, e->ystate, e->uin_stage,
@@ -567,6 +576,22 @@ static int build_wino_weights(gd_engine *e) {
     for (size_t i = 0; i < P.slots.size(); ++i)
         if (e->wino_off[i] >= 0)
             GD_TRY(launch_wino_weights(e->wbuf + e->slot_off[i], e->wwino + e->wino_off[i], dims[i].first, dims[i].second, nullptr));
+    // the same slots in the two-dimensional form (which launches use it is decided per batch size by conv3x3_wino2d_ok);
+    // only for convolutions on images the 2-D kernel can tile (W in {16, 32, 64})
+    e->wino2_off.assign(P.slots.size(), -1);
+    long long total2 = 0;
+    for (const Op &op : P.ops) {
+        if (op.kind != OP_GEMM || op.w_slot < 0 || e->wino_off[op.w_slot] < 0 || e->wino2_off[op.w_slot] >= 0) continue;
+        if ((op.W != 16 && op.W != 32 && op.W != 64) || op.H % 2 != 0 || (op.H * op.W / 4) % 32 != 0) continue;
+        e->wino2_off[op.w_slot] = total2;
+        total2 += (long long)dims[op.w_slot].first * 16 * dims[op.w_slot].second;
+    }
+    if (total2 > 0) {
+        if (!e->wwino2) GD_HIP(hipMalloc((void **)&e->wwino2, (size_t)total2 * sizeof(float)));
+        for (size_t i = 0; i < P.slots.size(); ++i)
+            if (e->wino2_off[i] >= 0)
+                GD_TRY(launch_wino2d_weights(e->wbuf + e->slot_off[i], e->wwino2 + e->wino2_off[i], dims[i].first, dims[i].second, nullptr));
+    }
     GD_HIP(hipDeviceSynchronize());
     return 0;
 }
@@ -1142,6 +1167,23 @@ int gd_conv3x3_winograd(const float *x_dev, const float *w_dev, float *u_scratch
     GD_TRY(launch_wino_weights(w_dev, u_scratch_dev, Cout, Cin, (hipStream_t)stream));
     g.b_wino = u_scratch_dev;
     return launch_conv3x3_wino(g, (hipStream_t)stream);
+}
+
+int gd_conv3x3_winograd2d(const float *x_dev, const float *w_dev, float *u_scratch_dev, const float *bias_dev, const float *res_dev,
+                          float *out_dev, int batch, int H, int W, int Cin, int Cout, float alpha, float out_scale, void *stream) {
+    GD_CHECK(x_dev && w_dev && u_scratch_dev && out_dev, "null pointer");
+    GemmParams g{};
+    g.a0 = x_dev; g.C0 = Cin; g.lda0 = Cin; g.lda1 = 4;
+    g.H = H; g.W = W; g.KH = 3; g.KW = 3; g.stride = 1; g.pad = 1; g.OH = H; g.OW = W;
+    g.M = batch * H * W; g.N = Cout; g.K = 9 * Cin;
+    g.b = w_dev; g.ldb = g.K;
+    g.out = out_dev; g.ldc = Cout; g.bias = bias_dev; g.res = res_dev; g.ldres = Cout;
+    g.rows_per_image = H * W;
+    g.alpha = alpha; g.out_scale = out_scale;
+    GD_CHECK(conv3x3_wino2d_shape_ok(g), "conv3x3_winograd2d: shape not eligible (B=%d H=%d W=%d Cin=%d Cout=%d)", batch, H, W, Cin, Cout);
+    GD_TRY(launch_wino2d_weights(w_dev, u_scratch_dev, Cout, Cin, (hipStream_t)stream));
+    g.b_wino = u_scratch_dev;
+    return launch_conv3x3_wino2d(g, (hipStream_t)stream);
 }
 
 int gd_group_norm(const float *x_dev, const float *scale_dev, const float *bias_dev, float *out_dev, int batch, int HW, int C,

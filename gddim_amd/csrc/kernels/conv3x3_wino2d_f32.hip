@@ -1,0 +1,404 @@
+// 3x3 / stride 1 / pad 1 convolution in fp32 with the TWO-dimensional Winograd transform F(2x2, 3x3).
+//
+// conv3x3_wino_f32.hip transforms along x only: 4 products per output pair and kernel row, 12 M N Cin flops instead of 18.  With
+// the matrix pipe saturated at the clock the chip sustains the only way further is fewer products again:
+// transforming along y as well needs 16 products per 2 x 2 output quad instead of 36, 8 M N Cin flops -- x 2.25 fewer than the direct
+// sum, x 1.5 fewer than the one-dimensional kernel.  For the quad with top-left output pixel (2 qy, 2 qx), its 4 x 4 input patch
+// d[r][s] = in[2 qy - 1 + r][2 qx - 1 + s] and the kernel g[ky][kx]:
+//     V = B^T d B,   U = G g G^T,   M_ij[quad][n] = sum_c V_ij[quad][c] U_ij[n][c],   Y = A^T M A   (2 x 2 outputs)
+//     B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1],  G = [1 0 0; 1/2 1/2 1/2; 1/2 -1/2 1/2; 0 0 1],  A^T = [1 1 1 0; 0 1 -1 -1]
+// i.e. the same one-dimensional F(2,3) of conv3x3_wino_f32.hip applied to rows and to columns.  Both activation-side transforms are
+// additions only; the 1/2 and 1/4 live in the pre-transformed weights (computed in double, rounded once): the benign Winograd size.
+//
+// Sixteen components x 32 x 32 accumulators do not fit one wave, so the components are split over the waves of a workgroup:
+// 512 threads = 8 wave64; workgroup tile 64 quads (256 pixels) x 64 outputs x 16 components; wave (wi, wq) owns component row i = wi
+// (its four components j = 0..3) of quad block wq (32 quads) x 64 outputs = eight 32x32x2 fp32 accumulators, exactly the register
+// budget of the one-dimensional kernel's wave.  K = Cin is consumed in chunks of 8 channels: LDS rows [quad or n][16 components x 8
+// channels + 4 pad] (132 floats = an odd number of 16-byte units: the ds_read_b128 of 16 consecutive rows cover all banks), two stages
+// of 66 KB, one workgroup per CU.  One ds_read_b128 per (fragment, component) feeds four MFMAs, 32 MFMAs per wave between barriers --
+// the same K-loop shape as the one-dimensional kernel -- while a chunk now carries 1.5 x the output work.
+// Staging: thread (quad, component row i, 4-channel half) loads the two input rows B^T row i combines (8 pixels x 16 B, out-of-image
+// pixels pushed out of the buffer bounds -> zero padding), combines them (4 FMA-class vector ops), applies the row transform (4
+// vector ops) and stores four component float4s; every thread also copies four 16-byte pieces of the weight chunk.  Chunk state in
+// SGPRs, per-thread pixel offsets precomputed (they do not depend on the channel), distance-one register prefetch as in
+// igemm_f32_fast_kernel.
+// Epilogue: the x-direction output transform is in-lane; the y-direction one combines the four component rows, which live in four
+// waves: they exchange their 64 partial registers through the (now idle) LDS stages, then wave (h, c) of a quad block finishes quad
+// half h x output tile c: bias, per-image bias row, residual, scale, store, fused GroupNorm quad statistics.
+// Shapes: W in {16, 32, 64} (W/2 a power of two >= 8, so a 16-quad unit is whole quad rows or an aligned piece of one and the 32-row
+// statistics slices stay inside one wave), H even, H W / 4 a multiple of 32, Cin % 32 == 0 (two-source concat: C0 % 32 == 0), N % 4 == 0.
+// Weights arrive as U[n][Cin/8][i][j][8] (launch_wino2d_weights), 16/9 of the direct size.
+#include <cstdio>
+#include <cstdlib>
+
+#include "../common.h"
+#include "act.h"
+#include "epilogue.h"
+
+namespace gd {
+
+typedef float w2f32x16 __attribute__((ext_vector_type(16)));
+typedef float w2f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int w2u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int W2_LD = 132;             // LDS row stride (floats): 16 components x 8 channels + 4 pad
+constexpr int W2_STAGE = 128 * W2_LD;  // floats per stage: V[64 quads] | U[64 outputs]
+
+__device__ __forceinline__ w2f32x4 w2_load16(__amdgpu_buffer_rsrc_t rsrc, int voffset, int soffset) {
+    w2u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voffset, soffset, 0);
+    return __builtin_bit_cast(w2f32x4, v);
+}
+
+__global__ __launch_bounds__(512, 2) void conv3x3_wino2d_f32_kernel(const GemmParams p) {
+    constexpr int OOB = (int)0x80000000u;
+    __shared__ __attribute__((aligned(16))) float smem[2 * W2_STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wi = wave & 3, wq = wave >> 2;  // component row, quad block
+    const int li = lane & 31, lh = lane >> 5;
+
+    // ---- XCD-aware block -> (mtile, ntile), as in the other GEMM kernels ----
+    const int nt = p.n_tiles;
+    int mtile, ntile;
+    if (p.flat_tiles) {
+        mtile = blockIdx.x / nt;
+        ntile = blockIdx.x - mtile * nt;
+    } else {
+        const int grp = blockIdx.x / (8 * nt);
+        const int rem = blockIdx.x - grp * 8 * nt;
+        ntile = rem >> 3;
+        mtile = grp * 8 + (rem & 7);
+    }
+    if (mtile >= p.m_tiles) return;
+    const int q0 = mtile * 64, n0 = ntile * 64;
+
+    const int W = p.W, H = p.H, HW = H * W;
+    const int Wq = W >> 1;        // quads per quad row: 8, 16 or 32
+    const int wqs = p.sh_ow;      // log2(Wq) (launch_conv3x3_wino2d)
+    const int QI = HW >> 2;       // quads per image (a multiple of 32)
+    const int Q = p.M >> 2;       // quads in the batch
+    const int Cin = p.C0 + p.C1;
+    const int a_imgs = p.M / HW;
+    const int bias0 = (W + 1) * p.lda0 * 4, bias1 = (W + 1) * p.lda1 * 4;
+    const __amdgpu_buffer_rsrc_t srd_a0 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(reinterpret_cast<const char *>(p.a0) - bias0), 0, a_imgs * HW * p.lda0 * 4 + bias0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srd_a1 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(reinterpret_cast<const char *>(p.C1 ? p.a1 : p.a0) - bias1), 0, a_imgs * HW * p.lda1 * 4 + bias1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srd_b = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(reinterpret_cast<const char *>(p.b_wino)), 0, p.N * p.ldb_wino * 4, 0x00020000);
+
+    // ---- staging role: (quad ql, component row si, channel half hq).  B^T row si combines input rows (ra, rb) of the patch
+    // with signs (sa, sb):  0: r0 - r2,  1: r1 + r2,  2: r2 - r1,  3: r1 - r3 ----
+    const int ql = tid >> 3, si = (tid >> 1) & 3, hq = tid & 1;
+    const int ra = si == 0 ? 0 : 1, rb = si == 3 ? 3 : 2;
+    const float sa = si == 2 ? -1.f : 1.f, sb = (si == 0 || si == 3) ? -1.f : 1.f;
+    int pix = 0;          // pixel index of the patch origin (2 qy - 1, 2 qx - 1); may be "negative" by at most W + 1: the bias covers it
+    unsigned bad = 0xFFu; // bit 4 t + s: pixel s of the thread's row t lies outside the image (or the quad is past the batch)
+    {
+        const int q = q0 + ql;
+        if (q < Q) {
+            const int img = (int)epi_div((unsigned)q, (unsigned)QI, p.mg_ohw, p.sh_ohw);
+            const int qr = q - img * QI;
+            const int qy = qr >> wqs;
+            const int qx = qr - (qy << wqs);
+            const int y0 = 2 * qy - 1, x0 = 2 * qx - 1;
+            pix = (img * H + y0) * W + x0;
+            unsigned xb = 0;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) xb |= ((unsigned)(x0 + s) < (unsigned)W ? 0u : 1u) << s;
+            bad = ((unsigned)(y0 + ra) < (unsigned)H ? xb : 15u) | (((unsigned)(y0 + rb) < (unsigned)H ? xb : 15u) << 4);
+        }
+    }
+    int vo[8];  // voffsets of the thread's 8 pixels in the current source (out-of-image ones already out of bounds)
+    auto set_vo = [&](int lda, int biasb) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int r = k < 4 ? ra : rb, s = k & 3;
+            const int off = (pix + r * W + s) * lda * 4 + biasb + hq * 16;
+            vo[k] = ((bad >> k) & 1u) ? OOB : off;
+        }
+    };
+    set_vo(p.lda0, bias0);
+    const int v_lds = ql * W2_LD + si * 32 + hq * 4;  // + j * 8
+    // weight pieces: row brow of the tile, 16-byte pieces bp + 8 k (k = 0..3) of the 128-float row chunk
+    const int brow = tid >> 3, bp = tid & 7;
+    const int bvo = (n0 + brow < p.N) ? ((n0 + brow) * p.ldb_wino + bp * 4) * 4 : OOB;
+    const int b_lds = (64 + brow) * W2_LD + bp * 4;  // + k * 32
+
+    // ---- wave-uniform state of the chunk whose loads are issued next ----
+    int s_kc = 0, s_c = 0;
+    bool s_first = true;  // s_c < C0: the chunk comes from source 0
+    const int nk = Cin >> 3;
+    auto advance = [&]() __attribute__((always_inline)) {
+        ++s_kc;
+        s_c += 8;
+        if (s_first && s_c >= p.C0 && p.C1 > 0) {  // once per tile: on to the second source of a channel concat
+            s_first = false;
+            set_vo(p.lda1, bias1);
+        }
+    };
+
+    w2f32x4 rr[8], wb[4], cm[4];
+    auto load_raw = [&](int k) __attribute__((always_inline)) {
+        const int kill = s_kc < nk ? 0 : OOB;
+        if (s_first) rr[k] = w2_load16(srd_a0, vo[k] | kill, s_c * 4);
+        else rr[k] = w2_load16(srd_a1, vo[k] | kill, (s_c - p.C0) * 4);
+    };
+    auto load_w = [&](int k) __attribute__((always_inline)) {
+        wb[k] = w2_load16(srd_b, s_kc < nk ? bvo : OOB, (s_kc * 128 + k * 32) * 4);
+    };
+    auto combine = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) cm[s] = sa * rr[s] + sb * rr[4 + s];
+    };
+    auto store_v = [&](int j, float *st) __attribute__((always_inline)) {
+        w2f32x4 v;
+        if (j == 0) v = cm[0] - cm[2];
+        else if (j == 1) v = cm[1] + cm[2];
+        else if (j == 2) v = cm[2] - cm[1];
+        else v = cm[1] - cm[3];
+        *reinterpret_cast<w2f32x4 *>(&st[v_lds + j * 8]) = v;
+    };
+    auto store_w = [&](int k, float *st) __attribute__((always_inline)) {
+        *reinterpret_cast<w2f32x4 *>(&st[b_lds + k * 32]) = wb[k];
+    };
+
+    w2f32x16 acc[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[j][c][v] = 0.f;
+
+    const int a_off = (wq * 32 + li) * W2_LD + wi * 32 + lh * 4;  // + j * 8
+    const int b_off = (64 + li) * W2_LD + wi * 32 + lh * 4;       // + c * 32 rows + j * 8
+
+    // ---- prologue: chunk 0 -> LDS stage 0, chunk 1 -> registers ----
+#pragma unroll
+    for (int k = 0; k < 8; ++k) load_raw(k);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) load_w(k);
+    advance();
+    combine();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) store_v(j, smem);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) store_w(k, smem);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) load_raw(k);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) load_w(k);
+    advance();
+    __syncthreads();
+
+    w2f32x4 af[2], bf[2][2];
+    for (int kc = 0; kc < nk; ++kc) {
+        const float *cur = smem + (kc & 1) * W2_STAGE;
+        float *nxt = smem + ((kc + 1) & 1) * W2_STAGE;
+        af[0] = *reinterpret_cast<const w2f32x4 *>(cur + a_off);
+        bf[0][0] = *reinterpret_cast<const w2f32x4 *>(cur + b_off);
+        bf[0][1] = *reinterpret_cast<const w2f32x4 *>(cur + b_off + 32 * W2_LD);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j & 1][jj], bf[j & 1][0][jj], acc[j][0], 0, 0, 0);
+                acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j & 1][jj], bf[j & 1][1][jj], acc[j][1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                const int gap = j * 4 + jj;
+                if (jj == 0 && j < 3) {  // fragments of the next component, one component ahead of their use
+                    af[(j + 1) & 1] = *reinterpret_cast<const w2f32x4 *>(cur + a_off + (j + 1) * 8);
+                    bf[(j + 1) & 1][0] = *reinterpret_cast<const w2f32x4 *>(cur + b_off + (j + 1) * 8);
+                    bf[(j + 1) & 1][1] = *reinterpret_cast<const w2f32x4 *>(cur + b_off + 32 * W2_LD + (j + 1) * 8);
+                }
+                // staging work in the shadow of the MFMA pair: chunk kc+1 (registers) -> the other stage, chunk kc+2 requested
+                if (gap == 0) { combine(); store_v(0, nxt); load_raw(0); load_raw(1); }
+                else if (gap == 1) { store_v(1, nxt); load_raw(2); load_raw(3); }
+                else if (gap == 2) { store_v(2, nxt); load_raw(4); load_raw(5); }
+                else if (gap == 3) { store_v(3, nxt); load_raw(6); load_raw(7); }
+                else if (gap < 8) { store_w(gap - 4, nxt); load_w(gap - 4); }
+                else if (gap == 8) advance();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- output transform along x (in-lane): z[b] = sum_j A^T[b][j] M_ij ----
+    // then along y across the four component-row waves of a quad block, through LDS (the stages are idle after the last barrier)
+    float *mine = smem + (wq * 4 + wi) * 4096 + lane;
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const float m0 = acc[0][c][v], m1 = acc[1][c][v], m2 = acc[2][c][v], m3 = acc[3][c][v];
+            mine[((0 * 2 + c) * 16 + v) * 64] = m0 + m1 + m2;
+            mine[((1 * 2 + c) * 16 + v) * 64] = m1 - m2 - m3;
+        }
+    __syncthreads();
+    const int h = wi & 1, c = wi >> 1;  // this wave finishes quad half h (16 quads) x output tile c (32 columns) of its quad block
+    const int qu = q0 + wq * 32 + 16 * h;  // first quad of the unit (wave-uniform)
+    if (qu >= Q) return;
+    float y[2][2][8];  // [a][b][vv]: output pixel (2 qy + a, 2 qx + b) of quad row (vv & 3) + 8 (vv >> 2) + 4 lh of the unit
+    {
+        const float *src = smem + (wq * 4) * 4096 + lane;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int vv = 0; vv < 8; ++vv) {
+                const int o = ((b * 2 + c) * 16 + 8 * h + vv) * 64;
+                const float z0 = src[o], z1 = src[4096 + o], z2 = src[2 * 4096 + o], z3 = src[3 * 4096 + o];
+                y[0][b][vv] = z0 + z1 + z2;
+                y[1][b][vv] = z1 - z2 - z3;
+            }
+    }
+
+    // ---- epilogue of the unit ----
+    const int img = (int)epi_div((unsigned)qu, (unsigned)QI, p.mg_ohw, p.sh_ohw);
+    const int qr = qu - img * QI;
+    const int qy = qr >> wqs, qxu = qr - (qy << wqs);
+    const int mu = img * HW + 2 * qy * W + 2 * qxu;  // pixel of the unit's first quad (top-left output)
+    const int n = n0 + c * 32 + li;
+    const bool nok = n < p.N;
+    const __amdgpu_buffer_rsrc_t srd_o =
+        __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(p.out), 0, p.M * p.ldc * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srd_r = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(reinterpret_cast<const char *>(p.res ? p.res : p.out)), 0, p.M * p.ldres * 4, 0x00020000);
+    const int vo_o = nok ? (8 * lh * p.ldc + n) * 4 : OOB;   // quad row + 4 lh -> 8 pixels further along x
+    const int vo_r = nok ? (8 * lh * p.ldres + n) * 4 : OOB;
+    float addv = (p.bias && nok) ? p.bias[n] : 0.f;
+    if (p.rowbias && nok) addv += p.rowbias[(size_t)img * p.ld_rowbias + n];
+    // pixel offset (from mu) of quad row vv of the unit, lane-independent part: Wq == 8: two quad rows of 8; else one aligned run
+    auto pix_off = [&](int vv, int a, int b) __attribute__((always_inline)) {
+        const int dq = (vv & 3) + 8 * (vv >> 2);
+        const int base = Wq == 8 ? (vv >> 2) * 2 * W + (vv & 3) * 2 : dq * 2;
+        return mu + base + a * W + b;
+    };
+    float rs[2][2][8];
+    if (p.res) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int vv = 0; vv < 8; ++vv)
+                    rs[a][b][vv] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_r, vo_r, pix_off(vv, a, b) * p.ldres * 4, 0));
+    }
+    float ps[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, pq[2][2] = {{0.f, 0.f}, {0.f, 0.f}};  // partial statistics by (a, vv >> 2)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int vv = 0; vv < 8; ++vv) {
+                float add = addv;
+                if (p.res) add += rs[a][b][vv];
+                const float val = (p.alpha * y[a][b][vv] + add) * p.out_scale;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), srd_o, vo_o, pix_off(vv, a, b) * p.ldc * 4, 0);
+                ps[a][vv >> 2] += val;
+                pq[a][vv >> 2] += val * val;
+            }
+    if (p.qstats) {
+        // the unit's 64 pixels are two 32-row slices of the output matrix: W = 16: its two quad rows (both pixel rows of each);
+        // W = 32 / 64: its two pixel rows (a whole row / an aligned half of one)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            float s = Wq == 8 ? ps[0][g] + ps[1][g] : ps[g][0] + ps[g][1];
+            float q = Wq == 8 ? pq[0][g] + pq[1][g] : pq[g][0] + pq[g][1];
+            if (!nok) { s = 0.f; q = 0.f; }
+            s += __shfl_xor(s, 1); q += __shfl_xor(q, 1);
+            s += __shfl_xor(s, 2); q += __shfl_xor(q, 2);
+            s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
+            if ((li & 3) == 0 && lh == 0 && nok) {
+                const int first = (mu - img * HW) + (Wq == 8 ? g * 2 * W : g * W);  // first pixel of the slice inside the image
+                float2 *o = reinterpret_cast<float2 *>(p.qstats) + ((size_t)img * p.qs_slices + (first >> 5)) * (p.N >> 2) + (n >> 2);
+                o[0] = make_float2(s, q);
+            }
+        }
+    }
+}
+
+// U[n][c/8][i][j][c%8] = (G g G^T)_ij from the packed direct weights w[n][(ky*3 + kx)*Cin + c]; sums in double, one rounding
+__global__ void wino2d_weights_kernel(const float *__restrict__ w, float *__restrict__ u, int N, int Cin) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)N * Cin) return;
+    const int c = (int)(idx % Cin);
+    const long long n = idx / Cin;
+    const float *wr = w + n * 9 * Cin + c;
+    double g[3][3];
+    for (int ky = 0; ky < 3; ++ky)
+        for (int kx = 0; kx < 3; ++kx) g[ky][kx] = wr[(ky * 3 + kx) * Cin];
+    const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    float *ur = u + n * 16 * Cin + (long long)(c / 8) * 128 + (c & 7);
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            double acc = 0;
+            for (int ky = 0; ky < 3; ++ky)
+                for (int kx = 0; kx < 3; ++kx) acc += G[i][ky] * g[ky][kx] * G[j][kx];
+            ur[(i * 4 + j) * 8] = (float)acc;
+        }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------------------
+int launch_wino2d_weights(const float *w, float *u, int N, int Cin, hipStream_t s) {
+    GD_CHECK(w && u && N > 0 && Cin > 0 && Cin % 8 == 0, "wino2d_weights: bad argument (N=%d Cin=%d)", N, Cin);
+    const long long total = (long long)N * Cin;
+    hipLaunchKernelGGL(wino2d_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, u, N, Cin);
+    GD_HIP(hipGetLastError());
+    return 0;
+}
+
+static void w2fill_div(unsigned d, unsigned &magic, unsigned &shift) {
+    unsigned s = 0;
+    while ((1ull << s) < d) ++s;
+    shift = s;
+    magic = (unsigned)((((1ull << 32) * ((1ull << s) - d)) / d) + 1);
+}
+
+// what the kernel can compute at all (p.b_wino is not looked at)
+bool conv3x3_wino2d_shape_ok(const GemmParams &p) {
+    if (p.in_act || p.b_kmajor || p.a_presplit || p.gn_table || p.egn_out) return false;
+    if (p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1 || p.OH != p.H || p.OW != p.W) return false;
+    const int Cin = p.C0 + p.C1;
+    if (Cin % 32 != 0 || (p.C1 > 0 && (p.C0 % 32 != 0 || !p.a1)) || p.K != 9 * Cin) return false;
+    if ((p.W != 16 && p.W != 32 && p.W != 64) || p.H % 2 != 0 || (p.H * p.W / 4) % 32 != 0) return false;
+    if (p.rows_per_image != p.H * p.W || p.M % (p.H * p.W) != 0 || p.N % 4 != 0 || p.N < 32) return false;
+    if (p.qstats && p.qs_slices != p.rows_per_image / 32) return false;
+    if (p.rowbias && p.ld_rowbias <= 0) return false;
+    if ((long long)p.M * p.ldc * 4 + 64 >= (1LL << 31) || (p.res && (long long)p.M * p.ldres * 4 + 64 >= (1LL << 31))) return false;
+    const long long ldmax = p.lda0 > p.lda1 ? p.lda0 : p.lda1;
+    const long long a_bytes = ((long long)p.M + 3 * p.W + 8) * ldmax * 4 + Cin * 4 + 64;
+    return a_bytes < (1LL << 31) && (long long)p.N * 16 * Cin * 4 + 64 < (1LL << 31);
+}
+
+// what the engine sends to it: an eligible shape with at least two workgroups per CU.  GDDIM_NOWINO2=1 routes everything back to the
+// one-dimensional kernel; GDDIM_WINO2_MINBLOCKS overrides the fill criterion (A/B).
+bool conv3x3_wino2d_ok(const GemmParams &p) {
+    static const int off = getenv("GDDIM_NOWINO2") ? atoi(getenv("GDDIM_NOWINO2")) : (getenv("GDDIM_NOWINO") ? atoi(getenv("GDDIM_NOWINO")) : 0);
+    static const int min_blocks = getenv("GDDIM_WINO2_MINBLOCKS") ? atoi(getenv("GDDIM_WINO2_MINBLOCKS")) : 512;
+    if (off || !conv3x3_wino2d_shape_ok(p)) return false;
+    return (long long)((p.M / 4 + 63) / 64) * ((p.N + 63) / 64) >= min_blocks;
+}
+
+const char *conv3x3_wino2d_name() { return "conv3x3_wino2d_f32_kernel"; }
+
+int launch_conv3x3_wino2d(const GemmParams &p_in, hipStream_t s) {
+    GemmParams p = p_in;
+    GD_CHECK(conv3x3_wino2d_shape_ok(p) && p.b_wino, "conv3x3_wino2d: problem not eligible");
+    p.ldb_wino = 16 * (p.C0 + p.C1);
+    if (p.C1 == 0) p.lda1 = 4;
+    w2fill_div((unsigned)(p.H * p.W / 4), p.mg_ohw, p.sh_ohw);  // quads per image
+    p.sh_ow = p.W == 16 ? 3 : p.W == 32 ? 4 : 5;               // log2(W / 2)
+    p.m_tiles = (p.M / 4 + 63) / 64;
+    p.n_tiles = (p.N + 63) / 64;
+    p.flat_tiles = p.m_tiles < 16;
+    const int gx = p.flat_tiles ? p.m_tiles * p.n_tiles : ((p.m_tiles + 7) / 8) * 8 * p.n_tiles;
+    hipLaunchKernelGGL(conv3x3_wino2d_f32_kernel, dim3(gx), dim3(512), 0, s, p);
+    GD_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace gd

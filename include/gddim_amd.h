@@ -256,6 +256,14 @@ int gd_conv2d(const float *x_dev, const float *w_dev, const float *bias_dev, con
 int gd_conv3x3_winograd(const float *x_dev, const float *w_dev, float *u_scratch_dev, const float *bias_dev,
                         const float *res_dev, float *out_dev, int batch, int H, int W, int Cin, int Cout, float alpha,
                         float out_scale, void *stream);
+/* The same convolution through the two-dimensional transform F(2x2, 3x3) (x 2.25 fewer matrix-core products than the direct sum):
+ * u_scratch_dev receives the transformed weights, 16 * Cout * Cin floats.  Shapes: W in {16, 32, 64}, H even, H*W/4 % 32 == 0,
+ * Cin % 32 == 0, Cout % 4 == 0.  What the engine runs for the 3x3 stride-1 convolutions of the 16x16 .. 64x64 levels at production
+ * batch sizes (kernels/conv3x3_wino2d_f32.hip).
+ * Replaces: the same nn.Conv call sites (cld_jax/models/layers.py:66-107). */
+int gd_conv3x3_winograd2d(const float *x_dev, const float *w_dev, float *u_scratch_dev, const float *bias_dev,
+                          const float *res_dev, float *out_dev, int batch, int H, int W, int Cin, int Cout, float alpha,
+                          float out_scale, void *stream);
 /* flax GroupNorm(num_groups, eps=1e-6) (+ swish when act != 0) on NHWC (B,H,W,C).
  * Replaces: nn.GroupNorm + nn.swish call sites (cld_jax/models/layerspp.py:69,196,218). */
 int gd_group_norm(const float *x_dev, const float *scale_dev, const float *bias_dev, float *out_dev, int batch,

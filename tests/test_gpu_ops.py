@@ -199,6 +199,64 @@ def test_conv3x3_winograd_big_tile(dev):
         assert (got[:2].double() - want).abs().max().item() < 2e-5, (B, H, Cin, Cout)
 
 
+WINO2D_CASES = [
+    # B, H, W, Cin, Cout, bias, res
+    (2, 32, 32, 128, 128, True, True),    # the dominant layer shape: 4 tiles per image, 2 N tiles
+    (3, 16, 16, 256, 256, True, True),    # W = 16: a 16-quad unit is two quad rows
+    (1, 64, 64, 32, 68, False, True),     # W = 64: a unit is half a quad row; ragged N tile (68 = 64 + 4); K of one slab
+    (5, 16, 32, 96, 132, True, True),     # non-square image (128 quads per image), Cin = 3 slabs, ragged N
+    (3, 8, 16, 64, 64, False, False),     # 32 quads per image: the last tile holds one image only (ragged M: 96 quads)
+    (2, 24, 32, 32, 32, True, False),     # H * W / 4 = 192 quads per image (not a power of two), N = 32
+]
+
+
+@pytest.mark.parametrize("case", WINO2D_CASES)
+def test_conv3x3_winograd2d_matches_torch_fp64(dev, case):
+    """gd_conv3x3_winograd2d (F(2x2,3x3): 16 products per 2x2 output quad) against the float64 direct convolution; same bar as the
+    one-dimensional kernel: both transforms are additions, the 1/2 and 1/4 of the weight transform are exact."""
+    from gddim_amd import ops
+    B, H, W, Cin, Cout, use_bias, use_res = case
+    g = torch.Generator().manual_seed(sum(case[:5]) + 1)
+    x = torch.randn(B, H, W, Cin, generator=g)
+    w = torch.randn(3, 3, Cin, Cout, generator=g) / math.sqrt(9 * Cin)
+    bias = torch.randn(Cout, generator=g) if use_bias else None
+    res = torch.randn(B, H, W, Cout, generator=g) if use_res else None
+    wp = w.permute(3, 0, 1, 2).reshape(Cout, 9 * Cin).contiguous()
+    got = ops.conv3x3_winograd2d(x.to(dev), wp.to(dev), None if bias is None else bias.to(dev), None if res is None else res.to(dev),
+                                 alpha=1.25, out_scale=0.7).cpu().double()
+    want = 1.25 * F.conv2d(x.permute(0, 3, 1, 2).double(), w.permute(3, 2, 0, 1).double(), padding=1).permute(0, 2, 3, 1)
+    if bias is not None:
+        want = want + bias.double()
+    if res is not None:
+        want = want + res.double()
+    want = want * 0.7
+    direct = ops.conv2d(x.to(dev), wp.to(dev), None if bias is None else bias.to(dev), None if res is None else res.to(dev),
+                        alpha=1.25, out_scale=0.7).cpu().double()
+    err, err_direct = (got - want).abs().max().item(), (direct - want).abs().max().item()
+    print("wino2d", case, "err %.2e direct %.2e" % (err, err_direct))
+    assert err < 2e-5 and err < 4 * err_direct + 1e-6, (case, err, err_direct)
+
+
+def test_conv3x3_winograd2d_impulse_and_rejects(dev):
+    """Impulses with an asymmetric kernel at corners, edges and odd / even positions (catches a swapped tap, parity or component
+    order in either direction); shapes the kernel cannot take are refused loudly."""
+    from gddim_amd import ops
+    from gddim_amd._abi import GddimError
+    B, H, W, Cin, Cout = 1, 16, 16, 32, 64
+    w = torch.arange(3 * 3 * Cin * Cout, dtype=torch.float32).reshape(3, 3, Cin, Cout) / 1000.0
+    wp = w.permute(3, 0, 1, 2).reshape(Cout, 9 * Cin).contiguous()
+    for (y, xx, c) in [(0, 0, 5), (3, 5, 17), (15, 15, 31), (4, 2, 0), (15, 0, 9), (0, 15, 3), (7, 8, 12), (8, 7, 1)]:
+        x = torch.zeros(B, H, W, Cin)
+        x[0, y, xx, c] = 1.0
+        got = ops.conv3x3_winograd2d(x.to(dev), wp.to(dev)).cpu().double()
+        want = F.conv2d(x.permute(0, 3, 1, 2).double(), w.permute(3, 2, 0, 1).double(), padding=1).permute(0, 2, 3, 1)
+        assert (got - want).abs().max() < 1e-4 * want.abs().max(), (y, xx, c)
+    for shape in [(1, 8, 8, 32, 64), (1, 16, 16, 24, 64), (1, 15, 16, 32, 64), (1, 4, 16, 32, 64)]:
+        b_, h_, w_, ci, co = shape
+        with pytest.raises(GddimError):
+            ops.conv3x3_winograd2d(torch.zeros(b_, h_, w_, ci, device=dev), torch.zeros(co, 9 * ci, device=dev))
+
+
 def test_conv3x3_winograd_impulse_and_rejects(dev):
     """An impulse input with an asymmetric kernel (catches a swapped tap, pixel-parity or component order), at an image corner and
     at an odd column; shapes the kernel cannot take (odd W, Cin % 32 != 0) are refused loudly."""
