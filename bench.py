@@ -98,7 +98,7 @@ def main():
     ap.add_argument("--image-size", type=int, default=32)
     ap.add_argument("--workload", choices=["cld", "blur"], default="cld", help="cld = BASELINE configs 2/4/5, blur = config 3")
     ap.add_argument("--precision", choices=["fp32", "bf16x3"], default="fp32",
-                    help="fp32 = fp32 operands on the fp32 matrix core, 3x3 convolutions through Winograd F(2,3) (headline); bf16x3 = split-precision weight contractions on the bf16 matrix core")
+                    help="fp32 = fp32 operands on the fp32 matrix core, 3x3 convolutions through Winograd F(2x2,3x3) / F(2,3) (headline); bf16x3 = split-precision weight contractions on the bf16 matrix core")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--graph", choices=["step", "loop", "none"], default="step",
                     help="step: one captured hipGraph per NFE step, replayed (default); loop: ONE graph for the whole sampler call; none: eager launches")
@@ -225,7 +225,7 @@ def main():
         # pipe the kernel keeps busy = ISSUED MFMA flops / time / peak (<= 1): Winograd F(2,3) issues 2/3 of the algorithmic
         # products, bf16x3 issues 3 bf16 MFMAs per algorithmic product.  `algorithmic_frac` = achieved / peak (may exceed 1
         # for Winograd: the kernel does less work than the direct algorithm).
-        issue_ratio = (2.0 / 3.0) if "wino" in dom["name"] else (3.0 if "bf16x3" in dom["name"] else 1.0)
+        issue_ratio = (4.0 / 9.0) if "wino2d" in dom["name"] else (2.0 / 3.0) if "wino" in dom["name"] else (3.0 if "bf16x3" in dom["name"] else 1.0)
         result["roofline"] = {"kernel": dom["name"], "bound": "mfma", "achieved": achieved, "peak": peak,
                               "unit": "TFLOP/s", "frac": achieved * issue_ratio / peak, "traffic": hbm_traffic(dom["name"]),
                               "algorithmic_frac": achieved / peak, "issued": achieved * issue_ratio,
@@ -233,7 +233,10 @@ def main():
                               "flops_per_launch": dom["flops"] / max(1, dom["launches"]),
                               "share_of_gpu_time": dom["ms"] / tot_ms if tot_ms else None,
                               "traffic_source": "committed rocprofv3 --pmc passes of this command (profiles/), not this run"}
-        if "wino" in dom["name"]:
+        if "wino2d" in dom["name"]:
+            result["roofline"]["note"] = ("Winograd F(2x2,3x3): achieved = algorithmic flops of the direct convolution / time; the kernel "
+                                          "issues 16 products per 2x2 output quad instead of 36, i.e. 4/9 of that; frac = issued / dense fp32 MFMA peak")
+        elif "wino" in dom["name"]:
             result["roofline"]["note"] = ("Winograd F(2,3) along x: achieved = algorithmic flops of the direct convolution / time; "
                                           "issued MFMA flops are 2/3 of that; frac = issued / dense fp32 MFMA peak")
         result["kernel_breakdown"] = [
