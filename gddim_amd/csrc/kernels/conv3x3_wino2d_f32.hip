@@ -27,7 +27,7 @@
 // half h x output tile c: bias, per-image bias row, residual, scale, store, fused GroupNorm quad statistics.
 // Shapes: W in {16, 32, 64} (W/2 a power of two >= 8, so a 16-quad unit is whole quad rows or an aligned piece of one and the 32-row
 // statistics slices stay inside one wave), H even, H W / 4 a multiple of 32, Cin % 32 == 0 (two-source concat: C0 % 32 == 0), N % 4 == 0.
-// Weights arrive as U[n][Cin/8][i][j][8] (launch_wino2d_weights), 16/9 of the direct size.
+// Weights arrive as U[n][Cin/8][i][j][8] (launch_wino2d_weights; component row i = 2 negated), 16/9 of the direct size.
 #include <cstdio>
 #include <cstdlib>
 
@@ -40,6 +40,11 @@ namespace gd {
 typedef float w2f32x16 __attribute__((ext_vector_type(16)));
 typedef float w2f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int w2u32x4 __attribute__((ext_vector_type(4)));
+
+#ifndef W2_ABL
+#define W2_ABL 0  // timing ablations (results wrong): 1 no global loads in the K loop, 2 no LDS stores, 4 no fragment reads, 8 no barrier,
+                  // 16 no transform arithmetic
+#endif
 
 constexpr int W2_LD = 132;             // LDS row stride (floats): 16 components x 8 channels + 4 pad
 constexpr int W2_STAGE = 128 * W2_LD;  // floats per stage: V[64 quads] | U[64 outputs]
@@ -89,11 +94,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_f32_kernel(const GemmPa
     const __amdgpu_buffer_rsrc_t srd_b = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char *>(reinterpret_cast<const char *>(p.b_wino)), 0, p.N * p.ldb_wino * 4, 0x00020000);
 
-    // ---- staging role: (quad ql, component row si, channel half hq).  B^T row si combines input rows (ra, rb) of the patch
-    // with signs (sa, sb):  0: r0 - r2,  1: r1 + r2,  2: r2 - r1,  3: r1 - r3 ----
+    // ---- staging role: (quad ql, component row si, channel half hq).  B^T row si combines input rows (ra, rb) of the patch:
+    // 0: r0 - r2,  1: r1 + r2,  2: r2 - r1,  3: r1 - r3.  Row 2 is staged NEGATED (r1 - r2) and so is row 2 of the transformed
+    // weights (wino2d_weights_kernel): the products are unchanged and every combination is ra + sb rb, one FMA per element.
+    // The four component rows of a quad sit in adjacent lanes: they share input rows 1 and 2, i.e. cache lines, within one load. ----
     const int ql = tid >> 3, si = (tid >> 1) & 3, hq = tid & 1;
     const int ra = si == 0 ? 0 : 1, rb = si == 3 ? 3 : 2;
-    const float sa = si == 2 ? -1.f : 1.f, sb = (si == 0 || si == 3) ? -1.f : 1.f;
+    const float sb = si == 1 ? 1.f : -1.f;
     int pix = 0;          // pixel index of the patch origin (2 qy - 1, 2 qx - 1); may be "negative" by at most W + 1: the bias covers it
     unsigned bad = 0xFFu; // bit 4 t + s: pixel s of the thread's row t lies outside the image (or the quad is past the batch)
     {
@@ -142,16 +149,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_f32_kernel(const GemmPa
 
     w2f32x4 rr[8], wb[4], cm[4];
     auto load_raw = [&](int k) __attribute__((always_inline)) {
+        if ((W2_ABL & 1) && s_kc >= 2) return;
         const int kill = s_kc < nk ? 0 : OOB;
         if (s_first) rr[k] = w2_load16(srd_a0, vo[k] | kill, s_c * 4);
         else rr[k] = w2_load16(srd_a1, vo[k] | kill, (s_c - p.C0) * 4);
     };
     auto load_w = [&](int k) __attribute__((always_inline)) {
+        if ((W2_ABL & 1) && s_kc >= 2) return;
         wb[k] = w2_load16(srd_b, s_kc < nk ? bvo : OOB, (s_kc * 128 + k * 32) * 4);
     };
     auto combine = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) cm[s] = sa * rr[s] + sb * rr[4 + s];
+        for (int s = 0; s < 4; ++s) cm[s] = rr[s] + sb * rr[4 + s];
     };
     auto store_v = [&](int j, float *st) __attribute__((always_inline)) {
         w2f32x4 v;
@@ -159,9 +168,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_f32_kernel(const GemmPa
         else if (j == 1) v = cm[1] + cm[2];
         else if (j == 2) v = cm[2] - cm[1];
         else v = cm[1] - cm[3];
+        if (W2_ABL & 16) v = cm[j];
+        if (W2_ABL & 2) { asm volatile("" ::"v"(v)); return; }
         *reinterpret_cast<w2f32x4 *>(&st[v_lds + j * 8]) = v;
     };
     auto store_w = [&](int k, float *st) __attribute__((always_inline)) {
+        if (W2_ABL & 2) { asm volatile("" ::"v"(wb[k])); return; }
         *reinterpret_cast<w2f32x4 *>(&st[b_lds + k * 32]) = wb[k];
     };
 
@@ -209,7 +221,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_f32_kernel(const GemmPa
                 acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j & 1][jj], bf[j & 1][1][jj], acc[j][1], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 const int gap = j * 4 + jj;
-                if (jj == 0 && j < 3) {  // fragments of the next component, one component ahead of their use
+                if (jj == 0 && j < 3 && !(W2_ABL & 4)) {  // fragments of the next component, one component ahead of their use
                     af[(j + 1) & 1] = *reinterpret_cast<const w2f32x4 *>(cur + a_off + (j + 1) * 8);
                     bf[(j + 1) & 1][0] = *reinterpret_cast<const w2f32x4 *>(cur + b_off + (j + 1) * 8);
                     bf[(j + 1) & 1][1] = *reinterpret_cast<const w2f32x4 *>(cur + b_off + 32 * W2_LD + (j + 1) * 8);
@@ -224,7 +236,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_f32_kernel(const GemmPa
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        __syncthreads();
+        if (!(W2_ABL & 8)) __syncthreads();
     }
 
     // ---- output transform along x (in-lane): z[b] = sum_j A^T[b][j] M_ij ----
@@ -338,7 +350,7 @@ __global__ void wino2d_weights_kernel(const float *__restrict__ w, float *__rest
             double acc = 0;
             for (int ky = 0; ky < 3; ++ky)
                 for (int kx = 0; kx < 3; ++kx) acc += G[i][ky] * g[ky][kx] * G[j][kx];
-            ur[(i * 4 + j) * 8] = (float)acc;
+            ur[(i * 4 + j) * 8] = (float)(i == 2 ? -acc : acc);  // row 2 negated, like the staged activations (see the kernel)
         }
 }
 

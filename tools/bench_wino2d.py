@@ -18,6 +18,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--only2d", action="store_true", help="time the two-dimensional kernel only (ablation builds: results are wrong by construction)")
     args = ap.parse_args()
     import torch
     from gddim_amd import ops
@@ -36,9 +37,10 @@ def main():
         got = ops.conv3x3_winograd2d(x, w, b, r, out_scale=0.7, u_scratch=u2)
         err = float((got - ref).abs().max()) / float(ref.abs().max())
         line = "H=%2d %3d->%3d  2d vs direct rel max diff %.2e " % (H, Cin, Cout, err)
-        for name, fn in (("direct", lambda: ops.conv2d(x, w, b, r, out_scale=0.7)),
-                         ("wino1d", lambda: ops.conv3x3_winograd(x, w, b, r, out_scale=0.7, u_scratch=u1)),
-                         ("wino2d", lambda: ops.conv3x3_winograd2d(x, w, b, r, out_scale=0.7, u_scratch=u2))):
+        variants = (("direct", lambda: ops.conv2d(x, w, b, r, out_scale=0.7)),
+                    ("wino1d", lambda: ops.conv3x3_winograd(x, w, b, r, out_scale=0.7, u_scratch=u1)),
+                    ("wino2d", lambda: ops.conv3x3_winograd2d(x, w, b, r, out_scale=0.7, u_scratch=u2)))
+        for name, fn in (variants[2:] if args.only2d else variants):
             fn()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -51,7 +53,7 @@ def main():
             line += " %s %7.3f ms %6.1f TF" % (name, ms, fl / ms / 1e9)
         tot_fl += fl * cnt
         print(line, flush=True)
-    print("per U-Net eval in these layers: " + ", ".join("%s %.1f ms (%.1f TF alg.)" % (k, v, tot_fl / v / 1e9) for k, v in tot.items()))
+    print("per U-Net eval in these layers: " + ", ".join("%s %.1f ms (%.1f TF alg.)" % (k, v, tot_fl / v / 1e9) for k, v in tot.items() if v > 0))
 
 
 if __name__ == "__main__":
