@@ -257,8 +257,10 @@ static bool egn_fused(gd_engine *e, const Bind &b, int batch, int gemm_index) {
             GemmParams g{};
             const int z = fill_gemm(e, op, b, batch, g);
             fill_egn(e, op, b, batch, g);
+            const bool wino2 = z == 1 && op.w_slot >= 0 && e->wwino2 && e->wino2_off[op.w_slot] >= 0;
             const bool wino = z == 1 && op.w_slot >= 0 && e->wwino && e->wino_off[op.w_slot] >= 0 && conv3x3_wino_ok(g);
-            ok[i] = (wino ? conv3x3_wino_egn_ok(g) : igemm_egn_ok(g, z)) ? 1 : 0;
+            if (wino2 && conv3x3_wino2d_ok(g)) ok[i] = 1;  // (its shape test covers the egn_* fields)
+            else ok[i] = (wino ? conv3x3_wino_egn_ok(g) : igemm_egn_ok(g, z)) ? 1 : 0;
         }
         it = e->egn_ok.emplace(batch, std::move(ok)).first;
     }
@@ -582,7 +584,7 @@ static int build_wino_weights(gd_engine *e) {
     long long total2 = 0;
     for (const Op &op : P.ops) {
         if (op.kind != OP_GEMM || op.w_slot < 0 || e->wino_off[op.w_slot] < 0 || e->wino2_off[op.w_slot] >= 0) continue;
-        if ((op.W != 16 && op.W != 32 && op.W != 64) || op.H % 2 != 0 || (op.H * op.W / 4) % 32 != 0) continue;
+        if ((op.W != 8 && op.W != 16 && op.W != 32 && op.W != 64) || op.H % 2 != 0 || (op.H * op.W / 4) % 16 != 0) continue;
         e->wino2_off[op.w_slot] = total2;
         total2 += (long long)dims[op.w_slot].first * 16 * dims[op.w_slot].second;
     }

@@ -25,8 +25,8 @@
 // Epilogue: the x-direction output transform is in-lane; the y-direction one combines the four component rows, which live in four
 // waves: they exchange their 64 partial registers through the (now idle) LDS stages, then wave (h, c) of a quad block finishes quad
 // half h x output tile c: bias, per-image bias row, residual, scale, store, fused GroupNorm quad statistics.
-// Shapes: W in {16, 32, 64} (W/2 a power of two >= 8, so a 16-quad unit is whole quad rows or an aligned piece of one and the 32-row
-// statistics slices stay inside one wave), H even, H W / 4 a multiple of 32, Cin % 32 == 0 (two-source concat: C0 % 32 == 0), N % 4 == 0.
+// Shapes: W in {8, 16, 32, 64} (W/2 a power of two, so a 16-quad unit is whole quad rows or an aligned piece of one and the 32-row
+// statistics slices stay inside one wave), H even, H W / 4 a multiple of 16, Cin % 32 == 0 (two-source concat: C0 % 32 == 0), N % 4 == 0.
 // Weights arrive as U[n][Cin/8][i][j][8] (launch_wino2d_weights; component row i = 2 negated), 16/9 of the direct size.
 #include <cstdio>
 #include <cstdlib>
@@ -80,9 +80,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_f32_kernel(const GemmPa
     const int q0 = mtile * 64, n0 = ntile * 64;
 
     const int W = p.W, H = p.H, HW = H * W;
-    const int Wq = W >> 1;        // quads per quad row: 8, 16 or 32
+    const int Wq = W >> 1;        // quads per quad row: 4, 8, 16 or 32
     const int wqs = p.sh_ow;      // log2(Wq) (launch_conv3x3_wino2d)
-    const int QI = HW >> 2;       // quads per image (a multiple of 32)
+    const int QI = HW >> 2;       // quads per image (a multiple of 16)
     const int Q = p.M >> 2;       // quads in the batch
     const int Cin = p.C0 + p.C1;
     const int a_imgs = p.M / HW;
@@ -279,14 +279,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_f32_kernel(const GemmPa
         __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(p.out), 0, p.M * p.ldc * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t srd_r = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char *>(reinterpret_cast<const char *>(p.res ? p.res : p.out)), 0, p.M * p.ldres * 4, 0x00020000);
-    const int vo_o = nok ? (8 * lh * p.ldc + n) * 4 : OOB;   // quad row + 4 lh -> 8 pixels further along x
-    const int vo_r = nok ? (8 * lh * p.ldres + n) * 4 : OOB;
+    // quad (vv & 3) + 8 (vv >> 2) + 4 lh of the unit: the half-wave adds 4 quads = 8 pixels along x, or, on 8-wide images (4 quads
+    // per quad row), one quad row = 2 W pixels
+    const int lane_px = Wq == 4 ? lh * 2 * W : 8 * lh;
+    const int vo_o = nok ? (lane_px * p.ldc + n) * 4 : OOB;
+    const int vo_r = nok ? (lane_px * p.ldres + n) * 4 : OOB;
     float addv = (p.bias && nok) ? p.bias[n] : 0.f;
     if (p.rowbias && nok) addv += p.rowbias[(size_t)img * p.ld_rowbias + n];
-    // pixel offset (from mu) of quad row vv of the unit, lane-independent part: Wq == 8: two quad rows of 8; else one aligned run
+    // pixel offset (from mu) of quad vv of the unit, lane-independent part: W = 8: four quad rows of 4 (vv >> 2 selects a pair of them),
+    // W = 16: two quad rows of 8; else one aligned run of 16 quads
     auto pix_off = [&](int vv, int a, int b) __attribute__((always_inline)) {
         const int dq = (vv & 3) + 8 * (vv >> 2);
-        const int base = Wq == 8 ? (vv >> 2) * 2 * W + (vv & 3) * 2 : dq * 2;
+        const int base = Wq == 4 ? (vv >> 2) * 4 * W + (vv & 3) * 2 : Wq == 8 ? (vv >> 2) * 2 * W + (vv & 3) * 2 : dq * 2;
         return mu + base + a * W + b;
     };
     float rs[2][2][8];
@@ -300,6 +304,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_f32_kernel(const GemmPa
                     rs[a][b][vv] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_r, vo_r, pix_off(vv, a, b) * p.ldres * 4, 0));
     }
     float ps[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, pq[2][2] = {{0.f, 0.f}, {0.f, 0.f}};  // partial statistics by (a, vv >> 2)
+    float vals[2][2][8];  // finished outputs (kept for the epilogue GroupNorm)
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -309,23 +314,49 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_f32_kernel(const GemmPa
                 float add = addv;
                 if (p.res) add += rs[a][b][vv];
                 const float val = (p.alpha * y[a][b][vv] + add) * p.out_scale;
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), srd_o, vo_o, pix_off(vv, a, b) * p.ldc * 4, 0);
+                vals[a][b][vv] = val;
+                if (!p.egn_skip_raw)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), srd_o, vo_o, pix_off(vv, a, b) * p.ldc * 4, 0);
                 ps[a][vv >> 2] += val;
                 pq[a][vv >> 2] += val * val;
             }
+    if (p.egn_out) {
+        // GroupNorm (+ swish) of the output, here (plan.h: Op::egn_peer): rows_per_image == 64, so this unit is exactly one image x 32
+        // columns; a group is egn_cpg consecutive columns = consecutive lanes
+        float gsum = (ps[0][0] + ps[0][1]) + (ps[1][0] + ps[1][1]), gsq = (pq[0][0] + pq[0][1]) + (pq[1][0] + pq[1][1]);
+        gsum += __shfl_xor(gsum, 32); gsq += __shfl_xor(gsq, 32);
+        for (int o = 1; o < p.egn_cpg; o <<= 1) { gsum += __shfl_xor(gsum, o); gsq += __shfl_xor(gsq, o); }
+        const float inv_n = 1.0f / (64.0f * (float)p.egn_cpg);
+        const float mean = gsum * inv_n;
+        const float rstd = rsqrtf(gsq * inv_n - mean * mean + 1e-6f);
+        const float ga = nok ? p.egn_gamma[n] : 0.f, be = nok ? p.egn_beta[n] : 0.f;
+        const float sc = rstd * ga, sh = be - mean * rstd * ga;
+        const __amdgpu_buffer_rsrc_t srd_g =
+            __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(p.egn_out), 0, p.M * p.ldc * 4, 0x00020000);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int vv = 0; vv < 8; ++vv) {
+                    float t = vals[a][b][vv] * sc + sh;
+                    if (p.egn_act) t = swish_e(t);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, t), srd_g, vo_o, pix_off(vv, a, b) * p.ldc * 4, 0);
+                }
+    }
     if (p.qstats) {
-        // the unit's 64 pixels are two 32-row slices of the output matrix: W = 16: its two quad rows (both pixel rows of each);
-        // W = 32 / 64: its two pixel rows (a whole row / an aligned half of one)
+        // the unit's 64 pixels are two 32-row slices of the output matrix: W = 8 / 16: its quads with vv >> 2 = 0 / 1 (two quad rows / one
+        // quad row, both pixel rows of each); W = 32 / 64: its two pixel rows (a whole row / an aligned half of one)
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
-            float s = Wq == 8 ? ps[0][g] + ps[1][g] : ps[g][0] + ps[g][1];
-            float q = Wq == 8 ? pq[0][g] + pq[1][g] : pq[g][0] + pq[g][1];
+            float s = Wq <= 8 ? ps[0][g] + ps[1][g] : ps[g][0] + ps[g][1];
+            float q = Wq <= 8 ? pq[0][g] + pq[1][g] : pq[g][0] + pq[g][1];
             if (!nok) { s = 0.f; q = 0.f; }
             s += __shfl_xor(s, 1); q += __shfl_xor(q, 1);
             s += __shfl_xor(s, 2); q += __shfl_xor(q, 2);
             s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
             if ((li & 3) == 0 && lh == 0 && nok) {
-                const int first = (mu - img * HW) + (Wq == 8 ? g * 2 * W : g * W);  // first pixel of the slice inside the image
+                const int first = (mu - img * HW) + (Wq <= 8 ? g * 32 : g * W);  // first pixel of the slice inside the image
                 float2 *o = reinterpret_cast<float2 *>(p.qstats) + ((size_t)img * p.qs_slices + (first >> 5)) * (p.N >> 2) + (n >> 2);
                 o[0] = make_float2(s, q);
             }
@@ -372,11 +403,13 @@ static void w2fill_div(unsigned d, unsigned &magic, unsigned &shift) {
 
 // what the kernel can compute at all (p.b_wino is not looked at)
 bool conv3x3_wino2d_shape_ok(const GemmParams &p) {
-    if (p.in_act || p.b_kmajor || p.a_presplit || p.gn_table || p.egn_out) return false;
+    if (p.in_act || p.b_kmajor || p.a_presplit || p.gn_table) return false;
+    if (p.egn_out && (p.rows_per_image != 64 || p.N % p.egn_cpg != 0 ||
+                      (p.egn_cpg != 4 && p.egn_cpg != 8 && p.egn_cpg != 16 && p.egn_cpg != 32))) return false;
     if (p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1 || p.OH != p.H || p.OW != p.W) return false;
     const int Cin = p.C0 + p.C1;
     if (Cin % 32 != 0 || (p.C1 > 0 && (p.C0 % 32 != 0 || !p.a1)) || p.K != 9 * Cin) return false;
-    if ((p.W != 16 && p.W != 32 && p.W != 64) || p.H % 2 != 0 || (p.H * p.W / 4) % 32 != 0) return false;
+    if ((p.W != 8 && p.W != 16 && p.W != 32 && p.W != 64) || p.H % 2 != 0 || (p.H * p.W / 4) % 16 != 0) return false;
     if (p.rows_per_image != p.H * p.W || p.M % (p.H * p.W) != 0 || p.N % 4 != 0 || p.N < 32) return false;
     if (p.qstats && p.qs_slices != p.rows_per_image / 32) return false;
     if (p.rowbias && p.ld_rowbias <= 0) return false;
@@ -390,7 +423,7 @@ bool conv3x3_wino2d_shape_ok(const GemmParams &p) {
 // one-dimensional kernel; GDDIM_WINO2_MINBLOCKS overrides the fill criterion (A/B).
 bool conv3x3_wino2d_ok(const GemmParams &p) {
     static const int off = getenv("GDDIM_NOWINO2") ? atoi(getenv("GDDIM_NOWINO2")) : (getenv("GDDIM_NOWINO") ? atoi(getenv("GDDIM_NOWINO")) : 0);
-    static const int min_blocks = getenv("GDDIM_WINO2_MINBLOCKS") ? atoi(getenv("GDDIM_WINO2_MINBLOCKS")) : 512;
+    static const int min_blocks = getenv("GDDIM_WINO2_MINBLOCKS") ? atoi(getenv("GDDIM_WINO2_MINBLOCKS")) : 256;
     if (off || !conv3x3_wino2d_shape_ok(p)) return false;
     return (long long)((p.M / 4 + 63) / 64) * ((p.N + 63) / 64) >= min_blocks;
 }
@@ -403,7 +436,7 @@ int launch_conv3x3_wino2d(const GemmParams &p_in, hipStream_t s) {
     p.ldb_wino = 16 * (p.C0 + p.C1);
     if (p.C1 == 0) p.lda1 = 4;
     w2fill_div((unsigned)(p.H * p.W / 4), p.mg_ohw, p.sh_ohw);  // quads per image
-    p.sh_ow = p.W == 16 ? 3 : p.W == 32 ? 4 : 5;               // log2(W / 2)
+    p.sh_ow = p.W == 8 ? 2 : p.W == 16 ? 3 : p.W == 32 ? 4 : 5;  // log2(W / 2)
     p.m_tiles = (p.M / 4 + 63) / 64;
     p.n_tiles = (p.N + 63) / 64;
     p.flat_tiles = p.m_tiles < 16;

@@ -110,9 +110,9 @@ def test_production_batch_kernels_match_oracle(native_lib):
     # short-K GEMMs (1x1 convolutions, NIN, attention products) on the persistent kernel, the 4x4 level on the split-K tile
     assert "igemm_f32_pers_kernel<128,128,2,4>" in seen["fp32"] and "igemm_f32_fast_kernel<128,64,4,2,false>" in seen["fp32"]
     assert "igemm_f32_fast_kernel<64,64,2,2,false,false,4>" in seen["fp32"]
-    # the 3x3 stride-1 convolutions of the 32x32 / 16x16 levels run through the two-dimensional Winograd kernel F(2x2,3x3), those of
-    # the 8x8 level through the one-dimensional F(2,3) kernel
-    assert {"conv3x3_wino2d_f32_kernel", "conv3x3_wino_f32_kernel<64,64>"} <= seen["fp32"]
+    # the 3x3 stride-1 convolutions of the 32x32 / 16x16 / 8x8 levels run through the two-dimensional Winograd kernel F(2x2,3x3)
+    # (and only those of the 4x4 level through the direct kernel: no 3x3 stride-1 launch is left on the generic 128x128 tile)
+    assert "conv3x3_wino2d_f32_kernel" in seen["fp32"] and not any(n.startswith("conv3x3_wino_f32_kernel") for n in seen["fp32"])
     assert "igemm_bf16x3_kernel<256,128,4,2>" in seen["bf16x3"]
     assert "igemm_bf16x3_kernel<256,128,4,2,act>" in seen["bf16x3"]  # attention products with both operands split in the kernel
     assert "conv3x3_halo_bf16x3_kernel<gn>" in seen["bf16x3"] and "gn_table" in seen["bf16x3"]  # the fused-GroupNorm variant

@@ -207,6 +207,9 @@ WINO2D_CASES = [
     (5, 16, 32, 96, 132, True, True),     # non-square image (128 quads per image), Cin = 3 slabs, ragged N
     (3, 8, 16, 64, 64, False, False),     # 32 quads per image: the last tile holds one image only (ragged M: 96 quads)
     (2, 24, 32, 32, 32, True, False),     # H * W / 4 = 192 quads per image (not a power of two), N = 32
+    (6, 8, 8, 64, 96, True, True),        # W = 8: a 16-quad unit is a whole 8x8 image (four quad rows); ragged M (96 quads), ragged N
+    (3, 16, 8, 32, 64, False, True),      # W = 8, H = 16: two units per image
+    (5, 4, 16, 32, 64, True, True),       # 16 quads per image: every unit is a whole (4 x 16) image
 ]
 
 
@@ -251,7 +254,7 @@ def test_conv3x3_winograd2d_impulse_and_rejects(dev):
         got = ops.conv3x3_winograd2d(x.to(dev), wp.to(dev)).cpu().double()
         want = F.conv2d(x.permute(0, 3, 1, 2).double(), w.permute(3, 2, 0, 1).double(), padding=1).permute(0, 2, 3, 1)
         assert (got - want).abs().max() < 1e-4 * want.abs().max(), (y, xx, c)
-    for shape in [(1, 8, 8, 32, 64), (1, 16, 16, 24, 64), (1, 15, 16, 32, 64), (1, 4, 16, 32, 64)]:
+    for shape in [(1, 4, 4, 32, 64), (1, 16, 16, 24, 64), (1, 15, 16, 32, 64), (1, 2, 16, 32, 64), (1, 12, 8, 32, 64)]:
         b_, h_, w_, ci, co = shape
         with pytest.raises(GddimError):
             ops.conv3x3_winograd2d(torch.zeros(b_, h_, w_, ci, device=dev), torch.zeros(co, 9 * ci, device=dev))

@@ -111,8 +111,8 @@ def test_unet_ddpmpp_style_matches_oracle(native_lib, nf, nrb, size):
 
 
 def test_unet_64x64_winograd_levels_match_oracle(native_lib):
-    """BASELINE config 5 geometry (64x64 input, nf = 128): at batch 16 the 64x64 level runs the two-dimensional Winograd kernel and a
-    lower level a one-dimensional 64-pair tile (asserted from the engine profile).  Images are independent units: the first image of the batch against the
+    """BASELINE config 5 geometry (64x64 input, nf = 128): at batch 16 the upper levels run the two-dimensional Winograd kernel (asserted
+    from the engine profile), the lower ones the direct kernel.  Images are independent units: the first image of the batch against the
     float64 oracle of that image (bar: 4x the float32 oracle's own error), and against the same image evaluated alone (direct kernels)."""
     from gddim_amd.engine import Engine
     cfg = tiny_config("cld", nf=128, num_res_blocks=1, image_size=64, ch_mult=(1, 2, 2, 2), attn=(16,))
@@ -136,7 +136,7 @@ def test_unet_64x64_winograd_levels_match_oracle(native_lib):
     eng.close()
     err = np.abs(got[:1] - want64).max() / scale
     print("64x64 B=16: |hip-f64| %.3e (float32 oracle %.3e), batch vs alone %.3e" % (err, e_f32, np.abs(got[:1] - alone).max() / scale))
-    # the 64x64 level has enough quads for the two-dimensional Winograd kernel, a lower level still runs a one-dimensional tile
-    assert "conv3x3_wino2d_f32_kernel" in seen and any(k.startswith("conv3x3_wino_f32_kernel<64,") for k in seen), seen
+    # the 64x64 and 32x32 levels have enough quads (>= 256 tiles) for the two-dimensional Winograd kernel
+    assert "conv3x3_wino2d_f32_kernel" in seen, seen
     assert np.isfinite(got).all() and err < max(4 * e_f32, 2e-5), (err, e_f32)
     assert np.abs(got[:1] - alone).max() / scale < 2e-5

@@ -11,6 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 SHAPES = [  # H, Cin, Cout, count per U-Net eval
     (32, 128, 128, 25), (32, 256, 128, 8), (32, 256, 256, 2), (32, 384, 128, 1),
     (16, 256, 256, 26), (16, 512, 256, 8), (16, 384, 256, 1), (16, 128, 256, 1), (16, 128, 128, 2),
+    (8, 256, 256, 29), (8, 512, 256, 9),
 ]
 
 
