@@ -1,6 +1,6 @@
 #!/bin/bash
 # timing ablations of the 2-D Winograd kernel (tools/build_variant.py w2abl<mask> ... -DW2_ABL=<mask>), same box
-for t in "" 1 2 3 4 8 11 16; do
+for t in "" ${ABLS:-1 2 3 4 8 11 16}; do
   lib=""; [ -n "$t" ] && lib=gddim_amd/libgddim_w2abl$t.so
   echo "ABL=${t:-0}: $(GDDIM_LIB=$lib python tools/bench_wino2d.py --only2d 2>/dev/null | tail -1)"
 done
