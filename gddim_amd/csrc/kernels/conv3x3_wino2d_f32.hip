@@ -27,9 +27,10 @@
 // half h x output tile c: bias, per-image bias row, residual, scale, store, fused GroupNorm quad statistics.
 // Shapes: W in {8, 16, 32, 64} (W/2 a power of two, so a 16-quad unit is whole quad rows or an aligned piece of one and the 32-row
 // statistics slices stay inside one wave), H even, H W / 4 a multiple of 16, Cin % 32 == 0 (two-source concat: C0 % 32 == 0), N % 4 == 0.
-// Weights arrive as U[n][Cin/8][i][j][8] (launch_wino2d_weights; component row i = 2 negated), 16/9 of the direct size.
+// Weights arrive as U[n][Cin/8][i][j][8] (launch_wino2d_weights; component row i = 3 negated), 16/9 of the direct size.
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #include "../common.h"
 #include "act.h"
@@ -47,7 +48,9 @@ typedef unsigned int w2u32x4 __attribute__((ext_vector_type(4)));
 #endif
 
 constexpr int W2_LD = 132;             // LDS row stride (floats): 16 components x 8 channels + 4 pad
-constexpr int W2_STAGE = 128 * W2_LD;  // floats per stage: V[64 quads] | U[64 outputs]
+constexpr int W2_HALF = 64 * W2_LD;    // floats per operand stage.  LDS image: V stage 0 | V stage 1 | U stage 0 | U stage 1, so that the
+                                       // stage of an access is an immediate offset (< 64 KB) on a per-thread base address
+constexpr int W2_STAGE = 2 * W2_HALF;
 
 __device__ __forceinline__ w2f32x4 w2_load16(__amdgpu_buffer_rsrc_t rsrc, int voffset, int soffset) {
     w2u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voffset, soffset, 0);
@@ -62,6 +65,20 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_f32_kernel(const GemmPa
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wi = wave & 3, wq = wave >> 2;  // component row, quad block
+#ifdef W2_TRACE  // in-kernel timeline (tools/wino2d_trace.py): thread 0 of a few workgroups stamps the 100 MHz wall clock into the tail of the residual
+    int trn = 0;
+    const int trslot = blockIdx.x == 0 ? 0 : blockIdx.x == 700 ? 1 : blockIdx.x == 1500 ? 2 : blockIdx.x == 2040 ? 3 : -1;
+    float *trbuf = const_cast<float *>(p.res) + (size_t)p.M * p.ldres - 64 + (trslot < 0 ? 0 : trslot) * 16;
+    const bool trw = trslot >= 0 && tid == 0 && p.res;
+    auto trace = [&]() __attribute__((always_inline)) {
+        if (trw) {
+            trbuf[trn] = (float)(wall_clock64() & 0xFFFFFFull);
+            trbuf[8 + trn] = (float)(__builtin_readcyclecounter() & 0xFFFFFFull);  // shader clock
+        }
+        ++trn;
+    };
+    trace();
+#endif
     const int li = lane & 31, lh = lane >> 5;
 
     // ---- XCD-aware block -> (mtile, ntile), as in the other GEMM kernels ----
@@ -94,15 +111,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_f32_kernel(const GemmPa
     const __amdgpu_buffer_rsrc_t srd_b = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char *>(reinterpret_cast<const char *>(p.b_wino)), 0, p.N * p.ldb_wino * 4, 0x00020000);
 
-    // ---- staging role: (quad ql, component row si, channel half hq).  B^T row si combines input rows (ra, rb) of the patch:
-    // 0: r0 - r2,  1: r1 + r2,  2: r2 - r1,  3: r1 - r3.  Row 2 is staged NEGATED (r1 - r2) and so is row 2 of the transformed
-    // weights (wino2d_weights_kernel): the products are unchanged and every combination is ra + sb rb, one FMA per element.
-    // The four component rows of a quad sit in adjacent lanes: they share input rows 1 and 2, i.e. cache lines, within one load. ----
-    const int ql = tid >> 3, si = (tid >> 1) & 3, hq = tid & 1;
-    const int ra = si == 0 ? 0 : 1, rb = si == 3 ? 3 : 2;
+    // ---- staging role: (quad ql, channel half hq, patch row si).  Thread si loads row si of the quad's 4 x 4 patch (four pixels x 16 B).
+    // B^T row si combines two patch rows -- 0: r0 - r2, 1: r1 + r2, 2: r2 - r1, 3: r1 - r3 -- and the partner row sits in a neighbouring
+    // lane of the same 4-lane group (lanes 2, 2, 1, 1): ONE v_fmac_f32 with a DPP quad_perm operand per element, mine + sb * partner, and
+    // every input line is requested once per quad instead of twice.  Row 3 comes out NEGATED that way (r3 - r1) and so is row 3 of the
+    // transformed weights (wino2d_weights_kernel): the products are unchanged. ----
+    const int ql = tid >> 3, hq = (tid >> 2) & 1, si = tid & 3;
     const float sb = si == 1 ? 1.f : -1.f;
-    int pix = 0;          // pixel index of the patch origin (2 qy - 1, 2 qx - 1); may be "negative" by at most W + 1: the bias covers it
-    unsigned bad = 0xFFu; // bit 4 t + s: pixel s of the thread's row t lies outside the image (or the quad is past the batch)
+    int pix = 0;         // pixel index of the patch origin (2 qy - 1, 2 qx - 1); may be "negative" by at most W + 1: the bias covers it
+    unsigned bad = 0xFu; // bit s: pixel s of the thread's patch row lies outside the image (or the quad is past the batch)
     {
         const int q = q0 + ql;
         if (q < Q) {
@@ -115,24 +132,28 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_f32_kernel(const GemmPa
             unsigned xb = 0;
 #pragma unroll
             for (int s = 0; s < 4; ++s) xb |= ((unsigned)(x0 + s) < (unsigned)W ? 0u : 1u) << s;
-            bad = ((unsigned)(y0 + ra) < (unsigned)H ? xb : 15u) | (((unsigned)(y0 + rb) < (unsigned)H ? xb : 15u) << 4);
+            bad = (unsigned)(y0 + si) < (unsigned)H ? xb : 15u;
         }
     }
-    int vo[8];  // voffsets of the thread's 8 pixels in the current source (out-of-image ones already out of bounds)
+    int vo[4];  // voffsets of the thread's 4 pixels in the current source (out-of-image ones already out of bounds)
     auto set_vo = [&](int lda, int biasb) __attribute__((always_inline)) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int r = k < 4 ? ra : rb, s = k & 3;
-            const int off = (pix + r * W + s) * lda * 4 + biasb + hq * 16;
+        for (int k = 0; k < 4; ++k) {
+            const int off = (pix + si * W + k) * lda * 4 + biasb + hq * 16;
             vo[k] = ((bad >> k) & 1u) ? OOB : off;
         }
     };
     set_vo(p.lda0, bias0);
-    const int v_lds = ql * W2_LD + si * 32 + hq * 4;  // + j * 8
+    // LDS slot (16 B) of component (i, j), channel half hq in a V row: i * 8 + ((2 j + hq + 2 i) & 7) -- the j / hq slots of component
+    // row i ROTATED by 2 i.  A ds_write_b128 is serviced in groups of 8 consecutive lanes = the (si, hq) of one quad, on 32 banks: without
+    // the rotation the four si of a group hit the same slot modulo 8 (4-way conflict, 44 % of the LDS cycles of the kernel).
+    int v_lds[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v_lds[j] = ql * W2_LD + si * 32 + ((2 * j + hq + 2 * si) & 7) * 4;
     // weight pieces: row brow of the tile, 16-byte pieces bp + 8 k (k = 0..3) of the 128-float row chunk
     const int brow = tid >> 3, bp = tid & 7;
     const int bvo = (n0 + brow < p.N) ? ((n0 + brow) * p.ldb_wino + bp * 4) * 4 : OOB;
-    const int b_lds = (64 + brow) * W2_LD + bp * 4;  // + k * 32
+    const int b_lds = 2 * W2_HALF + brow * W2_LD + bp * 4;  // + k * 32
 
     // ---- wave-uniform state of the chunk whose loads are issued next ----
     int s_kc = 0, s_c = 0;
@@ -147,22 +168,36 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_f32_kernel(const GemmPa
         }
     };
 
-    w2f32x4 rr[8], wb[4], cm[4];
+    w2f32x4 rr[4], wb[4], cm[4];
+    // (chunks past the tile's last one are never requested: the last two iterations of the K loop are peeled)
     auto load_raw = [&](int k) __attribute__((always_inline)) {
         if ((W2_ABL & 1) && s_kc >= 2) return;
-        const int kill = s_kc < nk ? 0 : OOB;
-        if (s_first) rr[k] = w2_load16(srd_a0, vo[k] | kill, s_c * 4);
-        else rr[k] = w2_load16(srd_a1, vo[k] | kill, (s_c - p.C0) * 4);
+        if (s_first) rr[k] = w2_load16(srd_a0, vo[k], s_c * 4);
+        else rr[k] = w2_load16(srd_a1, vo[k], (s_c - p.C0) * 4);
     };
     auto load_w = [&](int k) __attribute__((always_inline)) {
         if ((W2_ABL & 1) && s_kc >= 2) return;
-        wb[k] = w2_load16(srd_b, s_kc < nk ? bvo : OOB, (s_kc * 128 + k * 32) * 4);
+        wb[k] = w2_load16(srd_b, bvo, (s_kc * 128 + k * 32) * 4);
     };
     auto combine = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) cm[s] = rr[s] + sb * rr[4 + s];
+        for (int s = 0; s < 4; ++s) {
+            cm[s] = rr[s];
+            if (W2_ABL & 16) continue;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float m = rr[s][e];
+                // (s_nop: a VALU write of an operand right in front of a DPP read needs two wait states, and inline asm is opaque to the
+                // hazard recogniser)
+                if (s == 0 && e == 0)
+                    asm volatile("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf" : "+v"(m) : "v"(rr[s][e]), "v"(sb));
+                else
+                    asm volatile("v_fmac_f32_dpp %0, %1, %2 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf" : "+v"(m) : "v"(rr[s][e]), "v"(sb));
+                cm[s][e] = m;
+            }
+        }
     };
-    auto store_v = [&](int j, float *st) __attribute__((always_inline)) {
+    auto store_v = [&](int j, int par) __attribute__((always_inline)) {
         w2f32x4 v;
         if (j == 0) v = cm[0] - cm[2];
         else if (j == 1) v = cm[1] + cm[2];
@@ -170,11 +205,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_f32_kernel(const GemmPa
         else v = cm[1] - cm[3];
         if (W2_ABL & 16) v = cm[j];
         if (W2_ABL & 2) { asm volatile("" ::"v"(v)); return; }
-        *reinterpret_cast<w2f32x4 *>(&st[v_lds + j * 8]) = v;
+        *reinterpret_cast<w2f32x4 *>(&smem[v_lds[j] + par * W2_HALF]) = v;
     };
-    auto store_w = [&](int k, float *st) __attribute__((always_inline)) {
+    auto store_w = [&](int k, int par) __attribute__((always_inline)) {
         if (W2_ABL & 2) { asm volatile("" ::"v"(wb[k])); return; }
-        *reinterpret_cast<w2f32x4 *>(&st[b_lds + k * 32]) = wb[k];
+        *reinterpret_cast<w2f32x4 *>(&smem[b_lds + par * W2_HALF + k * 32]) = wb[k];
     };
 
     w2f32x16 acc[4][2];
@@ -185,32 +220,72 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_f32_kernel(const GemmPa
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[j][c][v] = 0.f;
 
-    const int a_off = (wq * 32 + li) * W2_LD + wi * 32 + lh * 4;  // + j * 8
-    const int b_off = (64 + li) * W2_LD + wi * 32 + lh * 4;       // + c * 32 rows + j * 8
+    int a_off[4];  // fragment of component (wi, j): rotated slot, see v_lds
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a_off[j] = (wq * 32 + li) * W2_LD + wi * 32 + ((j + wi) & 3) * 8 + lh * 4;
+    const int b_off = 2 * W2_HALF + li * W2_LD + wi * 32 + lh * 4;  // + c * 32 rows + j * 8
 
     // ---- prologue: chunk 0 -> LDS stage 0, chunk 1 -> registers ----
 #pragma unroll
-    for (int k = 0; k < 8; ++k) load_raw(k);
+    for (int k = 0; k < 4; ++k) load_raw(k);
 #pragma unroll
     for (int k = 0; k < 4; ++k) load_w(k);
     advance();
     combine();
 #pragma unroll
-    for (int j = 0; j < 4; ++j) store_v(j, smem);
+    for (int j = 0; j < 4; ++j) store_v(j, 0);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) store_w(k, smem);
+    for (int k = 0; k < 4; ++k) store_w(k, 0);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) load_raw(k);
+    for (int k = 0; k < 4; ++k) load_raw(k);
 #pragma unroll
     for (int k = 0; k < 4; ++k) load_w(k);
     advance();
     __syncthreads();
+#ifdef W2_TRACE
+    trace();
+#endif
 
+    // ---- epilogue geometry, needed already inside the K loop (the residual is requested one chunk before the loop ends): wave (h, c) of
+    // a quad block finishes quad half h (16 quads) x output tile c (32 columns) ----
+    const int h = wi & 1, c = wi >> 1;
+    const int qu = q0 + wq * 32 + 16 * h;  // first quad of the unit (wave-uniform)
+    const int img = (int)epi_div((unsigned)(qu < Q ? qu : 0), (unsigned)QI, p.mg_ohw, p.sh_ohw);
+    const int qr = (qu < Q ? qu : 0) - img * QI;
+    const int qy = qr >> wqs, qxu = qr - (qy << wqs);
+    const int mu = img * HW + 2 * qy * W + 2 * qxu;  // pixel of the unit's first quad (top-left output)
+    const int n = n0 + c * 32 + li;
+    const bool nok = n < p.N && qu < Q;
+    const __amdgpu_buffer_rsrc_t srd_r = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(reinterpret_cast<const char *>(p.res ? p.res : p.out)), 0, p.M * p.ldres * 4, 0x00020000);
+    // quad (vv & 3) + 8 (vv >> 2) + 4 lh of the unit: the half-wave adds 4 quads = 8 pixels along x, or, on 8-wide images (4 quads
+    // per quad row), one quad row = 2 W pixels
+    const int lane_px = Wq == 4 ? lh * 2 * W : 8 * lh;
+    const int vo_r = nok ? (lane_px * p.ldres + n) * 4 : OOB;
+    // pixel offset (from mu) of quad vv of the unit, lane-independent part: W = 8: four quad rows of 4 (vv >> 2 selects a pair of them),
+    // W = 16: two quad rows of 8; else one aligned run of 16 quads
+    auto pix_off = [&](int vv, int a, int b) __attribute__((always_inline)) {
+        const int dq = (vv & 3) + 8 * (vv >> 2);
+        const int base = Wq == 4 ? (vv >> 2) * 4 * W + (vv & 3) * 2 : Wq == 8 ? (vv >> 2) * 2 * W + (vv & 3) * 2 : dq * 2;
+        return mu + base + a * W + b;
+    };
+    float rs[2][2][8];
+    const bool has_res = p.res != nullptr;
+    auto load_res = [&](int idx) __attribute__((always_inline)) {  // idx = (a * 2 + b) * 8 + vv
+        const int a = idx >> 4, b = (idx >> 3) & 1, vv = idx & 7;
+        rs[a][b][vv] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_r, vo_r, pix_off(vv, a, b) * p.ldres * 4, 0));
+    };
+
+    // ---- K loop.  MODE 0: steady state (chunk kc multiplied, chunk kc+1 registers -> the other LDS stage, chunk kc+2 requested);
+    // MODE 1: the tile's second-to-last chunk (nothing left to request: the residual tile is requested instead, its latency hides
+    // behind the last chunk); MODE 2: the last chunk (no staging at all) ----
     w2f32x4 af[2], bf[2][2];
-    for (int kc = 0; kc < nk; ++kc) {
-        const float *cur = smem + (kc & 1) * W2_STAGE;
-        float *nxt = smem + ((kc + 1) & 1) * W2_STAGE;
-        af[0] = *reinterpret_cast<const w2f32x4 *>(cur + a_off);
+    auto chunk = [&](auto mode_tag, auto par_tag) __attribute__((always_inline)) {
+        constexpr int MODE = decltype(mode_tag)::value;
+        constexpr int PAR = decltype(par_tag)::value;  // stage the chunk is multiplied from (compile time: immediate offsets)
+        const float *cur = smem + PAR * W2_HALF;
+        constexpr int nxt = PAR ^ 1;
+        af[0] = *reinterpret_cast<const w2f32x4 *>(cur + a_off[0]);
         bf[0][0] = *reinterpret_cast<const w2f32x4 *>(cur + b_off);
         bf[0][1] = *reinterpret_cast<const w2f32x4 *>(cur + b_off + 32 * W2_LD);
 #pragma unroll
@@ -222,22 +297,42 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_f32_kernel(const GemmPa
                 __builtin_amdgcn_sched_barrier(0);
                 const int gap = j * 4 + jj;
                 if (jj == 0 && j < 3 && !(W2_ABL & 4)) {  // fragments of the next component, one component ahead of their use
-                    af[(j + 1) & 1] = *reinterpret_cast<const w2f32x4 *>(cur + a_off + (j + 1) * 8);
+                    af[(j + 1) & 1] = *reinterpret_cast<const w2f32x4 *>(cur + a_off[j + 1]);
                     bf[(j + 1) & 1][0] = *reinterpret_cast<const w2f32x4 *>(cur + b_off + (j + 1) * 8);
                     bf[(j + 1) & 1][1] = *reinterpret_cast<const w2f32x4 *>(cur + b_off + 32 * W2_LD + (j + 1) * 8);
                 }
-                // staging work in the shadow of the MFMA pair: chunk kc+1 (registers) -> the other stage, chunk kc+2 requested
-                if (gap == 0) { combine(); store_v(0, nxt); load_raw(0); load_raw(1); }
-                else if (gap == 1) { store_v(1, nxt); load_raw(2); load_raw(3); }
-                else if (gap == 2) { store_v(2, nxt); load_raw(4); load_raw(5); }
-                else if (gap == 3) { store_v(3, nxt); load_raw(6); load_raw(7); }
-                else if (gap < 8) { store_w(gap - 4, nxt); load_w(gap - 4); }
-                else if (gap == 8) advance();
+                // staging work in the shadow of the MFMA pair
+                if (MODE < 2) {
+                    if (gap == 0) combine();
+                    if (gap < 4) store_v(gap, nxt);
+                    else if (gap < 8) store_w(gap - 4, nxt);
+                }
+                if (MODE == 0) {
+                    if (gap < 4) load_raw(gap);
+                    else if (gap < 8) load_w(gap - 4);
+                    else if (gap == 8) advance();
+                }
+                if (MODE == 1 && has_res) {
+                    load_res(2 * gap);
+                    load_res(2 * gap + 1);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
         if (!(W2_ABL & 8)) __syncthreads();
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    for (int kc = 0; kc < nk - 2; kc += 2) {  // nk is a multiple of 4
+        chunk(I0{}, I0{});
+        chunk(I0{}, I1{});
     }
+    chunk(I1{}, I0{});
+    chunk(I2{}, I1{});
+#ifdef W2_TRACE
+    trace();
+#endif
 
     // ---- output transform along x (in-lane): z[b] = sum_j A^T[b][j] M_ij ----
     // then along y across the four component-row waves of a quad block, through LDS (the stages are idle after the last barrier)
@@ -251,8 +346,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_f32_kernel(const GemmPa
             mine[((1 * 2 + c) * 16 + v) * 64] = m1 - m2 - m3;
         }
     __syncthreads();
-    const int h = wi & 1, c = wi >> 1;  // this wave finishes quad half h (16 quads) x output tile c (32 columns) of its quad block
-    const int qu = q0 + wq * 32 + 16 * h;  // first quad of the unit (wave-uniform)
     if (qu >= Q) return;
     float y[2][2][8];  // [a][b][vv]: output pixel (2 qy + a, 2 qx + b) of quad row (vv & 3) + 8 (vv >> 2) + 4 lh of the unit
     {
@@ -268,41 +361,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_f32_kernel(const GemmPa
             }
     }
 
+#ifdef W2_TRACE
+    trace();
+#endif
     // ---- epilogue of the unit ----
-    const int img = (int)epi_div((unsigned)qu, (unsigned)QI, p.mg_ohw, p.sh_ohw);
-    const int qr = qu - img * QI;
-    const int qy = qr >> wqs, qxu = qr - (qy << wqs);
-    const int mu = img * HW + 2 * qy * W + 2 * qxu;  // pixel of the unit's first quad (top-left output)
-    const int n = n0 + c * 32 + li;
-    const bool nok = n < p.N;
     const __amdgpu_buffer_rsrc_t srd_o =
         __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(p.out), 0, p.M * p.ldc * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t srd_r = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char *>(reinterpret_cast<const char *>(p.res ? p.res : p.out)), 0, p.M * p.ldres * 4, 0x00020000);
-    // quad (vv & 3) + 8 (vv >> 2) + 4 lh of the unit: the half-wave adds 4 quads = 8 pixels along x, or, on 8-wide images (4 quads
-    // per quad row), one quad row = 2 W pixels
-    const int lane_px = Wq == 4 ? lh * 2 * W : 8 * lh;
     const int vo_o = nok ? (lane_px * p.ldc + n) * 4 : OOB;
-    const int vo_r = nok ? (lane_px * p.ldres + n) * 4 : OOB;
     float addv = (p.bias && nok) ? p.bias[n] : 0.f;
     if (p.rowbias && nok) addv += p.rowbias[(size_t)img * p.ld_rowbias + n];
-    // pixel offset (from mu) of quad vv of the unit, lane-independent part: W = 8: four quad rows of 4 (vv >> 2 selects a pair of them),
-    // W = 16: two quad rows of 8; else one aligned run of 16 quads
-    auto pix_off = [&](int vv, int a, int b) __attribute__((always_inline)) {
-        const int dq = (vv & 3) + 8 * (vv >> 2);
-        const int base = Wq == 4 ? (vv >> 2) * 4 * W + (vv & 3) * 2 : Wq == 8 ? (vv >> 2) * 2 * W + (vv & 3) * 2 : dq * 2;
-        return mu + base + a * W + b;
-    };
-    float rs[2][2][8];
-    if (p.res) {
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int vv = 0; vv < 8; ++vv)
-                    rs[a][b][vv] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_r, vo_r, pix_off(vv, a, b) * p.ldres * 4, 0));
-    }
     float ps[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, pq[2][2] = {{0.f, 0.f}, {0.f, 0.f}};  // partial statistics by (a, vv >> 2)
     float vals[2][2][8];  // finished outputs (kept for the epilogue GroupNorm)
 #pragma unroll
@@ -312,7 +379,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_f32_kernel(const GemmPa
 #pragma unroll
             for (int vv = 0; vv < 8; ++vv) {
                 float add = addv;
-                if (p.res) add += rs[a][b][vv];
+                if (has_res) add += rs[a][b][vv];
                 const float val = (p.alpha * y[a][b][vv] + add) * p.out_scale;
                 vals[a][b][vv] = val;
                 if (!p.egn_skip_raw)
@@ -320,6 +387,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_f32_kernel(const GemmPa
                 ps[a][vv >> 2] += val;
                 pq[a][vv >> 2] += val * val;
             }
+#ifdef W2_TRACE
+    trace();
+    __builtin_amdgcn_s_waitcnt(0);
+    trace();
+#endif
     if (p.egn_out) {
         // GroupNorm (+ swish) of the output, here (plan.h: Op::egn_peer): rows_per_image == 64, so this unit is exactly one image x 32
         // columns; a group is egn_cpg consecutive columns = consecutive lanes
@@ -381,7 +453,7 @@ __global__ void wino2d_weights_kernel(const float *__restrict__ w, float *__rest
             double acc = 0;
             for (int ky = 0; ky < 3; ++ky)
                 for (int kx = 0; kx < 3; ++kx) acc += G[i][ky] * g[ky][kx] * G[j][kx];
-            ur[(i * 4 + j) * 8] = (float)(i == 2 ? -acc : acc);  // row 2 negated, like the staged activations (see the kernel)
+            ur[(i * 4 + j) * 8] = (float)(i == 3 ? -acc : acc);  // row 3 negated, like the staged activations (see the kernel)
         }
 }
 

@@ -7,9 +7,23 @@ import shutil
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(REPO, "gpurun_out", "prof")
 DST = os.path.join(REPO, "profiles")
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+SRC = os.path.join(REPO, "gpurun_out", "prof" if tag == "r01" else "prof2")
+
+if tag != "r01":
+    # tools/collect_profiles_r2.sh layout: every small file of gpurun_out/prof2 is evidence; logs stay behind
+    import glob
+    for f in sorted(glob.glob(os.path.join(SRC, "*"))):
+        base = os.path.basename(f)
+        if os.path.isfile(f) and (base.endswith(".json") or base.endswith(".csv")) and os.path.getsize(f) > 0:
+            shutil.copy(f, os.path.join(DST, "%s_%s" % (tag, base)))
+    os.replace(os.path.join(DST, "%s_pmc_FETCH_SIZE_summary.json" % tag), os.path.join(DST, "%s_pmc_fetch_summary.json" % tag))
+    os.replace(os.path.join(DST, "%s_pmc_WRITE_SIZE_summary.json" % tag), os.path.join(DST, "%s_pmc_write_summary.json" % tag))
+    for a, b in (("pmc_FETCH_SIZE_summary.json", "pmc_fetch_summary.json"), ("pmc_WRITE_SIZE_summary.json", "pmc_write_summary.json"),
+                 ("bench_trace_summary.json", "trace_summary.json")):
+        if os.path.exists(os.path.join(SRC, a)):
+            shutil.copy(os.path.join(SRC, a), os.path.join(SRC, b))
 
 for name in ("bench_kernel_stats.csv", "bench_bf16x3_kernel_stats.csv", "trace_summary.json", "pmc_fetch_summary.json",
              "pmc_write_summary.json", "pmc_sq_summary.json", "trace_bench_line.json", "pmc_fetch_x3_summary.json",
