@@ -42,6 +42,10 @@ typedef float w2f32x16 __attribute__((ext_vector_type(16)));
 typedef float w2f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int w2u32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef W2_DMA
+#define W2_DMA 0  // 1: weight chunks go global -> LDS directly (buffer_load_dwordx4 ... lds) instead of through registers.  Measured
+                  // in-box (tools/r2_ab7.sh): 104.5 vs 106.5 images/s -- the issue cost of the pieces exceeds the four ds_write_b128 they replace
+#endif
 #ifndef W2_ABL
 #define W2_ABL 0  // timing ablations (results wrong): 1 no global loads in the K loop, 2 no LDS stores, 4 no fragment reads, 8 no barrier,
                   // 16 no transform arithmetic
@@ -55,6 +59,26 @@ constexpr int W2_STAGE = 2 * W2_HALF;
 __device__ __forceinline__ w2f32x4 w2_load16(__amdgpu_buffer_rsrc_t rsrc, int voffset, int soffset) {
     w2u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voffset, soffset, 0);
     return __builtin_bit_cast(w2f32x4, v);
+}
+
+// a - b on the packed-fp32 path (two v_pk_add_f32 with the negate modifiers; the compiler packs additions by itself but scalarises
+// subtractions, and on this chip every fp32 VALU cycle is taken from the fp32 matrix pipe)
+__device__ __forceinline__ w2f32x4 w2_sub4(w2f32x4 a, w2f32x4 b) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 alo = {a[0], a[1]}, ahi = {a[2], a[3]}, blo = {b[0], b[1]}, bhi = {b[2], b[3]};
+    f2 rlo, rhi;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(rlo) : "v"(alo), "v"(blo));
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(rhi) : "v"(ahi), "v"(bhi));
+    return w2f32x4{rlo[0], rlo[1], rhi[0], rhi[1]};
+}
+
+__device__ __forceinline__ w2f32x4 w2_add4(w2f32x4 a, w2f32x4 b) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 alo = {a[0], a[1]}, ahi = {a[2], a[3]}, blo = {b[0], b[1]}, bhi = {b[2], b[3]};
+    f2 rlo, rhi;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(rlo) : "v"(alo), "v"(blo));
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(rhi) : "v"(ahi), "v"(bhi));
+    return w2f32x4{rlo[0], rlo[1], rhi[0], rhi[1]};
 }
 
 __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_f32_kernel(const GemmParams p) {
@@ -154,6 +178,26 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_f32_kernel(const GemmPa
     const int brow = tid >> 3, bp = tid & 7;
     const int bvo = (n0 + brow < p.N) ? ((n0 + brow) * p.ldb_wino + bp * 4) * 4 : OOB;
     const int b_lds = 2 * W2_HALF + brow * W2_LD + bp * 4;  // + k * 32
+#if W2_DMA
+    // ---- weight chunks by LDS-DMA.  One buffer_load_dwordx4 ... lds writes 64 lanes x 16 B = 1 KB CONTIGUOUS LDS (two 512-byte rows of
+    // the chunk), so the U stages are unpadded and swizzled on the SOURCE side instead: LDS slot p' of row r holds the 16-byte piece
+    // p' ^ (r & 31) of that row.  Wave w's load k covers rows 8 w + 2 k + (lane >> 5); every lane's global offset is fixed for the tile
+    // (the chunk moves through the scalar offset).  The compiler does not count these loads: the K loop waits for them with its own
+    // s_waitcnt vmcnt(N) in front of the barrier that publishes the stage. ----
+    int dvo[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = wave * 8 + 2 * k + (lane >> 5);
+        const int piece = (lane & 31) ^ (r & 31);
+        dvo[k] = (n0 + r < p.N) ? ((n0 + r) * p.ldb_wino + piece * 4) * 4 : OOB;
+    }
+    const unsigned lds_u = (unsigned)(size_t)smem + (unsigned)(2 * W2_HALF * 4 + wave * 4096);  // + par * W2_HALF * 4 + k * 1024
+    auto dma_w = [&](int k, int chunk_id, int par) __attribute__((always_inline)) {
+        const unsigned dst = lds_u + (unsigned)(par * W2_HALF * 4 + k * 1024);
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                     :: "s"(dst), "v"(dvo[k]), "s"(srd_b), "s"(chunk_id * 512) : "memory");
+    };
+#endif
 
     // ---- wave-uniform state of the chunk whose loads are issued next ----
     int s_kc = 0, s_c = 0;
@@ -170,47 +214,51 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_f32_kernel(const GemmPa
 
     w2f32x4 rr[4], wb[4], cm[4];
     // (chunks past the tile's last one are never requested: the last two iterations of the K loop are peeled)
-    auto load_raw = [&](int k) __attribute__((always_inline)) {
+    auto load_raw_to = [&](w2f32x4 *dst, int k) __attribute__((always_inline)) {
         if ((W2_ABL & 1) && s_kc >= 2) return;
-        if (s_first) rr[k] = w2_load16(srd_a0, vo[k], s_c * 4);
-        else rr[k] = w2_load16(srd_a1, vo[k], (s_c - p.C0) * 4);
+        if (s_first) dst[k] = w2_load16(srd_a0, vo[k], s_c * 4);
+        else dst[k] = w2_load16(srd_a1, vo[k], (s_c - p.C0) * 4);
     };
-    auto load_w = [&](int k) __attribute__((always_inline)) {
+    auto load_raw = [&](int k) __attribute__((always_inline)) { load_raw_to(rr, k); };
+    auto load_w_to = [&](w2f32x4 *dst, int k) __attribute__((always_inline)) {
         if ((W2_ABL & 1) && s_kc >= 2) return;
-        wb[k] = w2_load16(srd_b, bvo, (s_kc * 128 + k * 32) * 4);
+        dst[k] = w2_load16(srd_b, bvo, (s_kc * 128 + k * 32) * 4);
     };
-    auto combine = [&]() __attribute__((always_inline)) {
+    auto load_w = [&](int k) __attribute__((always_inline)) { load_w_to(wb, k); };
+    auto combine_from = [&](const w2f32x4 *src) __attribute__((always_inline)) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            cm[s] = rr[s];
+            cm[s] = src[s];
             if (W2_ABL & 16) continue;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float m = rr[s][e];
+                float m = src[s][e];
                 // (s_nop: a VALU write of an operand right in front of a DPP read needs two wait states, and inline asm is opaque to the
                 // hazard recogniser)
                 if (s == 0 && e == 0)
-                    asm volatile("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf" : "+v"(m) : "v"(rr[s][e]), "v"(sb));
+                    asm volatile("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf" : "+v"(m) : "v"(src[s][e]), "v"(sb));
                 else
-                    asm volatile("v_fmac_f32_dpp %0, %1, %2 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf" : "+v"(m) : "v"(rr[s][e]), "v"(sb));
+                    asm volatile("v_fmac_f32_dpp %0, %1, %2 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf" : "+v"(m) : "v"(src[s][e]), "v"(sb));
                 cm[s][e] = m;
             }
         }
     };
+    auto combine = [&]() __attribute__((always_inline)) { combine_from(rr); };
     auto store_v = [&](int j, int par) __attribute__((always_inline)) {
         w2f32x4 v;
-        if (j == 0) v = cm[0] - cm[2];
-        else if (j == 1) v = cm[1] + cm[2];
-        else if (j == 2) v = cm[2] - cm[1];
-        else v = cm[1] - cm[3];
+        if (j == 0) v = w2_sub4(cm[0], cm[2]);
+        else if (j == 1) v = w2_add4(cm[1], cm[2]);
+        else if (j == 2) v = w2_sub4(cm[2], cm[1]);
+        else v = w2_sub4(cm[1], cm[3]);
         if (W2_ABL & 16) v = cm[j];
         if (W2_ABL & 2) { asm volatile("" ::"v"(v)); return; }
         *reinterpret_cast<w2f32x4 *>(&smem[v_lds[j] + par * W2_HALF]) = v;
     };
-    auto store_w = [&](int k, int par) __attribute__((always_inline)) {
-        if (W2_ABL & 2) { asm volatile("" ::"v"(wb[k])); return; }
-        *reinterpret_cast<w2f32x4 *>(&smem[b_lds + par * W2_HALF + k * 32]) = wb[k];
+    auto store_w_from = [&](const w2f32x4 *src, int k, int par) __attribute__((always_inline)) {
+        if (W2_ABL & 2) { asm volatile("" ::"v"(src[k])); return; }
+        *reinterpret_cast<w2f32x4 *>(&smem[b_lds + par * W2_HALF + k * 32]) = src[k];
     };
+    auto store_w = [&](int k, int par) __attribute__((always_inline)) { store_w_from(wb, k, par); };
 
     w2f32x16 acc[4][2];
 #pragma unroll
@@ -223,23 +271,48 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_f32_kernel(const GemmPa
     int a_off[4];  // fragment of component (wi, j): rotated slot, see v_lds
 #pragma unroll
     for (int j = 0; j < 4; ++j) a_off[j] = (wq * 32 + li) * W2_LD + wi * 32 + ((j + wi) & 3) * 8 + lh * 4;
-    const int b_off = 2 * W2_HALF + li * W2_LD + wi * 32 + lh * 4;  // + c * 32 rows + j * 8
+#if W2_DMA
+    constexpr int B_ROWS32 = 32 * 128;  // the second output tile of the wave: 32 rows further
+    int b_off[4];  // fragment (c = 0) of component (wi, j): row li, piece (wi * 8 + 2 j + lh) ^ li of the swizzled unpadded U stage
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b_off[j] = 2 * W2_HALF + li * 128 + (((wi * 8 + 2 * j + lh) ^ li) * 4);
+#else
+    constexpr int B_ROWS32 = 32 * W2_LD;
+    int b_off[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b_off[j] = 2 * W2_HALF + li * W2_LD + wi * 32 + lh * 4 + j * 8;
+#endif
 
-    // ---- prologue: chunk 0 -> LDS stage 0, chunk 1 -> registers ----
+    // ---- prologue: chunk 0 -> LDS stage 0, chunk 1 -> registers.  Both chunks are requested up front (chunk 0 into a second register
+    // set that only lives here, before the accumulators do): one memory latency per tile instead of two. ----
+    {
+        w2f32x4 r0[4], w0[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) load_raw(k);
+        for (int k = 0; k < 4; ++k) load_raw_to(r0, k);
+#if W2_DMA
 #pragma unroll
-    for (int k = 0; k < 4; ++k) load_w(k);
-    advance();
-    combine();
+        for (int k = 0; k < 4; ++k) dma_w(k, 0, 0);
+#else
 #pragma unroll
-    for (int j = 0; j < 4; ++j) store_v(j, 0);
+        for (int k = 0; k < 4; ++k) load_w_to(w0, k);
+#endif
+        advance();
 #pragma unroll
-    for (int k = 0; k < 4; ++k) store_w(k, 0);
+        for (int k = 0; k < 4; ++k) load_raw(k);
+#if !W2_DMA
 #pragma unroll
-    for (int k = 0; k < 4; ++k) load_raw(k);
+        for (int k = 0; k < 4; ++k) load_w(k);
+#endif
+        combine_from(r0);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) load_w(k);
+        for (int j = 0; j < 4; ++j) store_v(j, 0);
+#if W2_DMA
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // the four LDS-DMA pieces of chunk 0 (older than chunk 1's four register loads)
+#else
+#pragma unroll
+        for (int k = 0; k < 4; ++k) store_w_from(w0, k, 0);
+#endif
+    }
     advance();
     __syncthreads();
 #ifdef W2_TRACE
@@ -286,8 +359,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_f32_kernel(const GemmPa
         const float *cur = smem + PAR * W2_HALF;
         constexpr int nxt = PAR ^ 1;
         af[0] = *reinterpret_cast<const w2f32x4 *>(cur + a_off[0]);
-        bf[0][0] = *reinterpret_cast<const w2f32x4 *>(cur + b_off);
-        bf[0][1] = *reinterpret_cast<const w2f32x4 *>(cur + b_off + 32 * W2_LD);
+        bf[0][0] = *reinterpret_cast<const w2f32x4 *>(cur + b_off[0]);
+        bf[0][1] = *reinterpret_cast<const w2f32x4 *>(cur + b_off[0] + B_ROWS32);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
 #pragma unroll
@@ -298,10 +371,29 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_f32_kernel(const GemmPa
                 const int gap = j * 4 + jj;
                 if (jj == 0 && j < 3 && !(W2_ABL & 4)) {  // fragments of the next component, one component ahead of their use
                     af[(j + 1) & 1] = *reinterpret_cast<const w2f32x4 *>(cur + a_off[j + 1]);
-                    bf[(j + 1) & 1][0] = *reinterpret_cast<const w2f32x4 *>(cur + b_off + (j + 1) * 8);
-                    bf[(j + 1) & 1][1] = *reinterpret_cast<const w2f32x4 *>(cur + b_off + 32 * W2_LD + (j + 1) * 8);
+                    bf[(j + 1) & 1][0] = *reinterpret_cast<const w2f32x4 *>(cur + b_off[j + 1]);
+                    bf[(j + 1) & 1][1] = *reinterpret_cast<const w2f32x4 *>(cur + b_off[j + 1] + B_ROWS32);
                 }
                 // staging work in the shadow of the MFMA pair
+#if W2_DMA
+                // (the weights of the NEXT chunk, s_kc - 1, land in the other stage during this iteration: issued first, waited for below)
+                if (MODE < 2) {
+                    if (gap == 0) combine();
+                    if (gap < 4) store_v(gap, nxt);
+                }
+                if (MODE == 0) {
+                    if (gap == 0 && !((W2_ABL & 1) && s_kc >= 2)) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) dma_w(k, s_kc - 1, nxt);
+                    }
+                    if (gap < 4) load_raw(gap);
+                    else if (gap == 8) advance();
+                }
+                if (MODE == 1 && gap == 0) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) dma_w(k, s_kc - 1, nxt);
+                }
+#else
                 if (MODE < 2) {
                     if (gap == 0) combine();
                     if (gap < 4) store_v(gap, nxt);
@@ -312,6 +404,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_f32_kernel(const GemmPa
                     else if (gap < 8) load_w(gap - 4);
                     else if (gap == 8) advance();
                 }
+#endif
                 if (MODE == 1 && has_res) {
                     load_res(2 * gap);
                     load_res(2 * gap + 1);
@@ -319,6 +412,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_f32_kernel(const GemmPa
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+#if W2_DMA
+        // every LDS-DMA piece of this iteration has landed: all but the four register loads issued after the pieces (MODE 0), all but the 32
+        // residual loads (MODE 1)
+        if (MODE == 0) {
+            if (W2_ABL & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        }
+        if (MODE == 1) {
+            if (has_res) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+#endif
         if (!(W2_ABL & 8)) __syncthreads();
     };
     using I0 = std::integral_constant<int, 0>;
