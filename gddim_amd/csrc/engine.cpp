@@ -233,7 +233,7 @@ static bool gn_fused(gd_engine *e, const Bind &b, int batch, int gemm_index) {
 }
 
 // Epilogue GroupNorm (plan.h: Op::egn_peer), fp32 mode: taken when, at this batch size, the kernel the GEMM runs on implements it
-// (a 64-pair Winograd tile on 8x8 images, igemm_f32_fast_kernel on 4x4 images).  Fills the egn_* fields of g.  Decided once per
+// (the two-dimensional Winograd kernel on 16x16 / 8x8 images, a 64-pair one-dimensional tile on 8x8 images, igemm_f32_fast_kernel on 4x4 images).  Fills the egn_* fields of g.  Decided once per
 // batch size; GDDIM_NO_EGN=1 switches it off (A/B).
 static void fill_egn(gd_engine *e, const Op &op, const Bind &b, int batch, GemmParams &g) {
     const Op &a = e->plan.ops[op.egn_peer];

@@ -498,12 +498,27 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_f32_kernel(const GemmPa
     trace();
 #endif
     if (p.egn_out) {
-        // GroupNorm (+ swish) of the output, here (plan.h: Op::egn_peer): rows_per_image == 64, so this unit is exactly one image x 32
-        // columns; a group is egn_cpg consecutive columns = consecutive lanes
+        // GroupNorm (+ swish) of the output, here (plan.h: Op::egn_peer).  rows_per_image == 64 (8x8 images): this unit is exactly one
+        // image x 32 columns.  rows_per_image == 256 (16x16 images): the image is the whole workgroup tile, and the four units (wq, h) of
+        // a column block add their column sums through the 4 KB of LDS behind the exchange area.  A group is egn_cpg consecutive
+        // columns = consecutive lanes.
         float gsum = (ps[0][0] + ps[0][1]) + (ps[1][0] + ps[1][1]), gsq = (pq[0][0] + pq[0][1]) + (pq[1][0] + pq[1][1]);
         gsum += __shfl_xor(gsum, 32); gsq += __shfl_xor(gsq, 32);
+        float rows = 64.0f;
+        if (p.rows_per_image == 256) {
+            float2 *red = reinterpret_cast<float2 *>(smem + 8 * 4096);  // [c][unit][32 columns]
+            if (lh == 0) red[(c * 4 + wq * 2 + h) * 32 + li] = make_float2(gsum, gsq);
+            __syncthreads();  // (every wave of the workgroup is here: whole images, so no unit is past the batch)
+            gsum = 0.f; gsq = 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float2 v = red[(c * 4 + u) * 32 + li];
+                gsum += v.x; gsq += v.y;
+            }
+            rows = 256.0f;
+        }
         for (int o = 1; o < p.egn_cpg; o <<= 1) { gsum += __shfl_xor(gsum, o); gsq += __shfl_xor(gsq, o); }
-        const float inv_n = 1.0f / (64.0f * (float)p.egn_cpg);
+        const float inv_n = 1.0f / (rows * (float)p.egn_cpg);
         const float mean = gsum * inv_n;
         const float rstd = rsqrtf(gsq * inv_n - mean * mean + 1e-6f);
         const float ga = nok ? p.egn_gamma[n] : 0.f, be = nok ? p.egn_beta[n] : 0.f;
@@ -581,7 +596,7 @@ static void w2fill_div(unsigned d, unsigned &magic, unsigned &shift) {
 // what the kernel can compute at all (p.b_wino is not looked at)
 bool conv3x3_wino2d_shape_ok(const GemmParams &p) {
     if (p.in_act || p.b_kmajor || p.a_presplit || p.gn_table) return false;
-    if (p.egn_out && (p.rows_per_image != 64 || p.N % p.egn_cpg != 0 ||
+    if (p.egn_out && ((p.rows_per_image != 64 && p.rows_per_image != 256) || p.N % p.egn_cpg != 0 ||
                       (p.egn_cpg != 4 && p.egn_cpg != 8 && p.egn_cpg != 16 && p.egn_cpg != 32))) return false;
     if (p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1 || p.OH != p.H || p.OW != p.W) return false;
     const int Cin = p.C0 + p.C1;

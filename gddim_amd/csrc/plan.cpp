@@ -154,9 +154,10 @@ int Plan::gn(const std::string &label, const std::string &pname, int xa, int Ca,
         }
     }
     // candidate for normalisation in the producer's epilogue (Op::egn_peer): one source that carries fused statistics, an image of
-    // 16 or 64 pixels, groups of 4..32 channels that divide a 32-column accumulator tile
+    // 16, 64 or 256 pixels (256: one workgroup tile of the two-dimensional Winograd kernel), groups of 4..32 channels that divide a
+    // 32-column accumulator tile
     const int cpg = C / G;
-    const bool egn_candidate = Cb == 0 && (H * W == 16 || H * W == 64) && tensors[xa].stats_t >= 0 && tensors[xa].C == C &&
+    const bool egn_candidate = Cb == 0 && (H * W == 16 || H * W == 64 || (H == 16 && W == 16)) && tensors[xa].stats_t >= 0 && tensors[xa].C == C &&
                                (cpg == 4 || cpg == 8 || cpg == 16 || cpg == 32) && C % 32 == 0;
     int out = new_tensor(label + ".out", H, W, C, EXT_NONE, -1, egn_candidate);
     tensors[out].table_t = new_tensor(label + ".affine", 1, 1, 2 * C);  // lives as long as the output

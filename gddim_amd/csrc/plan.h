@@ -82,10 +82,11 @@ struct Op {
     int fuse_peer = -1;
     TRef gn_table, gn_src, gn_src1;
     int gn_C0 = 0, gn_C1 = 0;
-    // GroupNorm in the producer's epilogue (fp32 mode, run-time decision): a single-source GN_APPLY op on an 8x8 or 4x4 tensor and
-    // the GEMM that produces that tensor point at each other (egn_peer = op index).  At those sizes one wave's 32 x 32 accumulator
+    // GroupNorm in the producer's epilogue (fp32 mode, run-time decision): a single-source GN_APPLY op on a 16x16, 8x8 or 4x4 tensor
+    // and the GEMM that produces that tensor point at each other (egn_peer = op index).  At 8x8 / 4x4 one wave's 32 x 32 accumulator
     // tile holds whole images and whole groups, so the epilogue can reduce (mean, rstd) in registers and write the normalised
-    // (+ swish) tensor itself; the apply op is then skipped.  egn_sole: the apply op is the only reader of the raw output, which
+    // (+ swish) tensor itself; at 16x16 an image is one workgroup tile of the two-dimensional Winograd kernel, which adds the
+    // column sums of its waves through LDS; the apply op is then skipped.  egn_sole: the apply op is the only reader of the raw output, which
     // is then not stored at all.  The apply op's output tensor is `fresh` so that writing it early cannot hit live data.
     int egn_peer = -1, egn_sole = 0;
     TRef qstats;          // GEMM: quad statistics of the output (fused GroupNorm statistics), t = -1: none
