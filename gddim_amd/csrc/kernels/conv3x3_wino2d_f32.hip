@@ -15,13 +15,18 @@
 // (its four components j = 0..3) of quad block wq (32 quads) x 64 outputs = eight 32x32x2 fp32 accumulators, exactly the register
 // budget of the one-dimensional kernel's wave.  K = Cin is consumed in chunks of 8 channels: LDS rows [quad or n][16 components x 8
 // channels + 4 pad] (132 floats = an odd number of 16-byte units: the ds_read_b128 of 16 consecutive rows cover all banks), two stages
-// of 66 KB, one workgroup per CU.  One ds_read_b128 per (fragment, component) feeds four MFMAs, 32 MFMAs per wave between barriers --
-// the same K-loop shape as the one-dimensional kernel -- while a chunk now carries 1.5 x the output work.
-// Staging: thread (quad, component row i, 4-channel half) loads the two input rows B^T row i combines (8 pixels x 16 B, out-of-image
-// pixels pushed out of the buffer bounds -> zero padding), combines them (4 FMA-class vector ops), applies the row transform (4
-// vector ops) and stores four component float4s; every thread also copies four 16-byte pieces of the weight chunk.  Chunk state in
-// SGPRs, per-thread pixel offsets precomputed (they do not depend on the channel), distance-one register prefetch as in
-// igemm_f32_fast_kernel.
+// of 66 KB (V stage 0 | V stage 1 | U stage 0 | U stage 1: the stage is an immediate offset, the K loop is unrolled by two), one
+// workgroup per CU.  One ds_read_b128 per (fragment, component) feeds four MFMAs, 32 MFMAs per wave between barriers -- the same
+// K-loop shape as the one-dimensional kernel -- while a chunk now carries 1.5 x the output work.
+// Staging: thread (quad, 4-channel half, patch row i) loads ONE row of the quad's 4 x 4 patch (4 pixels x 16 B, out-of-image pixels
+// pushed out of the buffer bounds -> zero padding); the row B^T row i combines it with lives in a neighbouring lane and comes in
+// through a DPP operand (16 v_fmac_f32_dpp); the x-direction transform is 8 packed-fp32 additions; four component float4s go to
+// LDS, their slots rotated by the component row so that the ds_write_b128 lane groups are conflict-free.  Every thread also copies
+// four 16-byte pieces of the weight chunk.  Chunk state in SGPRs, per-thread pixel offsets precomputed (they do not depend on the
+// channel), distance-one register prefetch as in igemm_f32_fast_kernel; the last two chunks of a tile are peeled (nothing left to
+// request) and the residual tile is requested behind the second-to-last one.  On this chip every fp32 VALU cycle is taken from the
+// fp32 matrix pipe, and under this kernel the shader clock sits near 2.0 GHz (power): VALU work, LDS traffic and global requests per
+// MFMA are what the K loop is tuned for (profiles/r02_notes.md: timeline, ablations, what did not help).
 // Epilogue: the x-direction output transform is in-lane; the y-direction one combines the four component rows, which live in four
 // waves: they exchange their 64 partial registers through the (now idle) LDS stages, then wave (h, c) of a quad block finishes quad
 // half h x output tile c: bias, per-image bias row, residual, scale, store, fused GroupNorm quad statistics.
