@@ -140,3 +140,33 @@ def test_unet_64x64_winograd_levels_match_oracle(native_lib):
     assert "conv3x3_wino2d_f32_kernel" in seen, seen
     assert np.isfinite(got).all() and err < max(4 * e_f32, 2e-5), (err, e_f32)
     assert np.abs(got[:1] - alone).max() / scale < 2e-5
+
+
+def test_epilogue_groupnorm_16x16_level(native_lib, tmp_path):
+    """GroupNorm in the producer's epilogue (plan.h: Op::egn_peer) on 16x16 images, where the image is one workgroup tile of the
+    two-dimensional Winograd kernel and the column sums of its waves are added through LDS: a three-level network run with the kernel
+    forced on at a small batch (the switches are read once per process, hence the worker), with and without the fusion.  Both runs
+    match the float64 oracle, the fused one launches fewer GroupNorm passes, and the two agree with each other."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    res = {}
+    for tag, extra in (("egn", {}), ("noegn", {"GDDIM_NO_EGN": "1"})):
+        out = str(tmp_path / (tag + ".npz"))
+        env = dict(os.environ, GDDIM_WINO2_MINBLOCKS="1", **extra)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "egn_worker.py"), out], cwd=ROOT, env=env, capture_output=True,
+                           text=True, timeout=900)
+        assert r.returncode == 0 and "EGN_WORKER_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+        res[tag] = np.load(out)
+    want = res["egn"]["want"]
+    scale = max(1.0, np.abs(want).max())
+    counts = {tag: dict(zip(res[tag]["names"].tolist(), res[tag]["launches"].tolist())) for tag in res}
+    print("gn_apply launches: fused %d, unfused %d" % (counts["egn"].get("gn_apply", 0), counts["noegn"].get("gn_apply", 0)))
+    assert "conv3x3_wino2d_f32_kernel" in counts["egn"] and "conv3x3_wino2d_f32_kernel" in counts["noegn"]
+    # 16x16 level: 2 + 3 residual blocks with a 3x3 producer in front of their second GroupNorm; the 8x8 level adds its own
+    assert counts["egn"].get("gn_apply", 0) <= counts["noegn"]["gn_apply"] - 5
+    for tag in res:
+        err = np.abs(res[tag]["got"] - want).max()
+        assert np.isfinite(res[tag]["got"]).all() and err < 1e-4 * scale, (tag, err, scale)
+    assert np.abs(res["egn"]["got"] - res["noegn"]["got"]).max() < 2e-5 * scale

@@ -32,7 +32,7 @@ for name in ("bench_kernel_stats.csv", "bench_bf16x3_kernel_stats.csv", "trace_s
     if os.path.exists(p):
         shutil.copy(p, os.path.join(DST, "%s_%s" % (tag, name)))
 line = os.path.join(REPO, "gpurun_out", "bench_line.json")
-if os.path.exists(line):
+if tag == "r01" and os.path.exists(line):
     shutil.copy(line, os.path.join(DST, "%s_bench_line.json" % tag))
 
 fetch = json.load(open(os.path.join(SRC, "pmc_fetch_summary.json")))["kernels"]
