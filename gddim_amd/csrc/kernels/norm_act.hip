@@ -67,6 +67,12 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float *__restrict__
     }
 }
 
+#ifndef GN_UNROLL
+#define GN_UNROLL 4
+#endif
+#ifndef GN_NT
+#define GN_NT 1  // 1: nontemporal loads (the raw tensor is dead after this pass: 164.3 -> 159.5 ms per 50 evaluations in-box), 2: nontemporal stores (slower: the consumer reads the output next)
+#endif
 // grid (blocks per image, B), 256 threads.  Prologue: the block reduces the quad partial sums of its image to (mean, rstd)
 // per group in LDS (thread t -> group t % G, slice phase t / G), across two channel-concatenated sources when the GroupNorm
 // runs on a skip concat; then every thread normalises its fixed float4 column over the block's pixels.
@@ -159,17 +165,21 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float *__restrict__
             *reinterpret_cast<bf16x4 *>(row + c) = h;
             *reinterpret_cast<bf16x4 *>(row + C + c) = l;
         } else {
-            *reinterpret_cast<f32x4 *>(dst + (size_t)p * C) = v;
+            if (GN_NT & 2) __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(dst + (size_t)p * C));
+            else *reinterpret_cast<f32x4 *>(dst + (size_t)p * C) = v;
         }
     };
-    // four independent 16-byte loads in flight per thread (one per iteration leaves the kernel latency bound)
+    // GN_UNROLL independent 16-byte loads in flight per thread (one per iteration leaves the kernel latency bound)
     int p = p_beg + rp;
-    for (; p + 3 * rows_pp < p_end; p += 4 * rows_pp) {
-        f32x4 v[4];
+    for (; p + (GN_UNROLL - 1) * rows_pp < p_end; p += GN_UNROLL * rows_pp) {
+        f32x4 v[GN_UNROLL];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4 *>(src + (size_t)(p + u * rows_pp) * ld);
+        for (int u = 0; u < GN_UNROLL; ++u) {
+            const f32x4 *q = reinterpret_cast<const f32x4 *>(src + (size_t)(p + u * rows_pp) * ld);
+            v[u] = (GN_NT & 1) ? __builtin_nontemporal_load(q) : *q;
+        }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) finish(v[u], p + u * rows_pp);
+        for (int u = 0; u < GN_UNROLL; ++u) finish(v[u], p + u * rows_pp);
     }
     for (; p < p_end; p += rows_pp) finish(*reinterpret_cast<const f32x4 *>(src + (size_t)p * ld), p);
 }
