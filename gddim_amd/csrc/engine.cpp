@@ -578,15 +578,20 @@ static int build_wino_weights(gd_engine *e) {
     for (size_t i = 0; i < P.slots.size(); ++i)
         if (e->wino_off[i] >= 0)
             GD_TRY(launch_wino_weights(e->wbuf + e->slot_off[i], e->wwino + e->wino_off[i], dims[i].first, dims[i].second, nullptr));
-    // the same slots in the two-dimensional form (which launches use it is decided per batch size by conv3x3_wino2d_ok);
-    // only for convolutions on images the 2-D kernel can tile (W in {16, 32, 64})
+    // the two-dimensional form (which launches use it is decided per batch size by conv3x3_wino2d_ok) for the same slots and for
+    // those only the 2-D kernel takes (any N without fused statistics: the 6-channel head convolution), on images it can tile
     e->wino2_off.assign(P.slots.size(), -1);
     long long total2 = 0;
     for (const Op &op : P.ops) {
-        if (op.kind != OP_GEMM || op.w_slot < 0 || e->wino_off[op.w_slot] < 0 || e->wino2_off[op.w_slot] >= 0) continue;
+        if (op.kind != OP_GEMM || op.w_slot < 0 || op.a_slot >= 0 || op.z_per_image || e->wino2_off[op.w_slot] >= 0) continue;
+        const int Cin = op.C0 + op.C1;
+        if (op.KH != 3 || op.KW != 3 || op.stride != 1 || op.pad != 1 || Cin % 32 != 0 || op.K != 9 * Cin || op.ldb != op.K) continue;
+        if (P.slots[op.w_slot].rows != op.N || P.slots[op.w_slot].cols != op.K) continue;
+        if ((op.N % 4 != 0 || op.N < 32) && (op.qstats.t >= 0 || op.egn_peer >= 0)) continue;
         if ((op.W != 8 && op.W != 16 && op.W != 32 && op.W != 64) || op.H % 2 != 0 || (op.H * op.W / 4) % 16 != 0) continue;
         e->wino2_off[op.w_slot] = total2;
-        total2 += (long long)dims[op.w_slot].first * 16 * dims[op.w_slot].second;
+        dims[op.w_slot] = {op.N, Cin};
+        total2 += (long long)op.N * 16 * Cin;
     }
     if (total2 > 0) {
         if (!e->wwino2) GD_HIP(hipMalloc((void **)&e->wwino2, (size_t)total2 * sizeof(float)));

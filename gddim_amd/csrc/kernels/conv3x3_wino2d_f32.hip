@@ -31,7 +31,8 @@
 // waves: they exchange their 64 partial registers through the (now idle) LDS stages, then wave (h, c) of a quad block finishes quad
 // half h x output tile c: bias, per-image bias row, residual, scale, store, fused GroupNorm quad statistics.
 // Shapes: W in {8, 16, 32, 64} (W/2 a power of two, so a 16-quad unit is whole quad rows or an aligned piece of one and the 32-row
-// statistics slices stay inside one wave), H even, H W / 4 a multiple of 16, Cin % 32 == 0 (two-source concat: C0 % 32 == 0), N % 4 == 0.
+// statistics slices stay inside one wave), H even, H W / 4 a multiple of 16, Cin % 32 == 0 (two-source concat: C0 % 32 == 0); N % 4 == 0
+// and N >= 32 when the epilogue emits GroupNorm statistics (any N otherwise: the 6-channel head convolution).
 // Weights arrive as U[n][Cin/8][i][j][8] (launch_wino2d_weights; component row i = 3 negated), 16/9 of the direct size.
 #include <cstdio>
 #include <cstdlib>
@@ -607,7 +608,8 @@ bool conv3x3_wino2d_shape_ok(const GemmParams &p) {
     const int Cin = p.C0 + p.C1;
     if (Cin % 32 != 0 || (p.C1 > 0 && (p.C0 % 32 != 0 || !p.a1)) || p.K != 9 * Cin) return false;
     if ((p.W != 8 && p.W != 16 && p.W != 32 && p.W != 64) || p.H % 2 != 0 || (p.H * p.W / 4) % 16 != 0) return false;
-    if (p.rows_per_image != p.H * p.W || p.M % (p.H * p.W) != 0 || p.N % 4 != 0 || p.N < 32) return false;
+    if (p.rows_per_image != p.H * p.W || p.M % (p.H * p.W) != 0 || p.N < 1) return false;
+    if ((p.N % 4 != 0 || p.N < 32) && (p.qstats || p.egn_out)) return false;  // (a narrow or ragged N only without the column-quad statistics)
     if (p.qstats && p.qs_slices != p.rows_per_image / 32) return false;
     if (p.rowbias && p.ld_rowbias <= 0) return false;
     if ((long long)p.M * p.ldc * 4 + 64 >= (1LL << 31) || (p.res && (long long)p.M * p.ldres * 4 + 64 >= (1LL << 31))) return false;

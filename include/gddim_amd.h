@@ -257,8 +257,8 @@ int gd_conv3x3_winograd(const float *x_dev, const float *w_dev, float *u_scratch
                         const float *res_dev, float *out_dev, int batch, int H, int W, int Cin, int Cout, float alpha,
                         float out_scale, void *stream);
 /* The same convolution through the two-dimensional transform F(2x2, 3x3) (x 2.25 fewer matrix-core products than the direct sum):
- * u_scratch_dev receives the transformed weights, 16 * Cout * Cin floats.  Shapes: W in {16, 32, 64}, H even, H*W/4 % 32 == 0,
- * Cin % 32 == 0, Cout % 4 == 0.  What the engine runs for the 3x3 stride-1 convolutions of the 16x16 .. 64x64 levels at production
+ * u_scratch_dev receives the transformed weights, 16 * Cout * Cin floats.  Shapes: W in {8, 16, 32, 64}, H even, H*W/4 % 16 == 0,
+ * Cin % 32 == 0, any Cout.  What the engine runs for the 3x3 stride-1 convolutions of the 8x8 .. 64x64 levels at production
  * batch sizes (kernels/conv3x3_wino2d_f32.hip).
  * Replaces: the same nn.Conv call sites (cld_jax/models/layers.py:66-107). */
 int gd_conv3x3_winograd2d(const float *x_dev, const float *w_dev, float *u_scratch_dev, const float *bias_dev,

@@ -210,6 +210,8 @@ WINO2D_CASES = [
     (6, 8, 8, 64, 96, True, True),        # W = 8: a 16-quad unit is a whole 8x8 image (four quad rows); ragged M (96 quads), ragged N
     (3, 16, 8, 32, 64, False, True),      # W = 8, H = 16: two units per image
     (5, 4, 16, 32, 64, True, True),       # 16 quads per image: every unit is a whole (4 x 16) image
+    (2, 32, 32, 64, 6, True, False),      # N = 6: the U-Net's head convolution (one N tile, 58 of its 64 columns past the end)
+    (2, 16, 16, 32, 18, False, True),     # N = 18: not a multiple of 4, residual row stride 18
 ]
 
 
