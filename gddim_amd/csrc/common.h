@@ -155,6 +155,7 @@ int launch_gn_generic(const float *x0, int C0, const float *x1, int C1, float *m
 int launch_fir_up2(const float *x, float *out, int batch, int H, int W, int C, hipStream_t s);
 int launch_naive_resample2(const float *x, float *out, int batch, int H, int W, int C, int up, hipStream_t s);
 int launch_fir_down2(const float *x, float *out, int batch, int H, int W, int C, hipStream_t s);
+int launch_fir_pad(const float *x, float *out, int batch, int H, int W, int C, hipStream_t s);  // (H, W) -> (H + 1, W + 1), see the kernel
 int launch_softmax_rows(float *x, long long rows, int cols, hipStream_t s);
 int launch_swish(const float *x, float *out, long long n, hipStream_t s);
 // temb0[b][0:E] = sin(2 pi W log(label_b)), [E:2E] = cos(...); label_b = labels[b] or 999*ts[*step]

@@ -359,6 +359,10 @@ static int run_op(gd_engine *e, int op_index, const Bind &b, int batch, hipStrea
             if (op.act) return launch_naive_resample2(tptr(e, b, op.a0, batch), tptr(e, b, op.out, batch), batch, op.H, op.W, op.C0, 0, s);
             return launch_fir_down2(tptr(e, b, op.a0, batch), tptr(e, b, op.out, batch), batch, op.H, op.W, op.C0, s);
         }
+        case OP_FIR_PAD: {
+            ProfScope ps(e, s, "fir_pad", 0, 4.0 * batch * op.C0 * ((double)op.H * op.W + (double)(op.H + 1) * (op.W + 1)));
+            return launch_fir_pad(tptr(e, b, op.a0, batch), tptr(e, b, op.out, batch), batch, op.H, op.W, op.C0, s);
+        }
         case OP_SOFTMAX: {
             ProfScope ps(e, s, "softmax", 0, 8.0 * batch * op.rows_per_image * op.cols);
             return launch_softmax_rows(tptr(e, b, op.out, batch), (long long)batch * op.rows_per_image, op.cols, s);

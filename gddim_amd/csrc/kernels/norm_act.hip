@@ -362,6 +362,45 @@ __global__ __launch_bounds__(256) void fir_down2_kernel(const float *__restrict_
     reinterpret_cast<f32x4 *>(out)[idx] = acc;
 }
 
+// ---- the FIR of conv_downsample_2d at full resolution (up_or_down_sampling.py:168-209: upfirdn with k = outer([1,3,3,1]) / 64 and
+// pads (2, 2)): out (H + 1, W + 1), out[y][x] = sum_{i,j < 4} k[i] k[j] x[y + i - 2][x + j - 2], zero outside the image.  The 3x3
+// stride-2 VALID convolution that follows reads it as an ordinary GEMM source.
+__global__ __launch_bounds__(256) void fir_pad_kernel(const float *__restrict__ x, float *__restrict__ out, int H, int W, int C4,
+                                                       long long total) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int f = (int)(idx % C4);
+    long long r = idx / C4;
+    const int OW = W + 1, OH = H + 1;
+    const int ox = (int)(r % OW);
+    r /= OW;
+    const int oy = (int)(r % OH);
+    const int b = (int)(r / OH);
+    const float wt[4] = {0.125f, 0.375f, 0.375f, 0.125f};
+    const f32x4 *xb = reinterpret_cast<const f32x4 *>(x) + (size_t)b * H * W * C4 + f;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int yy = oy + a - 2;
+        if ((unsigned)yy >= (unsigned)H) continue;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int xx = ox + c - 2;
+            if ((unsigned)xx >= (unsigned)W) continue;
+            acc += xb[((size_t)yy * W + xx) * C4] * (wt[a] * wt[c]);
+        }
+    }
+    reinterpret_cast<f32x4 *>(out)[idx] = acc;
+}
+
+int launch_fir_pad(const float *x, float *out, int batch, int H, int W, int C, hipStream_t s) {
+    GD_CHECK(C % 4 == 0, "fir_pad: C %% 4 != 0");
+    const long long total = (long long)batch * (H + 1) * (W + 1) * (C / 4);
+    hipLaunchKernelGGL(fir_pad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, out, H, W, C / 4, total);
+    GD_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_fir_up2(const float *x, float *out, int batch, int H, int W, int C, hipStream_t s) {
     GD_CHECK(C % 4 == 0, "fir_up2: C %% 4 != 0");
     const long long total = (long long)batch * 4 * H * W * (C / 4);

@@ -483,24 +483,37 @@ int Plan::build(const gd_model_desc &d) {
             int o = resblock(rb++, hs.back().t, hs.back().C, -1, 0, res, res, C, false, true, oh);
             res = oh;
             if (d.progressive_input_residual) {
-                // Downsample_k/Conv2d_0: FIR pad + 3x3 stride-2 VALID conv == one 6x6 stride-2 pad-2 conv
+                // Downsample_k/Conv2d_0 = conv_downsample_2d: FIR at full resolution with pads (2, 2), then a 3x3 stride-2 VALID
+                // convolution.  With whole 32-channel slabs the two run as written (an HBM pass over the small pyramid tensor + a
+                // quarter of the products); the 8-channel first level composes them into one 6x6 stride-2 pad-2 convolution.
                 const std::string pn = "Downsample_" + std::to_string(dn++) + "/Conv2d_0";
-                int ws = new_slot(pn + "/weight", C, 36LL * pyrC), bs = new_slot(pn + "/bias", 1, C);
+                const bool two_step = pyrC % 32 == 0 && !d.no_fir;
+                int ws = new_slot(pn + "/weight", C, (two_step ? 9LL : 36LL) * pyrC), bs = new_slot(pn + "/bias", 1, C);
                 const int real_in = (pyr == t_x_in || tensors[pyr].name == "x_centered") ? d.in_channels : pyrC;
-                add_param(pn + "/weight", {3, 3, real_in, C}, P_CONV_FIR6, ws, 0, pyrC);
+                add_param(pn + "/weight", {3, 3, real_in, C}, two_step ? P_CONV : P_CONV_FIR6, ws, 0, pyrC);
                 add_param(pn + "/bias", {C}, P_VEC, bs, 0);
+                int src = pyr;
+                if (two_step) {
+                    src = new_tensor(pn + ".fir", 2 * res + 1, 2 * res + 1, pyrC);
+                    Op f;
+                    f.kind = OP_FIR_PAD; f.label = pn + ".fir_pad";
+                    f.a0 = {pyr, 0}; f.C0 = pyrC; f.H = 2 * res; f.W = 2 * res; f.out = {src, 0};
+                    ops.push_back(f);
+                }
                 int np = new_tensor(pn + ".out", res, res, C);
                 attach_stats(np, res * res);
                 Op g;
                 g.kind = OP_GEMM; g.label = "pyramid_down_" + std::to_string(dn - 1);
-                g.a0 = {pyr, 0}; g.C0 = pyrC; g.lda0 = pyrC; g.H = 2 * res; g.W = 2 * res; g.OH = res; g.OW = res;
-                g.KH = g.KW = 6; g.stride = 2; g.pad = 2; g.m_per_image = res * res; g.N = C; g.K = 36 * pyrC;
+                g.a0 = {src, 0}; g.C0 = pyrC; g.lda0 = pyrC; g.OH = res; g.OW = res; g.stride = 2; g.m_per_image = res * res; g.N = C;
+                if (two_step) { g.H = 2 * res + 1; g.W = 2 * res + 1; g.KH = g.KW = 3; g.pad = 0; g.K = 9 * pyrC; }
+                else { g.H = 2 * res; g.W = 2 * res; g.KH = g.KW = 6; g.pad = 2; g.K = 36 * pyrC; }
                 g.w_slot = ws; g.ldb = g.K; g.bias_slot = bs; g.res = {o, 0}; g.ldres = C; g.out = {np, 0}; g.ldc = C;
                 g.out_scale = d.skip_rescale ? (float)(1.0 / std::sqrt(2.0)) : 1.f;
                 if (tensors[np].stats_t >= 0) { g.qstats = {tensors[np].stats_t, 0}; g.qs_slices = tensors[np].qs_slices; }
                 g.flops_per_image = 2.0 * res * res * C * 9 * real_in;
                 g.is_conv3x3 = 1;
                 ops.push_back(g);
+                if (two_step) release(src);
                 release(pyr);
                 release(o);
                 pyr = np; pyrC = C;

@@ -22,6 +22,8 @@ enum OpKind {
     OP_AFFINE_PAD,
     OP_SCALE_ROWS,
     OP_GN_GENERIC,  // GroupNorm whose groups are not whole float4 columns (e.g. 192 channels in 32 groups of 6): direct two-kernel path
+    OP_FIR_PAD,     // a0 (H, W, C0) -> out (H + 1, W + 1, C0): the [1,3,3,1]^2 / 64 FIR at full resolution with pads (2, 2) -- the first half
+                    // of conv_downsample_2d (up_or_down_sampling.py:168-209); its 3x3 stride-2 VALID convolution follows as a GEMM
 };
 
 // external tensors are bound to caller pointers at run time

@@ -233,6 +233,14 @@ class PlanInterp(object):
     def _op5(self, op, B):
         self._fir(op, B, False)
 
+    def _op10(self, op, B):  # FIR of conv_downsample_2d at full resolution: (H, W) -> (H + 1, W + 1), pads (2, 2)
+        H, W, C = op["H"], op["W"], op["C0"]
+        x = self._rows(self._flat(op["a0"], B), B * H * W, C, C).reshape(B, H, W, C)
+        k = torch.tensor([1.0, 3.0, 3.0, 1.0], dtype=self.dtype) / 8
+        xp = F.pad(x.permute(0, 3, 1, 2), (2, 2, 2, 2))
+        y = sum(k[i] * k[j] * xp[:, :, i:i + H + 1, j:j + W + 1] for i in range(4) for j in range(4)).permute(0, 2, 3, 1)
+        self._rows(self._flat(op["out"], B), B * (H + 1) * (W + 1), C, C)[:] = y.reshape(B * (H + 1) * (W + 1), C)
+
     def _op6(self, op, B):  # softmax in place
         rows, cols = B * op["rows_per_image"], op["cols"]
         v = self._rows(self._flat(op["out"], B), rows, cols, cols)
