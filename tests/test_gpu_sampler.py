@@ -437,6 +437,16 @@ def test_production_batch_sampler_matches_oracle(native_lib):
     ex, ev = np.abs(x[:n_ref].cpu().numpy() - wx).max(), np.abs(v[:n_ref].cpu().numpy() - wv).max()
     print("B=256 sampler: max|dx| %.3e max|dv| %.3e (|x| %.3e |v| %.3e)" % (ex, ev, np.abs(wx).max(), np.abs(wv).max()))
     assert torch.isfinite(x).all() and ex < _tol(wx) and ev < _tol(wv)
+    # size-independent properties at the full batch: the call is deterministic (no atomics, fixed reduction orders: a second call, a
+    # call with eager launches and a call through one whole-loop graph are BIT-identical), and images are independent units (the batch
+    # with its images in reverse order gives the reversed result: every image goes through the same tiles' arithmetic wherever it sits)
+    ut = torch.as_tensor(u, device="cuda:0")
+    x2, v2, _ = fn(0, state, B, ut)
+    x3, v3, _ = fn(0, state, B, ut, use_graph=False)
+    x4, v4, _ = fn(0, state, B, ut, use_graph="loop")
+    assert torch.equal(x, x2) and torch.equal(v, v2) and torch.equal(x, x3) and torch.equal(v, v3) and torch.equal(x, x4) and torch.equal(v, v4)
+    xr, vr, _ = fn(0, state, B, torch.flip(ut, dims=(0,)).contiguous())
+    assert xr.shape[0] == B and torch.equal(torch.flip(xr, dims=(0,)), x) and torch.equal(torch.flip(vr, dims=(0,)), v)
 
 
 @pytest.mark.parametrize("order", [0, 1, 2])
