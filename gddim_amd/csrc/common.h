@@ -97,6 +97,12 @@ struct GemmParams {
     // U[n][ky][Cin/8][component][8] by launch_wino_weights (row stride ldb_wino = 12 Cin); null = direct kernel
     const float *b_wino;
     int ldb_wino;
+    // two-dimensional Winograd kernel with the channel range split over wk_split workgroups per tile (4x4 images, whose few tiles would
+    // leave most CUs idle): split s multiplies channels [s, s + 1) * Cin / wk_split and stores its partial outputs -- after the output
+    // transform, before bias / residual / scale -- to wk_partial[s][m][n] (row stride N); wino2d_splitk_finish_kernel adds the
+    // partials in index order and runs the epilogue.  0 / 1 = off.
+    int wk_split;
+    float *wk_partial;
 };
 
 int launch_igemm(const GemmParams &p, int batch_z, hipStream_t s);
@@ -133,6 +139,11 @@ bool conv3x3_wino2d_shape_ok(const GemmParams &p);
 const char *conv3x3_wino2d_name();
 int launch_conv3x3_wino2d(const GemmParams &p, hipStream_t s);
 int launch_wino2d_weights(const float *w, float *u, int N, int Cin, hipStream_t s);
+// ... on 4x4 images (rows_per_image == 16), split over the channels: the number of splits the launcher would use (0 = not eligible),
+// the floats of scratch it needs (wk_split * M * N), and the launch (main kernel + wino2d_splitk_finish_kernel; p.wk_partial set)
+int conv3x3_wino2d_splitk_factor(const GemmParams &p);
+const char *conv3x3_wino2d_splitk_finish_name();
+int launch_conv3x3_wino2d_splitk(const GemmParams &p, hipStream_t s);
 // per-device zero buffer used by the staging loads; allocates on first use (call once outside graph capture)
 const float *igemm_zero_buffer();
 

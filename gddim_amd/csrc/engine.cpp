@@ -61,6 +61,8 @@ struct gd_engine {
     std::vector<long long> wino_off;
     // ... and their two-dimensional F(2x2, 3x3) copies (kernels/conv3x3_wino2d_f32.hip), 16 N Cin floats per eligible slot
     float *wwino2 = nullptr;
+    float *splitk_ws = nullptr;  // partial outputs of the channel-split 2-D Winograd launches (4x4 level): 8 * max_batch * 16 * max N floats
+    long long splitk_ws_floats = 0;
     std::vector<long long> wino2_off;
     std::map<int, std::vector<char>> fuse_ok;      // batch size -> per GEMM op: the fused-GroupNorm halo kernel takes it
     std::map<int, std::vector<char>> egn_ok;       // batch size -> per GEMM op: normalises its output in the epilogue (Op::egn_peer)
@@ -260,6 +262,7 @@ static bool egn_fused(gd_engine *e, const Bind &b, int batch, int gemm_index) {
             const bool wino2 = z == 1 && op.w_slot >= 0 && e->wwino2 && e->wino2_off[op.w_slot] >= 0;
             const bool wino = z == 1 && op.w_slot >= 0 && e->wwino && e->wino_off[op.w_slot] >= 0 && conv3x3_wino_ok(g);
             if (wino2 && conv3x3_wino2d_ok(g)) ok[i] = 1;  // (its shape test covers the egn_* fields)
+            else if (wino2 && e->splitk_ws && conv3x3_wino2d_splitk_factor(g) > 1) ok[i] = 1;  // (the finishing pass normalises)
             else ok[i] = (wino ? conv3x3_wino_egn_ok(g) : igemm_egn_ok(g, z)) ? 1 : 0;
         }
         it = e->egn_ok.emplace(batch, std::move(ok)).first;
@@ -315,6 +318,14 @@ static int run_op(gd_engine *e, int op_index, const Bind &b, int batch, hipStrea
                 g.b_wino = e->wwino2 + e->wino2_off[op.w_slot];
                 ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(conv3x3_wino2d_name()), op.flops_per_image * batch, 0);
                 return launch_conv3x3_wino2d(g, s);
+            }
+            if (e->precision == 0 && z == 1 && op.w_slot >= 0 && e->wwino2 && e->wino2_off[op.w_slot] >= 0 && e->splitk_ws &&
+                conv3x3_wino2d_splitk_factor(g) > 1) {  // 4x4 images: the channel range split over workgroups + a finishing pass
+                g.b_wino = e->wwino2 + e->wino2_off[op.w_slot];
+                g.wk_partial = e->splitk_ws;
+                GD_CHECK((long long)conv3x3_wino2d_splitk_factor(g) * g.M * g.N <= e->splitk_ws_floats, "%s: split-K scratch too small", op.label.c_str());
+                ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(conv3x3_wino2d_name()), op.flops_per_image * batch, 0);
+                return launch_conv3x3_wino2d_splitk(g, s);
             }
             if (e->precision == 0 && z == 1 && op.w_slot >= 0 && e->wwino && e->wino_off[op.w_slot] >= 0 && conv3x3_wino_ok(g)) {
                 g.b_wino = e->wwino + e->wino_off[op.w_slot];
@@ -472,6 +483,7 @@ int gd_engine_destroy(gd_engine *e) {
         for (auto &p : e->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
         if (e->wwino) (void)hipFree(e->wwino);
         if (e->wwino2) (void)hipFree(e->wwino2);
+        if (e->splitk_ws) (void)hipFree(e->splitk_ws);
         if (e->wsplit_hi) (void)hipFree(e->wsplit_hi);
         if (e->wsplit_lo) (void)hipFree(e->wsplit_lo);
         float *bufs[] = {e->arena, e->wbuf, e->xin, e->epsb, e->eps_planar, e->labels, e->u8, e->ring, e->ystate, e->uin_stage,
@@ -585,17 +597,24 @@ static int build_wino_weights(gd_engine *e) {
     // the two-dimensional form (which launches use it is decided per batch size by conv3x3_wino2d_ok) for the same slots and for
     // those only the 2-D kernel takes (any N without fused statistics: the 6-channel head convolution), on images it can tile
     e->wino2_off.assign(P.slots.size(), -1);
-    long long total2 = 0;
+    long long total2 = 0, need_ws = 0;
     for (const Op &op : P.ops) {
         if (op.kind != OP_GEMM || op.w_slot < 0 || op.a_slot >= 0 || op.z_per_image || e->wino2_off[op.w_slot] >= 0) continue;
         const int Cin = op.C0 + op.C1;
         if (op.KH != 3 || op.KW != 3 || op.stride != 1 || op.pad != 1 || Cin % 32 != 0 || op.K != 9 * Cin || op.ldb != op.K) continue;
         if (P.slots[op.w_slot].rows != op.N || P.slots[op.w_slot].cols != op.K) continue;
         if ((op.N % 4 != 0 || op.N < 32) && (op.qstats.t >= 0 || op.egn_peer >= 0)) continue;
-        if ((op.W != 8 && op.W != 16 && op.W != 32 && op.W != 64) || op.H % 2 != 0 || (op.H * op.W / 4) % 16 != 0) continue;
+        const bool img4 = op.H == 4 && op.W == 4;  // the channel-split launch (conv3x3_wino2d_splitk_factor)
+        if (!img4 && ((op.W != 8 && op.W != 16 && op.W != 32 && op.W != 64) || op.H % 2 != 0 || (op.H * op.W / 4) % 16 != 0)) continue;
+        if (img4) need_ws = std::max(need_ws, 8LL * e->plan.desc.max_batch * 16 * op.N);
         e->wino2_off[op.w_slot] = total2;
         dims[op.w_slot] = {op.N, Cin};
         total2 += (long long)op.N * 16 * Cin;
+    }
+    if (need_ws > e->splitk_ws_floats) {  // (once: the plan and max_batch fix it)
+        if (e->splitk_ws) (void)hipFree(e->splitk_ws);
+        GD_HIP(hipMalloc((void **)&e->splitk_ws, (size_t)need_ws * sizeof(float)));
+        e->splitk_ws_floats = need_ws;
     }
     if (total2 > 0) {
         if (!e->wwino2) GD_HIP(hipMalloc((void **)&e->wwino2, (size_t)total2 * sizeof(float)));
@@ -1191,6 +1210,20 @@ int gd_conv3x3_winograd2d(const float *x_dev, const float *w_dev, float *u_scrat
     g.out = out_dev; g.ldc = Cout; g.bias = bias_dev; g.res = res_dev; g.ldres = Cout;
     g.rows_per_image = H * W;
     g.alpha = alpha; g.out_scale = out_scale;
+    if (H == 4 && W == 4) {  // 4x4 images: the channel-split launch (scratch of its own here; the engine keeps one)
+        g.qs_slices = 1;
+        const int ks = conv3x3_wino2d_splitk_factor(g);
+        GD_CHECK(ks > 1, "conv3x3_winograd2d: shape not eligible (B=%d H=%d W=%d Cin=%d Cout=%d)", batch, H, W, Cin, Cout);
+        float *ws = nullptr;
+        GD_HIP(hipMalloc((void **)&ws, (size_t)ks * g.M * g.N * sizeof(float)));
+        GD_TRY(launch_wino2d_weights(w_dev, u_scratch_dev, Cout, Cin, (hipStream_t)stream));
+        g.b_wino = u_scratch_dev;
+        g.wk_partial = ws;
+        const int r = launch_conv3x3_wino2d_splitk(g, (hipStream_t)stream);
+        (void)hipStreamSynchronize((hipStream_t)stream);
+        (void)hipFree(ws);
+        return r;
+    }
     GD_CHECK(conv3x3_wino2d_shape_ok(g), "conv3x3_winograd2d: shape not eligible (B=%d H=%d W=%d Cin=%d Cout=%d)", batch, H, W, Cin, Cout);
     GD_TRY(launch_wino2d_weights(w_dev, u_scratch_dev, Cout, Cin, (hipStream_t)stream));
     g.b_wino = u_scratch_dev;

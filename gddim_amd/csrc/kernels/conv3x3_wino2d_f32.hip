@@ -173,7 +173,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_f32_kernel(const GemmPa
             vo[k] = ((bad >> k) & 1u) ? OOB : off;
         }
     };
-    set_vo(p.lda0, bias0);
+    // (set_vo below, once the chunk state is known)
     // LDS slot (16 B) of component (i, j), channel half hq in a V row: i * 8 + ((2 j + hq + 2 i) & 7) -- the j / hq slots of component
     // row i ROTATED by 2 i.  A ds_write_b128 is serviced in groups of 8 consecutive lanes = the (si, hq) of one quad, on 32 banks: without
     // the rotation the four si of a group hit the same slot modulo 8 (4-way conflict, 44 % of the LDS cycles of the kernel).
@@ -205,10 +205,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_f32_kernel(const GemmPa
     };
 #endif
 
-    // ---- wave-uniform state of the chunk whose loads are issued next ----
-    int s_kc = 0, s_c = 0;
-    bool s_first = true;  // s_c < C0: the chunk comes from source 0
-    const int nk = Cin >> 3;
+    // ---- wave-uniform state of the chunk whose loads are issued next.  With wk_split > 1 (GemmParams: 4x4 images) this workgroup is
+    // split blockIdx.y of its tile and multiplies the channels [c_begin, c_begin + 8 nk) only ----
+    const int ksplit = p.wk_split > 1 ? p.wk_split : 1;
+    const int nk = (Cin >> 3) / ksplit;  // even, >= 4
+    const int c_begin = (int)blockIdx.y * nk * 8;
+    int s_kc = c_begin >> 3, s_c = c_begin;
+    bool s_first = p.C1 == 0 || c_begin < p.C0;  // s_c < C0: the chunk comes from source 0
     auto advance = [&]() __attribute__((always_inline)) {
         ++s_kc;
         s_c += 8;
@@ -218,16 +221,19 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_f32_kernel(const GemmPa
         }
     };
 
+    if (s_first) set_vo(p.lda0, bias0);
+    else set_vo(p.lda1, bias1);
+
     w2f32x4 rr[4], wb[4], cm[4];
     // (chunks past the tile's last one are never requested: the last two iterations of the K loop are peeled)
     auto load_raw_to = [&](w2f32x4 *dst, int k) __attribute__((always_inline)) {
-        if ((W2_ABL & 1) && s_kc >= 2) return;
+        if ((W2_ABL & 1) && s_kc >= (c_begin >> 3) + 2) return;
         if (s_first) dst[k] = w2_load16(srd_a0, vo[k], s_c * 4);
         else dst[k] = w2_load16(srd_a1, vo[k], (s_c - p.C0) * 4);
     };
     auto load_raw = [&](int k) __attribute__((always_inline)) { load_raw_to(rr, k); };
     auto load_w_to = [&](w2f32x4 *dst, int k) __attribute__((always_inline)) {
-        if ((W2_ABL & 1) && s_kc >= 2) return;
+        if ((W2_ABL & 1) && s_kc >= (c_begin >> 3) + 2) return;
         dst[k] = w2_load16(srd_b, bvo, (s_kc * 128 + k * 32) * 4);
     };
     auto load_w = [&](int k) __attribute__((always_inline)) { load_w_to(wb, k); };
@@ -339,17 +345,21 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_f32_kernel(const GemmPa
         const_cast<char *>(reinterpret_cast<const char *>(p.res ? p.res : p.out)), 0, p.M * p.ldres * 4, 0x00020000);
     // quad (vv & 3) + 8 (vv >> 2) + 4 lh of the unit: the half-wave adds 4 quads = 8 pixels along x, or, on 8-wide images (4 quads
     // per quad row), one quad row = 2 W pixels
-    const int lane_px = Wq == 4 ? lh * 2 * W : 8 * lh;
+    // (4-wide images, 4 quads each: one whole image = 16 pixels)
+    const int lane_px = Wq == 2 ? lh * 16 : Wq == 4 ? lh * 2 * W : 8 * lh;
     const int vo_r = nok ? (lane_px * p.ldres + n) * 4 : OOB;
     // pixel offset (from mu) of quad vv of the unit, lane-independent part: W = 8: four quad rows of 4 (vv >> 2 selects a pair of them),
     // W = 16: two quad rows of 8; else one aligned run of 16 quads
     auto pix_off = [&](int vv, int a, int b) __attribute__((always_inline)) {
         const int dq = (vv & 3) + 8 * (vv >> 2);
-        const int base = Wq == 4 ? (vv >> 2) * 4 * W + (vv & 3) * 2 : Wq == 8 ? (vv >> 2) * 2 * W + (vv & 3) * 2 : dq * 2;
+        const int base = Wq == 2   ? (vv >> 2) * 32 + ((vv & 3) >> 1) * 2 * W + (vv & 1) * 2  // W = 4: quads 8 apart are two images apart
+                         : Wq == 4 ? (vv >> 2) * 4 * W + (vv & 3) * 2
+                         : Wq == 8 ? (vv >> 2) * 2 * W + (vv & 3) * 2
+                                   : dq * 2;
         return mu + base + a * W + b;
     };
     float rs[2][2][8];
-    const bool has_res = p.res != nullptr;
+    const bool has_res = p.res != nullptr && ksplit == 1;
     auto load_res = [&](int idx) __attribute__((always_inline)) {  // idx = (a * 2 + b) * 8 + vv
         const int a = idx >> 4, b = (idx >> 3) & 1, vv = idx & 7;
         rs[a][b][vv] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_r, vo_r, pix_off(vv, a, b) * p.ldres * 4, 0));
@@ -475,6 +485,21 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_f32_kernel(const GemmPa
 #ifdef W2_TRACE
     trace();
 #endif
+    if (ksplit > 1) {
+        // one split of the channel range: the partial outputs go to wk_partial[split][m][n] as they are; bias, residual, scale,
+        // statistics and the GroupNorm belong to wino2d_splitk_finish_kernel
+        float *part = p.wk_partial + (size_t)blockIdx.y * p.M * p.N;
+        const __amdgpu_buffer_rsrc_t srd_p = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(part), 0, p.M * p.N * 4, 0x00020000);
+        const int vo_p = nok ? (lane_px * p.N + n) * 4 : OOB;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int vv = 0; vv < 8; ++vv)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y[a][b][vv]), srd_p, vo_p, pix_off(vv, a, b) * p.N * 4, 0);
+        return;
+    }
     // ---- epilogue of the unit ----
     const __amdgpu_buffer_rsrc_t srd_o =
         __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(p.out), 0, p.M * p.ldc * 4, 0x00020000);
@@ -607,7 +632,11 @@ bool conv3x3_wino2d_shape_ok(const GemmParams &p) {
     if (p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1 || p.OH != p.H || p.OW != p.W) return false;
     const int Cin = p.C0 + p.C1;
     if (Cin % 32 != 0 || (p.C1 > 0 && (p.C0 % 32 != 0 || !p.a1)) || p.K != 9 * Cin) return false;
-    if ((p.W != 8 && p.W != 16 && p.W != 32 && p.W != 64) || p.H % 2 != 0 || (p.H * p.W / 4) % 16 != 0) return false;
+    const bool img4 = p.W == 4 && p.H == 4 && p.wk_split > 1;  // 4x4 images: only with the channel range split (launch_conv3x3_wino2d_splitk)
+    if (!img4 && ((p.W != 8 && p.W != 16 && p.W != 32 && p.W != 64) || p.H % 2 != 0 || (p.H * p.W / 4) % 16 != 0)) return false;
+    // (a split's chunk count: even and >= 4, the K loop's unrolling; a split may start in either source of a channel concat)
+    if (p.wk_split > 1 && (((p.C0 + p.C1) / 8) % p.wk_split != 0 || ((p.C0 + p.C1) / 8 / p.wk_split) % 2 != 0 || (p.C0 + p.C1) / 8 / p.wk_split < 4 || !p.wk_partial))
+        return false;
     if (p.rows_per_image != p.H * p.W || p.M % (p.H * p.W) != 0 || p.N < 1) return false;
     if ((p.N % 4 != 0 || p.N < 32) && (p.qstats || p.egn_out)) return false;  // (a narrow or ragged N only without the column-quad statistics)
     if (p.qstats && p.qs_slices != p.rows_per_image / 32) return false;
@@ -635,12 +664,133 @@ int launch_conv3x3_wino2d(const GemmParams &p_in, hipStream_t s) {
     p.ldb_wino = 16 * (p.C0 + p.C1);
     if (p.C1 == 0) p.lda1 = 4;
     w2fill_div((unsigned)(p.H * p.W / 4), p.mg_ohw, p.sh_ohw);  // quads per image
-    p.sh_ow = p.W == 8 ? 2 : p.W == 16 ? 3 : p.W == 32 ? 4 : 5;  // log2(W / 2)
+    p.sh_ow = p.W == 4 ? 1 : p.W == 8 ? 2 : p.W == 16 ? 3 : p.W == 32 ? 4 : 5;  // log2(W / 2)
     p.m_tiles = (p.M / 4 + 63) / 64;
     p.n_tiles = (p.N + 63) / 64;
     p.flat_tiles = p.m_tiles < 16;
     const int gx = p.flat_tiles ? p.m_tiles * p.n_tiles : ((p.m_tiles + 7) / 8) * 8 * p.n_tiles;
-    hipLaunchKernelGGL(conv3x3_wino2d_f32_kernel, dim3(gx), dim3(512), 0, s, p);
+    hipLaunchKernelGGL(conv3x3_wino2d_f32_kernel, dim3(gx, p.wk_split > 1 ? p.wk_split : 1), dim3(512), 0, s, p);
+    GD_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---- 4x4 images: channel range split over workgroups + a finishing pass ------------------------------------------------------
+// The 4x4 level of the U-Net has M = 16 B rows: 64 workgroup tiles at B = 256, a quarter of the CUs.  Every tile is therefore given
+// wk_split workgroups, each with 1 / wk_split of the channels; they store their partial outputs (after the output transform) and this
+// kernel adds them IN INDEX ORDER (deterministic) and runs the shared epilogue: alpha, bias, per-image bias row, residual, scale,
+// store, GroupNorm quad statistics (one slice per 16-row image) and the epilogue GroupNorm (plan.h: Op::egn_peer).
+// A wave takes (image b, block of 16 column quads): lane = (pixel group pxg, column quad f_lo), four pixels per lane, so that a load
+// instruction covers four 256-byte row pieces and every partial is requested up front; the 16-pixel sums come from two shuffles.
+__global__ __launch_bounds__(256) void wino2d_splitk_finish_kernel(const GemmParams p, int images) {
+    const int NQ = p.N >> 2, FB = (NQ + 15) >> 4;
+    const int lane = threadIdx.x & 63;
+    const long long gw = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (gw >= (long long)images * FB) return;  // (whole waves leave: the shuffles below are among live lanes of one wave)
+    const int b = (int)(gw / FB), fb = (int)(gw - (long long)b * FB);
+    const int f = fb * 16 + (lane & 15), pxg = lane >> 4;
+    const bool live = f < NQ;
+    const int n = live ? f * 4 : 0;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f4 add = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) add = *reinterpret_cast<const f4 *>(p.bias + n);
+    if (p.rowbias) add += *reinterpret_cast<const f4 *>(p.rowbias + (size_t)b * p.ld_rowbias + n);
+    const size_t slice = (size_t)p.M * p.N;
+    f4 part[4][8], rs[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const size_t m = (size_t)b * 16 + pxg * 4 + i;
+#pragma unroll
+        for (int sp = 0; sp < 8; ++sp)
+            if (sp < p.wk_split) part[i][sp] = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(p.wk_partial + sp * slice + m * p.N + n));
+        if (p.res) rs[i] = *reinterpret_cast<const f4 *>(p.res + m * p.ldres + n);
+    }
+    f4 vals[4];
+    f4 s4 = {0.f, 0.f, 0.f, 0.f}, q4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const size_t m = (size_t)b * 16 + pxg * 4 + i;
+        f4 acc = part[i][0];
+#pragma unroll
+        for (int sp = 1; sp < 8; ++sp)
+            if (sp < p.wk_split) acc += part[i][sp];  // index order: deterministic
+        f4 v = p.alpha * acc + add;
+        if (p.res) v += rs[i];
+        v *= p.out_scale;
+        if (!live) v = f4{0.f, 0.f, 0.f, 0.f};
+        vals[i] = v;
+        if (live && !p.egn_skip_raw) *reinterpret_cast<f4 *>(p.out + m * p.ldc + n) = v;
+        s4 += v;
+        q4 += v * v;
+    }
+    float gs = (s4[0] + s4[1]) + (s4[2] + s4[3]), gq = (q4[0] + q4[1]) + (q4[2] + q4[3]);
+    gs += __shfl_xor(gs, 16); gq += __shfl_xor(gq, 16);
+    gs += __shfl_xor(gs, 32); gq += __shfl_xor(gq, 32);
+    if (p.qstats && live && pxg == 0) reinterpret_cast<float2 *>(p.qstats)[((size_t)b * p.qs_slices) * NQ + f] = make_float2(gs, gq);
+    if (p.egn_out) {
+        // a group is egn_cpg consecutive columns = egn_cpg / 4 consecutive quads, inside this wave's 16-quad block
+        for (int o = 1; o < (p.egn_cpg >> 2); o <<= 1) { gs += __shfl_xor(gs, o); gq += __shfl_xor(gq, o); }
+        const float inv_n = 1.0f / (16.0f * (float)p.egn_cpg);
+        const float mean = gs * inv_n;
+        const float rstd = rsqrtf(gq * inv_n - mean * mean + 1e-6f);
+        if (live) {
+            const f4 ga = *reinterpret_cast<const f4 *>(p.egn_gamma + n), be = *reinterpret_cast<const f4 *>(p.egn_beta + n);
+            const f4 sc = rstd * ga, sh = be - mean * rstd * ga;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f4 y = vals[i] * sc + sh;
+                if (p.egn_act) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) y[k] = swish_e(y[k]);
+                }
+                *reinterpret_cast<f4 *>(p.egn_out + ((size_t)b * 16 + pxg * 4 + i) * p.ldc + n) = y;
+            }
+        }
+    }
+}
+
+// The number of splits for this problem, 0 when the split path does not take it.  GDDIM_NOWINO2_SPLITK=1 switches it off (A/B).
+int conv3x3_wino2d_splitk_factor(const GemmParams &p) {
+    static const int off = getenv("GDDIM_NOWINO2_SPLITK") ? atoi(getenv("GDDIM_NOWINO2_SPLITK"))
+                                                          : (getenv("GDDIM_NOWINO2") ? atoi(getenv("GDDIM_NOWINO2")) : (getenv("GDDIM_NOWINO") ? atoi(getenv("GDDIM_NOWINO")) : 0));
+    if (off || p.H != 4 || p.W != 4 || p.rows_per_image != 16 || p.M % 16 != 0 || p.N % 4 != 0 || p.N < 32 || p.ldc % 4 != 0) return 0;
+    if (p.res && p.ldres % 4 != 0) return 0;
+    if (p.rowbias && p.ld_rowbias % 4 != 0) return 0;
+    if (p.qstats && p.qs_slices != 1) return 0;
+    if (p.egn_out && (p.N % p.egn_cpg != 0 || (p.egn_cpg != 4 && p.egn_cpg != 8 && p.egn_cpg != 16 && p.egn_cpg != 32) || (p.N / 4) % (p.egn_cpg / 4) != 0)) return 0;
+    const int Cin = p.C0 + p.C1;
+    if (Cin % 32 != 0) return 0;
+    const long long tiles = (long long)((p.M / 4 + 63) / 64) * ((p.N + 63) / 64);
+    if (tiles >= 256) return 0;  // (cannot happen on 4x4 images below B = 1024; the unsplit kernel does not take 4-wide images)
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    }
+    for (int ks = 8; ks >= 2; ks >>= 1) {
+        if (tiles * ks > cus) continue;  // at most one workgroup per CU
+        GemmParams q = p;
+        q.wk_split = ks;
+        q.wk_partial = reinterpret_cast<float *>(16);  // (only tested for null)
+        q.egn_out = nullptr; q.qstats = nullptr;        // (the main kernel emits neither)
+        if (conv3x3_wino2d_shape_ok(q)) return ks;
+    }
+    return 0;
+}
+
+const char *conv3x3_wino2d_splitk_finish_name() { return "wino2d_splitk_finish"; }
+
+int launch_conv3x3_wino2d_splitk(const GemmParams &p_in, hipStream_t s) {
+    GemmParams p = p_in;
+    p.wk_split = conv3x3_wino2d_splitk_factor(p_in);
+    GD_CHECK(p.wk_split > 1 && p.wk_partial && p.b_wino, "conv3x3_wino2d_splitk: problem not eligible");
+    GemmParams m = p;  // the main kernel: partial outputs only
+    m.bias = nullptr; m.rowbias = nullptr; m.res = nullptr; m.qstats = nullptr; m.egn_out = nullptr; m.egn_skip_raw = 0;
+    GD_TRY(launch_conv3x3_wino2d(m, s));
+    const long long waves = (long long)(p.M / 16) * ((p.N / 4 + 15) / 16);
+    static const int nofinish = getenv("GDDIM_SPLITK_NOFINISH") ? atoi(getenv("GDDIM_SPLITK_NOFINISH")) : 0;  // timing only (results wrong)
+    if (nofinish) return 0;
+    hipLaunchKernelGGL(wino2d_splitk_finish_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, p, p.M / 16);
     GD_HIP(hipGetLastError());
     return 0;
 }

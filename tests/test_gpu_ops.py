@@ -212,6 +212,9 @@ WINO2D_CASES = [
     (5, 4, 16, 32, 64, True, True),       # 16 quads per image: every unit is a whole (4 x 16) image
     (2, 32, 32, 64, 6, True, False),      # N = 6: the U-Net's head convolution (one N tile, 58 of its 64 columns past the end)
     (2, 16, 16, 32, 18, False, True),     # N = 18: not a multiple of 4, residual row stride 18
+    (64, 4, 4, 256, 256, True, True),     # 4x4 images: the channel range split over 8 workgroups per tile + the finishing pass
+    (7, 4, 4, 64, 36, True, True),        # ... 28 quads (a ragged tile, a unit that is half past the batch), two splits of four chunks, ragged N
+    (256, 4, 4, 128, 64, False, False),   # ... 16 tiles x 1 N tile, four splits of four chunks
 ]
 
 
@@ -256,7 +259,7 @@ def test_conv3x3_winograd2d_impulse_and_rejects(dev):
         got = ops.conv3x3_winograd2d(x.to(dev), wp.to(dev)).cpu().double()
         want = F.conv2d(x.permute(0, 3, 1, 2).double(), w.permute(3, 2, 0, 1).double(), padding=1).permute(0, 2, 3, 1)
         assert (got - want).abs().max() < 1e-4 * want.abs().max(), (y, xx, c)
-    for shape in [(1, 4, 4, 32, 64), (1, 16, 16, 24, 64), (1, 15, 16, 32, 64), (1, 2, 16, 32, 64), (1, 12, 8, 32, 64)]:
+    for shape in [(1, 4, 4, 32, 64), (1, 4, 4, 64, 30), (1, 16, 16, 24, 64), (1, 15, 16, 32, 64), (1, 2, 16, 32, 64), (1, 12, 8, 32, 64)]:
         b_, h_, w_, ci, co = shape
         with pytest.raises(GddimError):
             ops.conv3x3_winograd2d(torch.zeros(b_, h_, w_, ci, device=dev), torch.zeros(co, 9 * ci, device=dev))
