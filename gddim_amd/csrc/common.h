@@ -142,7 +142,7 @@ int launch_wino2d_weights(const float *w, float *u, int N, int Cin, hipStream_t 
 // ... on 4x4 images (rows_per_image == 16), split over the channels: the number of splits the launcher would use (0 = not eligible),
 // the floats of scratch it needs (wk_split * M * N), and the launch (main kernel + wino2d_splitk_finish_kernel; p.wk_partial set)
 int conv3x3_wino2d_splitk_factor(const GemmParams &p);
-const char *conv3x3_wino2d_splitk_finish_name();
+const char *conv3x3_wino2d_splitk_name();  // (the engine's profile entry: the split launch and its finishing pass)
 int launch_conv3x3_wino2d_splitk(const GemmParams &p, hipStream_t s);
 // per-device zero buffer used by the staging loads; allocates on first use (call once outside graph capture)
 const float *igemm_zero_buffer();

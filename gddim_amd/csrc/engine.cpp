@@ -324,7 +324,7 @@ static int run_op(gd_engine *e, int op_index, const Bind &b, int batch, hipStrea
                 g.b_wino = e->wwino2 + e->wino2_off[op.w_slot];
                 g.wk_partial = e->splitk_ws;
                 GD_CHECK((long long)conv3x3_wino2d_splitk_factor(g) * g.M * g.N <= e->splitk_ws_floats, "%s: split-K scratch too small", op.label.c_str());
-                ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(conv3x3_wino2d_name()), op.flops_per_image * batch, 0);
+                ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(conv3x3_wino2d_splitk_name()), op.flops_per_image * batch, 0);
                 return launch_conv3x3_wino2d_splitk(g, s);
             }
             if (e->precision == 0 && z == 1 && op.w_slot >= 0 && e->wwino && e->wino_off[op.w_slot] >= 0 && conv3x3_wino_ok(g)) {

@@ -87,9 +87,11 @@ __device__ __forceinline__ w2f32x4 w2_add4(w2f32x4 a, w2f32x4 b) {
     return w2f32x4{rlo[0], rlo[1], rhi[0], rhi[1]};
 }
 
-__global__ __launch_bounds__(512, 2) void conv3x3_wino2d_f32_kernel(const GemmParams p) {
+// The tile program.  SPLIT: the channel-split launch of the 4x4 level (GemmParams::wk_split), a kernel symbol of its own so that
+// profiles keep the two apart.
+template <bool SPLIT>
+__device__ __forceinline__ void wino2d_tile(const GemmParams &p, float *smem) {
     constexpr int OOB = (int)0x80000000u;
-    __shared__ __attribute__((aligned(16))) float smem[2 * W2_STAGE];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_f32_kernel(const GemmPa
 
     // ---- wave-uniform state of the chunk whose loads are issued next.  With wk_split > 1 (GemmParams: 4x4 images) this workgroup is
     // split blockIdx.y of its tile and multiplies the channels [c_begin, c_begin + 8 nk) only ----
-    const int ksplit = p.wk_split > 1 ? p.wk_split : 1;
+    const int ksplit = SPLIT ? p.wk_split : 1;
     const int nk = (Cin >> 3) / ksplit;  // even, >= 4
     const int c_begin = (int)blockIdx.y * nk * 8;
     int s_kc = c_begin >> 3, s_c = c_begin;
@@ -485,7 +487,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_f32_kernel(const GemmPa
 #ifdef W2_TRACE
     trace();
 #endif
-    if (ksplit > 1) {
+    if (SPLIT) {
         // one split of the channel range: the partial outputs go to wk_partial[split][m][n] as they are; bias, residual, scale,
         // statistics and the GroupNorm belong to wino2d_splitk_finish_kernel
         float *part = p.wk_partial + (size_t)blockIdx.y * p.M * p.N;
@@ -587,6 +589,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino2d_f32_kernel(const GemmPa
     }
 }
 
+__global__ __launch_bounds__(512, 2) void conv3x3_wino2d_f32_kernel(const GemmParams p) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * W2_STAGE];
+    wino2d_tile<false>(p, smem);
+}
+
+__global__ __launch_bounds__(512, 2) void conv3x3_wino2d_splitk_f32_kernel(const GemmParams p) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * W2_STAGE];
+    wino2d_tile<true>(p, smem);
+}
+
 // U[n][c/8][i][j][c%8] = (G g G^T)_ij from the packed direct weights w[n][(ky*3 + kx)*Cin + c]; sums in double, one rounding
 __global__ void wino2d_weights_kernel(const float *__restrict__ w, float *__restrict__ u, int N, int Cin) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -669,7 +681,8 @@ int launch_conv3x3_wino2d(const GemmParams &p_in, hipStream_t s) {
     p.n_tiles = (p.N + 63) / 64;
     p.flat_tiles = p.m_tiles < 16;
     const int gx = p.flat_tiles ? p.m_tiles * p.n_tiles : ((p.m_tiles + 7) / 8) * 8 * p.n_tiles;
-    hipLaunchKernelGGL(conv3x3_wino2d_f32_kernel, dim3(gx, p.wk_split > 1 ? p.wk_split : 1), dim3(512), 0, s, p);
+    if (p.wk_split > 1) hipLaunchKernelGGL(conv3x3_wino2d_splitk_f32_kernel, dim3(gx, p.wk_split), dim3(512), 0, s, p);
+    else hipLaunchKernelGGL(conv3x3_wino2d_f32_kernel, dim3(gx), dim3(512), 0, s, p);
     GD_HIP(hipGetLastError());
     return 0;
 }
@@ -778,7 +791,7 @@ int conv3x3_wino2d_splitk_factor(const GemmParams &p) {
     return 0;
 }
 
-const char *conv3x3_wino2d_splitk_finish_name() { return "wino2d_splitk_finish"; }
+const char *conv3x3_wino2d_splitk_name() { return "conv3x3_wino2d_splitk_f32_kernel"; }
 
 int launch_conv3x3_wino2d_splitk(const GemmParams &p_in, hipStream_t s) {
     GemmParams p = p_in;
