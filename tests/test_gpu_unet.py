@@ -170,3 +170,25 @@ def test_epilogue_groupnorm_16x16_level(native_lib, tmp_path):
         err = np.abs(res[tag]["got"] - want).max()
         assert np.isfinite(res[tag]["got"]).all() and err < 1e-4 * scale, (tag, err, scale)
     assert np.abs(res["egn"]["got"] - res["noegn"]["got"]).max() < 2e-5 * scale
+
+
+def test_unet_agrees_across_batch_sizes(native_lib):
+    """The kernel a layer runs on depends on the batch size (direct implicit GEMM, F(2,3), F(2x2,3x3), its channel-split launch, the
+    epilogue GroupNorm): the first images of the benchmarked architecture evaluated inside batches of 1 .. 320 agree to fp32 round-off."""
+    from gddim_amd.configs import cld_accr_dcifar10
+    from gddim_amd.engine import Engine
+    cfg = cld_accr_dcifar10.get_config()
+    params = onet.random_params(cfg, 6, seed=3)
+    eng = Engine(cfg, 6, max_batch=320, device=0)
+    eng.load_params(params)
+    rng = np.random.default_rng(5)
+    x = torch.as_tensor(rng.standard_normal((320, 32, 32, 6)).astype(np.float32), device="cuda:0")
+    lab = torch.as_tensor((rng.uniform(1e-3, 1, 320) * 999).astype(np.float32), device="cuda:0")
+    ref = eng.unet(x[:2], lab[:2]).cpu().numpy()
+    scale = np.abs(ref).max()
+    for B in (1, 5, 16, 31, 64, 65, 128, 200, 256, 320):
+        out = eng.unet(x[:B], lab[:B]).cpu().numpy()
+        n = min(2, B)
+        err = np.abs(out[:n] - ref[:n]).max() / scale
+        assert np.isfinite(out).all() and err < 2e-5, (B, err)
+    eng.close()
