@@ -235,7 +235,9 @@ def main():
                               "traffic_source": "committed rocprofv3 --pmc passes of this command (profiles/), not this run"}
         if "wino2d" in dom["name"]:
             result["roofline"]["note"] = ("Winograd F(2x2,3x3): achieved = algorithmic flops of the direct convolution / time; the kernel "
-                                          "issues 16 products per 2x2 output quad instead of 36, i.e. 4/9 of that; frac = issued / dense fp32 MFMA peak")
+                                          "issues 16 products per 2x2 output quad instead of 36, i.e. 4/9 of that; frac = issued / dense fp32 MFMA peak (nominal, 2.4 GHz); "
+                                          "the in-kernel timeline (profiles/r02_notes.md, tools/wino2d_trace.py) shows the shader clock at 1.9-2.1 GHz under this "
+                                          "kernel (power-limited) and its K loop at 82-88 % of the MFMA issue bound in shader cycles")
         elif "wino" in dom["name"]:
             result["roofline"]["note"] = ("Winograd F(2,3) along x: achieved = algorithmic flops of the direct convolution / time; "
                                           "issued MFMA flops are 2/3 of that; frac = issued / dense fp32 MFMA peak")
