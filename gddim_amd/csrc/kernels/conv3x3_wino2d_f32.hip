@@ -48,13 +48,10 @@ typedef float w2f32x16 __attribute__((ext_vector_type(16)));
 typedef float w2f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int w2u32x4 __attribute__((ext_vector_type(4)));
 
-#ifndef W2_DMA
-#define W2_DMA 0  // 1: weight chunks go global -> LDS directly (buffer_load_dwordx4 ... lds) instead of through registers.  Measured
-                  // in-box (tools/r2_ab7.sh): 104.5 vs 106.5 images/s -- the issue cost of the pieces exceeds the four ds_write_b128 they replace
-#endif
 #ifndef W2_ABL
 #define W2_ABL 0  // timing ablations (results wrong): 1 no global loads in the K loop, 2 no LDS stores, 4 no fragment reads, 8 no barrier,
-                  // 16 no transform arithmetic
+                  // 16 no transform arithmetic, 64 raw loads from L1-resident lines (no L2 -> L1 traffic for the activations), 128 raw loads at the addresses of a
+                  // channel-blocked activation layout [image][C / 8][H][W][8] (single-source problems)
 #endif
 
 constexpr int W2_LD = 132;             // LDS row stride (floats): 16 components x 8 channels + 4 pad
@@ -150,6 +147,7 @@ __device__ __forceinline__ void wino2d_tile(const GemmParams &p, float *smem) {
     // transformed weights (wino2d_weights_kernel): the products are unchanged. ----
     const int ql = tid >> 3, hq = (tid >> 2) & 1, si = tid & 3;
     const float sb = si == 1 ? 1.f : -1.f;
+    int img_t = 0;       // the thread's image (W2_ABL & 128)
     int pix = 0;         // pixel index of the patch origin (2 qy - 1, 2 qx - 1); may be "negative" by at most W + 1: the bias covers it
     unsigned bad = 0xFu; // bit s: pixel s of the thread's patch row lies outside the image (or the quad is past the batch)
     {
@@ -161,6 +159,7 @@ __device__ __forceinline__ void wino2d_tile(const GemmParams &p, float *smem) {
             const int qx = qr - (qy << wqs);
             const int y0 = 2 * qy - 1, x0 = 2 * qx - 1;
             pix = (img * H + y0) * W + x0;
+            img_t = img;
             unsigned xb = 0;
 #pragma unroll
             for (int s = 0; s < 4; ++s) xb |= ((unsigned)(x0 + s) < (unsigned)W ? 0u : 1u) << s;
@@ -171,7 +170,9 @@ __device__ __forceinline__ void wino2d_tile(const GemmParams &p, float *smem) {
     auto set_vo = [&](int lda, int biasb) __attribute__((always_inline)) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int off = (pix + si * W + k) * lda * 4 + biasb + hq * 16;
+            int off = (pix + si * W + k) * lda * 4 + biasb + hq * 16;
+            // timing ablation: addresses of a channel-blocked layout [image][C / 8][H][W][8] (the bytes read are the same tensor's, permuted)
+            if (W2_ABL & 128) off = ((img_t * (lda / 8 - 1)) * HW + (pix + si * W + k)) * 32 + biasb + hq * 16;
             vo[k] = ((bad >> k) & 1u) ? OOB : off;
         }
     };
@@ -186,26 +187,6 @@ __device__ __forceinline__ void wino2d_tile(const GemmParams &p, float *smem) {
     const int brow = tid >> 3, bp = tid & 7;
     const int bvo = (n0 + brow < p.N) ? ((n0 + brow) * p.ldb_wino + bp * 4) * 4 : OOB;
     const int b_lds = 2 * W2_HALF + brow * W2_LD + bp * 4;  // + k * 32
-#if W2_DMA
-    // ---- weight chunks by LDS-DMA.  One buffer_load_dwordx4 ... lds writes 64 lanes x 16 B = 1 KB CONTIGUOUS LDS (two 512-byte rows of
-    // the chunk), so the U stages are unpadded and swizzled on the SOURCE side instead: LDS slot p' of row r holds the 16-byte piece
-    // p' ^ (r & 31) of that row.  Wave w's load k covers rows 8 w + 2 k + (lane >> 5); every lane's global offset is fixed for the tile
-    // (the chunk moves through the scalar offset).  The compiler does not count these loads: the K loop waits for them with its own
-    // s_waitcnt vmcnt(N) in front of the barrier that publishes the stage. ----
-    int dvo[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int r = wave * 8 + 2 * k + (lane >> 5);
-        const int piece = (lane & 31) ^ (r & 31);
-        dvo[k] = (n0 + r < p.N) ? ((n0 + r) * p.ldb_wino + piece * 4) * 4 : OOB;
-    }
-    const unsigned lds_u = (unsigned)(size_t)smem + (unsigned)(2 * W2_HALF * 4 + wave * 4096);  // + par * W2_HALF * 4 + k * 1024
-    auto dma_w = [&](int k, int chunk_id, int par) __attribute__((always_inline)) {
-        const unsigned dst = lds_u + (unsigned)(par * W2_HALF * 4 + k * 1024);
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                     :: "s"(dst), "v"(dvo[k]), "s"(srd_b), "s"(chunk_id * 512) : "memory");
-    };
-#endif
 
     // ---- wave-uniform state of the chunk whose loads are issued next.  With wk_split > 1 (GemmParams: 4x4 images) this workgroup is
     // split blockIdx.y of its tile and multiplies the channels [c_begin, c_begin + 8 nk) only ----
@@ -230,6 +211,8 @@ __device__ __forceinline__ void wino2d_tile(const GemmParams &p, float *smem) {
     // (chunks past the tile's last one are never requested: the last two iterations of the K loop are peeled)
     auto load_raw_to = [&](w2f32x4 *dst, int k) __attribute__((always_inline)) {
         if ((W2_ABL & 1) && s_kc >= (c_begin >> 3) + 2) return;
+        if (W2_ABL & 64) { dst[k] = w2_load16(srd_a0, vo[0], 0); return; }  // every raw load of a thread hits one L1-resident line
+        if (W2_ABL & 128) { dst[k] = w2_load16(srd_a0, vo[k], (s_c >> 3) * HW * 32); return; }
         if (s_first) dst[k] = w2_load16(srd_a0, vo[k], s_c * 4);
         else dst[k] = w2_load16(srd_a1, vo[k], (s_c - p.C0) * 4);
     };
@@ -285,17 +268,10 @@ __device__ __forceinline__ void wino2d_tile(const GemmParams &p, float *smem) {
     int a_off[4];  // fragment of component (wi, j): rotated slot, see v_lds
 #pragma unroll
     for (int j = 0; j < 4; ++j) a_off[j] = (wq * 32 + li) * W2_LD + wi * 32 + ((j + wi) & 3) * 8 + lh * 4;
-#if W2_DMA
-    constexpr int B_ROWS32 = 32 * 128;  // the second output tile of the wave: 32 rows further
-    int b_off[4];  // fragment (c = 0) of component (wi, j): row li, piece (wi * 8 + 2 j + lh) ^ li of the swizzled unpadded U stage
-#pragma unroll
-    for (int j = 0; j < 4; ++j) b_off[j] = 2 * W2_HALF + li * 128 + (((wi * 8 + 2 * j + lh) ^ li) * 4);
-#else
     constexpr int B_ROWS32 = 32 * W2_LD;
     int b_off[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) b_off[j] = 2 * W2_HALF + li * W2_LD + wi * 32 + lh * 4 + j * 8;
-#endif
 
     // ---- prologue: chunk 0 -> LDS stage 0, chunk 1 -> registers.  Both chunks are requested up front (chunk 0 into a second register
     // set that only lives here, before the accumulators do): one memory latency per tile instead of two. ----
@@ -303,29 +279,18 @@ __device__ __forceinline__ void wino2d_tile(const GemmParams &p, float *smem) {
         w2f32x4 r0[4], w0[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) load_raw_to(r0, k);
-#if W2_DMA
-#pragma unroll
-        for (int k = 0; k < 4; ++k) dma_w(k, 0, 0);
-#else
 #pragma unroll
         for (int k = 0; k < 4; ++k) load_w_to(w0, k);
-#endif
         advance();
 #pragma unroll
         for (int k = 0; k < 4; ++k) load_raw(k);
-#if !W2_DMA
 #pragma unroll
         for (int k = 0; k < 4; ++k) load_w(k);
-#endif
         combine_from(r0);
 #pragma unroll
         for (int j = 0; j < 4; ++j) store_v(j, 0);
-#if W2_DMA
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // the four LDS-DMA pieces of chunk 0 (older than chunk 1's four register loads)
-#else
 #pragma unroll
         for (int k = 0; k < 4; ++k) store_w_from(w0, k, 0);
-#endif
     }
     advance();
     __syncthreads();
@@ -393,25 +358,6 @@ __device__ __forceinline__ void wino2d_tile(const GemmParams &p, float *smem) {
                     bf[(j + 1) & 1][1] = *reinterpret_cast<const w2f32x4 *>(cur + b_off[j + 1] + B_ROWS32);
                 }
                 // staging work in the shadow of the MFMA pair
-#if W2_DMA
-                // (the weights of the NEXT chunk, s_kc - 1, land in the other stage during this iteration: issued first, waited for below)
-                if (MODE < 2) {
-                    if (gap == 0) combine();
-                    if (gap < 4) store_v(gap, nxt);
-                }
-                if (MODE == 0) {
-                    if (gap == 0 && !((W2_ABL & 1) && s_kc >= 2)) {
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) dma_w(k, s_kc - 1, nxt);
-                    }
-                    if (gap < 4) load_raw(gap);
-                    else if (gap == 8) advance();
-                }
-                if (MODE == 1 && gap == 0) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) dma_w(k, s_kc - 1, nxt);
-                }
-#else
                 if (MODE < 2) {
                     if (gap == 0) combine();
                     if (gap < 4) store_v(gap, nxt);
@@ -422,7 +368,6 @@ __device__ __forceinline__ void wino2d_tile(const GemmParams &p, float *smem) {
                     else if (gap < 8) load_w(gap - 4);
                     else if (gap == 8) advance();
                 }
-#endif
                 if (MODE == 1 && has_res) {
                     load_res(2 * gap);
                     load_res(2 * gap + 1);
@@ -430,18 +375,6 @@ __device__ __forceinline__ void wino2d_tile(const GemmParams &p, float *smem) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-#if W2_DMA
-        // every LDS-DMA piece of this iteration has landed: all but the four register loads issued after the pieces (MODE 0), all but the 32
-        // residual loads (MODE 1)
-        if (MODE == 0) {
-            if (W2_ABL & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        }
-        if (MODE == 1) {
-            if (has_res) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-#endif
         if (!(W2_ABL & 8)) __syncthreads();
     };
     using I0 = std::integral_constant<int, 0>;
