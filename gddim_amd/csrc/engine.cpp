@@ -62,7 +62,7 @@ struct gd_engine {
     // ... and their two-dimensional F(2x2, 3x3) copies (kernels/conv3x3_wino2d_f32.hip), 16 N Cin floats per eligible slot
     float *wwino2 = nullptr;
     float *splitk_ws = nullptr;  // partial outputs of the channel-split 2-D Winograd launches (4x4 level): 8 * max_batch * 16 * max N floats
-    long long splitk_ws_floats = 0;
+    long long splitk_ws_floats = 0, splitk_per_image = 0;  // (a lane's sub-batch uses the slice that starts at its first image)
     std::vector<long long> wino2_off;
     std::map<int, std::vector<char>> fuse_ok;      // batch size -> per GEMM op: the fused-GroupNorm halo kernel takes it
     std::map<int, std::vector<char>> egn_ok;       // batch size -> per GEMM op: normalises its output in the epilogue (Op::egn_peer)
@@ -322,8 +322,10 @@ static int run_op(gd_engine *e, int op_index, const Bind &b, int batch, hipStrea
             if (e->precision == 0 && z == 1 && op.w_slot >= 0 && e->wwino2 && e->wino2_off[op.w_slot] >= 0 && e->splitk_ws &&
                 conv3x3_wino2d_splitk_factor(g) > 1) {  // 4x4 images: the channel range split over workgroups + a finishing pass
                 g.b_wino = e->wwino2 + e->wino2_off[op.w_slot];
-                g.wk_partial = e->splitk_ws;
-                GD_CHECK((long long)conv3x3_wino2d_splitk_factor(g) * g.M * g.N <= e->splitk_ws_floats, "%s: split-K scratch too small", op.label.c_str());
+                const long long img0 = (long long)(b.arena - e->arena) / e->plan.arena_per_image;  // first image of this sub-batch (lanes)
+                g.wk_partial = e->splitk_ws + img0 * e->splitk_per_image;
+                GD_CHECK(img0 * e->splitk_per_image + (long long)conv3x3_wino2d_splitk_factor(g) * g.M * g.N <= e->splitk_ws_floats,
+                         "%s: split-K scratch too small", op.label.c_str());
                 ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(conv3x3_wino2d_splitk_name()), op.flops_per_image * batch, 0);
                 return launch_conv3x3_wino2d_splitk(g, s);
             }
@@ -607,6 +609,7 @@ static int build_wino_weights(gd_engine *e) {
         const bool img4 = op.H == 4 && op.W == 4;  // the channel-split launch (conv3x3_wino2d_splitk_factor)
         if (!img4 && ((op.W != 8 && op.W != 16 && op.W != 32 && op.W != 64) || op.H % 2 != 0 || (op.H * op.W / 4) % 16 != 0)) continue;
         if (img4) need_ws = std::max(need_ws, 8LL * e->plan.desc.max_batch * 16 * op.N);
+        if (img4) e->splitk_per_image = std::max(e->splitk_per_image, 8LL * 16 * op.N);
         e->wino2_off[op.w_slot] = total2;
         dims[op.w_slot] = {op.N, Cin};
         total2 += (long long)op.N * 16 * Cin;
