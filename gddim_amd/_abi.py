@@ -93,6 +93,7 @@ SIGNATURES = {
     "gd_group_norm": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "gd_fir_resample": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "gd_attention": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "gd_attention_fused": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
 }
 
 _lib = None

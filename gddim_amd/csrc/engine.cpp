@@ -270,6 +270,28 @@ static bool egn_fused(gd_engine *e, const Bind &b, int batch, int gemm_index) {
     return it->second[gemm_index] != 0;
 }
 
+// The attention core q k^T -> softmax -> p v as ONE launch (kernels/attn_fused_f32.hip), fp32 mode, 256 tokens x 256 channels: op i is
+// the q k^T product of such a core when it is a per-image product of two column blocks of one tensor (q at column 0, k at column C),
+// followed by the in-place softmax of its output and by the product of that output with a k-contiguous V^T.
+static bool attn_core_at(const gd_engine *e, int i) {
+    const std::vector<Op> &ops = e->plan.ops;
+    if (e->precision != 0 || i < 0 || i + 2 >= (int)ops.size()) return false;
+    const Op &qk = ops[i], &sm = ops[i + 1], &av = ops[i + 2];
+    if (qk.kind != OP_GEMM || sm.kind != OP_SOFTMAX || av.kind != OP_GEMM) return false;
+    if (!qk.z_per_image || qk.w_slot >= 0 || qk.a_slot >= 0 || qk.bten.t != qk.a0.t || qk.a0.col != 0 || qk.bten.col != qk.C0 || qk.b_kmajor ||
+        qk.C1 != 0 || qk.K != qk.C0 || qk.m_per_image != qk.N || qk.lda0 != qk.ldb || qk.res.t >= 0 || qk.rowbias.t >= 0 || qk.bias_slot >= 0 ||
+        qk.qstats.t >= 0)
+        return false;
+    if (sm.out.t != qk.out.t || sm.cols != qk.N || sm.rows_per_image != qk.N) return false;
+    if (!av.z_per_image || av.w_slot >= 0 || av.a_slot >= 0 || av.a0.t != qk.out.t || av.C0 != qk.N || av.K != qk.N || av.N != qk.C0 || av.b_kmajor ||
+        av.ldb != qk.N || av.bten.col != 0 || av.res.t >= 0 || av.rowbias.t >= 0 || av.qstats.t >= 0 || av.alpha != 1.f || av.out_scale != 1.f ||
+        av.out.col != 0)
+        return false;
+    const float want = 1.0f / std::sqrt((float)qk.C0);
+    if (std::fabs(qk.alpha - want) > 1e-6f * want || qk.out_scale != 1.f) return false;
+    return attn_fused_ok(qk.N, qk.C0);
+}
+
 static int run_op(gd_engine *e, int op_index, const Bind &b, int batch, hipStream_t s) {
     const Op &op = e->plan.ops[op_index];
     const Plan &P = e->plan;
@@ -281,6 +303,15 @@ static int run_op(gd_engine *e, int op_index, const Bind &b, int batch, hipStrea
                                   op.N, op.act, s);
         }
         case OP_GEMM: {
+            if (attn_core_at(e, op_index)) {  // q k^T, softmax and p v in one launch; the next two ops return at once
+                const Op &av = P.ops[op_index + 2];
+                ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(attn_fused_name()),
+                             (op.flops_per_image + av.flops_per_image) * batch, 0);
+                return launch_attn_fused(tptr(e, b, op.a0, batch), tptr(e, b, op.bten, batch), op.lda0, tptr(e, b, av.bten, batch),
+                                         av.bias_slot >= 0 ? slot_ptr(e, av.bias_slot) + av.bias_off : nullptr, tptr(e, b, av.out, batch), av.ldc,
+                                         batch, op.N, op.C0, s);
+            }
+            if (attn_core_at(e, op_index - 2)) return 0;  // the p v product of a fused core
             GemmParams g{};
             const int z = fill_gemm(e, op, b, batch, g);
             if (e->precision == 1 && op.w_slot >= 0 && e->wsplit_valid) {
@@ -377,6 +408,7 @@ static int run_op(gd_engine *e, int op_index, const Bind &b, int batch, hipStrea
             return launch_fir_pad(tptr(e, b, op.a0, batch), tptr(e, b, op.out, batch), batch, op.H, op.W, op.C0, s);
         }
         case OP_SOFTMAX: {
+            if (attn_core_at(e, op_index - 1)) return 0;  // inside a fused attention core
             ProfScope ps(e, s, "softmax", 0, 8.0 * batch * op.rows_per_image * op.cols);
             return launch_softmax_rows(tptr(e, b, op.out, batch), (long long)batch * op.rows_per_image, op.cols, s);
         }
@@ -1281,6 +1313,13 @@ int gd_attention(const float *qkv_dev, float *scratch_dev, float *out_dev, int b
     h.out = out_dev; h.ldc = C; h.sC = (long long)N * C;
     h.alpha = 1.f; h.out_scale = 1.f; h.rows_per_image = N;
     return launch_igemm(h, batch, s);
+}
+
+int gd_attention_fused(const float *qk_dev, const float *vT_dev, const float *bias_v_dev, float *out_dev, int batch, int N, int C,
+                       void *stream) {
+    GD_CHECK(qk_dev && vT_dev && out_dev, "null pointer");
+    GD_CHECK(attn_fused_ok(N, C), "attention_fused: built for N = 256 tokens and C = 256 channels (N=%d C=%d)", N, C);
+    return launch_attn_fused(qk_dev, qk_dev + C, 2 * C, vT_dev, bias_v_dev, out_dev, C, batch, N, C, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -1,0 +1,221 @@
+// Fused single-head self-attention core for the U-Net's 16x16 attention blocks (N = 256 tokens, C = 256 channels), fp32:
+//     out[i][:] = sum_j softmax_j(q_i . k_j * C^-1/2) v_j  (+ b_v: softmax rows sum to one, so the value bias moves here)
+// (cld_jax/models/layerspp.py:74-78: the two einsums and the softmax of AttnBlockpp).  The unfused path is three launches -- QK^T,
+// softmax_rows_kernel over a B N N scratch in HBM, PV -- this kernel keeps a 64-query block of the scores in registers / LDS:
+//   phase A  S = Q_blk K^T        64 x 256 x 256, fp32 MFMA 32x32x2; 8 wave64 as 2 (rows) x 4 (keys), two accumulators per wave
+//   softmax  row maxima and sums: in-lane over the wave's two tiles, across the 32 column lanes by shuffles, across the four key waves
+//            through LDS; P = exp2((S - max) C^-1/2 log2 e) / sum written to LDS row-major (the A operand layout of phase B)
+//   phase B  O = P V              64 x 256 x 256, V read as V^T[c][token] (what the engine's v projection emits): k-contiguous
+// Both phases stream their B operand (K rows, V^T rows) through two LDS stages of 32-deep chunks with a register prefetch; rows are
+// padded to 36 floats (260 for P), an odd number of 16-byte slots, so fragment ds_read_b128 and staging ds_write_b128 are conflict-free.
+// One workgroup per (image, 64-query block): 4 B workgroups; LDS 139 KB, one workgroup per CU.
+#include <cstdio>
+#include <cstdlib>
+
+#include "../common.h"
+
+namespace gd {
+
+typedef float af32x16 __attribute__((ext_vector_type(16)));
+typedef float af32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int AT_N = 256, AT_C = 256;   // tokens, channels (fixed: the 16x16 level of the benchmarked family)
+constexpr int AT_LD = 36;               // LDS row stride of a 32-deep chunk
+constexpr int AT_PLD = 260;             // LDS row stride of P
+constexpr int AT_P = 64 * AT_PLD;       // floats of the P region (also the start of the phase-B stages)
+constexpr int AT_KST = 256 * AT_LD;     // one B-operand stage (256 rows)
+constexpr int AT_QST = 64 * AT_LD;      // one Q stage
+constexpr int AT_RED = AT_P + 2 * AT_KST;  // softmax scratch [64 rows][4 waves]
+constexpr int AT_SMEM = AT_RED + 64 * 4;
+
+struct AttnParams {
+    const float *q;   // q[(img * N + token) * ld_qk + c]
+    const float *k;   // k[(img * N + token) * ld_qk + c]
+    int ld_qk;
+    const float *vT;  // vT[(img * C + c) * N + token]
+    const float *bias;  // [C] or null
+    float *out;       // out[(img * N + token) * ld_o + c]
+    int ld_o;
+    float scale_log2e;  // C^-1/2 * log2(e)
+};
+
+__global__ __launch_bounds__(512, 2) void attn256_f32_kernel(const AttnParams p) {
+    __shared__ __attribute__((aligned(16))) float smem[AT_SMEM];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int li = lane & 31, lh = lane >> 5;
+    const int img = blockIdx.y, q0 = blockIdx.x * 64;
+
+    // staging roles: row (tid >> 3) [+ 64 j], 16-byte piece (tid & 7) of the 32-deep chunk
+    const int srow = tid >> 3, spc = tid & 7;
+    const float *gq = p.q + ((size_t)img * AT_N + q0 + srow) * p.ld_qk + spc * 4;
+    const float *gk = p.k + ((size_t)img * AT_N + srow) * p.ld_qk + spc * 4;
+    const float *gv = p.vT + ((size_t)img * AT_C + srow) * AT_N + spc * 4;
+    const int s_lds = srow * AT_LD + spc * 4;
+
+    // two register sets by chunk parity: a chunk is requested two iterations (of ~1 us) before it is written to LDS
+    af32x4 rq[2], rb[2][4];
+    auto load_a = [&](int kc) __attribute__((always_inline)) {  // phase A chunk kc: Q piece + four K pieces
+        rq[kc & 1] = *reinterpret_cast<const af32x4 *>(gq + kc * 32);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rb[kc & 1][j] = *reinterpret_cast<const af32x4 *>(gk + (size_t)j * 64 * p.ld_qk + kc * 32);
+    };
+    auto store_a = [&](int kc) __attribute__((always_inline)) {  // ... into LDS stage kc & 1
+        float *qs = smem + (kc & 1) * (AT_QST + AT_KST), *ks = qs + AT_QST;
+        *reinterpret_cast<af32x4 *>(qs + s_lds) = rq[kc & 1];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<af32x4 *>(ks + s_lds + j * 64 * AT_LD) = rb[kc & 1][j];
+    };
+    auto load_b = [&](int kc) __attribute__((always_inline)) {  // phase B chunk kc: four V^T pieces (rows = channels)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rb[kc & 1][j] = *reinterpret_cast<const af32x4 *>(gv + (size_t)j * 64 * AT_N + kc * 32);
+    };
+    auto store_b = [&](int kc) __attribute__((always_inline)) {
+        float *vs = smem + AT_P + (kc & 1) * AT_KST;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<af32x4 *>(vs + s_lds + j * 64 * AT_LD) = rb[kc & 1][j];
+    };
+
+    af32x16 acc[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[c][v] = 0.f;
+
+    // ---- phase A: S = Q_blk K^T over 8 chunks of 32 channels ----
+    const int a_frag = (wm * 32 + li) * AT_LD + lh * 4;           // + kk * 8
+    const int b_frag = (wn * 64 + li) * AT_LD + lh * 4;           // + c * 32 rows + kk * 8
+    load_a(0);
+    load_a(1);
+    store_a(0);
+    load_a(2);
+    __syncthreads();
+#pragma unroll
+    for (int kc = 0; kc < 8; ++kc) {  // (unrolled: the register set of a chunk is a compile-time choice)
+        const float *qs = smem + (kc & 1) * (AT_QST + AT_KST), *ks = qs + AT_QST;
+        if (kc + 1 < 8) store_a(kc + 1);
+        if (kc + 3 < 8) load_a(kc + 3);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const af32x4 a = *reinterpret_cast<const af32x4 *>(qs + a_frag + kk * 8);
+            const af32x4 b0 = *reinterpret_cast<const af32x4 *>(ks + b_frag + kk * 8);
+            const af32x4 b1 = *reinterpret_cast<const af32x4 *>(ks + b_frag + 32 * AT_LD + kk * 8);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[jj], b0[jj], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[jj], b1[jj], acc[1], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    load_b(0);  // the first V^T chunks travel while the softmax runs
+    load_b(1);
+
+    // ---- softmax over the 256 keys of every row.  Accumulator element v of lane (li, lh): row 8 (v >> 2) + (v & 3) + 4 lh of the
+    // wave's 32, column li of tile c ----
+    float *red = smem + AT_RED;
+    float mx[16];
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        float m = fmaxf(acc[0][v], acc[1][v]);
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
+        mx[v] = m;
+    }
+    if (li == 0) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) red[(wm * 32 + 8 * (v >> 2) + (v & 3) + 4 * lh) * 4 + wn] = mx[v];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        const af32x4 r = *reinterpret_cast<const af32x4 *>(red + (wm * 32 + 8 * (v >> 2) + (v & 3) + 4 * lh) * 4);
+        mx[v] = fmaxf(fmaxf(r[0], r[1]), fmaxf(r[2], r[3]));
+    }
+    __syncthreads();  // (red is rewritten with the sums)
+    float sm[16];
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        acc[0][v] = __builtin_amdgcn_exp2f((acc[0][v] - mx[v]) * p.scale_log2e);
+        acc[1][v] = __builtin_amdgcn_exp2f((acc[1][v] - mx[v]) * p.scale_log2e);
+        float s = acc[0][v] + acc[1][v];
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) s += __shfl_xor(s, o);
+        sm[v] = s;
+    }
+    if (li == 0) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) red[(wm * 32 + 8 * (v >> 2) + (v & 3) + 4 * lh) * 4 + wn] = sm[v];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        const af32x4 r = *reinterpret_cast<const af32x4 *>(red + (wm * 32 + 8 * (v >> 2) + (v & 3) + 4 * lh) * 4);
+        const float inv = 1.0f / ((r[0] + r[1]) + (r[2] + r[3]));
+        const int row = wm * 32 + 8 * (v >> 2) + (v & 3) + 4 * lh;
+        smem[row * AT_PLD + wn * 64 + li] = acc[0][v] * inv;
+        smem[row * AT_PLD + wn * 64 + 32 + li] = acc[1][v] * inv;
+    }
+    store_b(0);
+    load_b(2);
+    __syncthreads();
+
+    // ---- phase B: O = P V over 8 chunks of 32 keys ----
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[c][v] = 0.f;
+    const int p_frag = (wm * 32 + li) * AT_PLD + lh * 4;  // + kc * 32 + kk * 8
+#pragma unroll
+    for (int kc = 0; kc < 8; ++kc) {
+        const float *vs = smem + AT_P + (kc & 1) * AT_KST;
+        if (kc + 1 < 8) store_b(kc + 1);
+        if (kc + 3 < 8) load_b(kc + 3);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const af32x4 a = *reinterpret_cast<const af32x4 *>(smem + p_frag + kc * 32 + kk * 8);
+            const af32x4 b0 = *reinterpret_cast<const af32x4 *>(vs + b_frag + kk * 8);
+            const af32x4 b1 = *reinterpret_cast<const af32x4 *>(vs + b_frag + 32 * AT_LD + kk * 8);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[jj], b0[jj], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[jj], b1[jj], acc[1], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- store: row = query, column = channel ----
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int col = wn * 64 + c * 32 + li;
+        const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int row = wm * 32 + 8 * (v >> 2) + (v & 3) + 4 * lh;
+            p.out[((size_t)img * AT_N + q0 + row) * p.ld_o + col] = acc[c][v] + bv;
+        }
+    }
+}
+
+bool attn_fused_ok(int N, int C) {
+    static const int off = getenv("GDDIM_NO_FUSED_ATTN") ? atoi(getenv("GDDIM_NO_FUSED_ATTN")) : 0;
+    return !off && N == AT_N && C == AT_C;
+}
+
+const char *attn_fused_name() { return "attn256_f32_kernel"; }
+
+int launch_attn_fused(const float *q, const float *k, int ld_qk, const float *vT, const float *bias, float *out, int ld_o, int batch,
+                      int N, int C, hipStream_t s) {
+    GD_CHECK(q && k && vT && out && N == AT_N && C == AT_C && ld_qk % 4 == 0 && batch >= 1, "attn_fused: unsupported problem (N=%d C=%d)", N, C);
+    AttnParams p;
+    p.q = q; p.k = k; p.ld_qk = ld_qk; p.vT = vT; p.bias = bias; p.out = out; p.ld_o = ld_o;
+    p.scale_log2e = (float)(1.0 / 16.0 * 1.4426950408889634);  // C^-1/2 = 1/16
+    hipLaunchKernelGGL(attn256_f32_kernel, dim3(AT_N / 64, batch), dim3(512), 0, s, p);
+    GD_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace gd

@@ -176,6 +176,20 @@ def attention(qkv):
     return out
 
 
+def attention_fused(qk, vT, bias_v=None):
+    """softmax(q k^T C^-1/2) v (+ b_v) in one launch: qk (B,N,2C) packed projections, vT (B,C,N) the value projection transposed
+    per image (what the engine's attention block emits); N = C = 256 only (gd_attention_fused)."""
+    import torch
+    _need_gpu(qk)
+    qk, vT = _f32c(qk), _f32c(vT)
+    B, N, C2 = qk.shape
+    C = C2 // 2
+    out = torch.empty((B, N, C), dtype=torch.float32, device=qk.device)
+    bias_v = _f32c(bias_v) if bias_v is not None else None
+    check(_abi.lib().gd_attention_fused(_ptr(qk), _ptr(vT), _ptr(bias_v), _ptr(out), B, N, C, _stream(qk)))
+    return out
+
+
 def randn_pairs(n_pairs, seed, draw=0, elem0=0, device=None):
     """(n_pairs, 2) standard normals from the engine's counter-based generator (gd_randn_pairs)."""
     import torch

@@ -276,6 +276,12 @@ int gd_fir_resample(const float *x_dev, float *out_dev, int batch, int H, int W,
  * out (B,N,C) = softmax(q k^T C^-1/2) v; scratch_dev must hold B*N*N floats.
  * Replaces: the two einsums + softmax of AttnBlockpp (cld_jax/models/layerspp.py:74-78). */
 int gd_attention(const float *qkv_dev, float *scratch_dev, float *out_dev, int batch, int N, int C, void *stream);
+/* The same core as ONE launch without the B*N*N scratch, in the operand layout the engine's attention block produces: q and k packed
+ * as qk_dev (B,N,2C), v transposed per image vT_dev (B,C,N), optional value bias (C): out (B,N,C) = softmax(q k^T C^-1/2) v + b_v.
+ * Built for N = 256, C = 256 (the 16x16 attention blocks of the CIFAR-10 configurations); other sizes are refused.
+ * Replaces: the same call site (cld_jax/models/layerspp.py:74-78). */
+int gd_attention_fused(const float *qk_dev, const float *vT_dev, const float *bias_v_dev, float *out_dev, int batch, int N, int C,
+                       void *stream);
 
 #ifdef __cplusplus
 }

@@ -370,3 +370,28 @@ def test_naive_resample_matches_oracle(dev, up):
     assert got.shape == tuple(want.shape) and np.abs(got - want.numpy()).max() < 1e-6
     if up:
         assert np.array_equal(got, np.repeat(np.repeat(x, 2, axis=1), 2, axis=2))  # exact: pure replication
+
+
+def test_attention_fused_matches_float64(dev):
+    """gd_attention_fused (q k^T -> softmax -> p v in one launch, N = C = 256, operands in the engine's layout: q|k packed, v transposed per
+    image, value bias in the epilogue) against float64 and against the three-launch path; scores of very different magnitude per row
+    (the row maximum matters), other sizes refused."""
+    from gddim_amd import ops
+    from gddim_amd._abi import GddimError
+    B, N, C = 3, 256, 256
+    g = torch.Generator().manual_seed(7)
+    q = torch.randn(B, N, C, generator=g) * torch.linspace(0.2, 6.0, N).view(1, N, 1)  # rows with flat and with peaked distributions
+    k = torch.randn(B, N, C, generator=g)
+    v = torch.randn(B, N, C, generator=g)
+    bias = torch.randn(C, generator=g)
+    qk = torch.cat([q, k], dim=-1).contiguous()
+    vT = v.transpose(1, 2).contiguous()
+    got = ops.attention_fused(qk.to(dev), vT.to(dev), bias.to(dev)).cpu().double()
+    w = torch.softmax(torch.einsum("bic,bjc->bij", q.double(), k.double()) * C ** -0.5, dim=-1)
+    want = torch.einsum("bij,bjc->bic", w, v.double()) + bias.double()
+    three = ops.attention(torch.cat([q, k, v], dim=-1).contiguous().to(dev)).cpu().double() + bias.double()
+    err, err3 = (got - want).abs().max().item(), (three - want).abs().max().item()
+    print("fused attention: max|d| %.2e (three launches %.2e), |out| %.2f" % (err, err3, want.abs().max().item()))
+    assert err < 2e-5 and err < 4 * err3 + 1e-6
+    with pytest.raises(GddimError):
+        ops.attention_fused(torch.zeros(1, 64, 512, device=dev), torch.zeros(1, 256, 64, device=dev))
