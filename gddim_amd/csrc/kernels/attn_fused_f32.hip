@@ -6,7 +6,8 @@
 //   softmax  row maxima and sums: in-lane over the wave's two tiles, across the 32 column lanes by shuffles, across the four key waves
 //            through LDS; P = exp2((S - max) C^-1/2 log2 e) / sum written to LDS row-major (the A operand layout of phase B)
 //   phase B  O = P V              64 x 256 x 256, V read as V^T[c][token] (what the engine's v projection emits): k-contiguous
-// Both phases stream their B operand (K rows, V^T rows) through two LDS stages of 32-deep chunks with a register prefetch; rows are
+// Both phases stream their B operand (K rows, V^T rows) through two LDS stages of 32-deep chunks with a two-deep register prefetch,
+// staging pieces and next-step fragment reads hand-placed between the MFMA pairs as in the convolution kernels; rows are
 // padded to 36 floats (260 for P), an odd number of 16-byte slots, so fragment ds_read_b128 and staging ds_write_b128 are conflict-free.
 // One workgroup per (image, 64-query block): 4 B workgroups; LDS 139 KB, one workgroup per CU.
 #include <cstdio>
@@ -57,25 +58,37 @@ __global__ __launch_bounds__(512, 2) void attn256_f32_kernel(const AttnParams p)
 
     // two register sets by chunk parity: a chunk is requested two iterations (of ~1 us) before it is written to LDS
     af32x4 rq[2], rb[2][4];
-    auto load_a = [&](int kc) __attribute__((always_inline)) {  // phase A chunk kc: Q piece + four K pieces
-        rq[kc & 1] = *reinterpret_cast<const af32x4 *>(gq + kc * 32);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) rb[kc & 1][j] = *reinterpret_cast<const af32x4 *>(gk + (size_t)j * 64 * p.ld_qk + kc * 32);
+    // (piece j = 0..3: K / V^T rows srow + 64 j; piece 4: the Q row, phase A only)
+    auto load_a1 = [&](int kc, int j) __attribute__((always_inline)) {  // phase A chunk kc
+        if (j == 4) rq[kc & 1] = *reinterpret_cast<const af32x4 *>(gq + kc * 32);
+        else rb[kc & 1][j] = *reinterpret_cast<const af32x4 *>(gk + (size_t)j * 64 * p.ld_qk + kc * 32);
     };
-    auto store_a = [&](int kc) __attribute__((always_inline)) {  // ... into LDS stage kc & 1
+    auto store_a1 = [&](int kc, int j) __attribute__((always_inline)) {  // ... into LDS stage kc & 1
         float *qs = smem + (kc & 1) * (AT_QST + AT_KST), *ks = qs + AT_QST;
-        *reinterpret_cast<af32x4 *>(qs + s_lds) = rq[kc & 1];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) *reinterpret_cast<af32x4 *>(ks + s_lds + j * 64 * AT_LD) = rb[kc & 1][j];
+        if (j == 4) *reinterpret_cast<af32x4 *>(qs + s_lds) = rq[kc & 1];
+        else *reinterpret_cast<af32x4 *>(ks + s_lds + j * 64 * AT_LD) = rb[kc & 1][j];
     };
-    auto load_b = [&](int kc) __attribute__((always_inline)) {  // phase B chunk kc: four V^T pieces (rows = channels)
+    auto load_b1 = [&](int kc, int j) __attribute__((always_inline)) {  // phase B chunk kc: V^T pieces (rows = channels)
+        rb[kc & 1][j] = *reinterpret_cast<const af32x4 *>(gv + (size_t)j * 64 * AT_N + kc * 32);
+    };
+    auto store_b1 = [&](int kc, int j) __attribute__((always_inline)) {
+        *reinterpret_cast<af32x4 *>(smem + AT_P + (kc & 1) * AT_KST + s_lds + j * 64 * AT_LD) = rb[kc & 1][j];
+    };
+    auto load_a = [&](int kc) __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) rb[kc & 1][j] = *reinterpret_cast<const af32x4 *>(gv + (size_t)j * 64 * AT_N + kc * 32);
+        for (int j = 0; j < 5; ++j) load_a1(kc, j);
+    };
+    auto store_a = [&](int kc) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) store_a1(kc, j);
+    };
+    auto load_b = [&](int kc) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) load_b1(kc, j);
     };
     auto store_b = [&](int kc) __attribute__((always_inline)) {
-        float *vs = smem + AT_P + (kc & 1) * AT_KST;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) *reinterpret_cast<af32x4 *>(vs + s_lds + j * 64 * AT_LD) = rb[kc & 1][j];
+        for (int j = 0; j < 4; ++j) store_b1(kc, j);
     };
 
     af32x16 acc[2];
@@ -95,17 +108,27 @@ __global__ __launch_bounds__(512, 2) void attn256_f32_kernel(const AttnParams p)
 #pragma unroll
     for (int kc = 0; kc < 8; ++kc) {  // (unrolled: the register set of a chunk is a compile-time choice)
         const float *qs = smem + (kc & 1) * (AT_QST + AT_KST), *ks = qs + AT_QST;
-        if (kc + 1 < 8) store_a(kc + 1);
-        if (kc + 3 < 8) load_a(kc + 3);
+        af32x4 a[2], b0[2], b1[2];
+        a[0] = *reinterpret_cast<const af32x4 *>(qs + a_frag);
+        b0[0] = *reinterpret_cast<const af32x4 *>(ks + b_frag);
+        b1[0] = *reinterpret_cast<const af32x4 *>(ks + b_frag + 32 * AT_LD);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            const af32x4 a = *reinterpret_cast<const af32x4 *>(qs + a_frag + kk * 8);
-            const af32x4 b0 = *reinterpret_cast<const af32x4 *>(ks + b_frag + kk * 8);
-            const af32x4 b1 = *reinterpret_cast<const af32x4 *>(ks + b_frag + 32 * AT_LD + kk * 8);
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[jj], b0[jj], acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[jj], b1[jj], acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk & 1][jj], b0[kk & 1][jj], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk & 1][jj], b1[kk & 1][jj], acc[1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                const int gap = kk * 4 + jj;
+                if (jj == 0 && kk < 3) {  // fragments of the next 8-deep step, one step ahead of their use
+                    a[(kk + 1) & 1] = *reinterpret_cast<const af32x4 *>(qs + a_frag + (kk + 1) * 8);
+                    b0[(kk + 1) & 1] = *reinterpret_cast<const af32x4 *>(ks + b_frag + (kk + 1) * 8);
+                    b1[(kk + 1) & 1] = *reinterpret_cast<const af32x4 *>(ks + b_frag + 32 * AT_LD + (kk + 1) * 8);
+                }
+                // staging in the shadow of the MFMA pair: chunk kc+1 registers -> the other stage, chunk kc+3 requested into them
+                if (gap >= 1 && gap <= 5 && kc + 1 < 8) store_a1(kc + 1, gap - 1);
+                if (gap >= 6 && gap <= 10 && kc + 3 < 8) load_a1(kc + 3, gap - 6);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         __syncthreads();
@@ -171,17 +194,26 @@ __global__ __launch_bounds__(512, 2) void attn256_f32_kernel(const AttnParams p)
 #pragma unroll
     for (int kc = 0; kc < 8; ++kc) {
         const float *vs = smem + AT_P + (kc & 1) * AT_KST;
-        if (kc + 1 < 8) store_b(kc + 1);
-        if (kc + 3 < 8) load_b(kc + 3);
+        af32x4 a[2], b0[2], b1[2];
+        a[0] = *reinterpret_cast<const af32x4 *>(smem + p_frag + kc * 32);
+        b0[0] = *reinterpret_cast<const af32x4 *>(vs + b_frag);
+        b1[0] = *reinterpret_cast<const af32x4 *>(vs + b_frag + 32 * AT_LD);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            const af32x4 a = *reinterpret_cast<const af32x4 *>(smem + p_frag + kc * 32 + kk * 8);
-            const af32x4 b0 = *reinterpret_cast<const af32x4 *>(vs + b_frag + kk * 8);
-            const af32x4 b1 = *reinterpret_cast<const af32x4 *>(vs + b_frag + 32 * AT_LD + kk * 8);
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[jj], b0[jj], acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[jj], b1[jj], acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk & 1][jj], b0[kk & 1][jj], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk & 1][jj], b1[kk & 1][jj], acc[1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                const int gap = kk * 4 + jj;
+                if (jj == 0 && kk < 3) {
+                    a[(kk + 1) & 1] = *reinterpret_cast<const af32x4 *>(smem + p_frag + kc * 32 + (kk + 1) * 8);
+                    b0[(kk + 1) & 1] = *reinterpret_cast<const af32x4 *>(vs + b_frag + (kk + 1) * 8);
+                    b1[(kk + 1) & 1] = *reinterpret_cast<const af32x4 *>(vs + b_frag + 32 * AT_LD + (kk + 1) * 8);
+                }
+                if (gap >= 1 && gap <= 4 && kc + 1 < 8) store_b1(kc + 1, gap - 1);
+                if (gap >= 6 && gap <= 9 && kc + 3 < 8) load_b1(kc + 3, gap - 6);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         __syncthreads();
