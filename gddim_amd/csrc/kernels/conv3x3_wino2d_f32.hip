@@ -734,8 +734,6 @@ int launch_conv3x3_wino2d_splitk(const GemmParams &p_in, hipStream_t s) {
     m.bias = nullptr; m.rowbias = nullptr; m.res = nullptr; m.qstats = nullptr; m.egn_out = nullptr; m.egn_skip_raw = 0;
     GD_TRY(launch_conv3x3_wino2d(m, s));
     const long long waves = (long long)(p.M / 16) * ((p.N / 4 + 15) / 16);
-    static const int nofinish = getenv("GDDIM_SPLITK_NOFINISH") ? atoi(getenv("GDDIM_SPLITK_NOFINISH")) : 0;  // timing only (results wrong)
-    if (nofinish) return 0;
     hipLaunchKernelGGL(wino2d_splitk_finish_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, p, p.M / 16);
     GD_HIP(hipGetLastError());
     return 0;
