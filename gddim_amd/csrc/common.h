@@ -103,9 +103,16 @@ struct GemmParams {
     // partials in index order and runs the epilogue.  0 / 1 = off.
     int wk_split;
     float *wk_partial;
+    // persistent short-K kernel, 1x1 convolutions on the RAW input of a GroupNorm (the shortcut convolution of a residual block reads
+    // what the block's first GroupNorm normalises): the loader also applies that GroupNorm to every A element it stages -- gn_table[img]
+    // = [C scale | C shift] (gn_apply_kernel in table mode), gn_act = 1 applies swish -- and stores the result to
+    // gn_side_out[m * (C0 + C1) + c]: the separate GroupNorm-apply pass over the same tensor disappears.  null = off.
+    float *gn_side_out;
 };
 
 int launch_igemm(const GemmParams &p, int batch_z, hipStream_t s);
+// true when launch_igemm would run this 1x1 problem on the persistent short-K kernel, whose loader implements gn_side_out
+bool igemm_gn_side_ok(const GemmParams &p, int batch_z);
 // true when launch_igemm would run this problem on igemm_f32_fast_kernel (any tile, any split), whose epilogue implements egn_out
 bool igemm_egn_ok(const GemmParams &p, int batch_z);
 const char *igemm_variant_name(const GemmParams &p, int batch_z);

@@ -66,6 +66,7 @@ struct gd_engine {
     std::vector<long long> wino2_off;
     std::map<int, std::vector<char>> fuse_ok;      // batch size -> per GEMM op: the fused-GroupNorm halo kernel takes it
     std::map<int, std::vector<char>> egn_ok;       // batch size -> per GEMM op: normalises its output in the epilogue (Op::egn_peer)
+    std::map<int, std::vector<char>> side_ok;      // batch size -> per GEMM op: writes a GroupNorm of its input from its loader (Op::side_peer)
     std::map<int, std::vector<char>> presplit_ok;  // batch size -> per tensor: may be stored pre-split (see presplit_allowed)
     std::vector<long long> slot_off;  // floats into wbuf
     long long wbuf_floats = 0;
@@ -270,6 +271,42 @@ static bool egn_fused(gd_engine *e, const Bind &b, int batch, int gemm_index) {
     return it->second[gemm_index] != 0;
 }
 
+// GroupNorm as a side output of the shortcut convolution (plan.h: Op::side_peer), fp32 mode: taken when, at this batch size, the 1x1
+// convolution runs on the persistent short-K kernel and the GroupNorm is not already written by its producer's epilogue.  Decided once
+// per batch size; GDDIM_NO_SIDE_GN=1 switches it off (A/B).
+static void fill_side(gd_engine *e, const Op &op, const Bind &b, int batch, GemmParams &g) {
+    const Op &a = e->plan.ops[op.side_peer];
+    g.gn_table = tptr(e, b, a.gn_table, batch);
+    g.gn_act = a.act;
+    g.gn_side_out = tptr(e, b, a.out, batch);
+}
+
+static bool side_fused(gd_engine *e, const Bind &b, int batch, int gemm_index) {
+    static const bool off = getenv("GDDIM_NO_SIDE_GN") != nullptr;
+    if (off || e->precision != 0 || gemm_index < 0) return false;
+    auto it = e->side_ok.find(batch);
+    if (it == e->side_ok.end()) {
+        std::vector<char> ok(e->plan.ops.size(), 0);
+        for (size_t i = 0; i < e->plan.ops.size(); ++i) {
+            const Op &op = e->plan.ops[i];
+            if (op.kind != OP_GEMM || op.side_peer < 0) continue;
+            const Op &a = e->plan.ops[op.side_peer];
+            if (a.kind != OP_GN_APPLY || a.a0.t != op.a0.t || a.a1.t != op.a1.t || a.C0 != op.C0 || a.C1 != op.C1 || a.a0.col != 0 || op.a0.col != 0 ||
+                a.gn_table.t < 0 || e->plan.tensors[a.out.t].ext != EXT_NONE)
+                continue;
+            if (a.egn_peer >= 0 && egn_fused(e, b, batch, a.egn_peer)) continue;  // its producer writes it already
+            GemmParams g{};
+            const int z = fill_gemm(e, op, b, batch, g);
+            fill_side(e, op, b, batch, g);
+            ok[i] = igemm_gn_side_ok(g, z) ? 1 : 0;
+        }
+        it = e->side_ok.emplace(batch, std::move(ok)).first;
+    }
+    return it->second[gemm_index] != 0;
+}
+
+static int launch_apply_op(gd_engine *e, const Op &op, const Bind &b, int batch, bool table_only, hipStream_t s);
+
 // The attention core q k^T -> softmax -> p v as ONE launch (kernels/attn_fused_f32.hip), fp32 mode, 256 tokens x 256 channels: op i is
 // the q k^T product of such a core when it is a per-image product of two column blocks of one tensor (q at column 0, k at column C),
 // followed by the in-place softmax of its output and by the product of that output with a k-contiguous V^T.
@@ -290,6 +327,18 @@ static bool attn_core_at(const gd_engine *e, int i) {
     const float want = 1.0f / std::sqrt((float)qk.C0);
     if (std::fabs(qk.alpha - want) > 1e-6f * want || qk.out_scale != 1.f) return false;
     return attn_fused_ok(qk.N, qk.C0);
+}
+
+static int launch_apply_op(gd_engine *e, const Op &op, const Bind &b, int batch, bool table_only, hipStream_t s) {
+    const int HW = op.H * op.W;
+    const int rt = gn_slices(batch, HW);
+    ProfScope ps(e, s, table_only ? "gn_table" : "gn_apply", 0, table_only ? 0.0 : 8.0 * batch * HW * (op.C0 + op.C1));
+    return launch_gn_apply(tptr(e, b, op.a0, batch), op.C0, tptr(e, b, op.a1, batch), op.C1, tptr(e, b, op.stats, batch),
+                           op.S0 > 0 ? op.S0 : rt, tptr(e, b, op.stats1, batch), op.S1 > 0 ? op.S1 : rt,
+                           slot_ptr(e, op.gamma_slot), slot_ptr(e, op.beta_slot), tptr(e, b, op.out, batch), batch, HW,
+                           op.groups, op.act, 1e-6f,
+                           (e->precision == 1 && e->wsplit_valid && op.split_out && presplit_allowed(e, b, batch, op.out.t)) ? 1 : 0,
+                           table_only ? tptr(e, b, op.gn_table, batch) : nullptr, s);
 }
 
 static int run_op(gd_engine *e, int op_index, const Bind &b, int batch, hipStream_t s) {
@@ -365,7 +414,12 @@ static int run_op(gd_engine *e, int op_index, const Bind &b, int batch, hipStrea
                 ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(conv3x3_wino_name(g)), op.flops_per_image * batch, 0);
                 return launch_conv3x3_wino(g, s);
             }
-            ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(igemm_variant_name(g, z)), op.flops_per_image * batch, 0);
+            if (op.side_peer >= 0 && side_fused(e, b, batch, op_index)) {  // the per-image affine table first, then the GEMM whose loader applies it
+                GD_TRY(launch_apply_op(e, P.ops[op.side_peer], b, batch, true, s));
+                fill_side(e, op, b, batch, g);
+            }
+            ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(igemm_variant_name(g, z)) + (g.gn_side_out ? "+gn" : ""),
+                         op.flops_per_image * batch, 0);
             return launch_igemm(g, z, s);
         }
         case OP_GN_STATS: {
@@ -376,16 +430,9 @@ static int run_op(gd_engine *e, int op_index, const Bind &b, int batch, hipStrea
         }
         case OP_GN_APPLY: {
             if (op.egn_peer >= 0 && egn_fused(e, b, batch, op.egn_peer)) return 0;  // the producer's epilogue wrote op.out
-            const int HW = op.H * op.W;
-            const int rt = gn_slices(batch, HW);
+            if (op.side_peer >= 0 && side_fused(e, b, batch, op.side_peer)) return 0;  // the shortcut convolution's loader wrote op.out
             const bool table_only = op.fuse_peer >= 0 && gn_fused(e, b, batch, op.fuse_peer);
-            ProfScope ps(e, s, table_only ? "gn_table" : "gn_apply", 0, table_only ? 0.0 : 8.0 * batch * HW * (op.C0 + op.C1));
-            return launch_gn_apply(tptr(e, b, op.a0, batch), op.C0, tptr(e, b, op.a1, batch), op.C1, tptr(e, b, op.stats, batch),
-                                   op.S0 > 0 ? op.S0 : rt, tptr(e, b, op.stats1, batch), op.S1 > 0 ? op.S1 : rt,
-                                   slot_ptr(e, op.gamma_slot), slot_ptr(e, op.beta_slot), tptr(e, b, op.out, batch), batch, HW,
-                                   op.groups, op.act, 1e-6f,
-                                   (e->precision == 1 && e->wsplit_valid && op.split_out && presplit_allowed(e, b, batch, op.out.t)) ? 1 : 0,
-                                   table_only ? tptr(e, b, op.gn_table, batch) : nullptr, s);
+            return launch_apply_op(e, op, b, batch, table_only, s);
         }
         case OP_GN_GENERIC: {
             ProfScope ps(e, s, "gn_generic", 0, 12.0 * batch * op.H * op.W * (op.C0 + op.C1));
@@ -669,6 +716,7 @@ int gd_engine_set_precision(gd_engine *e, int mode) {
         GD_HIP(hipDeviceSynchronize());
         drop_graphs(e);  // captured graphs bake the kernel choice
         e->egn_ok.clear();
+        e->side_ok.clear();
         if (mode == 1 && e->params_uploaded && !e->wsplit_valid) GD_TRY(upload_split_weights(e));
     }
     e->precision = mode;

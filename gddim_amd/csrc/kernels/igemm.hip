@@ -806,14 +806,19 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_pers_kernel(const Gemm
     const int nk = p.K / KC;  // >= 3 (launch_igemm)
     int z_nx = 0, m0_nx = 0;  // the tile the load side moved on to (valid when `more`)
     bool more = false;
+    // gn_side_out (GemmParams): the chunk that sits in the staging registers -- requested before the last advance_k -- belongs to tile
+    // rows st_m0.., channels st_c0..; st_m0 < 0 once the load side has run past the workgroup's last tile
+    int ld_m0 = mt_ld * BM, st_m0 = 0, st_c0 = 0;
     auto roll = [&]() __attribute__((always_inline)) {
         int next = id + (int)gridDim.x, zz = 0, mt = 0, ntl = 0;
         while (next < total_ids && !tile_of(next, zz, mt, ntl)) next += (int)gridDim.x;
         more = next < total_ids;
         s_kc = 0; s_tap = 0; s_ty = 0; s_tx = 0; s_c0 = 0;
+        ld_m0 = -1;
         if (more) {
             id = next;
             z_nx = zz; m0_nx = mt * BM;
+            ld_m0 = m0_nx;
             if (p.z_count > 1) { srd_a0 = make_a0(zz); srd_b = make_b(zz); }
             setup_rows(m0_nx);
         } else {  // nothing left: the remaining requests of the pipeline fetch nothing (what they store is never read)
@@ -824,6 +829,8 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_pers_kernel(const Gemm
         }
     };
     auto advance_k = [&]() __attribute__((always_inline)) {
+        st_m0 = ld_m0;
+        st_c0 = s_c0;
         ++s_kc;
         ++s_tap;
         if (++s_tx == p.KW) { s_tx = 0; ++s_ty; }
@@ -848,9 +855,29 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_pers_kernel(const Gemm
             rb[j] = buf_load16(srd_b, bvo[j], (s_tap * Cin + s_c0) * 4);
         }
     };
+    const bool side = p.gn_side_out != nullptr && ntile == 0;  // (every N tile stages the same A elements: the first one writes them)
     auto store_piece = [&](int pc, float *st) __attribute__((always_inline)) {
-        if (pc < AJ) *reinterpret_cast<f32x4 *>(&st[(arow + RPP * pc) * LDT + kcol]) = ra[pc];
-        else *reinterpret_cast<f32x4 *>(&st[BM * LDT + (arow + RPP * (pc - AJ)) * LDT + kcol]) = rb[pc - AJ];
+        if (pc < AJ) {
+            *reinterpret_cast<f32x4 *>(&st[(arow + RPP * pc) * LDT + kcol]) = ra[pc];
+            if (side) {  // the GroupNorm (+ swish) of the raw element, as gn_apply_kernel computes it
+                const int m = st_m0 + arow + RPP * pc;
+                if (st_m0 >= 0 && m < p.M) {
+                    const unsigned img = fast_div((unsigned)m, (unsigned)p.rows_per_image, p.mg_rpi, p.sh_rpi);
+                    const int c = st_c0 + kcol;
+                    const float *tb = p.gn_table + (size_t)img * 2 * Cin + c;
+                    const f32x4 sc = *reinterpret_cast<const f32x4 *>(tb), sh = *reinterpret_cast<const f32x4 *>(tb + Cin);
+                    f32x4 y;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float t = ra[pc][i] * sc[i] + sh[i];
+                        y[i] = p.gn_act ? swish_e(t) : t;
+                    }
+                    *reinterpret_cast<f32x4 *>(p.gn_side_out + (size_t)m * Cin + c) = y;
+                }
+            }
+        } else {
+            *reinterpret_cast<f32x4 *>(&st[BM * LDT + (arow + RPP * (pc - AJ)) * LDT + kcol]) = rb[pc - AJ];
+        }
     };
 
     f32x16 acc[RM][RN];
@@ -1076,6 +1103,17 @@ static void fill_div(unsigned d, unsigned &magic, unsigned &shift) {
 }
 
 // Eligibility of the VALU-free fast path (see igemm_f32_fast_kernel).  GDDIM_IGEMM_NOFAST=1 forces the generic kernel.
+static bool pers_ok(const GemmParams &p, int batch_z, int bm, int bn);
+static void pick_tiles(const GemmParams &p, int batch_z, int &bm, int &bn);
+
+bool igemm_gn_side_ok(const GemmParams &p, int batch_z) {
+    if (batch_z != 1 || p.KH != 1 || p.KW != 1 || p.stride != 1 || p.pad != 0 || p.OH != p.H || p.OW != p.W) return false;
+    if (!p.gn_table || !p.gn_side_out || p.rows_per_image <= 0 || p.lda0 != p.C0 || (p.C1 > 0 && p.lda1 != p.C1)) return false;
+    int bm, bn;
+    pick_tiles(p, batch_z, bm, bn);
+    return pers_ok(p, batch_z, bm, bn);
+}
+
 static bool fast_ok(const GemmParams &p) {
     static const int off = getenv("GDDIM_IGEMM_NOFAST") ? atoi(getenv("GDDIM_IGEMM_NOFAST")) : 0;
     if (off || p.in_act) return false;

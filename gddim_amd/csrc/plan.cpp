@@ -206,8 +206,21 @@ int Plan::resblock(int idx, int xa, int Ca, int xb, int Cb, int H, int W, int O,
     const std::string n = "ResnetBlockBigGANpp_" + std::to_string(idx);
     const int C = Ca + Cb;
     const float scale = desc.skip_rescale ? (float)(1.0 / std::sqrt(2.0)) : 1.f;
+    // shortcut: conv1x1 iff C != out_ch or up or down (layerspp.py:221-222).  Without resampling it reads the block input itself --
+    // what GroupNorm_0 normalises -- and is planned FIRST, so that its loader can write act(GroupNorm_0(x)) on the way (Op::side_peer)
+    int xs = -1;
+    const bool early_shortcut = C != O && !up && !down;
+    if (early_shortcut) xs = conv(n + ".conv2", n + "/Conv_2", xa, Ca, xb, Cb, H, W, 1, O, -1, 1.f, -1, 0);
+    const int shortcut_op = early_shortcut ? (int)ops.size() - 1 : -1;
     // h = act(GroupNorm_0(x))
     int h0 = gn(n + ".gn0", n + "/GroupNorm_0", xa, Ca, xb, Cb, H, W, 1);
+    if (shortcut_op >= 0 && Ca % 4 == 0 && Cb % 4 == 0) {
+        const int apply_op = (int)ops.size() - 1;  // (Plan::gn pushes the apply op last)
+        if (ops[apply_op].kind == OP_GN_APPLY && ops[apply_op].out.t == h0) {
+            ops[apply_op].side_peer = shortcut_op;
+            ops[shortcut_op].side_peer = apply_op;
+        }
+    }
     int xs_src = xa;  // shortcut source (single tensor unless concat)
     int H2 = H, W2 = W;
     int xr = -1;  // resampled x
@@ -240,12 +253,10 @@ int Plan::resblock(int idx, int xa, int Ca, int xb, int Cb, int H, int W, int O,
     }
     // h = act(GroupNorm_1(h)); Dropout is the identity at inference
     int h2 = gn(n + ".gn1", n + "/GroupNorm_1", h1, O, -1, 0, H2, W2, 1);  // h1 stays alive until Conv_1 is out (fused GroupNorm)
-    // shortcut: conv1x1 iff C != out_ch or up or down (layerspp.py:221-222)
+    // the shortcut of a resampling block reads the resampled input
     int res_t;
-    int xs = -1;
     if (C != O || up || down) {
         if (up || down) xs = conv(n + ".conv2", n + "/Conv_2", xs_src, C, -1, 0, H2, W2, 1, O, -1, 1.f, -1, 0);
-        else xs = conv(n + ".conv2", n + "/Conv_2", xa, Ca, xb, Cb, H2, W2, 1, O, -1, 1.f, -1, 0);
         res_t = xs;
     } else {
         res_t = xa;
@@ -754,7 +765,7 @@ std::string Plan::json() const {
         jref(o, "a0", p.a0); jref(o, "a1", p.a1); jref(o, "bten", p.bten); jref(o, "rowbias", p.rowbias);
         jref(o, "res", p.res); jref(o, "out", p.out); jref(o, "stats", p.stats); jref(o, "stats1", p.stats1); jref(o, "qstats", p.qstats);
         o << "\"split_out\":" << p.split_out << ",\"a_split\":" << p.a_split << ",\"fuse_peer\":" << p.fuse_peer << ",\"egn_peer\":" << p.egn_peer
-          << ",\"egn_sole\":" << p.egn_sole << ",";
+          << ",\"egn_sole\":" << p.egn_sole << ",\"side_peer\":" << p.side_peer << ",";
         o << "\"C0\":" << p.C0 << ",\"C1\":" << p.C1 << ",\"lda0\":" << p.lda0 << ",\"lda1\":" << p.lda1 << ",\"H\":" << p.H
           << ",\"W\":" << p.W << ",\"OH\":" << p.OH << ",\"OW\":" << p.OW << ",\"KH\":" << p.KH << ",\"KW\":" << p.KW
           << ",\"stride\":" << p.stride << ",\"pad\":" << p.pad << ",\"m_per_image\":" << p.m_per_image

@@ -91,6 +91,11 @@ struct Op {
     // column sums of its waves through LDS; the apply op is then skipped.  egn_sole: the apply op is the only reader of the raw output, which
     // is then not stored at all.  The apply op's output tensor is `fresh` so that writing it early cannot hit live data.
     int egn_peer = -1, egn_sole = 0;
+    // GroupNorm as a side output of the 1x1 shortcut convolution that reads the same raw tensor(s) (fp32 mode, run-time decision): the
+    // GN_APPLY op of a residual block's GroupNorm_0 and the block's Conv_2 point at each other (side_peer = op index); Conv_2 is planned
+    // in FRONT of the GroupNorm.  When the persistent short-K kernel takes the convolution at the current batch size its loader writes
+    // the normalised tensor (GemmParams::gn_side_out) and the apply op only produces the per-image affine table, ahead of it.
+    int side_peer = -1;
     TRef qstats;          // GEMM: quad statistics of the output (fused GroupNorm statistics), t = -1: none
     int qs_slices = 0;
     // ---- GroupNorm ----
