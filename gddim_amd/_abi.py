@@ -106,6 +106,13 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise GddimError("native library %s not found: run `python -m gddim_amd.build` "
                              "(no CPU fallback exists)" % LIB_PATH)
+        # torch first: its wheel bundles a HIP runtime of its own, and whichever libamdhip64 is loaded first serves the whole process.
+        # Loading this library (linked against /opt/rocm) before torch left torch without a device (build() followed by smoke() in
+        # one process).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         try:
             l = ctypes.CDLL(LIB_PATH)
         except OSError as ex:
