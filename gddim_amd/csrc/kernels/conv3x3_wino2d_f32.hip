@@ -277,15 +277,16 @@ __device__ __forceinline__ void wino2d_tile(const GemmParams &p, float *smem) {
     // set that only lives here, before the accumulators do): one memory latency per tile instead of two. ----
     {
         w2f32x4 r0[4], w0[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) load_raw_to(r0, k);
+        // (the weight pieces first: their addresses need none of the pixel arithmetic)
 #pragma unroll
         for (int k = 0; k < 4; ++k) load_w_to(w0, k);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) load_raw_to(r0, k);
         advance();
 #pragma unroll
-        for (int k = 0; k < 4; ++k) load_raw(k);
-#pragma unroll
         for (int k = 0; k < 4; ++k) load_w(k);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) load_raw(k);
         combine_from(r0);
 #pragma unroll
         for (int j = 0; j < 4; ++j) store_v(j, 0);
