@@ -359,14 +359,15 @@ __device__ __forceinline__ void wino2d_tile(const GemmParams &p, float *smem) {
                     bf[(j + 1) & 1][1] = *reinterpret_cast<const w2f32x4 *>(cur + b_off[j + 1] + B_ROWS32);
                 }
                 // staging work in the shadow of the MFMA pair
+                // (the weights first: loads return in order, and theirs are the short ones)
                 if (MODE < 2) {
-                    if (gap == 0) combine();
-                    if (gap < 4) store_v(gap, nxt);
-                    else if (gap < 8) store_w(gap - 4, nxt);
+                    if (gap < 4) store_w(gap, nxt);
+                    if (gap == 4) combine();
+                    if (gap >= 4 && gap < 8) store_v(gap - 4, nxt);
                 }
                 if (MODE == 0) {
-                    if (gap < 4) load_raw(gap);
-                    else if (gap < 8) load_w(gap - 4);
+                    if (gap < 4) load_w(gap);
+                    else if (gap < 8) load_raw(gap - 4);
                     else if (gap == 8) advance();
                 }
                 if (MODE == 1 && has_res) {
