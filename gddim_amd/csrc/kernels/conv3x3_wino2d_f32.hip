@@ -257,14 +257,7 @@ __device__ __forceinline__ void wino2d_tile(const GemmParams &p, float *smem) {
     };
     auto store_w = [&](int k, int par) __attribute__((always_inline)) { store_w_from(wb, k, par); };
 
-    w2f32x16 acc[4][2];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-            for (int v = 0; v < 16; ++v) acc[j][c][v] = 0.f;
-
+    w2f32x16 acc[4][2];  // (never zeroed: the first MFMA of every accumulator, in the tile's first chunk, takes the constant 0 as its C operand)
     int a_off[4];  // fragment of component (wi, j): rotated slot, see v_lds
 #pragma unroll
     for (int j = 0; j < 4; ++j) a_off[j] = (wq * 32 + li) * W2_LD + wi * 32 + ((j + wi) & 3) * 8 + lh * 4;
@@ -337,9 +330,10 @@ __device__ __forceinline__ void wino2d_tile(const GemmParams &p, float *smem) {
     // MODE 1: the tile's second-to-last chunk (nothing left to request: the residual tile is requested instead, its latency hides
     // behind the last chunk); MODE 2: the last chunk (no staging at all) ----
     w2f32x4 af[2], bf[2][2];
-    auto chunk = [&](auto mode_tag, auto par_tag) __attribute__((always_inline)) {
+    auto chunk = [&](auto mode_tag, auto par_tag, auto first_tag) __attribute__((always_inline)) {
         constexpr int MODE = decltype(mode_tag)::value;
         constexpr int PAR = decltype(par_tag)::value;  // stage the chunk is multiplied from (compile time: immediate offsets)
+        constexpr bool FIRST = decltype(first_tag)::value != 0;  // the tile's first chunk: accumulators start from the constant 0
         const float *cur = smem + PAR * W2_HALF;
         constexpr int nxt = PAR ^ 1;
         af[0] = *reinterpret_cast<const w2f32x4 *>(cur + a_off[0]);
@@ -349,8 +343,14 @@ __device__ __forceinline__ void wino2d_tile(const GemmParams &p, float *smem) {
         for (int j = 0; j < 4; ++j) {
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
-                acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j & 1][jj], bf[j & 1][0][jj], acc[j][0], 0, 0, 0);
-                acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j & 1][jj], bf[j & 1][1][jj], acc[j][1], 0, 0, 0);
+                if (FIRST && jj == 0) {
+                    const w2f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j & 1][jj], bf[j & 1][0][jj], zero, 0, 0, 0);
+                    acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j & 1][jj], bf[j & 1][1][jj], zero, 0, 0, 0);
+                } else {
+                    acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j & 1][jj], bf[j & 1][0][jj], acc[j][0], 0, 0, 0);
+                    acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j & 1][jj], bf[j & 1][1][jj], acc[j][1], 0, 0, 0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 const int gap = j * 4 + jj;
                 if (jj == 0 && j < 3 && !(W2_ABL & 4)) {  // fragments of the next component, one component ahead of their use
@@ -382,12 +382,14 @@ __device__ __forceinline__ void wino2d_tile(const GemmParams &p, float *smem) {
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>;
-    for (int kc = 0; kc < nk - 2; kc += 2) {  // nk is a multiple of 4
-        chunk(I0{}, I0{});
-        chunk(I0{}, I1{});
+    chunk(I0{}, I0{}, I1{});  // (nk is even and >= 4: the first pair of chunks always has something to request)
+    chunk(I0{}, I1{}, I0{});
+    for (int kc = 2; kc < nk - 2; kc += 2) {
+        chunk(I0{}, I0{}, I0{});
+        chunk(I0{}, I1{}, I0{});
     }
-    chunk(I1{}, I0{});
-    chunk(I2{}, I1{});
+    chunk(I1{}, I0{}, I0{});
+    chunk(I2{}, I1{}, I0{});
 #ifdef W2_TRACE
     trace();
 #endif
