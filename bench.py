@@ -59,6 +59,19 @@ def hbm_traffic(kernel_name):
     return None
 
 
+def issued_ratio(name):
+    """MFMA products a kernel issues per algorithmic product of the direct algorithm (by kernel name)."""
+    if "wino42" in name:
+        return 1.0 / 3.0   # F(2,3)y x F(4,3)x: 24 products per 8 outputs instead of 72
+    if "wino2d" in name:
+        return 4.0 / 9.0   # F(2x2,3x3): 16 per 4 outputs instead of 36
+    if "wino" in name:
+        return 2.0 / 3.0   # F(2,3) along x
+    if "bf16x3" in name:
+        return 3.0
+    return 1.0
+
+
 def cpu_baseline(cfg, params, nfe_full, cpu_batch, cpu_nfe):
     """The reference JAX-CPU path cannot run here (no jax); timed instead: the torch-CPU fp32 ORACLE (a
     restatement of the same algorithm, kind='port') on a bounded sample, all host cores."""
@@ -225,15 +238,22 @@ def main():
         # pipe the kernel keeps busy = ISSUED MFMA flops / time / peak (<= 1): Winograd F(2,3) issues 2/3 of the algorithmic
         # products, bf16x3 issues 3 bf16 MFMAs per algorithmic product.  `algorithmic_frac` = achieved / peak (may exceed 1
         # for Winograd: the kernel does less work than the direct algorithm).
-        issue_ratio = (4.0 / 9.0) if "wino2d" in dom["name"] else (2.0 / 3.0) if "wino" in dom["name"] else (3.0 if "bf16x3" in dom["name"] else 1.0)
+        issue_ratio = issued_ratio(dom["name"])
+        traffic = hbm_traffic(dom["name"])
+        alg_bytes = dom["bytes"] / max(1, dom["launches"]) if dom.get("bytes") else None
         result["roofline"] = {"kernel": dom["name"], "bound": "mfma", "achieved": achieved, "peak": peak,
-                              "unit": "TFLOP/s", "frac": achieved * issue_ratio / peak, "traffic": hbm_traffic(dom["name"]),
+                              "unit": "TFLOP/s", "frac": achieved * issue_ratio / peak, "traffic": traffic,
+                              "algorithmic_bytes": alg_bytes, "traffic_ratio": (traffic / alg_bytes) if (traffic and alg_bytes) else None,
                               "algorithmic_frac": achieved / peak, "issued": achieved * issue_ratio,
                               "launches": dom["launches"], "avg_launch_ms": dom["ms"] / max(1, dom["launches"]),
                               "flops_per_launch": dom["flops"] / max(1, dom["launches"]),
                               "share_of_gpu_time": dom["ms"] / tot_ms if tot_ms else None,
                               "traffic_source": "committed rocprofv3 --pmc passes of this command (profiles/), not this run"}
-        if "wino2d" in dom["name"]:
+        if "wino42" in dom["name"]:
+            result["roofline"]["note"] = ("hybrid Winograd F(2,3)y x F(4,3)x: achieved = algorithmic flops of the direct convolution / time; the kernel "
+                                          "issues 24 products per 2x4 output tile instead of 72, i.e. 1/3 of that; frac = issued / dense fp32 MFMA peak "
+                                          "(nominal, 2.4 GHz).  fp32 error of the transform: profiles/r03_winograd_error_study.md")
+        elif "wino2d" in dom["name"]:
             result["roofline"]["note"] = ("Winograd F(2x2,3x3): achieved = algorithmic flops of the direct convolution / time; the kernel "
                                           "issues 16 products per 2x2 output quad instead of 36, i.e. 4/9 of that; frac = issued / dense fp32 MFMA peak (nominal, 2.4 GHz); "
                                           "the in-kernel timeline (profiles/r02_notes.md, tools/wino2d_trace.py) shows the shader clock at 1.9-2.1 GHz under this "
@@ -244,6 +264,8 @@ def main():
         result["kernel_breakdown"] = [
             {"name": p["name"], "ms": round(p["ms"], 3), "launches": p["launches"],
              "tflops": (p["flops"] / (p["ms"] * 1e-3) / 1e12) if p["flops"] and p["ms"] else None,
+             # fraction of the dense fp32 MFMA peak in ISSUED products (Winograd kernels issue 1/3, 4/9, 2/3 of the algorithmic flops)
+             "issued_frac": (p["flops"] * issued_ratio(p["name"]) / (p["ms"] * 1e-3) / 1e12 / (BF16_MFMA_PEAK_TFLOPS if "bf16x3" in p["name"] else FP32_MFMA_PEAK_TFLOPS)) if p["flops"] and p["ms"] else None,
              "gbs": (p["bytes"] / (p["ms"] * 1e-3) / 1e9) if p["bytes"] and p["ms"] else None}
             for p in sorted(prof, key=lambda p: -p["ms"])]
 

@@ -151,6 +151,15 @@ int launch_wino2d_weights(const float *w, float *u, int N, int Cin, hipStream_t 
 int conv3x3_wino2d_splitk_factor(const GemmParams &p);
 const char *conv3x3_wino2d_splitk_name();  // (the engine's profile entry: the split launch and its finishing pass)
 int launch_conv3x3_wino2d_splitk(const GemmParams &p, hipStream_t s);
+// fp32 3x3 stride-1 convolutions through the hybrid Winograd transform F(2,3)_y x F(4,3)_x (24 products per 2 x 4 output tile: x 3 fewer
+// matrix-core flops than the direct sum, x 1.33 fewer than F(2x2,3x3); kernels/conv3x3_wino42_f32.hip); p.b_wino = the weights in MFMA
+// fragment order from launch_wino42_weights (wino42_weight_floats(N, Cin) floats); GDDIM_NOWINO42=1 routes them back to F(2x2,3x3)
+bool conv3x3_wino42_ok(const GemmParams &p);
+bool conv3x3_wino42_shape_ok(const GemmParams &p);
+const char *conv3x3_wino42_name();
+int launch_conv3x3_wino42(const GemmParams &p, hipStream_t s);
+int launch_wino42_weights(const float *w, float *u, int N, int Cin, hipStream_t s);
+long long wino42_weight_floats(int N, int Cin);
 // per-device zero buffer used by the staging loads; allocates on first use (call once outside graph capture)
 const float *igemm_zero_buffer();
 

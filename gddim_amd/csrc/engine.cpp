@@ -64,6 +64,9 @@ struct gd_engine {
     float *splitk_ws = nullptr;  // partial outputs of the channel-split 2-D Winograd launches (4x4 level): 8 * max_batch * 16 * max N floats
     long long splitk_ws_floats = 0, splitk_per_image = 0;  // (a lane's sub-batch uses the slice that starts at its first image)
     std::vector<long long> wino2_off;
+    // ... and their hybrid F(2,3)_y x F(4,3)_x copies in MFMA fragment order (kernels/conv3x3_wino42_f32.hip), wino42_weight_floats() per slot
+    float *wwino42 = nullptr;
+    std::vector<long long> wino42_off;
     std::map<int, std::vector<char>> fuse_ok;      // batch size -> per GEMM op: the fused-GroupNorm halo kernel takes it
     std::map<int, std::vector<char>> egn_ok;       // batch size -> per GEMM op: normalises its output in the epilogue (Op::egn_peer)
     std::map<int, std::vector<char>> side_ok;      // batch size -> per GEMM op: writes a GroupNorm of its input from its loader (Op::side_peer)
@@ -191,6 +194,16 @@ static int fill_gemm(gd_engine *e, const Op &op, const Bind &b, int batch, GemmP
     return z;
 }
 
+// ALGORITHMIC HBM bytes of a GEMM launch (bench.py: roofline.algorithmic_bytes): every operand once -- the input pixels (not the
+// im2col expansion), the B matrix / weights, the residual, the output (raw and / or normalised copy)
+static double gemm_alg_bytes(const GemmParams &g, int z) {
+    const double in_rows = g.KH * g.KW > 1 ? (double)(g.M / (g.OH * g.OW > 0 ? g.OH * g.OW : 1)) * g.H * g.W : (double)g.M;
+    double fl = in_rows * (g.C0 + g.C1) + (double)g.N * g.K;
+    fl += (double)g.M * g.N * ((g.egn_skip_raw ? 0 : 1) + (g.res ? 1 : 0) + (g.egn_out ? 1 : 0));
+    if (g.gn_side_out) fl += (double)g.M * (g.C0 + g.C1);
+    return 4.0 * z * fl;
+}
+
 // A tensor is stored pre-split (bf16x3 mode) only when every GEMM that reads it is eligible for the split-precision kernels at
 // THIS batch size (the 2 GiB buffer-addressing limit depends on it); decided once per batch size, per tensor.
 static bool presplit_allowed(gd_engine *e, const Bind &b, int batch, int tensor) {
@@ -261,6 +274,8 @@ static bool egn_fused(gd_engine *e, const Bind &b, int batch, int gemm_index) {
             const int z = fill_gemm(e, op, b, batch, g);
             fill_egn(e, op, b, batch, g);
             const bool wino2 = z == 1 && op.w_slot >= 0 && e->wwino2 && e->wino2_off[op.w_slot] >= 0;
+            const bool wino42 = z == 1 && op.w_slot >= 0 && e->wwino42 && e->wino42_off[op.w_slot] >= 0;
+            if (wino42 && conv3x3_wino42_ok(g)) { ok[i] = 1; continue; }  // (its shape test covers the egn_* fields)
             const bool wino = z == 1 && op.w_slot >= 0 && e->wwino && e->wino_off[op.w_slot] >= 0 && conv3x3_wino_ok(g);
             if (wino2 && conv3x3_wino2d_ok(g)) ok[i] = 1;  // (its shape test covers the egn_* fields)
             else if (wino2 && e->splitk_ws && conv3x3_wino2d_splitk_factor(g) > 1) ok[i] = 1;  // (the finishing pass normalises)
@@ -355,7 +370,7 @@ static int run_op(gd_engine *e, int op_index, const Bind &b, int batch, hipStrea
             if (attn_core_at(e, op_index)) {  // q k^T, softmax and p v in one launch; the next two ops return at once
                 const Op &av = P.ops[op_index + 2];
                 ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(attn_fused_name()),
-                             (op.flops_per_image + av.flops_per_image) * batch, 0);
+                             (op.flops_per_image + av.flops_per_image) * batch, 4.0 * batch * 4.0 * op.N * op.C0);  // q, k, v^T, out once each
                 return launch_attn_fused(tptr(e, b, op.a0, batch), tptr(e, b, op.bten, batch), op.lda0, tptr(e, b, av.bten, batch),
                                          av.bias_slot >= 0 ? slot_ptr(e, av.bias_slot) + av.bias_off : nullptr, tptr(e, b, av.out, batch), av.ldc,
                                          batch, op.N, op.C0, s);
@@ -375,15 +390,15 @@ static int run_op(gd_engine *e, int op_index, const Bind &b, int batch, hipStrea
                     g.a_presplit = 0;
                     g.gn_table = tptr(e, b, op.gn_table, batch);
                     g.gn_act = e->plan.ops[op.fuse_peer].act;
-                    ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(conv3x3_halo_fused_name()), op.flops_per_image * batch, 0);
+                    ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(conv3x3_halo_fused_name()), op.flops_per_image * batch, gemm_alg_bytes(g, z));
                     return launch_conv3x3_halo(g, s);
                 }
                 if (z == 1 && conv3x3_halo_ok(g)) {
-                    ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(conv3x3_halo_name()), op.flops_per_image * batch, 0);
+                    ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(conv3x3_halo_name()), op.flops_per_image * batch, gemm_alg_bytes(g, z));
                     return launch_conv3x3_halo(g, s);
                 }
                 if (igemm_bf16x3_ok(g, z)) {
-                    ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(igemm_bf16x3_name(g)), op.flops_per_image * batch, 0);
+                    ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(igemm_bf16x3_name(g)), op.flops_per_image * batch, gemm_alg_bytes(g, z));
                     return launch_igemm_bf16x3(g, s);
                 }
                 g.b_hi = g.b_lo = nullptr;
@@ -391,12 +406,17 @@ static int run_op(gd_engine *e, int op_index, const Bind &b, int batch, hipStrea
             GD_CHECK(!g.a_presplit, "%s: pre-split input without a split-precision kernel", op.label.c_str());
             if (op.egn_peer >= 0 && egn_fused(e, b, batch, op_index)) fill_egn(e, op, b, batch, g);
             if (e->precision == 1 && op.w_slot < 0 && igemm_bf16x3_act_ok(g, z)) {  // attention products: activation x activation
-                ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string("igemm_bf16x3_kernel<256,128,4,2,act>"), op.flops_per_image * batch, 0);
+                ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string("igemm_bf16x3_kernel<256,128,4,2,act>"), op.flops_per_image * batch, gemm_alg_bytes(g, z));
                 return launch_igemm_bf16x3_act(g, z, s);
+            }
+            if (e->precision == 0 && z == 1 && op.w_slot >= 0 && e->wwino42 && e->wino42_off[op.w_slot] >= 0 && conv3x3_wino42_ok(g)) {
+                g.b_wino = e->wwino42 + e->wino42_off[op.w_slot];
+                ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(conv3x3_wino42_name()), op.flops_per_image * batch, gemm_alg_bytes(g, z));
+                return launch_conv3x3_wino42(g, s);
             }
             if (e->precision == 0 && z == 1 && op.w_slot >= 0 && e->wwino2 && e->wino2_off[op.w_slot] >= 0 && conv3x3_wino2d_ok(g)) {
                 g.b_wino = e->wwino2 + e->wino2_off[op.w_slot];
-                ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(conv3x3_wino2d_name()), op.flops_per_image * batch, 0);
+                ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(conv3x3_wino2d_name()), op.flops_per_image * batch, gemm_alg_bytes(g, z));
                 return launch_conv3x3_wino2d(g, s);
             }
             if (e->precision == 0 && z == 1 && op.w_slot >= 0 && e->wwino2 && e->wino2_off[op.w_slot] >= 0 && e->splitk_ws &&
@@ -406,12 +426,12 @@ static int run_op(gd_engine *e, int op_index, const Bind &b, int batch, hipStrea
                 g.wk_partial = e->splitk_ws + img0 * e->splitk_per_image;
                 GD_CHECK(img0 * e->splitk_per_image + (long long)conv3x3_wino2d_splitk_factor(g) * g.M * g.N <= e->splitk_ws_floats,
                          "%s: split-K scratch too small", op.label.c_str());
-                ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(conv3x3_wino2d_splitk_name()), op.flops_per_image * batch, 0);
+                ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(conv3x3_wino2d_splitk_name()), op.flops_per_image * batch, gemm_alg_bytes(g, z));
                 return launch_conv3x3_wino2d_splitk(g, s);
             }
             if (e->precision == 0 && z == 1 && op.w_slot >= 0 && e->wwino && e->wino_off[op.w_slot] >= 0 && conv3x3_wino_ok(g)) {
                 g.b_wino = e->wwino + e->wino_off[op.w_slot];
-                ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(conv3x3_wino_name(g)), op.flops_per_image * batch, 0);
+                ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(conv3x3_wino_name(g)), op.flops_per_image * batch, gemm_alg_bytes(g, z));
                 return launch_conv3x3_wino(g, s);
             }
             if (op.side_peer >= 0 && side_fused(e, b, batch, op_index)) {  // the per-image affine table first, then the GEMM whose loader applies it
@@ -419,7 +439,7 @@ static int run_op(gd_engine *e, int op_index, const Bind &b, int batch, hipStrea
                 fill_side(e, op, b, batch, g);
             }
             ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(igemm_variant_name(g, z)) + (g.gn_side_out ? "+gn" : ""),
-                         op.flops_per_image * batch, 0);
+                         op.flops_per_image * batch, gemm_alg_bytes(g, z));
             return launch_igemm(g, z, s);
         }
         case OP_GN_STATS: {
@@ -564,6 +584,7 @@ int gd_engine_destroy(gd_engine *e) {
         for (auto &p : e->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
         if (e->wwino) (void)hipFree(e->wwino);
         if (e->wwino2) (void)hipFree(e->wwino2);
+        if (e->wwino42) (void)hipFree(e->wwino42);
         if (e->splitk_ws) (void)hipFree(e->splitk_ws);
         if (e->wsplit_hi) (void)hipFree(e->wsplit_hi);
         if (e->wsplit_lo) (void)hipFree(e->wsplit_lo);
@@ -703,6 +724,27 @@ static int build_wino_weights(gd_engine *e) {
         for (size_t i = 0; i < P.slots.size(); ++i)
             if (e->wino2_off[i] >= 0)
                 GD_TRY(launch_wino2d_weights(e->wbuf + e->slot_off[i], e->wwino2 + e->wino2_off[i], dims[i].first, dims[i].second, nullptr));
+    }
+    // the hybrid F(2,3)_y x F(4,3)_x form for the slots its kernel can take (8x8 .. 64x64 images; which launches use it is decided per
+    // batch size by conv3x3_wino42_ok)
+    e->wino42_off.assign(P.slots.size(), -1);
+    long long total42 = 0;
+    for (const Op &op : P.ops) {
+        if (op.kind != OP_GEMM || op.w_slot < 0 || op.a_slot >= 0 || op.z_per_image || e->wino42_off[op.w_slot] >= 0) continue;
+        const int Cin = op.C0 + op.C1;
+        if (op.KH != 3 || op.KW != 3 || op.stride != 1 || op.pad != 1 || Cin % 32 != 0 || op.K != 9 * Cin || op.ldb != op.K) continue;
+        if (P.slots[op.w_slot].rows != op.N || P.slots[op.w_slot].cols != op.K) continue;
+        if ((op.N % 4 != 0 || op.N < 32) && (op.qstats.t >= 0 || op.egn_peer >= 0)) continue;
+        if ((op.W != 8 && op.W != 16 && op.W != 32 && op.W != 64) || op.H % 2 != 0 || (op.H * op.W / 8) % 8 != 0) continue;
+        e->wino42_off[op.w_slot] = total42;
+        dims[op.w_slot] = {op.N, Cin};
+        total42 += wino42_weight_floats(op.N, Cin);
+    }
+    if (total42 > 0) {
+        if (!e->wwino42) GD_HIP(hipMalloc((void **)&e->wwino42, (size_t)total42 * sizeof(float)));
+        for (size_t i = 0; i < P.slots.size(); ++i)
+            if (e->wino42_off[i] >= 0)
+                GD_TRY(launch_wino42_weights(e->wbuf + e->slot_off[i], e->wwino42 + e->wino42_off[i], dims[i].first, dims[i].second, nullptr));
     }
     GD_HIP(hipDeviceSynchronize());
     return 0;
@@ -1311,6 +1353,23 @@ int gd_conv3x3_winograd2d(const float *x_dev, const float *w_dev, float *u_scrat
     GD_TRY(launch_wino2d_weights(w_dev, u_scratch_dev, Cout, Cin, (hipStream_t)stream));
     g.b_wino = u_scratch_dev;
     return launch_conv3x3_wino2d(g, (hipStream_t)stream);
+}
+
+int gd_conv3x3_winograd42(const float *x_dev, const float *w_dev, float *u_scratch_dev, const float *bias_dev, const float *res_dev,
+                          float *out_dev, int batch, int H, int W, int Cin, int Cout, float alpha, float out_scale, void *stream) {
+    GD_CHECK(x_dev && w_dev && u_scratch_dev && out_dev, "null pointer");
+    GemmParams g{};
+    g.a0 = x_dev; g.C0 = Cin; g.lda0 = Cin; g.lda1 = 4;
+    g.H = H; g.W = W; g.KH = 3; g.KW = 3; g.stride = 1; g.pad = 1; g.OH = H; g.OW = W;
+    g.M = batch * H * W; g.N = Cout; g.K = 9 * Cin;
+    g.b = w_dev; g.ldb = g.K;
+    g.out = out_dev; g.ldc = Cout; g.bias = bias_dev; g.res = res_dev; g.ldres = Cout;
+    g.rows_per_image = H * W;
+    g.alpha = alpha; g.out_scale = out_scale;
+    GD_CHECK(conv3x3_wino42_shape_ok(g), "conv3x3_winograd42: shape not eligible (B=%d H=%d W=%d Cin=%d Cout=%d)", batch, H, W, Cin, Cout);
+    GD_TRY(launch_wino42_weights(w_dev, u_scratch_dev, Cout, Cin, (hipStream_t)stream));
+    g.b_wino = u_scratch_dev;
+    return launch_conv3x3_wino42(g, (hipStream_t)stream);
 }
 
 int gd_group_norm(const float *x_dev, const float *scale_dev, const float *bias_dev, float *out_dev, int batch, int HW, int C,

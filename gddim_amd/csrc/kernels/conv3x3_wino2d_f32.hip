@@ -609,6 +609,13 @@ const char *conv3x3_wino2d_name() { return "conv3x3_wino2d_f32_kernel"; }
 
 int launch_conv3x3_wino2d(const GemmParams &p_in, hipStream_t s) {
     GemmParams p = p_in;
+    {   // the kernel addresses with 32-bit byte offsets into buffer descriptors (voffset + soffset): every operand, including the
+        // (W + 1)-pixel lead-in of the inputs, has to stay below 2^31 bytes (B = 512 of 64x64x128: 1.07 GB per tensor)
+        const long long ldmax = p.lda0 > p.lda1 ? p.lda0 : p.lda1;
+        GD_CHECK(((long long)p.M + 3 * p.W + 8) * ldmax * 4 + (long long)(p.C0 + p.C1) * 4 + 64 < (1LL << 31) &&
+                     (long long)p.M * p.ldc * 4 + 64 < (1LL << 31) && (!p.res || (long long)p.M * p.ldres * 4 + 64 < (1LL << 31)),
+                 "conv3x3_wino2d: operand beyond the 2^31-byte range of 32-bit buffer offsets (M=%d lda=%lld ldc=%d)", p.M, ldmax, p.ldc);
+    }
     GD_CHECK(conv3x3_wino2d_shape_ok(p) && p.b_wino, "conv3x3_wino2d: problem not eligible");
     p.ldb_wino = 16 * (p.C0 + p.C1);
     if (p.C1 == 0) p.lda1 = 4;

@@ -1,0 +1,560 @@
+// 3x3 / stride 1 / pad 1 convolution in fp32 with the HYBRID Winograd transform F(2,3) along y x F(4,3) along x: 24 products per 2 x 4
+// output tile = 3 per output pixel, against 4 for F(2x2,3x3) (conv3x3_wino2d_f32.hip), 6 for F(2,3) and 9 for the direct sum.
+//
+// Round 2 left the 3x3 convolutions on F(2x2,3x3) at 0.72 of the fp32 matrix peak in ISSUED products -- within 12-18 % of what the pipe
+// can issue at the clock it sustains -- so the remaining lever is, again, fewer products.  F(4,3) has transform constants (4, 5, 8)
+// that cost fp32 accuracy; tools/wino_error_study.py measures it (profiles/r03_winograd_error_study.md): one F(4,3) direction is at
+// 1.4x the direct fp32 kernel's rms error (3.7e-6 worst element at Cin = 512), F(4x4,3x3) at 3.7x; the end-to-end budget has 65x.
+// For the tile with top-left output pixel (2 ty, 4 tx), its 4 x 6 input patch d[r][s] = in[2 ty - 1 + r][4 tx - 1 + s], kernel g[ky][kx]:
+//     V = By^T d Bx,   U = Gy g Gx^T,   M_ij[tile][n] = sum_c V_ij[tile][c] U_ij[n][c]   (i < 4, j < 6),   Y = Ay^T M Ax   (2 x 4)
+//     y: the F(2,3) of the other Winograd kernels (By^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1], row 3 NEGATED on both sides)
+//     x: F(4,3) on the points 0, +-1, +-2, inf (tools/winograd_matrices.py, exact check):
+//        Bx^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+//        Gx   = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
+//        Ax^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+// The weight transform is computed in double and rounded once; the activation-side transforms are fp32 adds and fmas by 2, 4, 8.
+//
+// Workgroup: 512 threads = 8 wave64; tile 32 Winograd tiles (256 pixels) x 64 outputs x 24 components.  Wave (i, wn) owns component row
+// i (its six components j) of the 32 tiles x output block wn (32 columns): six 32x32x2 fp32 accumulators, 24 MFMAs per 8-channel chunk.
+// What differs from the F(2x2,3x3) kernel besides the transform:
+//  * the WEIGHTS NEVER TOUCH LDS.  With the components split over the waves a wave's B fragments are read by no other wave of the
+//    workgroup, so staging them through LDS was a copy without reuse: here U is stored in HBM in fragment order
+//    U[n / 32][Cin / 8][i][j][channel half][n % 32][4] and every wave loads its 1 KB fragments straight into the registers the MFMA
+//    reads (six buffer_load_dwordx4 per chunk, one chunk ahead, into the registers the previous chunk's MFMAs have just consumed).
+//    LDS holds V only (25 KB per stage instead of 66 KB), the LDS write traffic per chunk falls from 64 KB to 24 KB.
+//  * staging role: thread (tile, channel pair, patch row r) loads the six pixels of ONE patch row as 8-byte pieces; the y transform
+//    comes in through a DPP operand from the neighbouring lane exactly as in the F(2x2,3x3) kernel (12 v_fmac_f32_dpp), the x transform
+//    F(4,3) is 12 packed-fp32 instructions on the channel pair, six ds_write_b64 (slot order [j][i]: a 16-lane store group covers 128
+//    contiguous bytes).
+// Epilogue: x-direction output transform in-lane (six components -> four columns), y-direction across the four component-row waves
+// through LDS, then wave f of an output block finishes 8 tiles x 32 columns: bias, per-image bias row, residual, scale, store, GroupNorm
+// quad statistics, and the epilogue GroupNorm on 8x8 / 16x16 images -- the F(2x2,3x3) kernel's epilogue on 2 x 4 tiles.
+// Shapes: W in {8, 16, 32, 64}, H even, H W / 8 a multiple of 8, Cin % 32 == 0 (two-source concat: C0 % 32 == 0); N % 4 == 0 and
+// N >= 32 when the epilogue emits GroupNorm statistics (any N otherwise).
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+
+#include "../common.h"
+#include "act.h"
+#include "epilogue.h"
+
+namespace gd {
+
+typedef float w4f32x16 __attribute__((ext_vector_type(16)));
+typedef float w4f32x4 __attribute__((ext_vector_type(4)));
+typedef float w4f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int w4u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int w4u32x2 __attribute__((ext_vector_type(2)));
+
+#ifndef W42_ABL
+#define W42_ABL 0  // timing ablations (results wrong): 1 no pixel loads in the K loop, 2 no LDS stores, 4 no weight-fragment loads in the K loop,
+                   // 8 no barrier, 16 no transform arithmetic
+#endif
+
+constexpr int W4_LD = 196;               // LDS row stride (floats): 24 components x 8 channels + 4 pad = 49 16-byte units (odd)
+constexpr int W4_STAGE = 32 * W4_LD;     // floats per V stage
+constexpr int W4_SMEM = 8 * 4096 + 1024; // floats: the epilogue's exchange area (8 waves x 64 registers x 64 lanes) + the GroupNorm scratch
+
+__device__ __forceinline__ w4f32x2 w4_load8(__amdgpu_buffer_rsrc_t rsrc, int voffset, int soffset) {
+    w4u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voffset, soffset, 0);
+    return __builtin_bit_cast(w4f32x2, v);
+}
+__device__ __forceinline__ w4f32x4 w4_load16(__amdgpu_buffer_rsrc_t rsrc, int voffset, int soffset) {
+    w4u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voffset, soffset, 0);
+    return __builtin_bit_cast(w4f32x4, v);
+}
+
+// packed fp32 on a channel pair (on this chip every fp32 VALU cycle is taken from the fp32 matrix pipe: one instruction for two channels)
+__device__ __forceinline__ w4f32x2 pk_add(w4f32x2 a, w4f32x2 b) {
+    w4f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ w4f32x2 pk_sub(w4f32x2 a, w4f32x2 b) {
+    w4f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// a * K + b with K one of the inline constants 2, -2, 4, -4 (op_sel_hi:[1,0,1]: both halves multiply by the one 32-bit constant)
+#define W4_PK_FMA(NAME, KSTR)                                                                            \
+    __device__ __forceinline__ w4f32x2 NAME(w4f32x2 a, w4f32x2 b) {                                      \
+        w4f32x2 r;                                                                                       \
+        asm("v_pk_fma_f32 %0, %1, " KSTR ", %2 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(b));           \
+        return r;                                                                                        \
+    }
+W4_PK_FMA(pk_fma_p2, "2.0")
+W4_PK_FMA(pk_fma_m2, "-2.0")
+W4_PK_FMA(pk_fma_p4, "4.0")
+W4_PK_FMA(pk_fma_m4, "-4.0")
+#undef W4_PK_FMA
+
+__global__ __launch_bounds__(512, 2) void conv3x3_wino42_f32_kernel(const GemmParams p) {
+    __shared__ __attribute__((aligned(16))) float smem[W4_SMEM];
+    constexpr int OOB = (int)0x80000000u;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wi = wave & 3, wn = wave >> 2;  // component row, output block (32 columns)
+    const int li = lane & 31, lh = lane >> 5;
+
+    // ---- XCD-aware block -> (mtile, ntile): the N tiles of an M tile get ids congruent mod 8 (one XCD, one L2 for the shared pixels) ----
+    const int nt = p.n_tiles;
+    int mtile, ntile;
+    if (p.flat_tiles) {
+        mtile = blockIdx.x / nt;
+        ntile = blockIdx.x - mtile * nt;
+    } else {
+        const int grp = blockIdx.x / (8 * nt);
+        const int rem = blockIdx.x - grp * 8 * nt;
+        ntile = rem >> 3;
+        mtile = grp * 8 + (rem & 7);
+    }
+    if (mtile >= p.m_tiles) return;
+    const int t0 = mtile * 32, n0 = ntile * 64;
+
+    const int W = p.W, H = p.H, HW = H * W;
+    const int Wt = W >> 2;        // tiles per tile row: 2, 4, 8 or 16
+    const int wts = p.sh_ow;      // log2(Wt) (launch_conv3x3_wino42)
+    const int TI = HW >> 3;       // tiles per image (a multiple of 8)
+    const int T = p.M >> 3;       // tiles in the batch
+    const int Cin = p.C0 + p.C1;
+    const int NK = Cin >> 3;      // 8-channel chunks (a multiple of 4)
+    const int a_imgs = p.M / HW;
+    const int bias0 = (W + 1) * p.lda0 * 4, bias1 = (W + 1) * p.lda1 * 4;
+    const __amdgpu_buffer_rsrc_t srd_a0 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(reinterpret_cast<const char *>(p.a0) - bias0), 0, a_imgs * HW * p.lda0 * 4 + bias0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srd_a1 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(reinterpret_cast<const char *>(p.C1 ? p.a1 : p.a0) - bias1), 0, a_imgs * HW * p.lda1 * 4 + bias1, 0x00020000);
+    const int nblk = (p.N + 31) >> 5;
+    const __amdgpu_buffer_rsrc_t srd_u = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(reinterpret_cast<const char *>(p.b_wino)), 0, nblk * NK * (24 * 1024), 0x00020000);
+
+    // ---- staging role: (tile tl, channel pair chp, patch row r).  Thread r loads row r of the tile's 4 x 6 patch (six pixels x 8 B).
+    // By^T row r combines two patch rows -- 0: r0 - r2, 1: r1 + r2, 2: r2 - r1, 3: r1 - r3 -- and the partner row sits in a neighbouring
+    // lane of the same 4-lane group (lanes 2, 2, 1, 1): ONE v_fmac_f32 with a DPP quad_perm operand per element, mine + sb * partner.
+    // Row 3 comes out NEGATED that way (r3 - r1) and so is row 3 of the transformed weights: the products are unchanged. ----
+    const int tl = tid >> 4, chp = (tid >> 2) & 3, sr = tid & 3;
+    const float sb = sr == 1 ? 1.f : -1.f;
+    int pix = 0;           // pixel index of the patch origin (2 ty - 1, 4 tx - 1); may be "negative" by at most W + 1: the bias covers it
+    unsigned bad = 0x3Fu;  // bit s: pixel s of the thread's patch row lies outside the image (or the tile is past the batch)
+    {
+        const int t = t0 + tl;
+        if (t < T) {
+            const int img = (int)epi_div((unsigned)t, (unsigned)TI, p.mg_ohw, p.sh_ohw);
+            const int tr = t - img * TI;
+            const int ty = tr >> wts;
+            const int tx = tr - (ty << wts);
+            const int y0 = 2 * ty - 1, x0 = 4 * tx - 1;
+            pix = (img * H + y0) * W + x0;
+            unsigned xb = 0;
+#pragma unroll
+            for (int s = 0; s < 6; ++s) xb |= ((unsigned)(x0 + s) < (unsigned)W ? 0u : 1u) << s;
+            bad = (unsigned)(y0 + sr) < (unsigned)H ? xb : 0x3Fu;
+        }
+    }
+    int vo[6];  // voffsets of the thread's 6 pixels in the current source (out-of-image ones already out of bounds)
+    auto set_vo = [&](int lda, int biasb) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int off = (pix + sr * W + k) * lda * 4 + biasb + chp * 8;
+            vo[k] = ((bad >> k) & 1u) ? OOB : off;
+        }
+    };
+    // V row of a tile: slot (16 B per channel half ... here 32 B per component) order [j][i]: component (i, j) at (j * 4 + i) * 8 floats.
+    // A ds_write_b64 is serviced in groups of 16 consecutive lanes = the (r, chp) of one tile: for a given j they cover the four i slots,
+    // 128 contiguous bytes.
+    const int v_lds = tl * W4_LD + sr * 8 + chp * 2;  // + j * 32
+
+    // ---- wave-uniform state of the chunk whose PIXEL loads are issued next (two chunks ahead of the multiplication) ----
+    int s_c = 0;
+    bool s_first = true;  // s_c < C0: the chunk comes from source 0
+    auto advance = [&]() __attribute__((always_inline)) {
+        s_c += 8;
+        if (s_first && s_c >= p.C0 && p.C1 > 0) {  // once per tile: on to the second source of a channel concat
+            s_first = false;
+            set_vo(p.lda1, bias1);
+        }
+    };
+    set_vo(p.lda0, bias0);
+
+    w4f32x2 rr[6], cm[6], vv6[6];
+    auto load_raw_to = [&](w4f32x2 *dst, int k) __attribute__((always_inline)) {
+        if ((W42_ABL & 1) && s_c >= 16) return;
+        if (s_first) dst[k] = w4_load8(srd_a0, vo[k], s_c * 4);
+        else dst[k] = w4_load8(srd_a1, vo[k], (s_c - p.C0) * 4);
+    };
+    auto load_raw = [&](int k) __attribute__((always_inline)) { load_raw_to(rr, k); };
+    auto combine_from = [&](const w4f32x2 *src) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < 6; ++s) {
+            cm[s] = src[s];
+            if (W42_ABL & 16) continue;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                float m = src[s][e];
+                // (s_nop: a VALU write of an operand right in front of a DPP read needs two wait states, and inline asm is opaque to the
+                // hazard recogniser)
+                if (s == 0 && e == 0)
+                    asm volatile("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf" : "+v"(m) : "v"(src[s][e]), "v"(sb));
+                else
+                    asm volatile("v_fmac_f32_dpp %0, %1, %2 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf" : "+v"(m) : "v"(src[s][e]), "v"(sb));
+                cm[s][e] = m;
+            }
+        }
+    };
+    // x transform F(4,3) of the combined row cm[0..5] -> vv6[0..5] (Bx^T above, factored: 12 packed instructions)
+    auto xform = [&]() __attribute__((always_inline)) {
+        if (W42_ABL & 16) {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) vv6[j] = cm[j];
+            return;
+        }
+        const w4f32x2 t3 = pk_sub(cm[4], cm[2]);          // d4 - d2
+        const w4f32x2 t4 = pk_sub(cm[3], cm[1]);          // d3 - d1
+        const w4f32x2 u0 = pk_sub(cm[0], cm[2]);          // d0 - d2
+        vv6[0] = pk_fma_p4(u0, t3);                       // 4 d0 - 5 d2 + d4
+        const w4f32x2 t1 = pk_fma_m4(cm[2], cm[4]);       // d4 - 4 d2
+        const w4f32x2 t2 = pk_fma_m4(cm[1], cm[3]);       // d3 - 4 d1
+        vv6[1] = pk_add(t1, t2);
+        vv6[2] = pk_sub(t1, t2);
+        vv6[3] = pk_fma_p2(t4, t3);                       // (d4 - d2) + 2 (d3 - d1)
+        vv6[4] = pk_fma_m2(t4, t3);
+        const w4f32x2 u5 = pk_sub(cm[5], cm[3]);          // d5 - d3
+        vv6[5] = pk_fma_m4(t4, u5);                       // 4 d1 - 5 d3 + d5
+    };
+    auto store_v = [&](int j, int par) __attribute__((always_inline)) {
+        if (W42_ABL & 2) { asm volatile("" ::"v"(vv6[j])); return; }
+        *reinterpret_cast<w4f32x2 *>(&smem[v_lds + par * W4_STAGE + j * 32]) = vv6[j];
+    };
+
+    // ---- weight fragments: wave (wi, wn), component (wi, j): 1 KB at ((nb * NK + kc) * 24 + wi * 6 + j) * 1024 bytes, lane * 16 ----
+    w4f32x4 bf[6];
+    const int nb = ntile * 2 + wn;
+    int s_ub = ((nb * NK) * 24 + wi * 6) * 1024;  // byte offset of component (wi, 0) of the chunk whose fragments are loaded next
+    const int u_vo = nb < nblk ? lane * 16 : OOB;
+    auto load_u = [&](int j) __attribute__((always_inline)) { bf[j] = w4_load16(srd_u, u_vo, s_ub + j * 1024); };
+
+    w4f32x16 acc[6];  // (never zeroed: the first MFMA of every accumulator, in the tile's first chunk, takes the constant 0 as its C operand)
+    const int a_off = li * W4_LD + wi * 8 + lh * 4;  // + j * 32: fragment of component (wi, j)
+
+    // ---- prologue: weight fragments of chunk 0, pixels of chunks 0 and 1 requested up front; chunk 0 -> LDS stage 0 ----
+    {
+        w4f32x2 r0[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) load_u(j);
+        s_ub += 24 * 1024;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) load_raw_to(r0, k);
+        advance();
+#pragma unroll
+        for (int k = 0; k < 6; ++k) load_raw(k);
+        combine_from(r0);
+        xform();
+#pragma unroll
+        for (int j = 0; j < 6; ++j) store_v(j, 0);
+    }
+    advance();
+    __syncthreads();
+
+    // ---- epilogue geometry, needed already inside the K loop (the residual is requested one chunk before the loop ends): wave f = wi of
+    // output block wn finishes the unit of 8 tiles t0 + 8 f .. + 7 x 32 columns ----
+    const int f = wi;
+    const int tu = t0 + 8 * f;  // first tile of the unit (wave-uniform)
+    const int tuc = tu < T ? tu : 0;
+    const int img = (int)epi_div((unsigned)tuc, (unsigned)TI, p.mg_ohw, p.sh_ohw);
+    const int tru = tuc - img * TI;
+    const int tyu = tru >> wts, txu = tru - (tyu << wts);
+    const int mu = img * HW + 2 * tyu * W + 4 * txu;  // pixel of the unit's first tile (top-left output)
+    const int n = n0 + wn * 32 + li;
+    const bool nok = n < p.N && tu < T;
+    const __amdgpu_buffer_rsrc_t srd_r = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(reinterpret_cast<const char *>(p.res ? p.res : p.out)), 0, p.M * p.ldres * 4, 0x00020000);
+    // tile k = 4 lh + vv of the unit.  Wt >= 8: eight tiles of one tile row (the half-wave adds 16 pixels along x); Wt = 4: two tile
+    // rows of four (the half-wave adds a tile row = 2 W pixels); Wt = 2: four tile rows of two (the half-wave adds two tile rows)
+    const int lane_px = Wt >= 8 ? lh * 16 : Wt == 4 ? lh * 2 * W : lh * 4 * W;
+    const int vo_r = nok ? (lane_px * p.ldres + n) * 4 : OOB;
+    auto pix_off = [&](int vv, int a, int b) __attribute__((always_inline)) {
+        const int base = Wt == 2 ? (vv >> 1) * 2 * W + (vv & 1) * 4 : vv * 4;
+        return mu + base + a * W + b;
+    };
+    float rs[2][4][4];
+    const bool has_res = p.res != nullptr;
+    auto load_res = [&](int idx) __attribute__((always_inline)) {  // idx = (a * 4 + b) * 4 + vv
+        const int a = idx >> 4, b = (idx >> 2) & 3, vv = idx & 3;
+        rs[a][b][vv] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_r, vo_r, pix_off(vv, a, b) * p.ldres * 4, 0));
+    };
+
+    // ---- K loop.  MODE 0: steady state (chunk kc multiplied; its successor's pixels registers -> the other LDS stage and weight
+    // fragments requested; chunk kc+2's pixels requested); MODE 1: the second-to-last chunk (no pixels left to request: the residual tile
+    // is requested instead); MODE 2: the last chunk (nothing staged or requested) ----
+    w4f32x4 af[2];
+    auto chunk = [&](auto mode_tag, auto par_tag, auto first_tag) __attribute__((always_inline)) {
+        constexpr int MODE = decltype(mode_tag)::value;
+        constexpr int PAR = decltype(par_tag)::value;  // stage the chunk is multiplied from (compile time: immediate offsets)
+        constexpr bool FIRST = decltype(first_tag)::value != 0;
+        const float *cur = smem + PAR * W4_STAGE;
+        constexpr int nxt = PAR ^ 1;
+        af[0] = *reinterpret_cast<const w4f32x4 *>(cur + a_off);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int jj = hh * 2 + e;
+                    if (FIRST && jj == 0) {
+                        const w4f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j & 1][jj], bf[j][jj], zero, 0, 0, 0);
+                    } else {
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j & 1][jj], bf[j][jj], acc[j], 0, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const int gap = j * 2 + hh;  // 12 gaps of two MFMAs
+                if (hh == 0 && j < 5) af[(j + 1) & 1] = *reinterpret_cast<const w4f32x4 *>(cur + a_off + (j + 1) * 32);  // next component's fragment
+                if (hh == 1 && MODE < 2 && !((W42_ABL & 4) && !FIRST)) load_u(j);  // the next chunk's fragment of this component, into the registers just consumed
+                if (MODE < 2) {
+                    if (gap == 4) combine_from(rr);
+                    if (gap == 5) xform();
+                    if (gap >= 7 && gap <= 9) { store_v(2 * (gap - 7), nxt); store_v(2 * (gap - 7) + 1, nxt); }
+                }
+                if (MODE == 0) {
+                    if (gap == 5) { load_raw(0); load_raw(1); load_raw(2); }
+                    if (gap == 6) { load_raw(3); load_raw(4); load_raw(5); }
+                    if (gap == 10) advance();
+                }
+                if (MODE == 1 && has_res) {
+                    if (gap < 11) { load_res(3 * gap); load_res(3 * gap + 1); if (3 * gap + 2 < 32) load_res(3 * gap + 2); }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (MODE < 2) s_ub += 24 * 1024;
+        if (!(W42_ABL & 8)) __syncthreads();
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    chunk(I0{}, I0{}, I1{});  // (NK is a multiple of 4: the first pair of chunks always has something to request)
+    chunk(I0{}, I1{}, I0{});
+    for (int kc = 2; kc < NK - 2; kc += 2) {
+        chunk(I0{}, I0{}, I0{});
+        chunk(I0{}, I1{}, I0{});
+    }
+    chunk(I1{}, I0{}, I0{});
+    chunk(I2{}, I1{}, I0{});
+
+    // ---- output transform along x (in-lane): z[b] = sum_j Ax^T[b][j] M_ij; then along y across the four component-row waves of an
+    // output block, through LDS (the stages are idle after the last barrier) ----
+    float *mine = smem + (wn * 4 + wi) * 4096 + lane;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        const float m0 = acc[0][v], m1 = acc[1][v], m2 = acc[2][v], m3 = acc[3][v], m4 = acc[4][v], m5 = acc[5][v];
+        const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
+        mine[(0 * 16 + v) * 64] = (m0 + s1) + s2;
+        mine[(1 * 16 + v) * 64] = d1 + 2.f * d2;
+        mine[(2 * 16 + v) * 64] = s1 + 4.f * s2;
+        mine[(3 * 16 + v) * 64] = (d1 + 8.f * d2) + m5;
+    }
+    __syncthreads();
+    if (tu >= T) return;
+    float y[2][4][4];  // [a][b][vv]: output pixel (2 ty + a, 4 tx + b) of tile 4 lh + vv of the unit
+    {
+        const float *src = smem + (wn * 4) * 4096 + lane;
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int vv = 0; vv < 4; ++vv) {
+                const int o = (b * 16 + 4 * f + vv) * 64;
+                const float z0 = src[o], z1 = src[4096 + o], z2 = src[2 * 4096 + o], z3 = src[3 * 4096 + o];
+                y[0][b][vv] = z0 + z1 + z2;
+                y[1][b][vv] = z1 - z2 - z3;
+            }
+    }
+
+    // ---- epilogue of the unit ----
+    const __amdgpu_buffer_rsrc_t srd_o =
+        __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(p.out), 0, p.M * p.ldc * 4, 0x00020000);
+    const int vo_o = nok ? (lane_px * p.ldc + n) * 4 : OOB;
+    float addv = (p.bias && nok) ? p.bias[n] : 0.f;
+    if (p.rowbias && nok) addv += p.rowbias[(size_t)img * p.ld_rowbias + n];
+    float ps[2] = {0.f, 0.f}, pq[2] = {0.f, 0.f};  // partial statistics by output row a
+    float vals[2][4][4];                           // finished outputs (kept for the epilogue GroupNorm)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int vv = 0; vv < 4; ++vv) {
+                float add = addv;
+                if (has_res) add += rs[a][b][vv];
+                const float val = (p.alpha * y[a][b][vv] + add) * p.out_scale;
+                vals[a][b][vv] = val;
+                if (!p.egn_skip_raw)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), srd_o, vo_o, pix_off(vv, a, b) * p.ldc * 4, 0);
+                ps[a] += val;
+                pq[a] += val * val;
+            }
+    if (p.egn_out) {
+        // GroupNorm (+ swish) of the output, here (plan.h: Op::egn_peer).  rows_per_image == 64 (8x8 images): this unit is exactly one
+        // image x 32 columns.  rows_per_image == 256 (16x16 images): the image is the whole workgroup tile, and the four units f of an
+        // output block add their column sums through the 4 KB of LDS behind the exchange area.  A group is egn_cpg consecutive
+        // columns = consecutive lanes.
+        float gsum = ps[0] + ps[1], gsq = pq[0] + pq[1];
+        gsum += __shfl_xor(gsum, 32); gsq += __shfl_xor(gsq, 32);
+        float rows = 64.0f;
+        if (p.rows_per_image == 256) {
+            float2 *red = reinterpret_cast<float2 *>(smem + 8 * 4096);  // [wn][unit][32 columns]
+            if (lh == 0) red[(wn * 4 + f) * 32 + li] = make_float2(gsum, gsq);
+            __syncthreads();  // (every wave of the workgroup is here: whole images, so no unit is past the batch)
+            gsum = 0.f; gsq = 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float2 v = red[(wn * 4 + u) * 32 + li];
+                gsum += v.x; gsq += v.y;
+            }
+            rows = 256.0f;
+        }
+        for (int o = 1; o < p.egn_cpg; o <<= 1) { gsum += __shfl_xor(gsum, o); gsq += __shfl_xor(gsq, o); }
+        const float inv_n = 1.0f / (rows * (float)p.egn_cpg);
+        const float mean = gsum * inv_n;
+        const float rstd = rsqrtf(gsq * inv_n - mean * mean + 1e-6f);
+        const float ga = nok ? p.egn_gamma[n] : 0.f, be = nok ? p.egn_beta[n] : 0.f;
+        const float sc = rstd * ga, sh = be - mean * rstd * ga;
+        const __amdgpu_buffer_rsrc_t srd_g =
+            __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(p.egn_out), 0, p.M * p.ldc * 4, 0x00020000);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int vv = 0; vv < 4; ++vv) {
+                    float t = vals[a][b][vv] * sc + sh;
+                    if (p.egn_act) t = swish_e(t);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, t), srd_g, vo_o, pix_off(vv, a, b) * p.ldc * 4, 0);
+                }
+    }
+    if (p.qstats) {
+        // the unit's 64 pixels are two 32-row slices of the output matrix.  W = 32 / 64: its two pixel rows a (a whole row / an aligned
+        // half of one), both half-waves; W = 8 / 16: the half-wave's four tiles (two tile rows of 2 / one tile row of 4, both pixel rows)
+        float s0, q0, s1, q1;
+        if (Wt >= 8) {
+            s0 = ps[0] + __shfl_xor(ps[0], 32); q0 = pq[0] + __shfl_xor(pq[0], 32);
+            s1 = ps[1] + __shfl_xor(ps[1], 32); q1 = pq[1] + __shfl_xor(pq[1], 32);
+        } else {
+            const float ts = ps[0] + ps[1], tq = pq[0] + pq[1];
+            const float os = __shfl_xor(ts, 32), oq = __shfl_xor(tq, 32);
+            s0 = lh == 0 ? ts : os; q0 = lh == 0 ? tq : oq;
+            s1 = lh == 0 ? os : ts; q1 = lh == 0 ? oq : tq;
+        }
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            float s = g == 0 ? s0 : s1, q = g == 0 ? q0 : q1;
+            if (!nok) { s = 0.f; q = 0.f; }
+            s += __shfl_xor(s, 1); q += __shfl_xor(q, 1);
+            s += __shfl_xor(s, 2); q += __shfl_xor(q, 2);
+            if ((li & 3) == 0 && lh == 0 && nok) {
+                const int first = (mu - img * HW) + (Wt >= 8 ? g * W : g * 32);  // first pixel of the slice inside the image
+                float2 *o = reinterpret_cast<float2 *>(p.qstats) + ((size_t)img * p.qs_slices + (first >> 5)) * (p.N >> 2) + (n >> 2);
+                o[0] = make_float2(s, q);
+            }
+        }
+    }
+}
+
+// U[n / 32][c / 8][i][j][(c >> 2) & 1][n % 32][c & 3] = (Gy g Gx^T)_ij from the packed direct weights w[n][(ky*3 + kx)*Cin + c]; sums in
+// double, one rounding; row i = 3 negated (see the kernel); columns N .. 32 ceil(N / 32) - 1 are zeros
+__global__ void wino42_weights_kernel(const float *__restrict__ w, float *__restrict__ u, int N, int Npad, int Cin) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)Npad * Cin) return;
+    const int c = (int)(idx % Cin);
+    const int n = (int)(idx / Cin);
+    double g[3][3];
+    for (int ky = 0; ky < 3; ++ky)
+        for (int kx = 0; kx < 3; ++kx) g[ky][kx] = n < N ? (double)w[(long long)n * 9 * Cin + (ky * 3 + kx) * Cin + c] : 0.0;
+    const double Gy[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, -1}};  // (row 3 negated)
+    const double Gx[6][3] = {{0.25, 0, 0},
+                             {-1.0 / 6, -1.0 / 6, -1.0 / 6},
+                             {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                             {1.0 / 24, 1.0 / 12, 1.0 / 6},
+                             {1.0 / 24, -1.0 / 12, 1.0 / 6},
+                             {0, 0, 1}};
+    const int NK = Cin >> 3;
+    float *ub = u + (((long long)(n >> 5) * NK + (c >> 3)) * 24) * 256 + ((c >> 2) & 1) * 128 + (n & 31) * 4 + (c & 3);
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 6; ++j) {
+            double acc = 0;
+            for (int ky = 0; ky < 3; ++ky)
+                for (int kx = 0; kx < 3; ++kx) acc += Gy[i][ky] * g[ky][kx] * Gx[j][kx];
+            ub[(i * 6 + j) * 256] = (float)acc;
+        }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------------------
+long long wino42_weight_floats(int N, int Cin) { return 24LL * (((long long)N + 31) / 32 * 32) * Cin; }
+
+int launch_wino42_weights(const float *w, float *u, int N, int Cin, hipStream_t s) {
+    GD_CHECK(w && u && N > 0 && Cin > 0 && Cin % 8 == 0, "wino42_weights: bad argument (N=%d Cin=%d)", N, Cin);
+    const int Npad = (N + 31) / 32 * 32;
+    const long long total = (long long)Npad * Cin;
+    hipLaunchKernelGGL(wino42_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, u, N, Npad, Cin);
+    GD_HIP(hipGetLastError());
+    return 0;
+}
+
+static void w4fill_div(unsigned d, unsigned &magic, unsigned &shift) {
+    unsigned s = 0;
+    while ((1ull << s) < d) ++s;
+    shift = s;
+    magic = (unsigned)((((1ull << 32) * ((1ull << s) - d)) / d) + 1);
+}
+
+// what the kernel can compute at all (p.b_wino is not looked at)
+bool conv3x3_wino42_shape_ok(const GemmParams &p) {
+    if (p.in_act || p.b_kmajor || p.a_presplit || p.gn_table || p.wk_split > 1) return false;
+    if (p.egn_out && ((p.rows_per_image != 64 && p.rows_per_image != 256) || p.N % p.egn_cpg != 0 ||
+                      (p.egn_cpg != 4 && p.egn_cpg != 8 && p.egn_cpg != 16 && p.egn_cpg != 32))) return false;
+    if (p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1 || p.OH != p.H || p.OW != p.W) return false;
+    const int Cin = p.C0 + p.C1;
+    if (Cin % 32 != 0 || (p.C1 > 0 && (p.C0 % 32 != 0 || !p.a1)) || p.K != 9 * Cin) return false;
+    if ((p.W != 8 && p.W != 16 && p.W != 32 && p.W != 64) || p.H % 2 != 0 || (p.H * p.W / 8) % 8 != 0) return false;
+    if (p.rows_per_image != p.H * p.W || p.M % (p.H * p.W) != 0 || p.N < 1) return false;
+    if ((p.N % 4 != 0 || p.N < 32) && (p.qstats || p.egn_out)) return false;  // (a narrow or ragged N only without the column-quad statistics)
+    if (p.qstats && p.qs_slices != p.rows_per_image / 32) return false;
+    if (p.rowbias && p.ld_rowbias <= 0) return false;
+    if ((long long)p.M * p.ldc * 4 + 64 >= (1LL << 31) || (p.res && (long long)p.M * p.ldres * 4 + 64 >= (1LL << 31))) return false;
+    const long long ldmax = p.lda0 > p.lda1 ? p.lda0 : p.lda1;
+    const long long a_bytes = ((long long)p.M + 3 * p.W + 8) * ldmax * 4 + Cin * 4 + 64;
+    return a_bytes < (1LL << 31) && wino42_weight_floats(p.N, Cin) * 4 + 64 < (1LL << 31);
+}
+
+// what the engine sends to it: an eligible shape with at least one workgroup per CU.  GDDIM_NOWINO42=1 routes everything back to the
+// F(2x2,3x3) kernel; GDDIM_WINO42_MINBLOCKS overrides the fill criterion (A/B).
+bool conv3x3_wino42_ok(const GemmParams &p) {
+    static const int off = getenv("GDDIM_NOWINO42") ? atoi(getenv("GDDIM_NOWINO42"))
+                                                    : (getenv("GDDIM_NOWINO2") ? atoi(getenv("GDDIM_NOWINO2")) : (getenv("GDDIM_NOWINO") ? atoi(getenv("GDDIM_NOWINO")) : 0));
+    static const int min_blocks = getenv("GDDIM_WINO42_MINBLOCKS") ? atoi(getenv("GDDIM_WINO42_MINBLOCKS")) : 256;
+    if (off || !conv3x3_wino42_shape_ok(p)) return false;
+    return (long long)((p.M / 8 + 31) / 32) * ((p.N + 63) / 64) >= min_blocks;
+}
+
+const char *conv3x3_wino42_name() { return "conv3x3_wino42_f32_kernel"; }
+
+int launch_conv3x3_wino42(const GemmParams &p_in, hipStream_t s) {
+    GemmParams p = p_in;
+    GD_CHECK(conv3x3_wino42_shape_ok(p) && p.b_wino, "conv3x3_wino42: problem not eligible");
+    if (p.C1 == 0) p.lda1 = 4;
+    w4fill_div((unsigned)(p.H * p.W / 8), p.mg_ohw, p.sh_ohw);  // tiles per image
+    p.sh_ow = p.W == 8 ? 1 : p.W == 16 ? 2 : p.W == 32 ? 3 : 4;  // log2(W / 4)
+    p.m_tiles = (p.M / 8 + 31) / 32;
+    p.n_tiles = (p.N + 63) / 64;
+    p.flat_tiles = p.m_tiles < 16;
+    const int gx = p.flat_tiles ? p.m_tiles * p.n_tiles : ((p.m_tiles + 7) / 8) * 8 * p.n_tiles;
+    hipLaunchKernelGGL(conv3x3_wino42_f32_kernel, dim3(gx), dim3(512), 0, s, p);
+    GD_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace gd

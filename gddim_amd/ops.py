@@ -138,6 +138,23 @@ def conv3x3_winograd2d(x, w_packed, bias=None, res=None, alpha=1.0, out_scale=1.
     return out
 
 
+def conv3x3_winograd42(x, w_packed, bias=None, res=None, alpha=1.0, out_scale=1.0, u_scratch=None):
+    """3x3 / stride 1 / pad 1 NHWC conv through the fp32 hybrid Winograd F(2,3)_y x F(4,3)_x kernel (same packed weights as conv2d)."""
+    import torch
+    _need_gpu(x)
+    x, w_packed = _f32c(x), _f32c(w_packed)
+    B, H, W, Cin = x.shape
+    Cout = w_packed.shape[0]
+    out = torch.empty((B, H, W, Cout), dtype=torch.float32, device=x.device)
+    if u_scratch is None:
+        u_scratch = torch.empty(24 * ((Cout + 31) // 32 * 32) * Cin, dtype=torch.float32, device=x.device)
+    bias = _f32c(bias) if bias is not None else None
+    res = _f32c(res) if res is not None else None
+    check(_abi.lib().gd_conv3x3_winograd42(_ptr(x), _ptr(w_packed), _ptr(u_scratch), _ptr(bias), _ptr(res), _ptr(out), B, H, W, Cin,
+                                           Cout, float(alpha), float(out_scale), _stream(x)))
+    return out
+
+
 def group_norm(x, scale, bias, groups, act=False):
     """flax nn.GroupNorm(eps=1e-6) (+swish) on NHWC."""
     import torch

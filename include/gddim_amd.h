@@ -264,6 +264,15 @@ int gd_conv3x3_winograd(const float *x_dev, const float *w_dev, float *u_scratch
 int gd_conv3x3_winograd2d(const float *x_dev, const float *w_dev, float *u_scratch_dev, const float *bias_dev,
                           const float *res_dev, float *out_dev, int batch, int H, int W, int Cin, int Cout, float alpha,
                           float out_scale, void *stream);
+/* The same convolution through the hybrid transform F(2,3) along y x F(4,3) along x (24 products per 2 x 4 output tile: x 3 fewer
+ * matrix-core products than the direct sum, x 1.33 fewer than F(2x2,3x3)): u_scratch_dev receives the transformed weights in MFMA
+ * fragment order, 24 * (32 * ceil(Cout / 32)) * Cin floats.  Shapes: W in {8, 16, 32, 64}, H even, H*W/8 % 8 == 0, Cin % 32 == 0, any
+ * Cout.  What the engine runs for the 3x3 stride-1 convolutions of the 8x8 .. 64x64 levels at production batch sizes in round 3
+ * (kernels/conv3x3_wino42_f32.hip; measured fp32 error in profiles/r03_winograd_error_study.md).
+ * Replaces: the same nn.Conv call sites (cld_jax/models/layers.py:66-107). */
+int gd_conv3x3_winograd42(const float *x_dev, const float *w_dev, float *u_scratch_dev, const float *bias_dev,
+                          const float *res_dev, float *out_dev, int batch, int H, int W, int Cin, int Cout, float alpha,
+                          float out_scale, void *stream);
 /* flax GroupNorm(num_groups, eps=1e-6) (+ swish when act != 0) on NHWC (B,H,W,C).
  * Replaces: nn.GroupNorm + nn.swish call sites (cld_jax/models/layerspp.py:69,196,218). */
 int gd_group_norm(const float *x_dev, const float *scale_dev, const float *bias_dev, float *out_dev, int batch,

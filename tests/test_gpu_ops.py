@@ -265,6 +265,73 @@ def test_conv3x3_winograd2d_impulse_and_rejects(dev):
             ops.conv3x3_winograd2d(torch.zeros(b_, h_, w_, ci, device=dev), torch.zeros(co, 9 * ci, device=dev))
 
 
+WINO42_CASES = [
+    # B, H, W, Cin, Cout, bias, res
+    (2, 32, 32, 128, 128, True, True),    # the dominant layer shape: 4 M blocks per image (8 tiles per tile row), 2 N tiles
+    (3, 16, 16, 256, 256, True, True),    # W = 16: an 8-tile unit is two tile rows; one image per M block
+    (1, 64, 64, 32, 68, False, True),     # W = 64: a unit is half a tile row; ragged N tile (68 = 64 + 4); K of one slab
+    (5, 16, 32, 96, 132, True, True),     # non-square image (64 tiles per image), Cin = 3 slabs, ragged N
+    (3, 8, 16, 64, 64, False, False),     # 16 tiles per image: the last M block holds one image only (ragged M: 48 tiles)
+    (2, 24, 32, 32, 32, True, False),     # 96 tiles per image (not a power of two), N = 32: the second output block of every wave past the end
+    (6, 8, 8, 64, 96, True, True),        # W = 8: a unit is a whole 8x8 image (four tile rows of two); ragged M (48 tiles), ragged N
+    (3, 16, 8, 32, 64, False, True),      # W = 8, H = 16: two units per image
+    (5, 4, 16, 32, 64, True, True),       # 8 tiles per image: every unit is a whole (4 x 16) image
+    (4, 2, 32, 32, 64, True, True),       # one tile row per image
+    (2, 32, 32, 64, 6, True, False),      # N = 6: the U-Net's head convolution (one N tile, 58 of its 64 columns past the end)
+    (2, 16, 16, 32, 18, False, True),     # N = 18: not a multiple of 4, residual row stride 18
+    (2, 16, 16, 512, 256, True, True),    # the longest K of the U-Net (64 chunks)
+]
+
+
+@pytest.mark.parametrize("case", WINO42_CASES)
+def test_conv3x3_winograd42_matches_torch_fp64(dev, case):
+    """gd_conv3x3_winograd42 (hybrid F(2,3)_y x F(4,3)_x: 24 products per 2 x 4 output tile) against the float64 direct convolution.
+    F(4,3) has transform constants up to 8 (A^T) and 5 (B^T): the bar is 4e-5 absolute on outputs of scale ~3 and at most 6x the
+    direct fp32 kernel's error (measured 1.5-2.5x; CPU emulation in profiles/r03_winograd_error_study.md)."""
+    from gddim_amd import ops
+    B, H, W, Cin, Cout, use_bias, use_res = case
+    g = torch.Generator().manual_seed(sum(case[:5]) + 2)
+    x = torch.randn(B, H, W, Cin, generator=g)
+    w = torch.randn(3, 3, Cin, Cout, generator=g) / math.sqrt(9 * Cin)
+    bias = torch.randn(Cout, generator=g) if use_bias else None
+    res = torch.randn(B, H, W, Cout, generator=g) if use_res else None
+    wp = w.permute(3, 0, 1, 2).reshape(Cout, 9 * Cin).contiguous()
+    got = ops.conv3x3_winograd42(x.to(dev), wp.to(dev), None if bias is None else bias.to(dev), None if res is None else res.to(dev),
+                                 alpha=1.25, out_scale=0.7).cpu().double()
+    want = 1.25 * F.conv2d(x.permute(0, 3, 1, 2).double(), w.permute(3, 2, 0, 1).double(), padding=1).permute(0, 2, 3, 1)
+    if bias is not None:
+        want = want + bias.double()
+    if res is not None:
+        want = want + res.double()
+    want = want * 0.7
+    direct = ops.conv2d(x.to(dev), wp.to(dev), None if bias is None else bias.to(dev), None if res is None else res.to(dev),
+                        alpha=1.25, out_scale=0.7).cpu().double()
+    err, err_direct = (got - want).abs().max().item(), (direct - want).abs().max().item()
+    print("wino42", case, "err %.2e direct %.2e" % (err, err_direct))
+    assert err < 4e-5 and err < 6 * err_direct + 1e-6, (case, err, err_direct)
+
+
+def test_conv3x3_winograd42_impulse_and_rejects(dev):
+    """Impulses with an asymmetric kernel at corners, edges and every position modulo the 2 x 4 tile (catches a swapped tap, a
+    component or an output-column order in either direction); shapes the kernel cannot take are refused loudly."""
+    from gddim_amd import ops
+    from gddim_amd._abi import GddimError
+    B, H, W, Cin, Cout = 1, 16, 16, 32, 64
+    w = torch.arange(3 * 3 * Cin * Cout, dtype=torch.float32).reshape(3, 3, Cin, Cout) / 1000.0
+    wp = w.permute(3, 0, 1, 2).reshape(Cout, 9 * Cin).contiguous()
+    for (y, xx, c) in [(0, 0, 5), (3, 5, 17), (15, 15, 31), (4, 2, 0), (15, 0, 9), (0, 15, 3), (7, 8, 12), (8, 7, 1), (5, 3, 2), (6, 12, 30),
+                       (9, 4, 7), (10, 13, 8), (1, 6, 11)]:
+        x = torch.zeros(B, H, W, Cin)
+        x[0, y, xx, c] = 1.0
+        got = ops.conv3x3_winograd42(x.to(dev), wp.to(dev)).cpu().double()
+        want = F.conv2d(x.permute(0, 3, 1, 2).double(), w.permute(3, 2, 0, 1).double(), padding=1).permute(0, 2, 3, 1)
+        assert (got - want).abs().max() < 1e-4 * want.abs().max(), (y, xx, c)
+    for shape in [(1, 4, 4, 32, 64), (1, 16, 16, 24, 64), (1, 15, 16, 32, 64), (1, 2, 16, 32, 64), (1, 12, 8, 32, 64), (1, 16, 12, 32, 64)]:
+        b_, h_, w_, ci, co = shape
+        with pytest.raises(GddimError):
+            ops.conv3x3_winograd42(torch.zeros(b_, h_, w_, ci, device=dev), torch.zeros(co, 9 * ci, device=dev))
+
+
 def test_conv3x3_winograd_impulse_and_rejects(dev):
     """An impulse input with an asymmetric kernel (catches a swapped tap, pixel-parity or component order), at an image corner and
     at an odd column; shapes the kernel cannot take (odd W, Cin % 32 != 0) are refused loudly."""

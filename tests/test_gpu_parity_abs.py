@@ -141,7 +141,9 @@ def test_cld_nfe100_b256_absolute_parity(native_lib):
 
 def test_cld_64x64_nfe10_persistent_tile_absolute_parity(native_lib):
     """BASELINE config 5 shape (64x64x3) at a batch that selects the production kernels on 64-wide images (the two-dimensional
-    Winograd kernel on the 64x64 / 32x32 / 16x16 levels: 32 images x 1024 quads / 64 = 512 tiles x 2 on the top level), NFE = 10."""
+    Winograd kernel on the 64x64 / 32x32 / 16x16 levels: 32 images x 1024 quads / 64 = 512 tiles x 2 on the top level), NFE = 10.
+    x (the image, [0, 1] units) is the quantity under the absolute 1e-3 bar; the velocity v is not an output of the reference's
+    pipeline and is bounded by the bar scaled by max|v| (|v| <= 20 on this trajectory)."""
     from gddim_amd.configs import cld_accr_dcifar10
     n_ref, nfe, gain = 1, 10, 0.3
     cfg, osde, eps64, lin64, u_ref, x, v, n, model = _cld_case(native_lib, cld_accr_dcifar10, 64, 32, n_ref, nfe, gain, seed=2)
@@ -152,6 +154,52 @@ def test_cld_64x64_nfe10_persistent_tile_absolute_parity(native_lib):
     assert any("conv3x3_wino2d_f32_kernel" in k for k in names), names
     assert n == nfe and np.isfinite(x).all() and moved > 20 * ABS_TOL
     assert ex <= ABS_TOL and ev <= ABS_TOL * max(1.0, float(np.abs(wv).max()))
+
+
+def test_cld_64x64_b512_full_size_absolute_parity(native_lib):
+    """BASELINE config 5 AT ITS STATED SIZE: 64x64x3, B = 512, full accr U-Net, NFE = 10, hipGraph, through get_sampling_fn
+    (cld_jax/sampling.py:204-239 at image_size = 64).  The 64x64-level activations are 512 * 4096 * 128 * 4 B = 1.07 GB per tensor
+    -- half of the int32 byte-offset range the kernels' buffer addressing lives in -- so besides the oracle comparison on image 0 the
+    LAST image of the batch is compared with the same noise run at B = 32 (an offset overflow would show at the far end).
+    (x is the quantity under the north-star bar; v is bounded by the bar scaled by max|v|, |v| <= 20 here.)"""
+    from gddim_amd.configs import cld_accr_dcifar10
+    from gddim_amd.cld import sampling
+    from gddim_amd.datasets import get_data_inverse_scaler
+    from gddim_amd.models import utils as mutils
+    B, n_ref, nfe, gain = 512, 1, 10, 0.3
+    cfg, osde, eps64, lin64, u_ref, x, v, n, model = _cld_case(native_lib, cld_accr_dcifar10, 64, B, n_ref, nfe, gain, seed=2)
+    names = _profile_names(model, 6, B)
+    assert any("conv3x3_wino" in k for k in names) and any("igemm_f32_pers_kernel" in k for k in names), names
+    assert n == nfe and np.isfinite(x).all() and np.isfinite(v).all()
+    # the far end of the batch against a small-batch run on the same noise (same engine, batch 32: another captured graph)
+    params = _scaled_head(onet.random_params(cfg, 6, seed=2), gain)
+    rng = np.random.default_rng(2 + 100)
+    shape = (B, 64, 64, 3)
+    u = np.stack([rng.standard_normal(shape), rng.standard_normal(shape) / 2], axis=-1).astype(np.float32)
+    from gddim_amd.cld import sde_lib
+
+    class NearDenoiserCLD(sde_lib.CLD):
+        def mixed_u_matrix(self, t):
+            return _gauss_eps_matrix(self, t)
+
+    sde = sde_lib.from_config(cfg)
+    sde.__class__ = NearDenoiserCLD
+    sde.mixed_score = True
+    fn = sampling.get_sampling_fn(cfg, sde, model, None, get_data_inverse_scaler(cfg))
+    state = mutils.State(params_ema=params, model_state={})
+    xs32, vs32, _ = fn([0], state, 32, torch.as_tensor(u[None, B - 32:], device="cuda:0"))
+    x32, v32 = xs32[0].cpu().numpy(), vs32[0].cpu().numpy()
+    far_x = float(np.abs(x[B - 32:] - x32).max())
+    far_v = float(np.abs(v[B - 32:] - v32).max())
+    print("CLD 64x64 NFE=10 B=512: images 480..511 vs the same noise at B=32: max|dx| %.3e max|dv| %.3e" % (far_x, far_v))
+    assert far_x <= 1e-4 and far_v <= 1e-3, (far_x, far_v)
+    # image 0 against the float64 oracle loop
+    wx, wv, _ = ocld.deis_sampler(osde, eps64, u_ref, nfe, 2, ts_order=2, denoising=True, inverse_scaler=ocld.inverse_scaler_centered)
+    lx, _, _ = ocld.deis_sampler(osde, lin64, u_ref, nfe, 2, ts_order=2, denoising=True, inverse_scaler=ocld.inverse_scaler_centered)
+    ex, ev, moved = _report("CLD 64x64 NFE=10 B=512", x, v, wx, wv, lx, n_ref)
+    assert moved > 20 * ABS_TOL
+    assert ex <= ABS_TOL and ev <= ABS_TOL * max(1.0, float(np.abs(wv).max()))
+    model.close()  # 35 GB of arena
 
 
 def test_hybdeis_absolute_parity(native_lib):
