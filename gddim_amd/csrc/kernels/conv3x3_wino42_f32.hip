@@ -52,8 +52,8 @@ typedef unsigned int w4u32x2 __attribute__((ext_vector_type(2)));
                    // 8 no barrier, 16 no transform arithmetic
 #endif
 
-constexpr int W4_LD = 196;               // LDS row stride (floats): 24 components x 8 channels + 4 pad = 49 16-byte units (odd)
-constexpr int W4_STAGE = 32 * W4_LD;     // floats per V stage
+constexpr int W4_LD = 388;               // LDS row stride (floats): 24 components x 16 channels + 4 pad = 97 16-byte units (odd)
+constexpr int W4_STAGE = 32 * W4_LD;     // floats per V stage (48.5 KB)
 constexpr int W4_SMEM = 8 * 4096 + 1024; // floats: the epilogue's exchange area (8 waves x 64 registers x 64 lanes) + the GroupNorm scratch
 
 __device__ __forceinline__ w4f32x2 w4_load8(__amdgpu_buffer_rsrc_t rsrc, int voffset, int soffset) {
@@ -89,8 +89,10 @@ W4_PK_FMA(pk_fma_p4, "4.0")
 W4_PK_FMA(pk_fma_m4, "-4.0")
 #undef W4_PK_FMA
 
-__global__ __launch_bounds__(512, 2) void conv3x3_wino42_f32_kernel(const GemmParams p) {
-    __shared__ __attribute__((aligned(16))) float smem[W4_SMEM];
+// The tile program.  SHORTK: Cin = 32 (two chunks: no steady state), a kernel symbol of its own -- as a run-time branch inside one
+// kernel the two chunk sequences made the register allocator keep the prologue's weight fragments alive across the main loop (41 spills).
+template <bool SHORTK>
+__device__ __forceinline__ void wino42_tile(const GemmParams &p, float *smem) {
     constexpr int OOB = (int)0x80000000u;
 
     const int tid = threadIdx.x;
@@ -120,7 +122,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino42_f32_kernel(const GemmPa
     const int TI = HW >> 3;       // tiles per image (a multiple of 8)
     const int T = p.M >> 3;       // tiles in the batch
     const int Cin = p.C0 + p.C1;
-    const int NK = Cin >> 3;      // 8-channel chunks (a multiple of 4)
+    const int NK8 = Cin >> 3;     // 8-channel groups (the granularity of the weight layout)
+    const int NK = Cin >> 4;      // 16-channel chunks of the K loop (even)
     const int a_imgs = p.M / HW;
     const int bias0 = (W + 1) * p.lda0 * 4, bias1 = (W + 1) * p.lda1 * 4;
     const __amdgpu_buffer_rsrc_t srd_a0 = __builtin_amdgcn_make_buffer_rsrc(
@@ -129,13 +132,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino42_f32_kernel(const GemmPa
         const_cast<char *>(reinterpret_cast<const char *>(p.C1 ? p.a1 : p.a0) - bias1), 0, a_imgs * HW * p.lda1 * 4 + bias1, 0x00020000);
     const int nblk = (p.N + 31) >> 5;
     const __amdgpu_buffer_rsrc_t srd_u = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char *>(reinterpret_cast<const char *>(p.b_wino)), 0, nblk * NK * (24 * 1024), 0x00020000);
+        const_cast<char *>(reinterpret_cast<const char *>(p.b_wino)), 0, nblk * NK8 * (24 * 1024), 0x00020000);
 
-    // ---- staging role: (tile tl, channel pair chp, patch row r).  Thread r loads row r of the tile's 4 x 6 patch (six pixels x 8 B).
-    // By^T row r combines two patch rows -- 0: r0 - r2, 1: r1 + r2, 2: r2 - r1, 3: r1 - r3 -- and the partner row sits in a neighbouring
-    // lane of the same 4-lane group (lanes 2, 2, 1, 1): ONE v_fmac_f32 with a DPP quad_perm operand per element, mine + sb * partner.
-    // Row 3 comes out NEGATED that way (r3 - r1) and so is row 3 of the transformed weights: the products are unchanged. ----
-    const int tl = tid >> 4, chp = (tid >> 2) & 3, sr = tid & 3;
+    // ---- staging role: (tile tl, channel quad chq, patch row r).  Thread r loads row r of the tile's 4 x 6 patch (six pixels x 16 B: four
+    // of the chunk's 16 channels).  By^T row r combines two patch rows -- 0: r0 - r2, 1: r1 + r2, 2: r2 - r1, 3: r1 - r3 -- and the
+    // partner row sits in a neighbouring lane of the same 4-lane group (lanes 2, 2, 1, 1): ONE v_fmac_f32 with a DPP quad_perm operand
+    // per element, mine + sb * partner.  Row 3 comes out NEGATED that way (r3 - r1) and so is row 3 of the transformed weights. ----
+    const int tl = tid >> 4, chq = (tid >> 2) & 3, sr = tid & 3;
     const float sb = sr == 1 ? 1.f : -1.f;
     int pix = 0;           // pixel index of the patch origin (2 ty - 1, 4 tx - 1); may be "negative" by at most W + 1: the bias covers it
     unsigned bad = 0x3Fu;  // bit s: pixel s of the thread's patch row lies outside the image (or the tile is past the batch)
@@ -158,20 +161,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino42_f32_kernel(const GemmPa
     auto set_vo = [&](int lda, int biasb) __attribute__((always_inline)) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
-            const int off = (pix + sr * W + k) * lda * 4 + biasb + chp * 8;
+            const int off = (pix + sr * W + k) * lda * 4 + biasb + chq * 16;
             vo[k] = ((bad >> k) & 1u) ? OOB : off;
         }
     };
-    // V row of a tile: slot (16 B per channel half ... here 32 B per component) order [j][i]: component (i, j) at (j * 4 + i) * 8 floats.
-    // A ds_write_b64 is serviced in groups of 16 consecutive lanes = the (r, chp) of one tile: for a given j they cover the four i slots,
-    // 128 contiguous bytes.
-    const int v_lds = tl * W4_LD + sr * 8 + chp * 2;  // + j * 32
+    // V row of a tile: component (i, j) at (j * 4 + i) * 16 floats, the chunk's 16 channels in order.
+    const int v_lds = tl * W4_LD + sr * 16 + chq * 4;  // + j * 64 (+ 2 for the quad's second channel pair)
 
     // ---- wave-uniform state of the chunk whose PIXEL loads are issued next (two chunks ahead of the multiplication) ----
     int s_c = 0;
     bool s_first = true;  // s_c < C0: the chunk comes from source 0
     auto advance = [&]() __attribute__((always_inline)) {
-        s_c += 8;
+        s_c += 16;
         if (s_first && s_c >= p.C0 && p.C1 > 0) {  // once per tile: on to the second source of a channel concat
             s_first = false;
             set_vo(p.lda1, bias1);
@@ -179,102 +180,115 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino42_f32_kernel(const GemmPa
     };
     set_vo(p.lda0, bias0);
 
-    w4f32x2 rr[6], cm[6], vv6[6];
-    auto load_raw_to = [&](w4f32x2 *dst, int k) __attribute__((always_inline)) {
-        if ((W42_ABL & 1) && s_c >= 16) return;
-        if (s_first) dst[k] = w4_load8(srd_a0, vo[k], s_c * 4);
-        else dst[k] = w4_load8(srd_a1, vo[k], (s_c - p.C0) * 4);
+    w4f32x4 rr[6];
+    w4f32x2 vv6[6];
+    auto load_raw_to = [&](w4f32x4 *dst, int k) __attribute__((always_inline)) {
+        if ((W42_ABL & 1) && s_c >= 32) return;
+        if (s_first) dst[k] = w4_load16(srd_a0, vo[k], s_c * 4);
+        else dst[k] = w4_load16(srd_a1, vo[k], (s_c - p.C0) * 4);
     };
     auto load_raw = [&](int k) __attribute__((always_inline)) { load_raw_to(rr, k); };
-    auto combine_from = [&](const w4f32x2 *src) __attribute__((always_inline)) {
+    // y transform IN PLACE (the DPP operand reads the partner lane's old value in the same instruction): x[s] <- By^T row sr of the patch
+    auto combine_in = [&](w4f32x4 *x) __attribute__((always_inline)) {
+        if (W42_ABL & 16) return;
 #pragma unroll
         for (int s = 0; s < 6; ++s) {
-            cm[s] = src[s];
-            if (W42_ABL & 16) continue;
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                float m = src[s][e];
+            for (int e = 0; e < 4; ++e) {
+                float m = x[s][e];
                 // (s_nop: a VALU write of an operand right in front of a DPP read needs two wait states, and inline asm is opaque to the
                 // hazard recogniser)
                 if (s == 0 && e == 0)
-                    asm volatile("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf" : "+v"(m) : "v"(src[s][e]), "v"(sb));
+                    asm volatile("s_nop 1\n\tv_fmac_f32_dpp %0, %0, %1 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf" : "+v"(m) : "v"(sb));
                 else
-                    asm volatile("v_fmac_f32_dpp %0, %1, %2 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf" : "+v"(m) : "v"(src[s][e]), "v"(sb));
-                cm[s][e] = m;
+                    asm volatile("v_fmac_f32_dpp %0, %0, %1 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf" : "+v"(m) : "v"(sb));
+                x[s][e] = m;
             }
         }
     };
-    // x transform F(4,3) of the combined row cm[0..5] -> vv6[0..5] (Bx^T above, factored: 12 packed instructions)
-    auto xform = [&]() __attribute__((always_inline)) {
+    // x transform F(4,3) of channel pair h of the combined row cm[0..5] -> vv6[0..5] (Bx^T above, factored: 12 packed instructions)
+    auto xform = [&](const w4f32x4 *cm, int h) __attribute__((always_inline)) {
+        w4f32x2 d[6];
+#pragma unroll
+        for (int s = 0; s < 6; ++s) d[s] = w4f32x2{cm[s][2 * h], cm[s][2 * h + 1]};
         if (W42_ABL & 16) {
 #pragma unroll
-            for (int j = 0; j < 6; ++j) vv6[j] = cm[j];
+            for (int j = 0; j < 6; ++j) vv6[j] = d[j];
             return;
         }
-        const w4f32x2 t3 = pk_sub(cm[4], cm[2]);          // d4 - d2
-        const w4f32x2 t4 = pk_sub(cm[3], cm[1]);          // d3 - d1
-        const w4f32x2 u0 = pk_sub(cm[0], cm[2]);          // d0 - d2
-        vv6[0] = pk_fma_p4(u0, t3);                       // 4 d0 - 5 d2 + d4
-        const w4f32x2 t1 = pk_fma_m4(cm[2], cm[4]);       // d4 - 4 d2
-        const w4f32x2 t2 = pk_fma_m4(cm[1], cm[3]);       // d3 - 4 d1
+        const w4f32x2 t3 = pk_sub(d[4], d[2]);          // d4 - d2
+        const w4f32x2 t4 = pk_sub(d[3], d[1]);          // d3 - d1
+        const w4f32x2 u0 = pk_sub(d[0], d[2]);          // d0 - d2
+        vv6[0] = pk_fma_p4(u0, t3);                     // 4 d0 - 5 d2 + d4
+        const w4f32x2 t1 = pk_fma_m4(d[2], d[4]);       // d4 - 4 d2
+        const w4f32x2 t2 = pk_fma_m4(d[1], d[3]);       // d3 - 4 d1
         vv6[1] = pk_add(t1, t2);
         vv6[2] = pk_sub(t1, t2);
-        vv6[3] = pk_fma_p2(t4, t3);                       // (d4 - d2) + 2 (d3 - d1)
+        vv6[3] = pk_fma_p2(t4, t3);                     // (d4 - d2) + 2 (d3 - d1)
         vv6[4] = pk_fma_m2(t4, t3);
-        const w4f32x2 u5 = pk_sub(cm[5], cm[3]);          // d5 - d3
-        vv6[5] = pk_fma_m4(t4, u5);                       // 4 d1 - 5 d3 + d5
+        const w4f32x2 u5 = pk_sub(d[5], d[3]);          // d5 - d3
+        vv6[5] = pk_fma_m4(t4, u5);                     // 4 d1 - 5 d3 + d5
     };
-    auto store_v = [&](int j, int par) __attribute__((always_inline)) {
+    auto store_v = [&](int j, int par, int h) __attribute__((always_inline)) {
         if (W42_ABL & 2) { asm volatile("" ::"v"(vv6[j])); return; }
-        *reinterpret_cast<w4f32x2 *>(&smem[v_lds + par * W4_STAGE + j * 32]) = vv6[j];
+        *reinterpret_cast<w4f32x2 *>(&smem[v_lds + par * W4_STAGE + j * 64 + 2 * h]) = vv6[j];
     };
 
-    // ---- weight fragments: wave (wi, wn), component (wi, j): 1 KB at ((nb * NK + kc) * 24 + wi * 6 + j) * 1024 bytes, lane * 16 ----
-    w4f32x4 bf[6];
+    // ---- weight fragments: wave (wi, wn), component (wi, j), channel group g (8 channels): 1 KB at
+    // ((nb * NK8 + 2 kc + g) * 24 + wi * 6 + j) * 1024 bytes, lane * 16 ----
+    w4f32x4 bf[6][2];
     const int nb = ntile * 2 + wn;
-    int s_ub = ((nb * NK) * 24 + wi * 6) * 1024;  // byte offset of component (wi, 0) of the chunk whose fragments are loaded next
+    int s_ub = ((nb * NK8) * 24 + wi * 6) * 1024;  // byte offset of component (wi, 0), group 0 of the chunk whose fragments are loaded next
     const int u_vo = nb < nblk ? lane * 16 : OOB;
-    auto load_u = [&](int j) __attribute__((always_inline)) { bf[j] = w4_load16(srd_u, u_vo, s_ub + j * 1024); };
+    auto load_u = [&](int j, int g) __attribute__((always_inline)) { bf[j][g] = w4_load16(srd_u, u_vo, s_ub + g * (24 * 1024) + j * 1024); };
 
     w4f32x16 acc[6];  // (never zeroed: the first MFMA of every accumulator, in the tile's first chunk, takes the constant 0 as its C operand)
-    const int a_off = li * W4_LD + wi * 8 + lh * 4;  // + j * 32: fragment of component (wi, j)
+    const int a_off = li * W4_LD + wi * 16 + lh * 4;  // + j * 64 + g * 8: fragment of component (wi, j), channel group g
 
     // ---- prologue: weight fragments of chunk 0, pixels of chunks 0 and 1 requested up front; chunk 0 -> LDS stage 0 ----
     {
-        w4f32x2 r0[6];
+        w4f32x4 r0[6];
 #pragma unroll
-        for (int j = 0; j < 6; ++j) load_u(j);
-        s_ub += 24 * 1024;
+        for (int j = 0; j < 6; ++j) { load_u(j, 0); load_u(j, 1); }
+        s_ub += 48 * 1024;
 #pragma unroll
         for (int k = 0; k < 6; ++k) load_raw_to(r0, k);
         advance();
 #pragma unroll
         for (int k = 0; k < 6; ++k) load_raw(k);
-        combine_from(r0);
-        xform();
+        combine_in(r0);
 #pragma unroll
-        for (int j = 0; j < 6; ++j) store_v(j, 0);
+        for (int h = 0; h < 2; ++h) {
+            xform(r0, h);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) store_v(j, 0, h);
+        }
     }
     advance();
     __syncthreads();
 
-    // ---- epilogue geometry, needed already inside the K loop (the residual is requested one chunk before the loop ends): wave f = wi of
-    // output block wn finishes the unit of 8 tiles t0 + 8 f .. + 7 x 32 columns ----
+    // ---- epilogue geometry: wave f = wi of output block wn finishes the unit of 8 tiles t0 + 8 f .. + 7 x 32 columns.  Set right before the
+    // tile's LAST chunk, which requests the residual tile (nothing here is live across the K loop: the loop is register-bound) ----
     const int f = wi;
     const int tu = t0 + 8 * f;  // first tile of the unit (wave-uniform)
-    const int tuc = tu < T ? tu : 0;
-    const int img = (int)epi_div((unsigned)tuc, (unsigned)TI, p.mg_ohw, p.sh_ohw);
-    const int tru = tuc - img * TI;
-    const int tyu = tru >> wts, txu = tru - (tyu << wts);
-    const int mu = img * HW + 2 * tyu * W + 4 * txu;  // pixel of the unit's first tile (top-left output)
-    const int n = n0 + wn * 32 + li;
-    const bool nok = n < p.N && tu < T;
-    const __amdgpu_buffer_rsrc_t srd_r = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char *>(reinterpret_cast<const char *>(p.res ? p.res : p.out)), 0, p.M * p.ldres * 4, 0x00020000);
-    // tile k = 4 lh + vv of the unit.  Wt >= 8: eight tiles of one tile row (the half-wave adds 16 pixels along x); Wt = 4: two tile
-    // rows of four (the half-wave adds a tile row = 2 W pixels); Wt = 2: four tile rows of two (the half-wave adds two tile rows)
-    const int lane_px = Wt >= 8 ? lh * 16 : Wt == 4 ? lh * 2 * W : lh * 4 * W;
-    const int vo_r = nok ? (lane_px * p.ldres + n) * 4 : OOB;
+    int img = 0, mu = 0, n = 0, lane_px = 0, vo_r = OOB;
+    bool nok = false;
+    __amdgpu_buffer_rsrc_t srd_r = srd_u;
+    auto set_geometry = [&]() __attribute__((always_inline)) {
+        const int tuc = tu < T ? tu : 0;
+        img = (int)epi_div((unsigned)tuc, (unsigned)TI, p.mg_ohw, p.sh_ohw);
+        const int tru = tuc - img * TI;
+        const int tyu = tru >> wts, txu = tru - (tyu << wts);
+        mu = img * HW + 2 * tyu * W + 4 * txu;  // pixel of the unit's first tile (top-left output)
+        n = n0 + wn * 32 + li;
+        nok = n < p.N && tu < T;
+        srd_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(reinterpret_cast<const char *>(p.res ? p.res : p.out)), 0,
+                                                  p.M * p.ldres * 4, 0x00020000);
+        // tile k = 4 lh + vv of the unit.  Wt >= 8: eight tiles of one tile row (the half-wave adds 16 pixels along x); Wt = 4: two tile
+        // rows of four (the half-wave adds a tile row = 2 W pixels); Wt = 2: four tile rows of two (the half-wave adds two tile rows)
+        lane_px = Wt >= 8 ? lh * 16 : Wt == 4 ? lh * 2 * W : lh * 4 * W;
+        vo_r = nok ? (lane_px * p.ldres + n) * 4 : OOB;
+    };
     auto pix_off = [&](int vv, int a, int b) __attribute__((always_inline)) {
         const int base = Wt == 2 ? (vv >> 1) * 2 * W + (vv & 1) * 4 : vv * 4;
         return mu + base + a * W + b;
@@ -286,65 +300,84 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino42_f32_kernel(const GemmPa
         rs[a][b][vv] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_r, vo_r, pix_off(vv, a, b) * p.ldres * 4, 0));
     };
 
-    // ---- K loop.  MODE 0: steady state (chunk kc multiplied; its successor's pixels registers -> the other LDS stage and weight
-    // fragments requested; chunk kc+2's pixels requested); MODE 1: the second-to-last chunk (no pixels left to request: the residual tile
-    // is requested instead); MODE 2: the last chunk (nothing staged or requested) ----
-    w4f32x4 af[2];
+    // ---- K loop over 16-channel chunks: 48 MFMAs per wave between barriers, in 24 gaps of two (two components side by side: no
+    // MFMA waits for its predecessor's accumulator).  MODE 0: steady state (chunk kc multiplied; its successor's pixels registers -> the
+    // other LDS stage and weight fragments requested into the registers just consumed; chunk kc+2's pixels requested); MODE 1: the
+    // second-to-last chunk (no pixels left to request); MODE 2: the last chunk (nothing staged; the residual tile is requested) ----
+    w4f32x4 af[2][2];  // [buffer][component of the pair]
     auto chunk = [&](auto mode_tag, auto par_tag, auto first_tag) __attribute__((always_inline)) {
         constexpr int MODE = decltype(mode_tag)::value;
         constexpr int PAR = decltype(par_tag)::value;  // stage the chunk is multiplied from (compile time: immediate offsets)
         constexpr bool FIRST = decltype(first_tag)::value != 0;
         const float *cur = smem + PAR * W4_STAGE;
         constexpr int nxt = PAR ^ 1;
-        af[0] = *reinterpret_cast<const w4f32x4 *>(cur + a_off);
+        af[0][0] = *reinterpret_cast<const w4f32x4 *>(cur + a_off);
+        af[0][1] = *reinterpret_cast<const w4f32x4 *>(cur + a_off + 64);
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {
+        for (int jp = 0; jp < 3; ++jp) {
 #pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
+            for (int g = 0; g < 2; ++g) {
+                const int grp = jp * 2 + g, buf = grp & 1;
 #pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const int jj = hh * 2 + e;
-                    if (FIRST && jj == 0) {
+                for (int jj = 0; jj < 4; ++jj) {
+                    if (FIRST && g == 0 && jj == 0) {
                         const w4f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j & 1][jj], bf[j][jj], zero, 0, 0, 0);
+                        acc[2 * jp] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[buf][0][jj], bf[2 * jp][g][jj], zero, 0, 0, 0);
+                        acc[2 * jp + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[buf][1][jj], bf[2 * jp + 1][g][jj], zero, 0, 0, 0);
                     } else {
-                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j & 1][jj], bf[j][jj], acc[j], 0, 0, 0);
+                        acc[2 * jp] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[buf][0][jj], bf[2 * jp][g][jj], acc[2 * jp], 0, 0, 0);
+                        acc[2 * jp + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[buf][1][jj], bf[2 * jp + 1][g][jj], acc[2 * jp + 1], 0, 0, 0);
                     }
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int gap = grp * 4 + jj;  // 24 gaps of two MFMAs
+                    if (jj == 0 && grp < 5) {  // the next group's fragments, one group ahead of their use
+                        const int nj = (grp + 1) >> 1, ng = (grp + 1) & 1;
+                        af[buf ^ 1][0] = *reinterpret_cast<const w4f32x4 *>(cur + a_off + (2 * nj) * 64 + ng * 8);
+                        af[buf ^ 1][1] = *reinterpret_cast<const w4f32x4 *>(cur + a_off + (2 * nj + 1) * 64 + ng * 8);
+                    }
+                    if (jj == 3 && MODE < 2 && !((W42_ABL & 4) && !FIRST)) {  // the next chunk's fragments of this group, into the registers just consumed
+                        load_u(2 * jp, g);
+                        load_u(2 * jp + 1, g);
+                    }
+                    if (MODE < 2) {
+                        if (gap == 6) combine_in(rr);
+                        if (gap == 7) xform(rr, 0);
+                        if (gap >= 8 && gap <= 10) { store_v(2 * (gap - 8), nxt, 0); store_v(2 * (gap - 8) + 1, nxt, 0); }
+                        if (gap == 11) xform(rr, 1);
+                        if (gap >= 12 && gap <= 14) { store_v(2 * (gap - 12), nxt, 1); store_v(2 * (gap - 12) + 1, nxt, 1); }
+                    }
+                    if (MODE == 0) {
+                        if (gap >= 12 && gap <= 17) load_raw(gap - 12);  // (rr is free once its second channel pair is transformed)
+                        if (gap == 18) advance();
+                    }
+                    if (MODE == 2 && has_res) {
+                        if (gap < 16) { load_res(2 * gap); load_res(2 * gap + 1); }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                __builtin_amdgcn_sched_barrier(0);
-                const int gap = j * 2 + hh;  // 12 gaps of two MFMAs
-                if (hh == 0 && j < 5) af[(j + 1) & 1] = *reinterpret_cast<const w4f32x4 *>(cur + a_off + (j + 1) * 32);  // next component's fragment
-                if (hh == 1 && MODE < 2 && !((W42_ABL & 4) && !FIRST)) load_u(j);  // the next chunk's fragment of this component, into the registers just consumed
-                if (MODE < 2) {
-                    if (gap == 4) combine_from(rr);
-                    if (gap == 5) xform();
-                    if (gap >= 7 && gap <= 9) { store_v(2 * (gap - 7), nxt); store_v(2 * (gap - 7) + 1, nxt); }
-                }
-                if (MODE == 0) {
-                    if (gap == 5) { load_raw(0); load_raw(1); load_raw(2); }
-                    if (gap == 6) { load_raw(3); load_raw(4); load_raw(5); }
-                    if (gap == 10) advance();
-                }
-                if (MODE == 1 && has_res) {
-                    if (gap < 11) { load_res(3 * gap); load_res(3 * gap + 1); if (3 * gap + 2 < 32) load_res(3 * gap + 2); }
-                }
-                __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (MODE < 2) s_ub += 24 * 1024;
+        if (MODE < 2) s_ub += 48 * 1024;
         if (!(W42_ABL & 8)) __syncthreads();
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>;
-    chunk(I0{}, I0{}, I1{});  // (NK is a multiple of 4: the first pair of chunks always has something to request)
-    chunk(I0{}, I1{}, I0{});
-    for (int kc = 2; kc < NK - 2; kc += 2) {
-        chunk(I0{}, I0{}, I0{});
+    if (SHORTK) {  // Cin = 32
+        chunk(I1{}, I0{}, I1{});
+        set_geometry();
+        chunk(I2{}, I1{}, I0{});
+    } else {       // (NK is even and >= 4: Cin % 32 == 0)
+        chunk(I0{}, I0{}, I1{});
         chunk(I0{}, I1{}, I0{});
+        for (int kc = 2; kc < NK - 2; kc += 2) {
+            chunk(I0{}, I0{}, I0{});
+            chunk(I0{}, I1{}, I0{});
+        }
+        chunk(I1{}, I0{}, I0{});
+        set_geometry();
+        chunk(I2{}, I1{}, I0{});
     }
-    chunk(I1{}, I0{}, I0{});
-    chunk(I2{}, I1{}, I0{});
 
     // ---- output transform along x (in-lane): z[b] = sum_j Ax^T[b][j] M_ij; then along y across the four component-row waves of an
     // output block, through LDS (the stages are idle after the last barrier) ----
@@ -464,6 +497,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino42_f32_kernel(const GemmPa
     }
 }
 
+__global__ __launch_bounds__(512, 2) void conv3x3_wino42_f32_kernel(const GemmParams p) {
+    __shared__ __attribute__((aligned(16))) float smem[W4_SMEM];
+    wino42_tile<false>(p, smem);
+}
+
+__global__ __launch_bounds__(512, 2) void conv3x3_wino42_k32_f32_kernel(const GemmParams p) {
+    __shared__ __attribute__((aligned(16))) float smem[W4_SMEM];
+    wino42_tile<true>(p, smem);
+}
+
 // U[n / 32][c / 8][i][j][(c >> 2) & 1][n % 32][c & 3] = (Gy g Gx^T)_ij from the packed direct weights w[n][(ky*3 + kx)*Cin + c]; sums in
 // double, one rounding; row i = 3 negated (see the kernel); columns N .. 32 ceil(N / 32) - 1 are zeros
 __global__ void wino42_weights_kernel(const float *__restrict__ w, float *__restrict__ u, int N, int Npad, int Cin) {
@@ -552,7 +595,8 @@ int launch_conv3x3_wino42(const GemmParams &p_in, hipStream_t s) {
     p.n_tiles = (p.N + 63) / 64;
     p.flat_tiles = p.m_tiles < 16;
     const int gx = p.flat_tiles ? p.m_tiles * p.n_tiles : ((p.m_tiles + 7) / 8) * 8 * p.n_tiles;
-    hipLaunchKernelGGL(conv3x3_wino42_f32_kernel, dim3(gx), dim3(512), 0, s, p);
+    if (p.C0 + p.C1 == 32) hipLaunchKernelGGL(conv3x3_wino42_k32_f32_kernel, dim3(gx), dim3(512), 0, s, p);
+    else hipLaunchKernelGGL(conv3x3_wino42_f32_kernel, dim3(gx), dim3(512), 0, s, p);
     GD_HIP(hipGetLastError());
     return 0;
 }
