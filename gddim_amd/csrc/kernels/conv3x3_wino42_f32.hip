@@ -497,9 +497,488 @@ __device__ __forceinline__ void wino42_tile(const GemmParams &p, float *smem) {
     }
 }
 
+// ---- the persistent form (Cin >= 64) -------------------------------------------------------------------------------------------------
+// One workgroup per CU walks over tiles vb = blockIdx.x + k gridDim.x, and the K-loop pipeline RUNS ACROSS TILES: the loading state of
+// the pixels (two chunks ahead of the multiplication) and of the weight fragments (one chunk ahead) simply rolls over to the next tile
+// when the current one has no channels left, so the last two chunks of a tile stage the first two of its successor and only the first
+// tile of a workgroup has a prologue.  The epilogue then runs with the successor's first loads in flight.  Per tile this removes the
+// workgroup launch, the exposed first-load latency and the kernel-argument set-up: measured ~11 us of every tile's 33-100 us with one
+// workgroup per tile (profiles/r03_notes.md).  LDS: V stage 0 | V stage 1, the epilogue's exchange area over stage 1 onwards (stage 0
+// already holds the successor's first chunk); a wave keeps the z values of its own unit in registers, so the area is 96 KB, not 128.
+constexpr int W4P_EXB = W4_STAGE;                       // exchange area base (floats)
+constexpr int W4P_EXW = 48 * 64;                        // floats per wave in it (48 registers x 64 lanes)
+constexpr int W4P_RED = W4P_EXB + 8 * W4P_EXW;          // GroupNorm scratch
+constexpr int W4P_SMEM = W4P_RED + 512;                 // 150 016 bytes
+
+__device__ __forceinline__ void wino42_persistent(const GemmParams &p, float *smem) {
+    constexpr int OOB = (int)0x80000000u;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wi = wave & 3, wn = wave >> 2;  // component row, output block (32 columns)
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int W = p.W, H = p.H, HW = H * W;
+    const int Wt = W >> 2;        // tiles per tile row: 2, 4, 8 or 16
+    const int wts = p.sh_ow;      // log2(Wt) (launch_conv3x3_wino42)
+    const int TI = HW >> 3;       // tiles per image (a multiple of 8)
+    const int T = p.M >> 3;       // tiles in the batch
+    const int Cin = p.C0 + p.C1;
+    const int NK8 = Cin >> 3;     // 8-channel groups (the granularity of the weight layout)
+    const int NK = Cin >> 4;      // 16-channel chunks of the K loop (even, >= 4)
+    const int a_imgs = p.M / HW;
+    const int bias0 = (W + 1) * p.lda0 * 4, bias1 = (W + 1) * p.lda1 * 4;
+    const __amdgpu_buffer_rsrc_t srd_a0 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(reinterpret_cast<const char *>(p.a0) - bias0), 0, a_imgs * HW * p.lda0 * 4 + bias0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srd_a1 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(reinterpret_cast<const char *>(p.C1 ? p.a1 : p.a0) - bias1), 0, a_imgs * HW * p.lda1 * 4 + bias1, 0x00020000);
+    const int nblk = (p.N + 31) >> 5;
+    const __amdgpu_buffer_rsrc_t srd_u = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(reinterpret_cast<const char *>(p.b_wino)), 0, nblk * NK8 * (24 * 1024), 0x00020000);
+
+    // ---- virtual block id -> (mtile, ntile), XCD-aware as in the one-tile form (gridDim.x is a multiple of 8 or the whole tile count) ----
+    const int nt = p.n_tiles;
+    const int nvb = p.flat_tiles ? p.m_tiles * nt : ((p.m_tiles + 7) / 8) * 8 * nt;
+    auto decode = [&](int vb, int &mt, int &ntl) __attribute__((always_inline)) {
+        if (p.flat_tiles) {
+            mt = vb / nt;
+            ntl = vb - mt * nt;
+        } else {
+            const int grp = vb / (8 * nt);
+            const int rem = vb - grp * 8 * nt;
+            ntl = rem >> 3;
+            mt = grp * 8 + (rem & 7);
+        }
+    };
+    // the first valid tile at or after vb (stride gridDim.x); vb >= nvb: none
+    auto next_valid = [&](int vb, int &mt, int &ntl) __attribute__((always_inline)) {
+        while (vb < nvb) {
+            decode(vb, mt, ntl);
+            if (mt < p.m_tiles) break;
+            vb += (int)gridDim.x;
+        }
+        return vb;
+    };
+    int cur_vb, cur_mt = 0, cur_nt = 0;
+    cur_vb = next_valid((int)blockIdx.x, cur_mt, cur_nt);
+    if (cur_vb >= nvb) return;
+#ifdef W42_TRACE  // in-kernel timeline (tools/wino42_trace.py): thread 0 of workgroups 0 and 100 stamps the 100 MHz wall clock and the shader
+                  // clock at five points of its first four tiles into the tail of the residual tensor
+    int trn = 0;
+    const int trslot = blockIdx.x == 0 ? 0 : blockIdx.x == 100 ? 1 : -1;
+    float *trbuf = const_cast<float *>(p.res) + (size_t)p.M * p.ldres - 128 + (trslot < 0 ? 0 : trslot) * 64;
+    const bool trw = trslot >= 0 && tid == 0 && p.res;
+    auto trace = [&]() __attribute__((always_inline)) {
+        if (trw && trn < 20) {
+            trbuf[trn] = (float)(wall_clock64() & 0xFFFFFFull);
+            trbuf[32 + trn] = (float)(__builtin_readcyclecounter() & 0xFFFFFFull);
+        }
+        ++trn;
+    };
+#endif
+    int nx_vb, nx_mt = 0, nx_nt = 0;
+    nx_vb = next_valid(cur_vb + (int)gridDim.x, nx_mt, nx_nt);
+
+    // ---- staging role: (tile tl, channel quad chq, patch row r), see wino42_tile ----
+    const int tl = tid >> 4, chq = (tid >> 2) & 3, sr = tid & 3;
+    const float sb = sr == 1 ? 1.f : -1.f;
+    int pix = 0;
+    unsigned bad = 0x3Fu;
+    int vo[6];
+    auto set_vo = [&](int lda, int biasb) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int off = (pix + sr * W + k) * lda * 4 + biasb + chq * 16;
+            vo[k] = ((bad >> k) & 1u) ? OOB : off;
+        }
+    };
+    // pixel-loading state -> M tile mt (mt < 0: no tile, every load out of bounds)
+    auto setup_pix = [&](int mt) __attribute__((always_inline)) {
+        pix = 0;
+        bad = 0x3Fu;
+        const int t = mt * 32 + tl;
+        if (mt >= 0 && t < T) {
+            const int img = (int)epi_div((unsigned)t, (unsigned)TI, p.mg_ohw, p.sh_ohw);
+            const int tr = t - img * TI;
+            const int ty = tr >> wts;
+            const int tx = tr - (ty << wts);
+            const int y0 = 2 * ty - 1, x0 = 4 * tx - 1;
+            pix = (img * H + y0) * W + x0;
+            unsigned xb = 0;
+#pragma unroll
+            for (int s = 0; s < 6; ++s) xb |= ((unsigned)(x0 + s) < (unsigned)W ? 0u : 1u) << s;
+            bad = (unsigned)(y0 + sr) < (unsigned)H ? xb : 0x3Fu;
+        }
+        set_vo(p.lda0, bias0);
+    };
+    const int v_lds = tl * W4_LD + sr * 16 + chq * 4;  // + j * 64 (+ 2 for the quad's second channel pair)
+
+    int s_c = 0;
+    bool s_first = true;
+    auto px_advance = [&]() __attribute__((always_inline)) {
+        s_c += 16;
+        if (s_c >= Cin) {  // the tile has no channels left: on to the next tile of this workgroup (or to nothing)
+            s_c = 0;
+            s_first = true;
+            setup_pix(nx_vb < nvb ? nx_mt : -1);
+        } else if (s_first && s_c >= p.C0 && p.C1 > 0) {  // on to the second source of a channel concat
+            s_first = false;
+            set_vo(p.lda1, bias1);
+        }
+    };
+
+    w4f32x4 rr[6];
+    w4f32x2 vv6[6];
+    auto load_raw_to = [&](w4f32x4 *dst, int k) __attribute__((always_inline)) {
+        if (s_first) dst[k] = w4_load16(srd_a0, vo[k], s_c * 4);
+        else dst[k] = w4_load16(srd_a1, vo[k], (s_c - p.C0) * 4);
+    };
+    auto load_raw = [&](int k) __attribute__((always_inline)) { load_raw_to(rr, k); };
+    auto combine_in = [&](w4f32x4 *x) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < 6; ++s) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float m = x[s][e];
+                if (s == 0 && e == 0)
+                    asm volatile("s_nop 1\n\tv_fmac_f32_dpp %0, %0, %1 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf" : "+v"(m) : "v"(sb));
+                else
+                    asm volatile("v_fmac_f32_dpp %0, %0, %1 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf" : "+v"(m) : "v"(sb));
+                x[s][e] = m;
+            }
+        }
+    };
+    auto xform = [&](const w4f32x4 *cm, int h) __attribute__((always_inline)) {
+        w4f32x2 d[6];
+#pragma unroll
+        for (int s = 0; s < 6; ++s) d[s] = w4f32x2{cm[s][2 * h], cm[s][2 * h + 1]};
+        const w4f32x2 t3 = pk_sub(d[4], d[2]);
+        const w4f32x2 t4 = pk_sub(d[3], d[1]);
+        const w4f32x2 u0 = pk_sub(d[0], d[2]);
+        vv6[0] = pk_fma_p4(u0, t3);
+        const w4f32x2 t1 = pk_fma_m4(d[2], d[4]);
+        const w4f32x2 t2 = pk_fma_m4(d[1], d[3]);
+        vv6[1] = pk_add(t1, t2);
+        vv6[2] = pk_sub(t1, t2);
+        vv6[3] = pk_fma_p2(t4, t3);
+        vv6[4] = pk_fma_m2(t4, t3);
+        const w4f32x2 u5 = pk_sub(d[5], d[3]);
+        vv6[5] = pk_fma_m4(t4, u5);
+    };
+    auto store_v = [&](int j, int par, int h) __attribute__((always_inline)) {
+        *reinterpret_cast<w4f32x2 *>(&smem[v_lds + par * W4_STAGE + j * 64 + 2 * h]) = vv6[j];
+    };
+
+    // ---- weight-fragment loading state (one chunk ahead) ----
+    w4f32x4 bf[6][2];
+    int s_ub = 0, u_vo = OOB, ukc = 0;
+    auto setup_u = [&](int ntl) __attribute__((always_inline)) {  // ntl < 0: no tile
+        const int nb = ntl * 2 + wn;
+        s_ub = ((nb * NK8) * 24 + wi * 6) * 1024;
+        u_vo = (ntl >= 0 && nb < nblk) ? lane * 16 : OOB;
+        ukc = 0;
+    };
+    auto u_advance = [&]() __attribute__((always_inline)) {
+        s_ub += 48 * 1024;
+        if (++ukc == NK) setup_u(nx_vb < nvb ? nx_nt : -1);
+    };
+    auto load_u = [&](int j, int g) __attribute__((always_inline)) { bf[j][g] = w4_load16(srd_u, u_vo, s_ub + g * (24 * 1024) + j * 1024); };
+
+    w4f32x16 acc[6];
+    const int a_off = li * W4_LD + wi * 16 + lh * 4;  // + j * 64 + g * 8
+
+    // ---- prologue (first tile of the workgroup only) ----
+    setup_pix(cur_mt);
+    setup_u(cur_nt);
+    {
+        w4f32x4 r0[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) { load_u(j, 0); load_u(j, 1); }
+        u_advance();
+#pragma unroll
+        for (int k = 0; k < 6; ++k) load_raw_to(r0, k);
+        px_advance();
+#pragma unroll
+        for (int k = 0; k < 6; ++k) load_raw(k);
+        px_advance();
+        combine_in(r0);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            xform(r0, h);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) store_v(j, 0, h);
+        }
+    }
+    __syncthreads();
+
+    // ---- epilogue geometry of the CURRENT tile (set before its last chunk, which requests the residual) ----
+    const int f = wi;
+    int tu = 0, img = 0, mu = 0, n = 0, lane_px = 0, vo_r = OOB;
+    bool nok = false;
+    const __amdgpu_buffer_rsrc_t srd_r = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(reinterpret_cast<const char *>(p.res ? p.res : p.out)), 0, p.M * p.ldres * 4, 0x00020000);
+    auto set_geometry = [&]() __attribute__((always_inline)) {
+        tu = cur_mt * 32 + 8 * f;
+        const int tuc = tu < T ? tu : 0;
+        img = (int)epi_div((unsigned)tuc, (unsigned)TI, p.mg_ohw, p.sh_ohw);
+        const int tru = tuc - img * TI;
+        const int tyu = tru >> wts, txu = tru - (tyu << wts);
+        mu = img * HW + 2 * tyu * W + 4 * txu;
+        n = cur_nt * 64 + wn * 32 + li;
+        nok = n < p.N && tu < T;
+        lane_px = Wt >= 8 ? lh * 16 : Wt == 4 ? lh * 2 * W : lh * 4 * W;
+        vo_r = nok ? (lane_px * p.ldres + n) * 4 : OOB;
+    };
+    auto pix_off = [&](int vv, int a, int b) __attribute__((always_inline)) {
+        const int base = Wt == 2 ? (vv >> 1) * 2 * W + (vv & 1) * 4 : vv * 4;
+        return mu + base + a * W + b;
+    };
+    float rs[2][4][4];
+    const bool has_res = p.res != nullptr;
+    auto load_res = [&](int idx) __attribute__((always_inline)) {  // idx = (a * 4 + b) * 4 + vv
+        const int a = idx >> 4, b = (idx >> 2) & 3, vv = idx & 3;
+        rs[a][b][vv] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_r, vo_r, pix_off(vv, a, b) * p.ldres * 4, 0));
+    };
+
+    // ---- one 16-channel chunk: 48 MFMAs per wave between barriers, in 24 gaps of two.  Every chunk stages the chunk after it (registers
+    // -> the other LDS stage), requests the pixels two chunks ahead and the weight fragments one chunk ahead -- of this tile or of the next.
+    // FIRST: the tile's first chunk (accumulators start from the constant 0); LAST: its last one (the residual tile is requested) ----
+    w4f32x4 af[2][2];
+    auto chunk = [&](auto par_tag, auto first_tag, auto last_tag) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(par_tag)::value;
+        constexpr bool FIRST = decltype(first_tag)::value != 0;
+        constexpr bool LAST = decltype(last_tag)::value != 0;
+        const float *cur = smem + PAR * W4_STAGE;
+        constexpr int nxt = PAR ^ 1;
+        af[0][0] = *reinterpret_cast<const w4f32x4 *>(cur + a_off);
+        af[0][1] = *reinterpret_cast<const w4f32x4 *>(cur + a_off + 64);
+#pragma unroll
+        for (int jp = 0; jp < 3; ++jp) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const int grp = jp * 2 + g, buf = grp & 1;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    if (FIRST && g == 0 && jj == 0) {
+                        const w4f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        acc[2 * jp] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[buf][0][jj], bf[2 * jp][g][jj], zero, 0, 0, 0);
+                        acc[2 * jp + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[buf][1][jj], bf[2 * jp + 1][g][jj], zero, 0, 0, 0);
+                    } else {
+                        acc[2 * jp] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[buf][0][jj], bf[2 * jp][g][jj], acc[2 * jp], 0, 0, 0);
+                        acc[2 * jp + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[buf][1][jj], bf[2 * jp + 1][g][jj], acc[2 * jp + 1], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int gap = grp * 4 + jj;
+                    if (jj == 0 && grp < 5) {
+                        const int nj = (grp + 1) >> 1, ng = (grp + 1) & 1;
+                        af[buf ^ 1][0] = *reinterpret_cast<const w4f32x4 *>(cur + a_off + (2 * nj) * 64 + ng * 8);
+                        af[buf ^ 1][1] = *reinterpret_cast<const w4f32x4 *>(cur + a_off + (2 * nj + 1) * 64 + ng * 8);
+                    }
+                    if (jj == 3) {  // the next chunk's fragments of this group, into the registers just consumed
+                        load_u(2 * jp, g);
+                        load_u(2 * jp + 1, g);
+                    }
+                    if (gap == 6) combine_in(rr);
+                    if (gap == 7) xform(rr, 0);
+                    if (gap >= 8 && gap <= 10) { store_v(2 * (gap - 8), nxt, 0); store_v(2 * (gap - 8) + 1, nxt, 0); }
+                    if (gap == 11) xform(rr, 1);
+                    if (gap >= 12 && gap <= 14) { store_v(2 * (gap - 12), nxt, 1); store_v(2 * (gap - 12) + 1, nxt, 1); }
+                    if (gap >= 12 && gap <= 17) load_raw(gap - 12);
+                    if (gap == 18) px_advance();
+                    if (LAST && has_res && gap < 16) { load_res(2 * gap); load_res(2 * gap + 1); }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        u_advance();
+        __syncthreads();
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+
+    for (;;) {
+#ifdef W42_TRACE
+        trace();
+#endif
+        chunk(I0{}, I1{}, I0{});
+        chunk(I1{}, I0{}, I0{});
+        for (int kc = 2; kc < NK - 2; kc += 2) {
+            chunk(I0{}, I0{}, I0{});
+            chunk(I1{}, I0{}, I0{});
+        }
+        chunk(I0{}, I0{}, I0{});
+        set_geometry();
+        chunk(I1{}, I0{}, I1{});
+#ifdef W42_TRACE
+        trace();
+#endif
+
+        // ---- output transform along x (in-lane): z[b][v] = sum_j Ax^T[b][j] M_ij for tile 4 lh + (v & 3) + 8 (v >> 2); then along y across
+        // the four component-row waves of an output block through LDS: wave i keeps the z of its own unit (v >> 2 == i) and writes the
+        // three other units' to its 48-register slab ----
+        float zo[4][4];  // [b][vv]: own unit
+        {
+            float *mine = smem + W4P_EXB + (wn * 4 + wi) * W4P_EXW + lane;
+            auto emit = [&](auto f_tag) __attribute__((always_inline)) {
+                constexpr int F = decltype(f_tag)::value;  // == wi
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const float m0 = acc[0][v], m1 = acc[1][v], m2 = acc[2][v], m3 = acc[3][v], m4 = acc[4][v], m5 = acc[5][v];
+                    const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
+                    const float z0 = (m0 + s1) + s2, z1 = d1 + 2.f * d2, z2 = s1 + 4.f * s2, z3 = (d1 + 8.f * d2) + m5;
+                    const int fu = v >> 2, vv = v & 3;
+                    if (fu == F) {
+                        zo[0][vv] = z0; zo[1][vv] = z1; zo[2][vv] = z2; zo[3][vv] = z3;
+                    } else {
+                        const int r = fu < F ? fu : fu - 1;  // rank of unit fu among the three foreign ones
+                        mine[((0 * 3 + r) * 4 + vv) * 64] = z0;
+                        mine[((1 * 3 + r) * 4 + vv) * 64] = z1;
+                        mine[((2 * 3 + r) * 4 + vv) * 64] = z2;
+                        mine[((3 * 3 + r) * 4 + vv) * 64] = z3;
+                    }
+                }
+            };
+            if (wi == 0) emit(std::integral_constant<int, 0>{});
+            else if (wi == 1) emit(std::integral_constant<int, 1>{});
+            else if (wi == 2) emit(std::integral_constant<int, 2>{});
+            else emit(std::integral_constant<int, 3>{});
+        }
+        __syncthreads();
+#ifdef W42_TRACE
+        trace();
+#endif
+        float y[2][4][4];  // [a][b][vv]: output pixel (2 ty + a, 4 tx + b) of tile 4 lh + vv of the unit
+        {
+            // component row k of my unit: from wave k's slab at rank (f < k ? f : f - 1), or my own registers (k == f)
+            const float *slab = smem + W4P_EXB + (wn * 4) * W4P_EXW + lane;
+            auto gather = [&](auto f_tag) __attribute__((always_inline)) {
+                constexpr int F = decltype(f_tag)::value;  // == f == wi
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+#pragma unroll
+                    for (int vv = 0; vv < 4; ++vv) {
+                        float z[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            if (k == F) z[k] = zo[b][vv];
+                            else {
+                                const int r = F < k ? F : F - 1;
+                                z[k] = slab[k * W4P_EXW + ((b * 3 + r) * 4 + vv) * 64];
+                            }
+                        }
+                        y[0][b][vv] = z[0] + z[1] + z[2];
+                        y[1][b][vv] = z[1] - z[2] - z[3];
+                    }
+            };
+            if (wi == 0) gather(std::integral_constant<int, 0>{});
+            else if (wi == 1) gather(std::integral_constant<int, 1>{});
+            else if (wi == 2) gather(std::integral_constant<int, 2>{});
+            else gather(std::integral_constant<int, 3>{});
+        }
+        __syncthreads();  // (the successor's first chunk writes stage 1, which the exchange area covers)
+#ifdef W42_TRACE
+        trace();
+#endif
+
+        // ---- epilogue of the unit ----
+        if (tu < T) {
+            const __amdgpu_buffer_rsrc_t srd_o =
+                __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(p.out), 0, p.M * p.ldc * 4, 0x00020000);
+            const int vo_o = nok ? (lane_px * p.ldc + n) * 4 : OOB;
+            float addv = (p.bias && nok) ? p.bias[n] : 0.f;
+            if (p.rowbias && nok) addv += p.rowbias[(size_t)img * p.ld_rowbias + n];
+            float ps[2] = {0.f, 0.f}, pq[2] = {0.f, 0.f};
+            float vals[2][4][4];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+#pragma unroll
+                    for (int vv = 0; vv < 4; ++vv) {
+                        float add = addv;
+                        if (has_res) add += rs[a][b][vv];
+                        const float val = (p.alpha * y[a][b][vv] + add) * p.out_scale;
+                        vals[a][b][vv] = val;
+                        if (!p.egn_skip_raw)
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), srd_o, vo_o, pix_off(vv, a, b) * p.ldc * 4, 0);
+                        ps[a] += val;
+                        pq[a] += val * val;
+                    }
+            if (p.egn_out) {
+                // GroupNorm (+ swish) of the output (plan.h: Op::egn_peer), see wino42_tile.  rows_per_image == 256: every wave of the
+                // workgroup is here (whole images: no unit is past the batch), the scratch is rewritten only after the next tile's barriers
+                float gsum = ps[0] + ps[1], gsq = pq[0] + pq[1];
+                gsum += __shfl_xor(gsum, 32); gsq += __shfl_xor(gsq, 32);
+                float rows = 64.0f;
+                if (p.rows_per_image == 256) {
+                    float2 *red = reinterpret_cast<float2 *>(smem + W4P_RED);  // [wn][unit][32 columns]
+                    if (lh == 0) red[(wn * 4 + f) * 32 + li] = make_float2(gsum, gsq);
+                    __syncthreads();
+                    gsum = 0.f; gsq = 0.f;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float2 v = red[(wn * 4 + u) * 32 + li];
+                        gsum += v.x; gsq += v.y;
+                    }
+                    rows = 256.0f;
+                }
+                for (int o = 1; o < p.egn_cpg; o <<= 1) { gsum += __shfl_xor(gsum, o); gsq += __shfl_xor(gsq, o); }
+                const float inv_n = 1.0f / (rows * (float)p.egn_cpg);
+                const float mean = gsum * inv_n;
+                const float rstd = rsqrtf(gsq * inv_n - mean * mean + 1e-6f);
+                const float ga = nok ? p.egn_gamma[n] : 0.f, be = nok ? p.egn_beta[n] : 0.f;
+                const float sc = rstd * ga, sh = be - mean * rstd * ga;
+                const __amdgpu_buffer_rsrc_t srd_g =
+                    __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(p.egn_out), 0, p.M * p.ldc * 4, 0x00020000);
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+#pragma unroll
+                        for (int vv = 0; vv < 4; ++vv) {
+                            float t = vals[a][b][vv] * sc + sh;
+                            if (p.egn_act) t = swish_e(t);
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, t), srd_g, vo_o, pix_off(vv, a, b) * p.ldc * 4, 0);
+                        }
+            }
+            if (p.qstats) {
+                float s0, q0, s1, q1;
+                if (Wt >= 8) {
+                    s0 = ps[0] + __shfl_xor(ps[0], 32); q0 = pq[0] + __shfl_xor(pq[0], 32);
+                    s1 = ps[1] + __shfl_xor(ps[1], 32); q1 = pq[1] + __shfl_xor(pq[1], 32);
+                } else {
+                    const float ts = ps[0] + ps[1], tq = pq[0] + pq[1];
+                    const float os = __shfl_xor(ts, 32), oq = __shfl_xor(tq, 32);
+                    s0 = lh == 0 ? ts : os; q0 = lh == 0 ? tq : oq;
+                    s1 = lh == 0 ? os : ts; q1 = lh == 0 ? oq : tq;
+                }
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    float s = g == 0 ? s0 : s1, q = g == 0 ? q0 : q1;
+                    if (!nok) { s = 0.f; q = 0.f; }
+                    s += __shfl_xor(s, 1); q += __shfl_xor(q, 1);
+                    s += __shfl_xor(s, 2); q += __shfl_xor(q, 2);
+                    if ((li & 3) == 0 && lh == 0 && nok) {
+                        const int first = (mu - img * HW) + (Wt >= 8 ? g * W : g * 32);
+                        float2 *o = reinterpret_cast<float2 *>(p.qstats) + ((size_t)img * p.qs_slices + (first >> 5)) * (p.N >> 2) + (n >> 2);
+                        o[0] = make_float2(s, q);
+                    }
+                }
+            }
+        }
+#ifdef W42_TRACE
+        trace();
+#endif
+        if (nx_vb >= nvb) break;
+        cur_vb = nx_vb; cur_mt = nx_mt; cur_nt = nx_nt;
+        nx_vb = next_valid(cur_vb + (int)gridDim.x, nx_mt, nx_nt);
+    }
+}
+
 __global__ __launch_bounds__(512, 2) void conv3x3_wino42_f32_kernel(const GemmParams p) {
-    __shared__ __attribute__((aligned(16))) float smem[W4_SMEM];
-    wino42_tile<false>(p, smem);
+    __shared__ __attribute__((aligned(16))) float smem[W4P_SMEM];
+    wino42_persistent(p, smem);
 }
 
 __global__ __launch_bounds__(512, 2) void conv3x3_wino42_k32_f32_kernel(const GemmParams p) {
@@ -595,8 +1074,25 @@ int launch_conv3x3_wino42(const GemmParams &p_in, hipStream_t s) {
     p.n_tiles = (p.N + 63) / 64;
     p.flat_tiles = p.m_tiles < 16;
     const int gx = p.flat_tiles ? p.m_tiles * p.n_tiles : ((p.m_tiles + 7) / 8) * 8 * p.n_tiles;
-    if (p.C0 + p.C1 == 32) hipLaunchKernelGGL(conv3x3_wino42_k32_f32_kernel, dim3(gx), dim3(512), 0, s, p);
-    else hipLaunchKernelGGL(conv3x3_wino42_f32_kernel, dim3(gx), dim3(512), 0, s, p);
+    if (p.C0 + p.C1 == 32) {
+        hipLaunchKernelGGL(conv3x3_wino42_k32_f32_kernel, dim3(gx), dim3(512), 0, s, p);
+    } else {
+        // persistent: one workgroup per CU (a multiple of 8, so that a workgroup's tiles keep their XCD); GDDIM_WINO42_GRID overrides the
+        // workgroup count (tests: a small grid makes every workgroup walk over several tiles)
+        static int cus = 0;
+        if (!cus) {
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+            cus = cus / 8 * 8 > 0 ? cus / 8 * 8 : 8;
+        }
+        int grid = gx < cus ? gx : cus;
+        if (const char *e = getenv("GDDIM_WINO42_GRID")) {
+            const int g = atoi(e);
+            if (g > 0 && g < grid) grid = g;
+        }
+        hipLaunchKernelGGL(conv3x3_wino42_f32_kernel, dim3(grid), dim3(512), 0, s, p);
+    }
     GD_HIP(hipGetLastError());
     return 0;
 }

@@ -311,6 +311,40 @@ def test_conv3x3_winograd42_matches_torch_fp64(dev, case):
     assert err < 4e-5 and err < 6 * err_direct + 1e-6, (case, err, err_direct)
 
 
+@pytest.mark.parametrize("grid", [1, 3, 8])
+@pytest.mark.parametrize("case", [(2, 32, 32, 128, 128, True, True), (5, 32, 32, 64, 132, True, True), (6, 8, 8, 64, 96, True, False),
+                                  (3, 16, 16, 256, 256, False, True)])
+def test_conv3x3_winograd42_persistent_walk(dev, case, grid):
+    """The hybrid kernel is persistent (Cin >= 64): a workgroup walks over tiles and its K-loop pipeline runs across them (the last two
+    chunks of a tile stage the first two of the next).  Unit-test problems have fewer tiles than CUs, so GDDIM_WINO42_GRID forces a small
+    grid: every workgroup then takes several tiles -- including the XCD-grouped mapping's padding ids (20 M tiles: ids 20..23 of the last
+    group of 8 are skipped), ragged last tiles and a walk that ends on different tiles per workgroup.  Result must equal the default
+    launch bit for bit (same arithmetic, another schedule) and match float64."""
+    import os
+    from gddim_amd import ops
+    B, H, W, Cin, Cout, use_bias, use_res = case
+    g = torch.Generator().manual_seed(sum(case[:5]) + 3)
+    x = torch.randn(B, H, W, Cin, generator=g)
+    w = torch.randn(3, 3, Cin, Cout, generator=g) / math.sqrt(9 * Cin)
+    bias = torch.randn(Cout, generator=g) if use_bias else None
+    res = torch.randn(B, H, W, Cout, generator=g) if use_res else None
+    wp = w.permute(3, 0, 1, 2).reshape(Cout, 9 * Cin).contiguous()
+    args = (x.to(dev), wp.to(dev), None if bias is None else bias.to(dev), None if res is None else res.to(dev))
+    ref = ops.conv3x3_winograd42(*args, alpha=1.25, out_scale=0.7).cpu()
+    os.environ["GDDIM_WINO42_GRID"] = str(grid)
+    try:
+        got = ops.conv3x3_winograd42(*args, alpha=1.25, out_scale=0.7).cpu()
+    finally:
+        del os.environ["GDDIM_WINO42_GRID"]
+    assert torch.equal(got, ref), (case, grid, (got - ref).abs().max().item())
+    want = 1.25 * F.conv2d(x.permute(0, 3, 1, 2).double(), w.permute(3, 2, 0, 1).double(), padding=1).permute(0, 2, 3, 1)
+    if bias is not None:
+        want = want + bias.double()
+    if res is not None:
+        want = want + res.double()
+    assert (got.double() - want * 0.7).abs().max().item() < 4e-5
+
+
 def test_conv3x3_winograd42_impulse_and_rejects(dev):
     """Impulses with an asymmetric kernel at corners, edges and every position modulo the 2 x 4 tile (catches a swapped tap, a
     component or an output-column order in either direction); shapes the kernel cannot take are refused loudly."""
