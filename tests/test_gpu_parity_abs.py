@@ -106,9 +106,9 @@ def test_cld_nfe50_b256_absolute_parity(native_lib):
     wx, wv, _ = ocld.deis_sampler(osde, eps64, u_ref, nfe, 2, ts_order=2, denoising=True, inverse_scaler=ocld.inverse_scaler_centered, trace=trace)
     lx, _, _ = ocld.deis_sampler(osde, lin64, u_ref, nfe, 2, ts_order=2, denoising=True, inverse_scaler=ocld.inverse_scaler_centered)
     ex, ev, moved = _report("CLD NFE=50 B=256", x, v, wx, wv, lx, n_ref, trace)
-    # the kernels of the benchmark ran (two-dimensional Winograd kernel, persistent short-K GEMM), not a small-batch fallback
+    # the kernels of the benchmark ran (hybrid Winograd kernel, persistent short-K GEMM), not a small-batch fallback
     names = _profile_names(model, 6, 256)
-    assert any("conv3x3_wino2d_f32_kernel" in k for k in names) and any("igemm_f32_pers_kernel" in k for k in names), names
+    assert any("conv3x3_wino42_f32_kernel" in k for k in names) and any("igemm_f32_pers_kernel" in k for k in names), names
     assert n == nfe and np.isfinite(x).all() and np.isfinite(v).all()
     assert moved > 20 * ABS_TOL, "the network must matter for the test to mean anything (moved x by %.3e)" % moved
     assert max(float(np.abs(a).max()) for a in trace) < 100.0
@@ -140,8 +140,8 @@ def test_cld_nfe100_b256_absolute_parity(native_lib):
 
 
 def test_cld_64x64_nfe10_persistent_tile_absolute_parity(native_lib):
-    """BASELINE config 5 shape (64x64x3) at a batch that selects the production kernels on 64-wide images (the two-dimensional
-    Winograd kernel on the 64x64 / 32x32 / 16x16 levels: 32 images x 1024 quads / 64 = 512 tiles x 2 on the top level), NFE = 10.
+    """BASELINE config 5 shape (64x64x3) at a batch that selects the production kernels on 64-wide images (the hybrid Winograd
+    kernel on the 64x64 / 32x32 / 16x16 levels: 32 images x 512 tiles / 32 = 512 workgroup tiles x 2 on the top level), NFE = 10.
     x (the image, [0, 1] units) is the quantity under the absolute 1e-3 bar; the velocity v is not an output of the reference's
     pipeline and is bounded by the bar scaled by max|v| (|v| <= 20 on this trajectory)."""
     from gddim_amd.configs import cld_accr_dcifar10
@@ -151,7 +151,7 @@ def test_cld_64x64_nfe10_persistent_tile_absolute_parity(native_lib):
     lx, _, _ = ocld.deis_sampler(osde, lin64, u_ref, nfe, 2, ts_order=2, denoising=True, inverse_scaler=ocld.inverse_scaler_centered)
     ex, ev, moved = _report("CLD 64x64 NFE=10 B=32", x, v, wx, wv, lx, n_ref)
     names = _profile_names(model, 6, 32)
-    assert any("conv3x3_wino2d_f32_kernel" in k for k in names), names
+    assert any("conv3x3_wino42_f32_kernel" in k for k in names), names
     assert n == nfe and np.isfinite(x).all() and moved > 20 * ABS_TOL
     assert ex <= ABS_TOL and ev <= ABS_TOL * max(1.0, float(np.abs(wv).max()))
 

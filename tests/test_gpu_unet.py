@@ -136,17 +136,19 @@ def test_unet_64x64_winograd_levels_match_oracle(native_lib):
     eng.close()
     err = np.abs(got[:1] - want64).max() / scale
     print("64x64 B=16: |hip-f64| %.3e (float32 oracle %.3e), batch vs alone %.3e" % (err, e_f32, np.abs(got[:1] - alone).max() / scale))
-    # the 64x64 and 32x32 levels have enough quads (>= 256 tiles) for the two-dimensional Winograd kernel
-    assert "conv3x3_wino2d_f32_kernel" in seen, seen
+    # the 64x64 and 32x32 levels have enough tiles (>= 256 workgroup tiles) for the hybrid Winograd kernel
+    assert "conv3x3_wino42_f32_kernel" in seen, seen
     assert np.isfinite(got).all() and err < max(4 * e_f32, 2e-5), (err, e_f32)
     assert np.abs(got[:1] - alone).max() / scale < 2e-5
 
 
-def test_epilogue_groupnorm_16x16_level(native_lib, tmp_path):
+@pytest.mark.parametrize("kernel", ["wino42", "wino2d"])
+def test_epilogue_groupnorm_16x16_level(native_lib, tmp_path, kernel):
     """GroupNorm in the producer's epilogue (plan.h: Op::egn_peer) on 16x16 images, where the image is one workgroup tile of the
-    two-dimensional Winograd kernel and the column sums of its waves are added through LDS: a three-level network run with the kernel
-    forced on at a small batch (the switches are read once per process, hence the worker), with and without the fusion.  Both runs
-    match the float64 oracle, the fused one launches fewer GroupNorm passes, and the two agree with each other."""
+    Winograd kernel -- the hybrid F(2,3)y x F(4,3)x kernel of round 3 (persistent form for Cin = 64, one-tile form for Cin = 32) and the
+    F(2x2,3x3) kernel it replaced (kept as the fallback) -- and the column sums of its waves are added through LDS: a three-level network
+    run with the kernel forced on at a small batch (the switches are read once per process, hence the worker), with and without the
+    fusion.  Both runs match the float64 oracle, the fused one launches fewer GroupNorm passes, and the two agree with each other."""
     import os
     import subprocess
     import sys
@@ -154,7 +156,8 @@ def test_epilogue_groupnorm_16x16_level(native_lib, tmp_path):
     res = {}
     for tag, extra in (("egn", {}), ("noegn", {"GDDIM_NO_EGN": "1"})):
         out = str(tmp_path / (tag + ".npz"))
-        env = dict(os.environ, GDDIM_WINO2_MINBLOCKS="1", **extra)
+        force = {"GDDIM_WINO42_MINBLOCKS": "1"} if kernel == "wino42" else {"GDDIM_NOWINO42": "1", "GDDIM_WINO2_MINBLOCKS": "1"}
+        env = dict(os.environ, **force, **extra)
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "egn_worker.py"), out], cwd=ROOT, env=env, capture_output=True,
                            text=True, timeout=900)
         assert r.returncode == 0 and "EGN_WORKER_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
@@ -163,7 +166,8 @@ def test_epilogue_groupnorm_16x16_level(native_lib, tmp_path):
     scale = max(1.0, np.abs(want).max())
     counts = {tag: dict(zip(res[tag]["names"].tolist(), res[tag]["launches"].tolist())) for tag in res}
     print("gn_apply launches: fused %d, unfused %d" % (counts["egn"].get("gn_apply", 0), counts["noegn"].get("gn_apply", 0)))
-    assert "conv3x3_wino2d_f32_kernel" in counts["egn"] and "conv3x3_wino2d_f32_kernel" in counts["noegn"]
+    kname = "conv3x3_%s_f32_kernel" % kernel
+    assert kname in counts["egn"] and kname in counts["noegn"], counts["egn"]
     # 16x16 level: 2 + 3 residual blocks with a 3x3 producer in front of their second GroupNorm; the 8x8 level adds its own
     assert counts["egn"].get("gn_apply", 0) <= counts["noegn"]["gn_apply"] - 5
     for tag in res:
