@@ -18,6 +18,11 @@ trajectory.  Third-party arithmetic the reference delegates to (flax ``nn.Conv``
 ``nn.GroupNorm(epsilon=1e-6)`` / ``nn.Dense``, ``jax.nn.softmax``, ``lax.conv_general_dilated``)
 is restated from its published semantics.
 
+PINNING IT IS ONE COMMAND AWAY: ``tools/make_reference_fixtures.py`` (run once inside the reference's own image) imports ``cld_jax`` /
+``blur_jax``, and writes the reference's coefficient tables, R(t) anchors, a tiny-NCSN++ ``eps_fn`` output with its flax checkpoint,
+a 5-step ``get_deis_sampler`` run with injected noise and a blur ``order0`` run to ``tests/golden/ref_*``;
+``tests/test_reference_fixtures.py`` then checks this oracle (CPU) and the HIP path (GPU) against them and skips while they are absent.
+
 Modules: ``cld`` (CLD SDE algebra, DEIS tables, deis / order0 samplers), ``cld_ext`` (LSDE, MLCLD, LambdaSDE and the ldeis /
 mldeis / sdeis / em / sscs / ode samplers, mixed score), ``ncsnpp`` (the U-Net incl. the fir=False / positional-embedding
 configurations), ``blur`` (blur SDE, DCT, order0 sampler, scalar DEIS; plus an independent float64 formulation of the package's
