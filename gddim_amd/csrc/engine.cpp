@@ -309,6 +309,10 @@ static bool side_fused(gd_engine *e, const Bind &b, int batch, int gemm_index) {
             if (a.kind != OP_GN_APPLY || a.a0.t != op.a0.t || a.a1.t != op.a1.t || a.C0 != op.C0 || a.C1 != op.C1 || a.a0.col != 0 || op.a0.col != 0 ||
                 a.gn_table.t < 0 || e->plan.tensors[a.out.t].ext != EXT_NONE)
                 continue;
+            // the affine table is built at the convolution's op index: the GroupNorm's statistics must already exist there, i.e. no
+            // stand-alone statistics op may sit between the two (the apply op directly follows the convolution, both sources with
+            // statistics from their producers' epilogues)
+            if (op.side_peer != (int)i + 1 || a.stats.t < 0 || (a.C1 > 0 && a.stats1.t < 0)) continue;
             if (a.egn_peer >= 0 && egn_fused(e, b, batch, a.egn_peer)) continue;  // its producer writes it already
             GemmParams g{};
             const int z = fill_gemm(e, op, b, batch, g);
@@ -339,6 +343,16 @@ static bool attn_core_at(const gd_engine *e, int i) {
         av.ldb != qk.N || av.bten.col != 0 || av.res.t >= 0 || av.rowbias.t >= 0 || av.qstats.t >= 0 || av.alpha != 1.f || av.out_scale != 1.f ||
         av.out.col != 0)
         return false;
+    // what launch_attn_fused hard-codes: no activation on load, a single source, q / k rows of one image contiguous at stride lda0
+    // (image stride N * lda0), V^T as [C][N] per image (image stride C * N), scores of one image N x N, and no other reader of the scores
+    if (qk.in_act || av.in_act || av.C1 != 0 || av.lda0 != qk.N || qk.sA != (long long)qk.N * qk.lda0 || qk.sB != (long long)qk.N * qk.ldb ||
+        qk.sC != (long long)qk.N * qk.N || av.sA != (long long)qk.N * qk.N || av.sB != (long long)qk.C0 * qk.N || qk.ldc != qk.N || qk.out.col != 0)
+        return false;
+    for (int j = 0; j < (int)ops.size(); ++j) {
+        if (j == i + 1 || j == i + 2) continue;
+        const Op &o = ops[j];
+        if (j != i && (o.a0.t == qk.out.t || o.a1.t == qk.out.t || o.bten.t == qk.out.t || o.res.t == qk.out.t)) return false;
+    }
     const float want = 1.0f / std::sqrt((float)qk.C0);
     if (std::fabs(qk.alpha - want) > 1e-6f * want || qk.out_scale != 1.f) return false;
     return attn_fused_ok(qk.N, qk.C0);
@@ -777,6 +791,9 @@ int gd_engine_params_ready(gd_engine *e) {
     GD_CHECK(nmiss == 0, "%d parameters not loaded: %s%s", nmiss, missing.c_str(), nmiss > 8 ? ", ..." : "");
     if (!e->plan_only) {
         GD_HIP(hipSetDevice(e->device));
+        // the upload and the Winograd weight transforms below run on the null stream while the engine's lanes are non-blocking streams:
+        // a sampler call still in flight (another parameter tree re-uploaded into this engine) must not see its weights change under it
+        GD_HIP(hipDeviceSynchronize());
         for (size_t i = 0; i < e->plan.slots.size(); ++i) {
             const WSlot &s = e->plan.slots[i];
             GD_HIP(hipMemcpy(e->wbuf + e->slot_off[i], s.host.data(), s.host.size() * sizeof(float), hipMemcpyHostToDevice));

@@ -49,7 +49,8 @@ typedef unsigned int w4u32x2 __attribute__((ext_vector_type(2)));
 
 #ifndef W42_ABL
 #define W42_ABL 0  // timing ablations (results wrong): 1 no pixel loads in the K loop, 2 no LDS stores, 4 no weight-fragment loads in the K loop,
-                   // 8 no barrier, 16 no transform arithmetic
+                   // 8 no barrier, 16 no transform arithmetic, 64 (persistent form) every pixel load from one L1-resident line: the instruction
+                   // count stays, the L2 / HBM traffic and latency go
 #endif
 
 constexpr int W4_LD = 388;               // LDS row stride (floats): 24 components x 16 channels + 4 pad = 97 16-byte units (odd)
@@ -60,10 +61,20 @@ __device__ __forceinline__ w4f32x2 w4_load8(__amdgpu_buffer_rsrc_t rsrc, int vof
     w4u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voffset, soffset, 0);
     return __builtin_bit_cast(w4f32x2, v);
 }
+template <int AUX = 0>
 __device__ __forceinline__ w4f32x4 w4_load16(__amdgpu_buffer_rsrc_t rsrc, int voffset, int soffset) {
-    w4u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voffset, soffset, 0);
+    w4u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voffset, soffset, AUX);
     return __builtin_bit_cast(w4f32x4, v);
 }
+#ifndef W42_U_AUX
+#define W42_U_AUX 0   // cache-policy bits of the weight-fragment loads (A/B: 1 sc0, 2 nt -> streaming, 3 both)
+#endif
+#ifndef W42_PX_AUX
+#define W42_PX_AUX 0  // ... of the pixel loads
+#endif
+#ifndef W42_PRIO
+#define W42_PRIO 0    // 1: s_setprio 1 for the second-dispatched half of the workgroup (waves 4-7) before the main loop
+#endif
 
 // packed fp32 on a channel pair (on this chip every fp32 VALU cycle is taken from the fp32 matrix pipe: one instruction for two channels)
 __device__ __forceinline__ w4f32x2 pk_add(w4f32x2 a, w4f32x2 b) {
@@ -630,12 +641,16 @@ __device__ __forceinline__ void wino42_persistent(const GemmParams &p, float *sm
 
     w4f32x4 rr[6];
     w4f32x2 vv6[6];
+    bool steady = false;  // (timing ablations only: set after the prologue)
     auto load_raw_to = [&](w4f32x4 *dst, int k) __attribute__((always_inline)) {
-        if (s_first) dst[k] = w4_load16(srd_a0, vo[k], s_c * 4);
-        else dst[k] = w4_load16(srd_a1, vo[k], (s_c - p.C0) * 4);
+        if ((W42_ABL & 1) && steady) return;
+        if ((W42_ABL & 64) && steady) { dst[k] = w4_load16<W42_PX_AUX>(srd_a0, bias0 + (lane & 3) * 16, 0); return; }  // every pixel load from ONE L1-resident line
+        if (s_first) dst[k] = w4_load16<W42_PX_AUX>(srd_a0, vo[k], s_c * 4);
+        else dst[k] = w4_load16<W42_PX_AUX>(srd_a1, vo[k], (s_c - p.C0) * 4);
     };
     auto load_raw = [&](int k) __attribute__((always_inline)) { load_raw_to(rr, k); };
     auto combine_in = [&](w4f32x4 *x) __attribute__((always_inline)) {
+        if (W42_ABL & 16) return;
 #pragma unroll
         for (int s = 0; s < 6; ++s) {
 #pragma unroll
@@ -653,6 +668,11 @@ __device__ __forceinline__ void wino42_persistent(const GemmParams &p, float *sm
         w4f32x2 d[6];
 #pragma unroll
         for (int s = 0; s < 6; ++s) d[s] = w4f32x2{cm[s][2 * h], cm[s][2 * h + 1]};
+        if (W42_ABL & 16) {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) vv6[j] = d[j];
+            return;
+        }
         const w4f32x2 t3 = pk_sub(d[4], d[2]);
         const w4f32x2 t4 = pk_sub(d[3], d[1]);
         const w4f32x2 u0 = pk_sub(d[0], d[2]);
@@ -667,6 +687,7 @@ __device__ __forceinline__ void wino42_persistent(const GemmParams &p, float *sm
         vv6[5] = pk_fma_m4(t4, u5);
     };
     auto store_v = [&](int j, int par, int h) __attribute__((always_inline)) {
+        if (W42_ABL & 2) { asm volatile("" ::"v"(vv6[j])); return; }
         *reinterpret_cast<w4f32x2 *>(&smem[v_lds + par * W4_STAGE + j * 64 + 2 * h]) = vv6[j];
     };
 
@@ -683,7 +704,10 @@ __device__ __forceinline__ void wino42_persistent(const GemmParams &p, float *sm
         s_ub += 48 * 1024;
         if (++ukc == NK) setup_u(nx_vb < nvb ? nx_nt : -1);
     };
-    auto load_u = [&](int j, int g) __attribute__((always_inline)) { bf[j][g] = w4_load16(srd_u, u_vo, s_ub + g * (24 * 1024) + j * 1024); };
+    auto load_u = [&](int j, int g) __attribute__((always_inline)) {
+        if ((W42_ABL & 4) && steady) return;
+        bf[j][g] = w4_load16<W42_U_AUX>(srd_u, u_vo, s_ub + g * (24 * 1024) + j * 1024);
+    };
 
     w4f32x16 acc[6];
     const int a_off = li * W4_LD + wi * 16 + lh * 4;  // + j * 64 + g * 8
@@ -792,11 +816,13 @@ __device__ __forceinline__ void wino42_persistent(const GemmParams &p, float *sm
             }
         }
         u_advance();
-        __syncthreads();
+        if (!(W42_ABL & 8)) __syncthreads();
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
 
+    if (W42_PRIO && wave >= 4) __builtin_amdgcn_s_setprio(1);
+    steady = true;
     for (;;) {
 #ifdef W42_TRACE
         trace();

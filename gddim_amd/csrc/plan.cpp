@@ -37,9 +37,23 @@ long long Plan::arena_alloc(long long size) {
     return off;
 }
 
-// a block above everything handed out so far: whatever is written there early cannot alias a tensor that was live before
-long long Plan::arena_alloc_fresh(long long size) {
+// A block for a tensor that its producer's epilogue may write EARLY, at op index `producer` (Op::egn_peer: the GroupNorm output written
+// by the GEMM in front of the GroupNorm op): the block must have been free, without interruption, since before that op -- a block freed
+// or handed out in between could belong to a tensor that lives across the early write.  Free blocks carry the op count since which they
+// have been free; when none qualifies the arena grows (round 2 always grew: 3.0 of 4.5 M floats per image were such one-shot blocks).
+long long Plan::arena_alloc_fresh(long long size, int producer) {
     size = (size + 63) / 64 * 64;
+    if (producer >= 0) {
+        for (size_t i = 0; i < free_list_.size(); ++i) {
+            if (free_list_[i].size >= size && free_list_[i].since <= producer) {
+                const long long off = free_list_[i].off;
+                free_list_[i].off += size;
+                free_list_[i].size -= size;
+                if (free_list_[i].size == 0) free_list_.erase(free_list_.begin() + i);
+                return off;
+            }
+        }
+    }
     const long long off = arena_per_image;
     arena_per_image = off + size;
     return off;
@@ -47,7 +61,7 @@ long long Plan::arena_alloc_fresh(long long size) {
 
 void Plan::arena_free(long long off, long long size) {
     size = (size + 63) / 64 * 64;
-    Block b{off, size};
+    Block b{off, size, (long long)ops.size()};
     auto it = std::lower_bound(free_list_.begin(), free_list_.end(), b,
                                [](const Block &x, const Block &y) { return x.off < y.off; });
     it = free_list_.insert(it, b);
@@ -55,10 +69,12 @@ void Plan::arena_free(long long off, long long size) {
     size_t i = it - free_list_.begin();
     if (i + 1 < free_list_.size() && free_list_[i].off + free_list_[i].size == free_list_[i + 1].off) {
         free_list_[i].size += free_list_[i + 1].size;
+        free_list_[i].since = std::max(free_list_[i].since, free_list_[i + 1].since);  // (the merged block is as young as its youngest part)
         free_list_.erase(free_list_.begin() + i + 1);
     }
     if (i > 0 && free_list_[i - 1].off + free_list_[i - 1].size == free_list_[i].off) {
         free_list_[i - 1].size += free_list_[i].size;
+        free_list_[i - 1].since = std::max(free_list_[i - 1].since, free_list_[i].since);
         free_list_.erase(free_list_.begin() + i);
     }
 }
@@ -70,7 +86,7 @@ int Plan::new_tensor(const std::string &name, int H, int W, int C, int ext, long
     t.per_image = per_image >= 0 ? per_image : (long long)H * W * C;
     t.ext = ext;
     t.refs = 1;
-    if (ext == EXT_NONE) t.offset = fresh ? arena_alloc_fresh(t.per_image) : arena_alloc(t.per_image);
+    if (ext == EXT_NONE) t.offset = fresh ? arena_alloc_fresh(t.per_image, fresh_producer_) : arena_alloc(t.per_image);
     t.fresh = fresh ? 1 : 0;
     tensors.push_back(t);
     return (int)tensors.size() - 1;
@@ -159,6 +175,10 @@ int Plan::gn(const std::string &label, const std::string &pname, int xa, int Ca,
     const int cpg = C / G;
     const bool egn_candidate = Cb == 0 && (H * W == 16 || H * W == 64 || (H == 16 && W == 16)) && tensors[xa].stats_t >= 0 && tensors[xa].C == C &&
                                (cpg == 4 || cpg == 8 || cpg == 16 || cpg == 32) && C % 32 == 0;
+    fresh_producer_ = -1;
+    if (egn_candidate)
+        for (int j = (int)ops.size() - 1; j >= 0; --j)
+            if (ops[j].out.t == xa) { fresh_producer_ = ops[j].kind == OP_GEMM ? j : -1; break; }
     int out = new_tensor(label + ".out", H, W, C, EXT_NONE, -1, egn_candidate);
     tensors[out].table_t = new_tensor(label + ".affine", 1, 1, 2 * C);  // lives as long as the output
     Op a;

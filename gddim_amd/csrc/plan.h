@@ -159,10 +159,11 @@ struct Plan {
 
    private:
     // arena
-    struct Block { long long off, size; };
+    struct Block { long long off, size; long long since; };  // since: the op count from which the block has been free without interruption
     std::vector<Block> free_list_;
+    int fresh_producer_ = -1;  // op index of the GEMM that may write the next `fresh` tensor early (set by Plan::gn)
     long long arena_alloc(long long size);
-    long long arena_alloc_fresh(long long size);
+    long long arena_alloc_fresh(long long size, int producer);
     void arena_free(long long off, long long size);
     // builders
     int new_tensor(const std::string &name, int H, int W, int C, int ext = EXT_NONE, long long per_image = -1, bool fresh = false);

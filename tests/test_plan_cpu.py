@@ -175,3 +175,63 @@ def test_epilogue_groupnorm_links(native_lib):
     # 1x1 shortcuts are produced by GEMMs too, but only a 3x3 producer on the two-dimensional Winograd kernel normalises them (run time)
     assert all(ops[i]["egn_peer"] < 0 for i in gns if ops[i]["H"] >= 32)
     assert sum(1 for i in linked if ops[i]["H"] == 16) >= 20
+
+
+def _live_intervals(plan):
+    """[first write, last access] (op indices) of every arena tensor.  A GroupNorm output that its producer's epilogue (egn_peer) or
+    the block's shortcut convolution (side_peer) may write EARLY starts living at that op."""
+    first, last = {}, {}
+
+    def touch(t, k, write=False):
+        if t < 0:
+            return
+        if write:
+            first[t] = min(first.get(t, k), k)
+        first.setdefault(t, k)
+        last[t] = max(last.get(t, k), k)
+
+    for k, op in enumerate(plan["ops"]):
+        for key in ("a0", "a1", "bten", "rowbias", "res"):
+            touch(op[key][0], k)
+        if op["kind"] == 3:  # GN_APPLY reads its statistics
+            touch(op["stats"][0], k)
+            touch(op["stats1"][0], k)
+            early = min([p for p in (op["egn_peer"], op["side_peer"]) if p >= 0] + [k])
+            touch(op["out"][0], early, write=True)
+            touch(op["out"][0], k)
+        else:
+            touch(op["stats"][0], k, write=True)   # GN_STATS / GN_GENERIC write theirs
+            touch(op["out"][0], k, write=True)
+            touch(op["qstats"][0], k, write=True)
+    return first, last
+
+
+@pytest.mark.parametrize("which", ["accr", "tiny", "variant"])
+def test_no_live_tensors_alias_including_early_epilogue_writes(native_lib, which):
+    """The arena planner recycles blocks; a GroupNorm output that the producing GEMM's epilogue writes early (Op::egn_peer) may only sit
+    in a block that has been free since before that GEMM (plan.cpp: arena_alloc_fresh, round 3: recycled instead of always growing the
+    arena).  Check the whole plan: no two tensors whose address ranges overlap are alive at the same time."""
+    from gddim_amd.configs import cld_accr_dcifar10
+    from gddim_amd.engine import Engine
+    cfg = {"accr": cld_accr_dcifar10.get_config(), "tiny": tiny_config("cld"),
+           "variant": tiny_config("cld", nf=16, num_res_blocks=2, image_size=32, ch_mult=(1, 2, 2), attn=(16,))}[which]
+    eng = Engine(cfg, 6, max_batch=1, plan_only=True)
+    plan = eng.plan()
+    eng.close()
+    first, last = _live_intervals(plan)
+    T = plan["tensors"]
+    live = [(t, T[t]["offset"], T[t]["offset"] + (T[t]["per_image"] + 63) // 64 * 64, first[t], last[t])
+            for t in first if T[t]["ext"] == 0 and T[t]["offset"] >= 0]
+    live.sort(key=lambda r: r[1])
+    bad = []
+    for i, (ta, a0, a1, fa, la) in enumerate(live):
+        for tb, b0, b1, fb, lb in live[i + 1:]:
+            if b0 >= a1:
+                break
+            if fa <= lb and fb <= la:  # address ranges overlap and so do the lifetimes
+                bad.append((T[ta]["name"], (fa, la), T[tb]["name"], (fb, lb)))
+    assert not bad, bad[:5]
+    assert plan["arena_per_image"] <= max(r[2] for r in live)
+    if which == "accr":
+        # 4.51 M floats per image in round 2 (every early-written block fresh), 2.79 M before the epilogue GroupNorm existed
+        assert plan["arena_per_image"] < 3.8e6, plan["arena_per_image"]
