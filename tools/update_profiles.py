@@ -9,7 +9,7 @@ import sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DST = os.path.join(REPO, "profiles")
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-SRC = os.path.join(REPO, "gpurun_out", "prof" if tag == "r01" else "prof2")
+SRC = os.path.join(REPO, "gpurun_out", {"r01": "prof", "r02": "prof2"}.get(tag, "prof" + tag[1:].lstrip("0")))
 
 if tag != "r01":
     # tools/collect_profiles_r2.sh layout: every small file of gpurun_out/prof2 is evidence; logs stay behind
