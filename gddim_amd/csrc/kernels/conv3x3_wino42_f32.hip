@@ -15,20 +15,26 @@
 // The weight transform is computed in double and rounded once; the activation-side transforms are fp32 adds and fmas by 2, 4, 8.
 //
 // Workgroup: 512 threads = 8 wave64; tile 32 Winograd tiles (256 pixels) x 64 outputs x 24 components.  Wave (i, wn) owns component row
-// i (its six components j) of the 32 tiles x output block wn (32 columns): six 32x32x2 fp32 accumulators, 24 MFMAs per 8-channel chunk.
+// i (its six components j) of the 32 tiles x output block wn (32 columns): six 32x32x2 fp32 accumulators, 48 MFMAs per 16-channel chunk.
 // What differs from the F(2x2,3x3) kernel besides the transform:
 //  * the WEIGHTS NEVER TOUCH LDS.  With the components split over the waves a wave's B fragments are read by no other wave of the
 //    workgroup, so staging them through LDS was a copy without reuse: here U is stored in HBM in fragment order
 //    U[n / 32][Cin / 8][i][j][channel half][n % 32][4] and every wave loads its 1 KB fragments straight into the registers the MFMA
-//    reads (six buffer_load_dwordx4 per chunk, one chunk ahead, into the registers the previous chunk's MFMAs have just consumed).
-//    LDS holds V only (25 KB per stage instead of 66 KB), the LDS write traffic per chunk falls from 64 KB to 24 KB.
-//  * staging role: thread (tile, channel pair, patch row r) loads the six pixels of ONE patch row as 8-byte pieces; the y transform
-//    comes in through a DPP operand from the neighbouring lane exactly as in the F(2x2,3x3) kernel (12 v_fmac_f32_dpp), the x transform
-//    F(4,3) is 12 packed-fp32 instructions on the channel pair, six ds_write_b64 (slot order [j][i]: a 16-lane store group covers 128
-//    contiguous bytes).
+//    reads (twelve buffer_load_dwordx4 per chunk, one chunk ahead, into the registers the previous chunk's MFMAs have just consumed).
+//    LDS holds V only (48.5 KB per 16-channel stage).
+//  * K loop in 16-channel chunks: 48 MFMAs per wave between barriers in 24 gaps of two -- two components side by side, so that no MFMA
+//    waits for its predecessor's accumulator.  Staging role: thread (tile, channel quad, patch row r) loads the six pixels of ONE patch row
+//    as 16-byte pieces; the y transform comes in through a DPP operand from the neighbouring lane exactly as in the F(2x2,3x3) kernel
+//    (24 v_fmac_f32_dpp, in place), the x transform F(4,3) is 12 packed-fp32 instructions per channel pair, twelve ds_write_b64 (slot
+//    order [j][i]).
+//  * wino42_persistent (Cin >= 64): one workgroup per CU walks over tiles and the K-loop pipeline runs ACROSS tiles (the loading state
+//    rolls over to the workgroup's next tile; only its first tile has a prologue).  wino42_tile<true> is the one-tile form for Cin = 32.
 // Epilogue: x-direction output transform in-lane (six components -> four columns), y-direction across the four component-row waves
 // through LDS, then wave f of an output block finishes 8 tiles x 32 columns: bias, per-image bias row, residual, scale, store, GroupNorm
 // quad statistics, and the epilogue GroupNorm on 8x8 / 16x16 images -- the F(2x2,3x3) kernel's epilogue on 2 x 4 tiles.
+// Measured (profiles/r03_notes.md): 324-330 TFLOP/s algorithmic in the sampler = 0.69-0.70 of the nominal fp32 MFMA peak in issued products
+// at a power-limited 1.7-2.0 GHz; the loop lives at 256 VGPRs (a second pixel register set spills), the weight-fragment stream and the LDS
+// stores cost clock rather than cycles.
 // Shapes: W in {8, 16, 32, 64}, H even, H W / 8 a multiple of 8, Cin % 32 == 0 (two-source concat: C0 % 32 == 0); N % 4 == 0 and
 // N >= 32 when the epilogue emits GroupNorm statistics (any N otherwise).
 #include <cstdio>
