@@ -95,6 +95,7 @@ SIGNATURES = {
     "gd_fir_resample": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "gd_attention": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "gd_attention_fused": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "gd_attention_block_fused": (_I, [_P, _P, _P, _P, _P, _F, _P, _P, _I, _I, _I, _P]),
 }
 
 _lib = None

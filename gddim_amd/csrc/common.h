@@ -61,6 +61,8 @@ struct GemmParams {
     int rows_per_image;
     const float *res;  // [m * ldres + n] or null
     int ldres;
+    long long sR;      // z-stride of res (floats)
+    long long sQ;      // z-stride of qstats (floats)
     float alpha;
     float out_scale;
     int in_act;  // 1: swish applied to A elements on load
@@ -184,12 +186,14 @@ int launch_naive_resample2(const float *x, float *out, int batch, int H, int W, 
 int launch_fir_down2(const float *x, float *out, int batch, int H, int W, int C, hipStream_t s);
 int launch_fir_pad(const float *x, float *out, int batch, int H, int W, int C, hipStream_t s);  // (H, W) -> (H + 1, W + 1), see the kernel
 int launch_softmax_rows(float *x, long long rows, int cols, hipStream_t s);
-// fused attention core softmax(q k^T C^-1/2) v (+ bias) for N = 256 tokens, C = 256 channels (kernels/attn_fused_f32.hip): q, k rows
-// of stride ld_qk, v transposed per image (vT[c][token]); GDDIM_NO_FUSED_ATTN=1 keeps the three-launch path
+// fused attention core out = (softmax(q k^T C^-1/2) v + bias [+ res]) * out_scale for N = 256 tokens, C = 256 channels
+// (kernels/attn_fused_f32.hip): q / k rows of stride ld_q / ld_k, v transposed per image (vT[c][token]), res rows of stride ld_res (null:
+// none), qstats (null: none) = the fused GroupNorm statistics of out, 8 slices per image (kernels/qstats.h);
+// GDDIM_NO_FUSED_ATTN=1 keeps the three-launch path
 bool attn_fused_ok(int N, int C);
 const char *attn_fused_name();
-int launch_attn_fused(const float *q, const float *k, int ld_qk, const float *vT, const float *bias, float *out, int ld_o, int batch,
-                      int N, int C, hipStream_t s);
+int launch_attn_fused(const float *q, int ld_q, const float *k, int ld_k, const float *vT, const float *bias, const float *res, int ld_res,
+                      float out_scale, float *qstats, float *out, int ld_o, int batch, int N, int C, hipStream_t s);
 int launch_swish(const float *x, float *out, long long n, hipStream_t s);
 // temb0[b][0:E] = sin(2 pi W log(label_b)), [E:2E] = cos(...); label_b = labels[b] or 999*ts[*step]
 int launch_fourier(const float *labels, const float *ts_table, const int *step, const float *W, float *out, int batch,

@@ -188,7 +188,7 @@ static int fill_gemm(gd_engine *e, const Op &op, const Bind &b, int batch, GemmP
     g.out = tptr(e, b, op.out, batch); g.ldc = op.ldc;
     g.bias = op.bias_slot >= 0 ? slot_ptr(e, op.bias_slot) + op.bias_off : nullptr;
     g.rowbias = tptr(e, b, op.rowbias, batch); g.ld_rowbias = op.ld_rowbias; g.rows_per_image = op.m_per_image;
-    g.res = tptr(e, b, op.res, batch); g.ldres = op.ldres;
+    g.res = tptr(e, b, op.res, batch); g.ldres = op.ldres; g.sR = op.sR; g.sQ = op.sQ;
     g.alpha = op.alpha; g.out_scale = op.out_scale; g.in_act = op.in_act;
     g.qstats = tptr(e, b, op.qstats, batch); g.qs_slices = op.qs_slices;
     return z;
@@ -327,27 +327,31 @@ static bool side_fused(gd_engine *e, const Bind &b, int batch, int gemm_index) {
 static int launch_apply_op(gd_engine *e, const Op &op, const Bind &b, int batch, bool table_only, hipStream_t s);
 
 // The attention core q k^T -> softmax -> p v as ONE launch (kernels/attn_fused_f32.hip), fp32 mode, 256 tokens x 256 channels: op i is
-// the q k^T product of such a core when it is a per-image product of two column blocks of one tensor (q at column 0, k at column C),
-// followed by the in-place softmax of its output and by the product of that output with a k-contiguous V^T.
+// the q k^T product of such a core when it is a per-image product of two row-major activation matrices (two column blocks of one tensor,
+// or -- the planner's folded form -- the folded query projection and the GroupNorm output), followed by the in-place softmax of its
+// output and by the product of that output with a k-contiguous V^T (whose epilogue may carry the block's residual, scale and statistics).
 static bool attn_core_at(const gd_engine *e, int i) {
     const std::vector<Op> &ops = e->plan.ops;
     if (e->precision != 0 || i < 0 || i + 2 >= (int)ops.size()) return false;
     const Op &qk = ops[i], &sm = ops[i + 1], &av = ops[i + 2];
     if (qk.kind != OP_GEMM || sm.kind != OP_SOFTMAX || av.kind != OP_GEMM) return false;
-    if (!qk.z_per_image || qk.w_slot >= 0 || qk.a_slot >= 0 || qk.bten.t != qk.a0.t || qk.a0.col != 0 || qk.bten.col != qk.C0 || qk.b_kmajor ||
-        qk.C1 != 0 || qk.K != qk.C0 || qk.m_per_image != qk.N || qk.lda0 != qk.ldb || qk.res.t >= 0 || qk.rowbias.t >= 0 || qk.bias_slot >= 0 ||
+    if (!qk.z_per_image || qk.w_slot >= 0 || qk.a_slot >= 0 || qk.bten.t < 0 || qk.b_kmajor ||
+        qk.C1 != 0 || qk.K != qk.C0 || qk.m_per_image != qk.N || qk.res.t >= 0 || qk.rowbias.t >= 0 || qk.bias_slot >= 0 ||
         qk.qstats.t >= 0)
         return false;
     if (sm.out.t != qk.out.t || sm.cols != qk.N || sm.rows_per_image != qk.N) return false;
     if (!av.z_per_image || av.w_slot >= 0 || av.a_slot >= 0 || av.a0.t != qk.out.t || av.C0 != qk.N || av.K != qk.N || av.N != qk.C0 || av.b_kmajor ||
-        av.ldb != qk.N || av.bten.col != 0 || av.res.t >= 0 || av.rowbias.t >= 0 || av.qstats.t >= 0 || av.alpha != 1.f || av.out_scale != 1.f ||
-        av.out.col != 0)
+        av.ldb != qk.N || av.bten.col != 0 || av.rowbias.t >= 0 || av.alpha != 1.f || av.out.col != 0)
         return false;
-    // what launch_attn_fused hard-codes: no activation on load, a single source, q / k rows of one image contiguous at stride lda0
-    // (image stride N * lda0), V^T as [C][N] per image (image stride C * N), scores of one image N x N, and no other reader of the scores
+    // what launch_attn_fused hard-codes: no activation on load, a single source, q / k rows of one image contiguous at their strides
+    // (image stride N * ld), V^T as [C][N] per image (image stride C * N), scores of one image N x N, residual / output rows of one image
+    // contiguous, eight statistics slices per image, and no other reader of the scores
     if (qk.in_act || av.in_act || av.C1 != 0 || av.lda0 != qk.N || qk.sA != (long long)qk.N * qk.lda0 || qk.sB != (long long)qk.N * qk.ldb ||
-        qk.sC != (long long)qk.N * qk.N || av.sA != (long long)qk.N * qk.N || av.sB != (long long)qk.C0 * qk.N || qk.ldc != qk.N || qk.out.col != 0)
+        qk.sC != (long long)qk.N * qk.N || av.sA != (long long)qk.N * qk.N || av.sB != (long long)qk.C0 * qk.N || qk.ldc != qk.N || qk.out.col != 0 ||
+        av.sC != (long long)qk.N * av.ldc)
         return false;
+    if (av.res.t >= 0 && av.sR != (long long)qk.N * av.ldres) return false;
+    if (av.qstats.t >= 0 && (av.qs_slices != qk.N / 32 || av.sQ != (long long)av.qs_slices * (av.N / 4) * 2)) return false;
     for (int j = 0; j < (int)ops.size(); ++j) {
         if (j == i + 1 || j == i + 2) continue;
         const Op &o = ops[j];
@@ -384,10 +388,10 @@ static int run_op(gd_engine *e, int op_index, const Bind &b, int batch, hipStrea
             if (attn_core_at(e, op_index)) {  // q k^T, softmax and p v in one launch; the next two ops return at once
                 const Op &av = P.ops[op_index + 2];
                 ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(attn_fused_name()),
-                             (op.flops_per_image + av.flops_per_image) * batch, 4.0 * batch * 4.0 * op.N * op.C0);  // q, k, v^T, out once each
-                return launch_attn_fused(tptr(e, b, op.a0, batch), tptr(e, b, op.bten, batch), op.lda0, tptr(e, b, av.bten, batch),
-                                         av.bias_slot >= 0 ? slot_ptr(e, av.bias_slot) + av.bias_off : nullptr, tptr(e, b, av.out, batch), av.ldc,
-                                         batch, op.N, op.C0, s);
+                             (op.flops_per_image + av.flops_per_image) * batch, 4.0 * batch * (av.res.t >= 0 ? 5.0 : 4.0) * op.N * op.C0);  // q, k, v^T, out (, residual) once each
+                return launch_attn_fused(tptr(e, b, op.a0, batch), op.lda0, tptr(e, b, op.bten, batch), op.ldb, tptr(e, b, av.bten, batch),
+                                         av.bias_slot >= 0 ? slot_ptr(e, av.bias_slot) + av.bias_off : nullptr, tptr(e, b, av.res, batch), av.ldres,
+                                         av.out_scale, tptr(e, b, av.qstats, batch), tptr(e, b, av.out, batch), av.ldc, batch, op.N, op.C0, s);
             }
             if (attn_core_at(e, op_index - 2)) return 0;  // the p v product of a fused core
             GemmParams g{};
@@ -789,6 +793,7 @@ int gd_engine_params_ready(gd_engine *e) {
             ++nmiss;
         }
     GD_CHECK(nmiss == 0, "%d parameters not loaded: %s%s", nmiss, missing.c_str(), nmiss > 8 ? ", ..." : "");
+    e->plan.fold_params();  // derived weight slots (the folded attention projections)
     if (!e->plan_only) {
         GD_HIP(hipSetDevice(e->device));
         // the upload and the Winograd weight transforms below run on the null stream while the engine's lanes are non-blocking streams:
@@ -1443,7 +1448,14 @@ int gd_attention_fused(const float *qk_dev, const float *vT_dev, const float *bi
                        void *stream) {
     GD_CHECK(qk_dev && vT_dev && out_dev, "null pointer");
     GD_CHECK(attn_fused_ok(N, C), "attention_fused: built for N = 256 tokens and C = 256 channels (N=%d C=%d)", N, C);
-    return launch_attn_fused(qk_dev, qk_dev + C, 2 * C, vT_dev, bias_v_dev, out_dev, C, batch, N, C, (hipStream_t)stream);
+    return launch_attn_fused(qk_dev, 2 * C, qk_dev + C, 2 * C, vT_dev, bias_v_dev, nullptr, 0, 1.f, nullptr, out_dev, C, batch, N, C, (hipStream_t)stream);
+}
+
+int gd_attention_block_fused(const float *q_dev, const float *k_dev, const float *vT_dev, const float *bias_dev, const float *res_dev,
+                             float out_scale, float *qstats_dev, float *out_dev, int batch, int N, int C, void *stream) {
+    GD_CHECK(q_dev && k_dev && vT_dev && out_dev, "null pointer");
+    GD_CHECK(attn_fused_ok(N, C), "attention_block_fused: built for N = 256 tokens and C = 256 channels (N=%d C=%d)", N, C);
+    return launch_attn_fused(q_dev, C, k_dev, C, vT_dev, bias_dev, res_dev, C, out_scale, qstats_dev, out_dev, C, batch, N, C, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -1,5 +1,8 @@
 // Fused single-head self-attention core for the U-Net's 16x16 attention blocks (N = 256 tokens, C = 256 channels), fp32:
-//     out[i][:] = sum_j softmax_j(q_i . k_j * C^-1/2) v_j  (+ b_v: softmax rows sum to one, so the value bias moves here)
+//     out[i][:] = (sum_j softmax_j(q_i . k_j * C^-1/2) v_j  + bias [+ res[i][:]]) * out_scale
+// (the value bias moves to the output because softmax rows sum to one; in the planner's folded form -- Plan::attn -- k is the GroupNorm
+// output itself, v already carries the output projection, and the block's residual, 1/sqrt(2) and the fused GroupNorm statistics of the
+// result live in this epilogue)
 // (cld_jax/models/layerspp.py:74-78: the two einsums and the softmax of AttnBlockpp).  The unfused path is three launches -- QK^T,
 // softmax_rows_kernel over a B N N scratch in HBM, PV -- this kernel keeps a 64-query block of the scores in registers / LDS:
 //   phase A  S = Q_blk K^T        64 x 256 x 256, fp32 MFMA 32x32x2; 8 wave64 as 2 (rows) x 4 (keys), two accumulators per wave
@@ -30,11 +33,15 @@ constexpr int AT_RED = AT_P + 2 * AT_KST;  // softmax scratch [64 rows][4 waves]
 constexpr int AT_SMEM = AT_RED + 64 * 4;
 
 struct AttnParams {
-    const float *q;   // q[(img * N + token) * ld_qk + c]
-    const float *k;   // k[(img * N + token) * ld_qk + c]
-    int ld_qk;
+    const float *q;   // q[(img * N + token) * ld_q + c]
+    const float *k;   // k[(img * N + token) * ld_k + c]
+    int ld_q, ld_k;
     const float *vT;  // vT[(img * C + c) * N + token]
     const float *bias;  // [C] or null
+    const float *res;   // res[(img * N + token) * ld_res + c] or null
+    int ld_res;
+    float out_scale;
+    float *qstats;    // qstats[img][8 slices of 32 tokens][C / 4] = (sum, sum of squares) of out (kernels/qstats.h) or null
     float *out;       // out[(img * N + token) * ld_o + c]
     int ld_o;
     float scale_log2e;  // C^-1/2 * log2(e)
@@ -58,8 +65,8 @@ __global__ __launch_bounds__(512, 2) void attn256_f32_kernel(const AttnParams p)
 
     // staging roles: row (tid >> 3) [+ 64 j], 16-byte piece (tid & 7) of the 32-deep chunk
     const int srow = tid >> 3, spc = tid & 7;
-    const float *gq = p.q + ((size_t)img * AT_N + q0 + srow) * p.ld_qk + spc * 4;
-    const float *gk = p.k + ((size_t)img * AT_N + srow) * p.ld_qk + spc * 4;
+    const float *gq = p.q + ((size_t)img * AT_N + q0 + srow) * p.ld_q + spc * 4;
+    const float *gk = p.k + ((size_t)img * AT_N + srow) * p.ld_k + spc * 4;
     const float *gv = p.vT + ((size_t)img * AT_C + srow) * AT_N + spc * 4;
     const int s_lds = srow * AT_LD + spc * 4;
 
@@ -68,7 +75,7 @@ __global__ __launch_bounds__(512, 2) void attn256_f32_kernel(const AttnParams p)
     // (piece j = 0..3: K / V^T rows srow + 64 j; piece 4: the Q row, phase A only)
     auto load_a1 = [&](int kc, int j) __attribute__((always_inline)) {  // phase A chunk kc
         if (j == 4) rq[kc & 1] = *reinterpret_cast<const af32x4 *>(gq + kc * 32);
-        else rb[kc & 1][j] = *reinterpret_cast<const af32x4 *>(gk + (size_t)j * 64 * p.ld_qk + kc * 32);
+        else rb[kc & 1][j] = *reinterpret_cast<const af32x4 *>(gk + (size_t)j * 64 * p.ld_k + kc * 32);
     };
     auto store_a1 = [&](int kc, int j) __attribute__((always_inline)) {  // ... into LDS stage kc & 1
         float *qs = smem + (kc & 1) * (AT_QST + AT_KST), *ks = qs + AT_QST;
@@ -226,15 +233,40 @@ __global__ __launch_bounds__(512, 2) void attn256_f32_kernel(const AttnParams p)
         __syncthreads();
     }
 
-    // ---- store: row = query, column = channel ----
+    // ---- epilogue: row = query, column = channel.  Element v of lane (li, lh): row 8 (v >> 2) + (v & 3) + 4 lh of the wave's 32 ----
+    float rv[2][16];
+    if (p.res) {  // all 32 residual values requested before any is consumed
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int col = wn * 64 + c * 32 + li;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int row = wm * 32 + 8 * (v >> 2) + (v & 3) + 4 * lh;
+                rv[c][v] = p.res[((size_t)img * AT_N + q0 + row) * p.ld_res + col];
+            }
+        }
+    }
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         const int col = wn * 64 + c * 32 + li;
         const float bv = p.bias ? p.bias[col] : 0.f;
+        float s = 0.f, q = 0.f;
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
             const int row = wm * 32 + 8 * (v >> 2) + (v & 3) + 4 * lh;
-            p.out[((size_t)img * AT_N + q0 + row) * p.ld_o + col] = acc[c][v] + bv;
+            float val = acc[c][v] + bv;
+            if (p.res) val += rv[c][v];
+            val *= p.out_scale;
+            p.out[((size_t)img * AT_N + q0 + row) * p.ld_o + col] = val;
+            s += val;
+            q += val * val;
+        }
+        if (p.qstats) {  // the wave's 32 rows are one slice; four consecutive columns = four consecutive lanes, rows + 4 in the other half-wave
+            s += __shfl_xor(s, 1); q += __shfl_xor(q, 1);
+            s += __shfl_xor(s, 2); q += __shfl_xor(q, 2);
+            s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
+            if ((li & 3) == 0 && lh == 0)
+                reinterpret_cast<float2 *>(p.qstats)[((size_t)img * (AT_N / 32) + ((q0 + wm * 32) >> 5)) * (AT_C / 4) + (col >> 2)] = make_float2(s, q);
         }
     }
 }
@@ -246,11 +278,13 @@ bool attn_fused_ok(int N, int C) {
 
 const char *attn_fused_name() { return "attn256_f32_kernel"; }
 
-int launch_attn_fused(const float *q, const float *k, int ld_qk, const float *vT, const float *bias, float *out, int ld_o, int batch,
-                      int N, int C, hipStream_t s) {
-    GD_CHECK(q && k && vT && out && N == AT_N && C == AT_C && ld_qk % 4 == 0 && batch >= 1, "attn_fused: unsupported problem (N=%d C=%d)", N, C);
+int launch_attn_fused(const float *q, int ld_q, const float *k, int ld_k, const float *vT, const float *bias, const float *res, int ld_res,
+                      float out_scale, float *qstats, float *out, int ld_o, int batch, int N, int C, hipStream_t s) {
+    GD_CHECK(q && k && vT && out && N == AT_N && C == AT_C && ld_q % 4 == 0 && ld_k % 4 == 0 && batch >= 1,
+             "attn_fused: unsupported problem (N=%d C=%d)", N, C);
     AttnParams p;
-    p.q = q; p.k = k; p.ld_qk = ld_qk; p.vT = vT; p.bias = bias; p.out = out; p.ld_o = ld_o;
+    p.q = q; p.k = k; p.ld_q = ld_q; p.ld_k = ld_k; p.vT = vT; p.bias = bias; p.res = res; p.ld_res = ld_res; p.out_scale = out_scale;
+    p.qstats = qstats; p.out = out; p.ld_o = ld_o;
     p.scale_log2e = (float)(1.0 / 16.0 * 1.4426950408889634);  // C^-1/2 = 1/16
     p.batch = batch;
     hipLaunchKernelGGL(attn256_f32_kernel, dim3(((batch + 7) / 8) * 8 * (AT_N / 64)), dim3(512), 0, s, p);

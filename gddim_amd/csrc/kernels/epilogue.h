@@ -19,12 +19,12 @@ __device__ __forceinline__ unsigned epi_div(unsigned n, unsigned d, unsigned mag
 // mbase / nbase: first row / column of the wave's (RM x RN) x 32 tile block (wave-uniform)
 template <int RM, int RN>
 __device__ __forceinline__ void epilogue_rows(const GemmParams &p, const epi_f32x16 (&acc)[RM][RN], int mbase, int nbase, int li,
-                                              int lh, bool no_store, float *out_base = nullptr) {
+                                              int lh, bool no_store, float *out_base = nullptr, int z = 0) {
     constexpr int OOB = (int)0x80000000u;
     char *outc = reinterpret_cast<char *>(out_base ? out_base : p.out);  // out_base: the z slice of a batched product
     const __amdgpu_buffer_rsrc_t srd_o = __builtin_amdgcn_make_buffer_rsrc(outc, 0, p.M * p.ldc * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t srd_r =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(reinterpret_cast<const char *>(p.res ? p.res : p.out)), 0,
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(reinterpret_cast<const char *>(p.res ? p.res + (size_t)z * p.sR : p.out)), 0,
                                           p.M * p.ldres * 4, 0x00020000);
     const unsigned rpi = p.rows_per_image;
     // all residual values of the wave's tile are requested at once (RM*RN*16 loads in flight) before any is consumed
@@ -88,7 +88,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams &p, const epi_f32
                     for (int v = 0; v < 16; ++v)
                         if (!nok || mrow + (v & 3) + 8 * (v >> 2) + 4 * lh >= p.M) vals[v] = 0.f;
                 }
-                emit_qstats(p, vals, mrow, n, nok, li, lh);
+                emit_qstats(p, vals, mrow, n, nok, li, lh, p.qstats + (size_t)z * p.sQ);
             }
         }
     }

@@ -268,6 +268,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_kernel(const GemmParam
     // Residual / per-image bias loads are issued 16 at a time (one 32x32 tile) before any is consumed, so the
     // epilogue pays one memory round trip per tile instead of one per element.
     float *outp = p.out + (size_t)z * p.sC;
+    const float *resp = p.res ? p.res + (size_t)z * p.sR : nullptr;
     const int rpi = p.rows_per_image;
 #pragma unroll
     for (int c = 0; c < RN; ++c) {
@@ -285,7 +286,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_kernel(const GemmParam
 #pragma unroll
                 for (int v = 0; v < 16; ++v) {
                     const int m = mb + (v & 3) + 8 * (v >> 2);
-                    const float *ptr = (nok && m < p.M) ? p.res + (size_t)m * p.ldres + n : p.res;
+                    const float *ptr = (nok && m < p.M) ? resp + (size_t)m * p.ldres + n : resp;
                     t[v] = *ptr;
                 }
 #pragma unroll
@@ -315,7 +316,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_kernel(const GemmParam
                 if (ok) outp[(size_t)m * p.ldc + n] = val;
                 vals[v] = ok ? val : 0.f;
             }
-            if (p.qstats) emit_qstats(p, vals, mb - 4 * lh, n, nok, li, lh);
+            if (p.qstats) emit_qstats(p, vals, mb - 4 * lh, n, nok, li, lh, p.qstats + (size_t)z * p.sQ);
         }
     }
 }
@@ -610,7 +611,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void igemm_f32_fast_kernel(const
         char *outc = reinterpret_cast<char *>(p.out + (size_t)z * p.sC);
         const __amdgpu_buffer_rsrc_t srd_o = __builtin_amdgcn_make_buffer_rsrc(outc, 0, p.M * p.ldc * 4, 0x00020000);
         const __amdgpu_buffer_rsrc_t srd_r =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(reinterpret_cast<const char *>(p.res ? p.res : p.out)), 0,
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(reinterpret_cast<const char *>(p.res ? p.res + (size_t)z * p.sR : p.out)), 0,
                                               p.M * p.ldres * 4, 0x00020000);
         const unsigned rpi = p.rows_per_image;
 #pragma unroll
@@ -689,7 +690,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void igemm_f32_fast_kernel(const
                         for (int v = 0; v < 16; ++v)
                             if (!nok || mrow + (v & 3) + 8 * (v >> 2) + 4 * lh >= p.M) vals[v] = 0.f;
                     }
-                    emit_qstats(p, vals, mrow, n, nok, li, lh);
+                    emit_qstats(p, vals, mrow, n, nok, li, lh, p.qstats + (size_t)z * p.sQ);
                 }
             }
         }
@@ -953,7 +954,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_pers_kernel(const Gemm
             char *outc = reinterpret_cast<char *>(p.out + (size_t)z_ep * p.sC);
             const __amdgpu_buffer_rsrc_t srd_o = __builtin_amdgcn_make_buffer_rsrc(outc, 0, p.M * p.ldc * 4, 0x00020000);
             const __amdgpu_buffer_rsrc_t srd_r =
-                __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(reinterpret_cast<const char *>(p.res ? p.res : p.out)), 0,
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(reinterpret_cast<const char *>(p.res ? p.res + (size_t)z_ep * p.sR : p.out)), 0,
                                                   p.M * p.ldres * 4, 0x00020000);
             const unsigned rpi = p.rows_per_image;
 #pragma unroll
@@ -1002,7 +1003,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_pers_kernel(const Gemm
                             for (int v = 0; v < 16; ++v)
                                 if (!nok || mrow + (v & 3) + 8 * (v >> 2) + 4 * lh >= p.M) vals[v] = 0.f;
                         }
-                        emit_qstats(p, vals, mrow, n, nok, li, lh);
+                        emit_qstats(p, vals, mrow, n, nok, li, lh, p.qstats + (size_t)z_ep * p.sQ);
                     }
                 }
             }

@@ -317,7 +317,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_bf16x3_kernel(const GemmPa
         if (sink == 1.2345e-30f) p.out[0] = sink;
     } else {
         epilogue_rows<RM, RN>(p, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), li, lh, DIAG && (dg & 1),
-                              BACT ? p.out + (size_t)z * p.sC : nullptr);
+                              BACT ? p.out + (size_t)z * p.sC : nullptr, BACT ? z : 0);
     }
 }
 
@@ -342,7 +342,8 @@ bool igemm_bf16x3_ok(const GemmParams &p, int batch_z) {
 bool igemm_bf16x3_act_ok(const GemmParams &p, int batch_z) {
     static const int off = getenv("GDDIM_X3_NOATTN") ? atoi(getenv("GDDIM_X3_NOATTN")) : 0;
     if (off || batch_z < 1 || p.b_kmajor || p.in_act || !p.b || p.a_presplit || p.C1 != 0 || p.KH != 1 || p.KW != 1) return false;
-    if (p.C0 % 32 != 0 || p.K != p.C0 || p.ldb % 4 != 0 || p.lda0 % 4 != 0 || p.rowbias || p.res || p.qstats) return false;
+    if (p.C0 % 32 != 0 || p.K != p.C0 || p.ldb % 4 != 0 || p.lda0 % 4 != 0 || p.rowbias) return false;
+    if (p.res && (long long)p.M * p.ldres * 4 + 64 >= (1LL << 31)) return false;
     if ((long long)((p.M + 255) / 256) * ((p.N + 127) / 128) * batch_z < 256) return false;  // only the 256x128 tile is instantiated
     const long long a_bytes = (long long)p.M * p.lda0 * 4 + 64, b_bytes = (long long)p.N * p.ldb * 4 + 64;
     return a_bytes + (long long)p.K * 4 < (1LL << 31) && b_bytes + (long long)p.K * 4 < (1LL << 31) &&

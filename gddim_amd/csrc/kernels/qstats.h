@@ -8,8 +8,10 @@
 
 namespace gd {
 
+// qbase: p.qstats advanced to the z slice of a batched product (p.sQ floats per slice); null = p.qstats
 __device__ __forceinline__ void emit_qstats(const GemmParams &p, const float (&vals)[16], int mrow, int n, bool nok, int li,
-                                            int lh) {
+                                            int lh, float *qbase = nullptr) {
+    float *const qs = qbase ? qbase : p.qstats;
     float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
 #pragma unroll
     for (int v = 0; v < 8; ++v) { s0 += vals[v]; q0 += vals[v] * vals[v]; }
@@ -24,13 +26,13 @@ __device__ __forceinline__ void emit_qstats(const GemmParams &p, const float (&v
         const int rpi = p.rows_per_image;
         if (rpi == 16) {
             const int img = mrow >> 4;
-            float2 *o = reinterpret_cast<float2 *>(p.qstats) + (size_t)img * Q + (n >> 2);
+            float2 *o = reinterpret_cast<float2 *>(qs) + (size_t)img * Q + (n >> 2);
             o[0] = make_float2(s0, q0);
             if (mrow + 16 < p.M) o[Q] = make_float2(s1, q1);
         } else {
             const int img = mrow / rpi;
             const int sl = (mrow - img * rpi) >> 5;
-            float2 *o = reinterpret_cast<float2 *>(p.qstats) + ((size_t)img * p.qs_slices + sl) * Q + (n >> 2);
+            float2 *o = reinterpret_cast<float2 *>(qs) + ((size_t)img * p.qs_slices + sl) * Q + (n >> 2);
             o[0] = make_float2(s0 + s1, q0 + q1);
         }
     }

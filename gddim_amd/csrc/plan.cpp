@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <sstream>
 
@@ -293,7 +294,140 @@ int Plan::resblock(int idx, int xa, int Ca, int xb, int Cb, int H, int W, int O,
 }
 
 // ---------------------------------------------------------------- AttnBlockpp (layerspp.py:61-83)
+// Folded form (default; GDDIM_NO_ATTN_FOLD=1 at engine creation keeps the four projections): two of the four C x C projections are
+// algebra, not work.  With q = h W_q + b_q, k = h W_k + b_k the score q_i . k_j = (h_i W_q + b_q) W_k^T h_j^T + (a term that depends on i
+// only and cancels in the softmax over j), so q' = h (W_q W_k^T) + W_k b_q meets k' = h, the GroupNorm output itself; and because
+// softmax rows sum to one, NIN_3(P (h W_v + b_v)) = P (h W_v W_3) + (b_v W_3 + b_3), so v'' = h (W_v W_3) and the output projection
+// disappears: residual, 1/sqrt(2) and the fused statistics move to the P v'' epilogue.  The products W_q W_k^T and W_v W_3 are formed
+// once per parameter load in float64 (Plan::fold_params) and rounded once.
 int Plan::attn(int idx, int x, int H, int W, int C) {
+    static const bool no_fold = getenv("GDDIM_NO_ATTN_FOLD") && atoi(getenv("GDDIM_NO_ATTN_FOLD")) != 0;
+    if (no_fold) return attn_unfolded(idx, x, H, W, C);
+    const std::string n = "AttnBlockpp_" + std::to_string(idx);
+    const int HW = H * W;
+    const float scale = desc.skip_rescale ? (float)(1.0 / std::sqrt(2.0)) : 1.f;
+    int hn = gn(n + ".gn", n + "/GroupNorm_0", x, C, -1, 0, H, W, 0);
+    AttnFold f;
+    f.C = C;
+    f.raw_w = new_slot(n + "/qkv_W", 3 * C, C); f.raw_b = new_slot(n + "/qkv_b", 1, 3 * C);
+    for (int i = 0; i < 3; ++i) {
+        add_param(n + "/NIN_" + std::to_string(i) + "/W", {C, C}, P_DENSE, f.raw_w, (long long)i * C);
+        add_param(n + "/NIN_" + std::to_string(i) + "/b", {C}, P_VEC, f.raw_b, (long long)i * C);
+    }
+    f.raw_wo = new_slot(n + "/NIN_3/W", C, C); f.raw_bo = new_slot(n + "/NIN_3/b", 1, C);
+    add_param(n + "/NIN_3/W", {C, C}, P_DENSE, f.raw_wo, 0);
+    add_param(n + "/NIN_3/b", {C}, P_VEC, f.raw_bo, 0);
+    f.fold_w = new_slot(n + "/fold_W", 2 * C, C); f.fold_b = new_slot(n + "/fold_b", 1, 2 * C);
+    attn_folds.push_back(f);
+    // q' = h (W_q W_k^T) + W_k b_q
+    int qp = new_tensor(n + ".qf", H, W, C);
+    {
+        Op g;
+        g.kind = OP_GEMM; g.label = n + ".q_proj";
+        g.a0 = {hn, 0}; g.C0 = C; g.lda0 = C; g.H = H; g.W = W; g.OH = H; g.OW = W;
+        g.m_per_image = HW; g.N = C; g.K = C; g.w_slot = f.fold_w; g.ldb = C; g.bias_slot = f.fold_b;
+        g.out = {qp, 0}; g.ldc = C;
+        g.flops_per_image = 2.0 * HW * C * C;
+        ops.push_back(g);
+    }
+    // v''^T[c][token] = sum_k (W_v W_3)[k][c] h[token][k], per image, k-contiguous for the P v'' product
+    int vT = new_tensor(n + ".vT", 1, 1, 1, EXT_NONE, (long long)C * HW);
+    {
+        Op g;
+        g.kind = OP_GEMM; g.label = n + ".v_proj_T";
+        g.a_slot = f.fold_w; g.a_off = (long long)C * C; g.C0 = C; g.lda0 = C; g.H = 1; g.W = C; g.OH = 1; g.OW = C;
+        g.m_per_image = C; g.z_per_image = 1; g.N = HW; g.K = C;
+        g.bten = {hn, 0}; g.ldb = C; g.b_kmajor = 0;
+        g.sA = 0; g.sB = (long long)HW * C; g.sC = (long long)C * HW;
+        g.out = {vT, 0}; g.ldc = HW;
+        g.flops_per_image = 2.0 * HW * C * C;
+        ops.push_back(g);
+    }
+    // w = softmax(q' h^T * C^-1/2)
+    int S = new_tensor(n + ".scores", 1, 1, 1, EXT_NONE, (long long)HW * HW);
+    {
+        Op g;
+        g.kind = OP_GEMM; g.label = n + ".qk";
+        g.a0 = {qp, 0}; g.C0 = C; g.lda0 = C; g.H = 1; g.W = HW; g.OH = 1; g.OW = HW;
+        g.m_per_image = HW; g.z_per_image = 1; g.N = HW; g.K = C;
+        g.bten = {hn, 0}; g.ldb = C; g.b_kmajor = 0;
+        g.sA = (long long)HW * C; g.sB = g.sA; g.sC = (long long)HW * HW;
+        g.out = {S, 0}; g.ldc = HW; g.alpha = (float)std::pow((double)C, -0.5);
+        g.flops_per_image = 2.0 * HW * HW * C;
+        ops.push_back(g);
+        Op sm;
+        sm.kind = OP_SOFTMAX; sm.label = n + ".softmax"; sm.out = {S, 0}; sm.rows_per_image = HW; sm.cols = HW;
+        ops.push_back(sm);
+    }
+    release(qp);
+    release(hn);
+    // (x + w v'' + (b_v W_3 + b_3)) / sqrt(2), with the statistics of the block output
+    int out = new_tensor(n + ".out", H, W, C);
+    attach_stats(out, HW);
+    {
+        Op g;
+        g.kind = OP_GEMM; g.label = n + ".av";
+        g.a0 = {S, 0}; g.C0 = HW; g.lda0 = HW; g.H = 1; g.W = HW; g.OH = 1; g.OW = HW;
+        g.m_per_image = HW; g.z_per_image = 1; g.N = C; g.K = HW;
+        g.bten = {vT, 0}; g.ldb = HW; g.b_kmajor = 0;
+        g.sA = (long long)HW * HW; g.sB = (long long)C * HW; g.sC = (long long)HW * C;
+        g.bias_slot = f.fold_b; g.bias_off = C;
+        g.res = {x, 0}; g.ldres = C; g.sR = (long long)HW * C;
+        g.out = {out, 0}; g.ldc = C; g.out_scale = scale;
+        if (tensors[out].stats_t >= 0) {
+            g.qstats = {tensors[out].stats_t, 0}; g.qs_slices = tensors[out].qs_slices;
+            g.sQ = (long long)g.qs_slices * (C / 4) * 2;
+        }
+        g.flops_per_image = 2.0 * HW * HW * C;
+        ops.push_back(g);
+    }
+    release(S);
+    release(vT);
+    folded_flops_per_image += 2 * (2.0 * HW * C * C);  // NIN_1 (k) and NIN_3 (output) of the reference
+    return out;
+}
+
+void Plan::fold_params() {
+    for (const AttnFold &f : attn_folds) {
+        const int C = f.C;
+        const std::vector<float> &w = slots[f.raw_w].host, &b = slots[f.raw_b].host, &wo = slots[f.raw_wo].host, &bo = slots[f.raw_bo].host;
+        std::vector<float> &fw = slots[f.fold_w].host, &fb = slots[f.fold_b].host;
+        const float *Q = w.data(), *K = w.data() + (size_t)C * C, *V = w.data() + 2 * (size_t)C * C;  // row m = W[:, m]
+        std::vector<double> acc((size_t)C * C);
+        // rows 0..C-1: fold[c'][i] = sum_m W_q[i][m] W_k[c'][m] = sum_m Q[m][i] K[m][c']
+        std::fill(acc.begin(), acc.end(), 0.0);
+        for (int m = 0; m < C; ++m)
+            for (int c = 0; c < C; ++c) {
+                const double kc = K[(size_t)m * C + c];
+                double *a = acc.data() + (size_t)c * C;
+                const float *q = Q + (size_t)m * C;
+                for (int i = 0; i < C; ++i) a[i] += kc * (double)q[i];
+            }
+        for (size_t i = 0; i < (size_t)C * C; ++i) fw[i] = (float)acc[i];
+        for (int c = 0; c < C; ++c) {  // b'[c'] = sum_m b_q[m] W_k[c'][m]
+            double s = 0;
+            for (int m = 0; m < C; ++m) s += (double)b[m] * (double)K[(size_t)m * C + c];
+            fb[c] = (float)s;
+        }
+        // rows C..2C-1: fold[C + c][k] = sum_m W_v[k][m] W_3[m][c] = sum_m V[m][k] wo[c][m]
+        std::fill(acc.begin(), acc.end(), 0.0);
+        for (int c = 0; c < C; ++c)
+            for (int m = 0; m < C; ++m) {
+                const double w3 = wo[(size_t)c * C + m];
+                double *a = acc.data() + (size_t)c * C;
+                const float *v = V + (size_t)m * C;
+                for (int k = 0; k < C; ++k) a[k] += w3 * (double)v[k];
+            }
+        for (size_t i = 0; i < (size_t)C * C; ++i) fw[(size_t)C * C + i] = (float)acc[i];
+        for (int c = 0; c < C; ++c) {  // b''[c] = sum_m b_v[m] W_3[m][c] + b_3[c]
+            double s = bo[c];
+            for (int m = 0; m < C; ++m) s += (double)b[2 * C + m] * (double)wo[(size_t)c * C + m];
+            fb[C + c] = (float)s;
+        }
+    }
+}
+
+int Plan::attn_unfolded(int idx, int x, int H, int W, int C) {
     const std::string n = "AttnBlockpp_" + std::to_string(idx);
     const int HW = H * W;
     const float scale = desc.skip_rescale ? (float)(1.0 / std::sqrt(2.0)) : 1.f;
@@ -616,6 +750,7 @@ int Plan::build(const gd_model_desc &d) {
         flops_per_image += o.flops_per_image;
         if (o.is_conv3x3) conv3x3_flops_per_image += o.flops_per_image;
     }
+    flops_per_image += folded_flops_per_image;  // (the reference multiplies them; the price of an evaluation is the reference's)
     return 0;
 }
 
@@ -768,7 +903,7 @@ std::string Plan::json() const {
     std::ostringstream o;
     o.precision(9);
     o << "{\"CP\":" << CP << ",\"arena_per_image\":" << arena_per_image << ",\"flops_per_image\":" << flops_per_image
-      << ",\"conv3x3_flops_per_image\":" << conv3x3_flops_per_image << ",\"gn_max_slices\":" << GN_MAX_SLICES
+      << ",\"conv3x3_flops_per_image\":" << conv3x3_flops_per_image << ",\"folded_flops_per_image\":" << folded_flops_per_image << ",\"gn_max_slices\":" << GN_MAX_SLICES
       << ",\"tensors\":[";
     for (size_t i = 0; i < tensors.size(); ++i) {
         const Tensor &t = tensors[i];
@@ -791,7 +926,7 @@ std::string Plan::json() const {
           << ",\"stride\":" << p.stride << ",\"pad\":" << p.pad << ",\"m_per_image\":" << p.m_per_image
           << ",\"z_per_image\":" << p.z_per_image << ",\"N\":" << p.N << ",\"K\":" << p.K << ",\"a_slot\":" << p.a_slot << ",\"a_off\":" << p.a_off << ",\"w_slot\":" << p.w_slot
           << ",\"ldb\":" << p.ldb << ",\"b_kmajor\":" << p.b_kmajor << ",\"sA\":" << p.sA << ",\"sB\":" << p.sB
-          << ",\"sC\":" << p.sC << ",\"bias_slot\":" << p.bias_slot << ",\"bias_off\":" << p.bias_off
+          << ",\"sC\":" << p.sC << ",\"sR\":" << p.sR << ",\"sQ\":" << p.sQ << ",\"bias_slot\":" << p.bias_slot << ",\"bias_off\":" << p.bias_off
           << ",\"ld_rowbias\":" << p.ld_rowbias << ",\"ldres\":" << p.ldres << ",\"ldc\":" << p.ldc << ",\"alpha\":" << p.alpha
           << ",\"out_scale\":" << p.out_scale << ",\"in_act\":" << p.in_act << ",\"qs_slices\":" << p.qs_slices << ",\"S0\":" << p.S0 << ",\"S1\":" << p.S1 << ",\"groups\":" << p.groups
           << ",\"act\":" << p.act << ",\"gamma_slot\":" << p.gamma_slot << ",\"beta_slot\":" << p.beta_slot

@@ -65,6 +65,7 @@ struct Op {
     TRef bten;            // ... or from a tensor
     int ldb = 0, b_kmajor = 0;
     long long sA = 0, sB = 0, sC = 0;  // per-image strides when z_per_image
+    long long sR = 0, sQ = 0;          // ... of the residual and of the fused statistics (floats), when z_per_image
     int bias_slot = -1;
     int bias_off = 0;
     TRef rowbias;
@@ -138,6 +139,15 @@ struct Param {
     bool loaded = false;
 };
 
+// An attention block whose four NIN projections are folded into two at parameter-load time (Plan::attn): the checkpoint's
+// NIN_0..3 land in the raw slots, Plan::fold_params writes the derived ones the GEMMs read.
+struct AttnFold {
+    int C = 0;
+    int raw_w = -1, raw_b = -1;    // [3C][C] rows q | k | v (row o = W[:, o]) and [3C] biases
+    int raw_wo = -1, raw_bo = -1;  // NIN_3: [C][C], [C]
+    int fold_w = -1, fold_b = -1;  // [2C][C]: rows 0..C-1 of W_q W_k^T (row c' = column c'), rows C..2C-1 of (W_v W_3)^T ; [2C] biases
+};
+
 struct Plan {
     gd_model_desc desc{};
     int CP = 0;  // U-Net input channels padded to a multiple of 4
@@ -149,6 +159,11 @@ struct Plan {
     long long arena_per_image = 0;  // floats
     int t_x_in = -1, t_labels = -1, t_eps_out = -1;
     double flops_per_image = 0, conv3x3_flops_per_image = 0;
+    // algorithmic flops of the reference the engine does not issue: the k and output projections of the folded attention blocks
+    // (Plan::attn).  flops_per_image (what bench.py prices) includes them; the ops' own flops_per_image are what they really multiply.
+    double folded_flops_per_image = 0;
+    std::vector<AttnFold> attn_folds;
+    void fold_params();  // derived weight slots from the loaded ones (float64 on the host); call once all parameters are loaded
 
     int build(const gd_model_desc &d);  // 0 ok
     void mark_split();
@@ -177,6 +192,7 @@ struct Plan {
     void attach_stats(int t, int rows_per_image);
     int resblock(int idx, int xa, int Ca, int xb, int Cb, int H, int W, int O, bool up, bool down, int &outH);
     int attn(int idx, int x, int H, int W, int C);
+    int attn_unfolded(int idx, int x, int H, int W, int C);
     int temb_t_ = -1, tproj_t_ = -1, tproj_slot_w_ = -1, tproj_slot_b_ = -1;
     std::vector<int> rb_tproj_off_;
     int sum_cout_ = 0;

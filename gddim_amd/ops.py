@@ -207,6 +207,22 @@ def attention_fused(qk, vT, bias_v=None):
     return out
 
 
+def attention_block_fused(q, k, vT, bias=None, res=None, out_scale=1.0, want_stats=False):
+    """(res + softmax(q k^T C^-1/2) v + bias) * out_scale in one launch: q, k, res (B,N,C), vT (B,C,N); with want_stats also the fused
+    GroupNorm statistics (B, N/32, C/4, 2) of the result.  N = C = 256 only (gd_attention_block_fused)."""
+    import torch
+    _need_gpu(q)
+    q, k, vT = _f32c(q), _f32c(k), _f32c(vT)
+    B, N, C = q.shape
+    out = torch.empty((B, N, C), dtype=torch.float32, device=q.device)
+    bias = _f32c(bias) if bias is not None else None
+    res = _f32c(res) if res is not None else None
+    qs = torch.empty((B, N // 32, C // 4, 2), dtype=torch.float32, device=q.device) if want_stats else None
+    check(_abi.lib().gd_attention_block_fused(_ptr(q), _ptr(k), _ptr(vT), _ptr(bias), _ptr(res), float(out_scale), _ptr(qs), _ptr(out),
+                                              B, N, C, _stream(q)))
+    return (out, qs) if want_stats else out
+
+
 def randn_pairs(n_pairs, seed, draw=0, elem0=0, device=None):
     """(n_pairs, 2) standard normals from the engine's counter-based generator (gd_randn_pairs)."""
     import torch

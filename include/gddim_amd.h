@@ -291,6 +291,14 @@ int gd_attention(const float *qkv_dev, float *scratch_dev, float *out_dev, int b
  * Replaces: the same call site (cld_jax/models/layerspp.py:74-78). */
 int gd_attention_fused(const float *qk_dev, const float *vT_dev, const float *bias_v_dev, float *out_dev, int batch, int N, int C,
                        void *stream);
+/* The whole tail of AttnBlockpp in that launch, as the engine runs it after folding the projections at parameter-load time (W_q W_k^T
+ * into the query projection, W_v W_3 into the value projection: the key is the GroupNorm output itself and NIN_3 disappears):
+ *   out (B,N,C) = (res + softmax(q k^T C^-1/2) v + bias) * out_scale,   q_dev, k_dev, res_dev, out_dev (B,N,C) row-major, vT_dev (B,C,N);
+ * bias_dev (C), res_dev, qstats_dev optional (null).  qstats_dev (B, N/32, C/4, 2) receives the fused GroupNorm statistics of out: sum
+ * and sum of squares over each 32-token slice of every four consecutive channels.  N = C = 256 only.
+ * Replaces: cld_jax/models/layerspp.py:74-83 (einsums, softmax, NIN_3, skip_rescale residual). */
+int gd_attention_block_fused(const float *q_dev, const float *k_dev, const float *vT_dev, const float *bias_dev, const float *res_dev,
+                             float out_scale, float *qstats_dev, float *out_dev, int batch, int N, int C, void *stream);
 
 #ifdef __cplusplus
 }

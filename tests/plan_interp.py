@@ -122,7 +122,7 @@ class PlanInterp(object):
                 rb = self._rows(self._flat(op["rowbias"], B), B, op["ld_rowbias"], N)
                 acc = acc + rb.repeat_interleave(op["m_per_image"], dim=0)
             if op["res"][0] >= 0:
-                acc = acc + self._rows(self._flat(op["res"], B), Mz, op["ldres"], N)
+                acc = acc + self._rows(self._flat(op["res"], B)[z * op["sR"]:], Mz, op["ldres"], N)
             oflat = self._flat(op["out"], B)[z * op["sC"]:]
             res_out = acc * op["out_scale"]
             self._rows(oflat, Mz, op["ldc"], N)[:] = res_out
@@ -131,9 +131,11 @@ class PlanInterp(object):
                 # 16 rows), per 4 consecutive channels: (sum, sum of squares)
                 rpi, S, Q = op["m_per_image"], op["qs_slices"], N // 4
                 rows_per_slice = 32 if rpi % 32 == 0 else rpi
-                assert S == rpi // rows_per_slice and not op["z_per_image"]
-                v = res_out.reshape(B, S, rows_per_slice, Q, 4)
-                qs = self._rows(self._flat(op["qstats"], B), B * S * Q, 2, 2).reshape(B, S, Q, 2)
+                assert S == rpi // rows_per_slice
+                nb = 1 if op["z_per_image"] else B  # a batched product writes the slices of image z at z * sQ
+                assert not op["z_per_image"] or op["sQ"] == S * Q * 2
+                v = res_out.reshape(nb, S, rows_per_slice, Q, 4)
+                qs = self._rows(self._flat(op["qstats"], B)[z * op["sQ"]:], nb * S * Q, 2, 2).reshape(nb, S, Q, 2)
                 qs[..., 0] = v.sum(dim=(2, 4))
                 qs[..., 1] = (v * v).sum(dim=(2, 4))
 

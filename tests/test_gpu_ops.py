@@ -496,3 +496,30 @@ def test_attention_fused_matches_float64(dev):
     assert err < 2e-5 and err < 4 * err3 + 1e-6
     with pytest.raises(GddimError):
         ops.attention_fused(torch.zeros(1, 64, 512, device=dev), torch.zeros(1, 256, 64, device=dev))
+
+
+def test_attention_block_fused_epilogue(dev):
+    """gd_attention_block_fused: the fused core with separate q / k tensors and the block tail in its epilogue -- bias, residual,
+    1/sqrt(2) and the GroupNorm quad statistics of the result (kernels/qstats.h layout) -- against float64; a batch that is not a
+    multiple of the 8 images one XCD round holds."""
+    from gddim_amd import ops
+    B, N, C = 11, 256, 256
+    g = torch.Generator().manual_seed(11)
+    q = torch.randn(B, N, C, generator=g) * 1.5
+    k = torch.randn(B, N, C, generator=g)
+    v = torch.randn(B, N, C, generator=g)
+    bias = torch.randn(C, generator=g)
+    res = torch.randn(B, N, C, generator=g) * 2
+    sc = 2 ** -0.5
+    out, qs = ops.attention_block_fused(q.to(dev), k.to(dev), v.transpose(1, 2).contiguous().to(dev), bias.to(dev), res.to(dev), sc, want_stats=True)
+    w = torch.softmax(torch.einsum("bic,bjc->bij", q.double(), k.double()) * C ** -0.5, dim=-1)
+    want = (res.double() + torch.einsum("bij,bjc->bic", w, v.double()) + bias.double()) * sc
+    err = (out.cpu().double() - want).abs().max().item()
+    wv = want.reshape(B, N // 32, 32, C // 4, 4)
+    ws, wq = wv.sum(dim=(2, 4)), (wv * wv).sum(dim=(2, 4))
+    es = (qs[..., 0].cpu().double() - ws).abs().max().item()
+    eq = ((qs[..., 1].cpu().double() - wq).abs() / wq).max().item()
+    print("attention block epilogue: max|d| %.2e, statistics |d sum| %.2e, rel d sumsq %.2e" % (err, es, eq))
+    assert err < 2e-5 and es < 2e-3 and eq < 1e-5
+    plain = ops.attention_block_fused(q.to(dev), k.to(dev), v.transpose(1, 2).contiguous().to(dev))  # no bias, residual, statistics
+    assert (plain.cpu().double() - torch.einsum("bij,bjc->bic", w, v.double())).abs().max().item() < 2e-5
