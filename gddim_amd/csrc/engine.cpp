@@ -172,26 +172,53 @@ static std::string label_class(const Op &op) {
     return r + buf;
 }
 
-// GemmParams of a GEMM op for this batch; returns the z-batch count
-static int fill_gemm(gd_engine *e, const Op &op, const Bind &b, int batch, GemmParams &g) {
-    g.a0 = op.a_slot >= 0 ? slot_ptr(e, op.a_slot) + op.a_off : tptr(e, b, op.a0, batch);
-    g.a1 = tptr(e, b, op.a1, batch);
+// pointer of a tensor reference advanced to image i0 of the batch (tensors are stored image after image, per_image floats each)
+static float *tptr_at(gd_engine *e, const Bind &b, const TRef &r, int batch, int i0) {
+    float *p = tptr(e, b, r, batch);
+    return p && i0 ? p + (size_t)i0 * e->plan.tensors[r.t].per_image : p;
+}
+
+// The buffer-addressed kernels (Winograd, fast / persistent GEMM) reach 2 GiB per operand.  A weight GEMM over a larger tensor -- the
+// 256-channel tensors of the 64x64 level at batch 512 are exactly 2 GiB -- runs as several launches over image sub-ranges instead of
+// falling back to the 64-bit-addressed generic kernel (images are independent rows of the GEMM).  Returns the number of launches.
+static int gemm_parts(const gd_engine *e, const Op &op, int batch) {
+    if (e->precision != 0 || op.kind != OP_GEMM || op.z_per_image || op.w_slot < 0 || op.a_slot >= 0 || batch < 2) return 1;
+    long long per = (long long)op.H * op.W * std::max(op.lda0, op.C1 > 0 ? op.lda1 : 0) * 4;
+    per = std::max(per, (long long)op.m_per_image * op.ldc * 4);
+    if (op.res.t >= 0) per = std::max(per, (long long)op.m_per_image * op.ldres * 4);
+    const long long limit = (1LL << 31) - (8LL << 20);  // (the kernels' own tests add halo rows and a few cache lines)
+    int parts = 1;
+    while (parts < batch && (long long)((batch + parts - 1) / parts) * per >= limit) ++parts;
+    return parts;
+}
+
+// GemmParams of a GEMM op for images [i0, i0 + nb) of this batch (nb < 0: the whole batch); returns the z-batch count
+static int fill_gemm(gd_engine *e, const Op &op, const Bind &b, int batch, GemmParams &g, int i0 = 0, int nb = -1) {
+    if (nb < 0) nb = batch;
+    g.a0 = op.a_slot >= 0 ? slot_ptr(e, op.a_slot) + op.a_off : tptr_at(e, b, op.a0, batch, i0);
+    g.a1 = tptr_at(e, b, op.a1, batch, i0);
     g.C0 = op.C0; g.C1 = op.C1; g.lda0 = op.lda0; g.lda1 = op.lda1 ? op.lda1 : 4;
     g.H = op.H; g.W = op.W; g.OH = op.OH; g.OW = op.OW; g.KH = op.KH; g.KW = op.KW; g.stride = op.stride; g.pad = op.pad;
     g.N = op.N; g.K = op.K;
     int z = 1;
-    if (op.z_per_image) { g.M = op.m_per_image; z = batch; g.sA = op.sA; g.sB = op.sB; g.sC = op.sC; }
-    else g.M = op.m_per_image * batch;
+    if (op.z_per_image) { g.M = op.m_per_image; z = nb; g.sA = op.sA; g.sB = op.sB; g.sC = op.sC; }
+    else g.M = op.m_per_image * nb;
     if (op.w_slot >= 0) g.b = slot_ptr(e, op.w_slot);
-    else g.b = tptr(e, b, op.bten, batch);
+    else g.b = tptr_at(e, b, op.bten, batch, i0);
     g.ldb = op.ldb; g.b_kmajor = op.b_kmajor;
-    g.out = tptr(e, b, op.out, batch); g.ldc = op.ldc;
+    g.out = tptr_at(e, b, op.out, batch, i0); g.ldc = op.ldc;
     g.bias = op.bias_slot >= 0 ? slot_ptr(e, op.bias_slot) + op.bias_off : nullptr;
-    g.rowbias = tptr(e, b, op.rowbias, batch); g.ld_rowbias = op.ld_rowbias; g.rows_per_image = op.m_per_image;
-    g.res = tptr(e, b, op.res, batch); g.ldres = op.ldres; g.sR = op.sR; g.sQ = op.sQ;
+    g.rowbias = tptr_at(e, b, op.rowbias, batch, i0); g.ld_rowbias = op.ld_rowbias; g.rows_per_image = op.m_per_image;
+    g.res = tptr_at(e, b, op.res, batch, i0); g.ldres = op.ldres; g.sR = op.sR; g.sQ = op.sQ;
     g.alpha = op.alpha; g.out_scale = op.out_scale; g.in_act = op.in_act;
-    g.qstats = tptr(e, b, op.qstats, batch); g.qs_slices = op.qs_slices;
+    g.qstats = tptr_at(e, b, op.qstats, batch, i0); g.qs_slices = op.qs_slices;
     return z;
+}
+
+// ... of the launch that covers the first image: what the per-batch-size kernel choices below are made on
+static int fill_gemm_first(gd_engine *e, const Op &op, const Bind &b, int batch, GemmParams &g) {
+    const int parts = gemm_parts(e, op, batch);
+    return fill_gemm(e, op, b, batch, g, 0, (batch + parts - 1) / parts);
 }
 
 // ALGORITHMIC HBM bytes of a GEMM launch (bench.py: roofline.algorithmic_bytes): every operand once -- the input pixels (not the
@@ -251,9 +278,9 @@ static bool gn_fused(gd_engine *e, const Bind &b, int batch, int gemm_index) {
 // Epilogue GroupNorm (plan.h: Op::egn_peer), fp32 mode: taken when, at this batch size, the kernel the GEMM runs on implements it
 // (the two-dimensional Winograd kernel on 16x16 / 8x8 images, a 64-pair one-dimensional tile on 8x8 images, igemm_f32_fast_kernel on 4x4 images).  Fills the egn_* fields of g.  Decided once per
 // batch size; GDDIM_NO_EGN=1 switches it off (A/B).
-static void fill_egn(gd_engine *e, const Op &op, const Bind &b, int batch, GemmParams &g) {
+static void fill_egn(gd_engine *e, const Op &op, const Bind &b, int batch, GemmParams &g, int i0 = 0) {
     const Op &a = e->plan.ops[op.egn_peer];
-    g.egn_out = tptr(e, b, a.out, batch);
+    g.egn_out = tptr_at(e, b, a.out, batch, i0);
     g.egn_gamma = slot_ptr(e, a.gamma_slot);
     g.egn_beta = slot_ptr(e, a.beta_slot);
     g.egn_cpg = a.C0 / a.groups;
@@ -271,7 +298,7 @@ static bool egn_fused(gd_engine *e, const Bind &b, int batch, int gemm_index) {
             const Op &op = e->plan.ops[i];
             if (op.kind != OP_GEMM || op.egn_peer < 0) continue;
             GemmParams g{};
-            const int z = fill_gemm(e, op, b, batch, g);
+            const int z = fill_gemm_first(e, op, b, batch, g);
             fill_egn(e, op, b, batch, g);
             const bool wino2 = z == 1 && op.w_slot >= 0 && e->wwino2 && e->wino2_off[op.w_slot] >= 0;
             const bool wino42 = z == 1 && op.w_slot >= 0 && e->wwino42 && e->wino42_off[op.w_slot] >= 0;
@@ -289,11 +316,11 @@ static bool egn_fused(gd_engine *e, const Bind &b, int batch, int gemm_index) {
 // GroupNorm as a side output of the shortcut convolution (plan.h: Op::side_peer), fp32 mode: taken when, at this batch size, the 1x1
 // convolution runs on the persistent short-K kernel and the GroupNorm is not already written by its producer's epilogue.  Decided once
 // per batch size; GDDIM_NO_SIDE_GN=1 switches it off (A/B).
-static void fill_side(gd_engine *e, const Op &op, const Bind &b, int batch, GemmParams &g) {
+static void fill_side(gd_engine *e, const Op &op, const Bind &b, int batch, GemmParams &g, int i0 = 0) {
     const Op &a = e->plan.ops[op.side_peer];
-    g.gn_table = tptr(e, b, a.gn_table, batch);
+    g.gn_table = tptr_at(e, b, a.gn_table, batch, i0);
     g.gn_act = a.act;
-    g.gn_side_out = tptr(e, b, a.out, batch);
+    g.gn_side_out = tptr_at(e, b, a.out, batch, i0);
 }
 
 static bool side_fused(gd_engine *e, const Bind &b, int batch, int gemm_index) {
@@ -315,7 +342,7 @@ static bool side_fused(gd_engine *e, const Bind &b, int batch, int gemm_index) {
             if (op.side_peer != (int)i + 1 || a.stats.t < 0 || (a.C1 > 0 && a.stats1.t < 0)) continue;
             if (a.egn_peer >= 0 && egn_fused(e, b, batch, a.egn_peer)) continue;  // its producer writes it already
             GemmParams g{};
-            const int z = fill_gemm(e, op, b, batch, g);
+            const int z = fill_gemm_first(e, op, b, batch, g);
             fill_side(e, op, b, batch, g);
             ok[i] = igemm_gn_side_ok(g, z) ? 1 : 0;
         }
@@ -365,13 +392,88 @@ static bool attn_core_at(const gd_engine *e, int i) {
 static int launch_apply_op(gd_engine *e, const Op &op, const Bind &b, int batch, bool table_only, hipStream_t s) {
     const int HW = op.H * op.W;
     const int rt = gn_slices(batch, HW);
-    ProfScope ps(e, s, table_only ? "gn_table" : "gn_apply", 0, table_only ? 0.0 : 8.0 * batch * HW * (op.C0 + op.C1));
+    static const bool by_label = getenv("GD_PROF_BY_LABEL") != nullptr;
+    ProfScope ps(e, s, !e->prof ? std::string() : by_label ? std::string(table_only ? "gn_table:" : "gn_apply:") + label_class(op) : std::string(table_only ? "gn_table" : "gn_apply"), 0,
+                 table_only ? 0.0 : 8.0 * batch * HW * (op.C0 + op.C1));
     return launch_gn_apply(tptr(e, b, op.a0, batch), op.C0, tptr(e, b, op.a1, batch), op.C1, tptr(e, b, op.stats, batch),
                            op.S0 > 0 ? op.S0 : rt, tptr(e, b, op.stats1, batch), op.S1 > 0 ? op.S1 : rt,
                            slot_ptr(e, op.gamma_slot), slot_ptr(e, op.beta_slot), tptr(e, b, op.out, batch), batch, HW,
                            op.groups, op.act, 1e-6f,
                            (e->precision == 1 && e->wsplit_valid && op.split_out && presplit_allowed(e, b, batch, op.out.t)) ? 1 : 0,
                            table_only ? tptr(e, b, op.gn_table, batch) : nullptr, s);
+}
+
+// One launch of a GEMM op over images [i0, i0 + nb) of the batch (run_op: the whole batch, or one of gemm_parts sub-ranges).  The
+// kernel choices that other ops depend on (egn_fused, side_fused, gn_fused) are keyed by the FULL batch size.
+static int run_gemm(gd_engine *e, int op_index, const Bind &b, int batch, int i0, int nb, bool first, hipStream_t s) {
+    const Op &op = e->plan.ops[op_index];
+    const Plan &P = e->plan;
+    static const bool by_label = getenv("GD_PROF_BY_LABEL") != nullptr;
+    GemmParams g{};
+    const int z = fill_gemm(e, op, b, batch, g, i0, nb);
+    if (e->precision == 1 && op.w_slot >= 0 && e->wsplit_valid) {
+        g.b_hi = e->wsplit_hi + e->slot_off[op.w_slot];
+        g.b_lo = e->wsplit_lo + e->slot_off[op.w_slot];
+        g.a_presplit = op.a_split && presplit_allowed(e, b, batch, op.a0.t);
+        GD_CHECK(!g.a_presplit || igemm_bf16x3_ok(g, z), "%s: pre-split input but the GEMM is not eligible for bf16x3", op.label.c_str());
+        if (op.fuse_peer >= 0 && gn_fused(e, b, batch, op_index)) {
+            g.a0 = tptr(e, b, op.gn_src, batch);  // the raw input(s) of the GroupNorm
+            g.a1 = tptr(e, b, op.gn_src1, batch);
+            g.C0 = op.gn_C0; g.C1 = op.gn_C1; g.lda0 = op.gn_C0; g.lda1 = op.gn_C1 ? op.gn_C1 : 4;
+            g.a_presplit = 0;
+            g.gn_table = tptr(e, b, op.gn_table, batch);
+            g.gn_act = e->plan.ops[op.fuse_peer].act;
+            ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(conv3x3_halo_fused_name()), op.flops_per_image * nb, gemm_alg_bytes(g, z));
+            return launch_conv3x3_halo(g, s);
+        }
+        if (z == 1 && conv3x3_halo_ok(g)) {
+            ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(conv3x3_halo_name()), op.flops_per_image * nb, gemm_alg_bytes(g, z));
+            return launch_conv3x3_halo(g, s);
+        }
+        if (igemm_bf16x3_ok(g, z)) {
+            ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(igemm_bf16x3_name(g)), op.flops_per_image * nb, gemm_alg_bytes(g, z));
+            return launch_igemm_bf16x3(g, s);
+        }
+        g.b_hi = g.b_lo = nullptr;
+    }
+    GD_CHECK(!g.a_presplit, "%s: pre-split input without a split-precision kernel", op.label.c_str());
+    if (op.egn_peer >= 0 && egn_fused(e, b, batch, op_index)) fill_egn(e, op, b, batch, g, i0);
+    if (e->precision == 1 && op.w_slot < 0 && igemm_bf16x3_act_ok(g, z)) {  // attention products: activation x activation
+        ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string("igemm_bf16x3_kernel<256,128,4,2,act>"), op.flops_per_image * nb, gemm_alg_bytes(g, z));
+        return launch_igemm_bf16x3_act(g, z, s);
+    }
+    if (e->precision == 0 && z == 1 && op.w_slot >= 0 && e->wwino42 && e->wino42_off[op.w_slot] >= 0 && conv3x3_wino42_ok(g)) {
+        g.b_wino = e->wwino42 + e->wino42_off[op.w_slot];
+        ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(conv3x3_wino42_name()), op.flops_per_image * nb, gemm_alg_bytes(g, z));
+        return launch_conv3x3_wino42(g, s);
+    }
+    if (e->precision == 0 && z == 1 && op.w_slot >= 0 && e->wwino2 && e->wino2_off[op.w_slot] >= 0 && conv3x3_wino2d_ok(g)) {
+        g.b_wino = e->wwino2 + e->wino2_off[op.w_slot];
+        ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(conv3x3_wino2d_name()), op.flops_per_image * nb, gemm_alg_bytes(g, z));
+        return launch_conv3x3_wino2d(g, s);
+    }
+    if (e->precision == 0 && z == 1 && op.w_slot >= 0 && e->wwino2 && e->wino2_off[op.w_slot] >= 0 && e->splitk_ws &&
+        conv3x3_wino2d_splitk_factor(g) > 1) {  // 4x4 images: the channel range split over workgroups + a finishing pass
+        g.b_wino = e->wwino2 + e->wino2_off[op.w_slot];
+        const long long img0 = (long long)(b.arena - e->arena) / e->plan.arena_per_image + i0;  // first image of this sub-batch (lanes)
+        g.wk_partial = e->splitk_ws + img0 * e->splitk_per_image;
+        GD_CHECK(img0 * e->splitk_per_image + (long long)conv3x3_wino2d_splitk_factor(g) * g.M * g.N <= e->splitk_ws_floats,
+                 "%s: split-K scratch too small", op.label.c_str());
+        ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(conv3x3_wino2d_splitk_name()), op.flops_per_image * nb, gemm_alg_bytes(g, z));
+        return launch_conv3x3_wino2d_splitk(g, s);
+    }
+    if (e->precision == 0 && z == 1 && op.w_slot >= 0 && e->wwino && e->wino_off[op.w_slot] >= 0 && conv3x3_wino_ok(g)) {
+        g.b_wino = e->wwino + e->wino_off[op.w_slot];
+        ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(conv3x3_wino_name(g)), op.flops_per_image * nb, gemm_alg_bytes(g, z));
+        return launch_conv3x3_wino(g, s);
+    }
+    if (op.side_peer >= 0 && side_fused(e, b, batch, op_index)) {  // the per-image affine table first, then the GEMM whose loader applies it
+        if (first) GD_TRY(launch_apply_op(e, P.ops[op.side_peer], b, batch, true, s));  // (the table of the whole batch)
+        fill_side(e, op, b, batch, g, i0);
+    }
+    ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(igemm_variant_name(g, z)) + (g.gn_side_out ? "+gn" : ""),
+                 op.flops_per_image * nb, gemm_alg_bytes(g, z));
+    return launch_igemm(g, z, s);
 }
 
 static int run_op(gd_engine *e, int op_index, const Bind &b, int batch, hipStream_t s) {
@@ -394,71 +496,14 @@ static int run_op(gd_engine *e, int op_index, const Bind &b, int batch, hipStrea
                                          av.out_scale, tptr(e, b, av.qstats, batch), tptr(e, b, av.out, batch), av.ldc, batch, op.N, op.C0, s);
             }
             if (attn_core_at(e, op_index - 2)) return 0;  // the p v product of a fused core
-            GemmParams g{};
-            const int z = fill_gemm(e, op, b, batch, g);
-            if (e->precision == 1 && op.w_slot >= 0 && e->wsplit_valid) {
-                g.b_hi = e->wsplit_hi + e->slot_off[op.w_slot];
-                g.b_lo = e->wsplit_lo + e->slot_off[op.w_slot];
-                g.a_presplit = op.a_split && presplit_allowed(e, b, batch, op.a0.t);
-                GD_CHECK(!g.a_presplit || igemm_bf16x3_ok(g, z), "%s: pre-split input but the GEMM is not eligible for bf16x3", op.label.c_str());
-                if (op.fuse_peer >= 0 && gn_fused(e, b, batch, op_index)) {
-                    g.a0 = tptr(e, b, op.gn_src, batch);  // the raw input(s) of the GroupNorm
-                    g.a1 = tptr(e, b, op.gn_src1, batch);
-                    g.C0 = op.gn_C0; g.C1 = op.gn_C1; g.lda0 = op.gn_C0; g.lda1 = op.gn_C1 ? op.gn_C1 : 4;
-                    g.a_presplit = 0;
-                    g.gn_table = tptr(e, b, op.gn_table, batch);
-                    g.gn_act = e->plan.ops[op.fuse_peer].act;
-                    ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(conv3x3_halo_fused_name()), op.flops_per_image * batch, gemm_alg_bytes(g, z));
-                    return launch_conv3x3_halo(g, s);
-                }
-                if (z == 1 && conv3x3_halo_ok(g)) {
-                    ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(conv3x3_halo_name()), op.flops_per_image * batch, gemm_alg_bytes(g, z));
-                    return launch_conv3x3_halo(g, s);
-                }
-                if (igemm_bf16x3_ok(g, z)) {
-                    ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(igemm_bf16x3_name(g)), op.flops_per_image * batch, gemm_alg_bytes(g, z));
-                    return launch_igemm_bf16x3(g, s);
-                }
-                g.b_hi = g.b_lo = nullptr;
+            const int parts = gemm_parts(e, op, batch);
+            if (parts == 1) return run_gemm(e, op_index, b, batch, 0, batch, true, s);
+            for (int pi = 0, i0 = 0; pi < parts; ++pi) {  // image sub-ranges (operands beyond the 2 GiB buffer range)
+                const int nb = batch / parts + (pi < batch % parts ? 1 : 0);
+                GD_TRY(run_gemm(e, op_index, b, batch, i0, nb, pi == 0, s));
+                i0 += nb;
             }
-            GD_CHECK(!g.a_presplit, "%s: pre-split input without a split-precision kernel", op.label.c_str());
-            if (op.egn_peer >= 0 && egn_fused(e, b, batch, op_index)) fill_egn(e, op, b, batch, g);
-            if (e->precision == 1 && op.w_slot < 0 && igemm_bf16x3_act_ok(g, z)) {  // attention products: activation x activation
-                ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string("igemm_bf16x3_kernel<256,128,4,2,act>"), op.flops_per_image * batch, gemm_alg_bytes(g, z));
-                return launch_igemm_bf16x3_act(g, z, s);
-            }
-            if (e->precision == 0 && z == 1 && op.w_slot >= 0 && e->wwino42 && e->wino42_off[op.w_slot] >= 0 && conv3x3_wino42_ok(g)) {
-                g.b_wino = e->wwino42 + e->wino42_off[op.w_slot];
-                ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(conv3x3_wino42_name()), op.flops_per_image * batch, gemm_alg_bytes(g, z));
-                return launch_conv3x3_wino42(g, s);
-            }
-            if (e->precision == 0 && z == 1 && op.w_slot >= 0 && e->wwino2 && e->wino2_off[op.w_slot] >= 0 && conv3x3_wino2d_ok(g)) {
-                g.b_wino = e->wwino2 + e->wino2_off[op.w_slot];
-                ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(conv3x3_wino2d_name()), op.flops_per_image * batch, gemm_alg_bytes(g, z));
-                return launch_conv3x3_wino2d(g, s);
-            }
-            if (e->precision == 0 && z == 1 && op.w_slot >= 0 && e->wwino2 && e->wino2_off[op.w_slot] >= 0 && e->splitk_ws &&
-                conv3x3_wino2d_splitk_factor(g) > 1) {  // 4x4 images: the channel range split over workgroups + a finishing pass
-                g.b_wino = e->wwino2 + e->wino2_off[op.w_slot];
-                const long long img0 = (long long)(b.arena - e->arena) / e->plan.arena_per_image;  // first image of this sub-batch (lanes)
-                g.wk_partial = e->splitk_ws + img0 * e->splitk_per_image;
-                GD_CHECK(img0 * e->splitk_per_image + (long long)conv3x3_wino2d_splitk_factor(g) * g.M * g.N <= e->splitk_ws_floats,
-                         "%s: split-K scratch too small", op.label.c_str());
-                ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(conv3x3_wino2d_splitk_name()), op.flops_per_image * batch, gemm_alg_bytes(g, z));
-                return launch_conv3x3_wino2d_splitk(g, s);
-            }
-            if (e->precision == 0 && z == 1 && op.w_slot >= 0 && e->wwino && e->wino_off[op.w_slot] >= 0 && conv3x3_wino_ok(g)) {
-                g.b_wino = e->wwino + e->wino_off[op.w_slot];
-                ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(conv3x3_wino_name(g)), op.flops_per_image * batch, gemm_alg_bytes(g, z));
-                return launch_conv3x3_wino(g, s);
-            }
-            if (op.side_peer >= 0 && side_fused(e, b, batch, op_index)) {  // the per-image affine table first, then the GEMM whose loader applies it
-                GD_TRY(launch_apply_op(e, P.ops[op.side_peer], b, batch, true, s));
-                fill_side(e, op, b, batch, g);
-            }
-            ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(igemm_variant_name(g, z)) + (g.gn_side_out ? "+gn" : ""),
-                         op.flops_per_image * batch, gemm_alg_bytes(g, z));
-            return launch_igemm(g, z, s);
+            return 0;
         }
         case OP_GN_STATS: {
             const int HW = op.H * op.W;
