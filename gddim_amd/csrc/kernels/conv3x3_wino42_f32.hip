@@ -56,7 +56,8 @@ typedef unsigned int w4u32x2 __attribute__((ext_vector_type(2)));
 #ifndef W42_ABL
 #define W42_ABL 0  // timing ablations (results wrong): 1 no pixel loads in the K loop, 2 no LDS stores, 4 no weight-fragment loads in the K loop,
                    // 8 no barrier, 16 no transform arithmetic, 64 (persistent form) every pixel load from one L1-resident line: the instruction
-                   // count stays, the L2 / HBM traffic and latency go
+                   // count stays, the L2 / HBM traffic and latency go, 256 (persistent form) half of them, 128 (persistent form) the pixel
+                   // addresses of a channel-blocked activation layout [C/16][pixel][16]: whole 128-byte lines per request, the same bytes from HBM
 #endif
 
 constexpr int W4_LD = 388;               // LDS row stride (floats): 24 components x 16 channels + 4 pad = 97 16-byte units (odd)
@@ -606,7 +607,8 @@ __device__ __forceinline__ void wino42_persistent(const GemmParams &p, float *sm
     auto set_vo = [&](int lda, int biasb) __attribute__((always_inline)) {
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
-            const int off = (pix + sr * W + k) * lda * 4 + biasb + chq * 16;
+            int off = (pix + sr * W + k) * lda * 4 + biasb + chq * 16;
+            if (W42_ABL & 128) off = (pix + sr * W + k) * 64 + biasb + chq * 16;  // timing ablation: a channel-blocked layout [C/16][pixel][16]
             vo[k] = ((bad >> k) & 1u) ? OOB : off;
         }
     };
@@ -651,6 +653,12 @@ __device__ __forceinline__ void wino42_persistent(const GemmParams &p, float *sm
     auto load_raw_to = [&](w4f32x4 *dst, int k) __attribute__((always_inline)) {
         if ((W42_ABL & 1) && steady) return;
         if ((W42_ABL & 64) && steady) { dst[k] = w4_load16<W42_PX_AUX>(srd_a0, bias0 + (lane & 3) * 16, 0); return; }  // every pixel load from ONE L1-resident line
+        if ((W42_ABL & 256) && steady && k >= 3) { dst[k] = w4_load16<W42_PX_AUX>(srd_a0, bias0 + (lane & 3) * 16, 0); return; }  // ... half of them
+        if (W42_ABL & 128) {  // (whole 128-byte lines per request: pixels x 64 B contiguous inside a 16-channel block of a_imgs HW pixels)
+            if (s_first) dst[k] = w4_load16<W42_PX_AUX>(srd_a0, vo[k], (s_c >> 4) * a_imgs * HW * 64);
+            else dst[k] = w4_load16<W42_PX_AUX>(srd_a1, vo[k], ((s_c - p.C0) >> 4) * a_imgs * HW * 64);
+            return;
+        }
         if (s_first) dst[k] = w4_load16<W42_PX_AUX>(srd_a0, vo[k], s_c * 4);
         else dst[k] = w4_load16<W42_PX_AUX>(srd_a1, vo[k], (s_c - p.C0) * 4);
     };
@@ -814,8 +822,13 @@ __device__ __forceinline__ void wino42_persistent(const GemmParams &p, float *sm
                     if (gap >= 8 && gap <= 10) { store_v(2 * (gap - 8), nxt, 0); store_v(2 * (gap - 8) + 1, nxt, 0); }
                     if (gap == 11) xform(rr, 1);
                     if (gap >= 12 && gap <= 14) { store_v(2 * (gap - 12), nxt, 1); store_v(2 * (gap - 12) + 1, nxt, 1); }
+#ifdef W42_LATE  // timing experiment: the pixel requests W42_LATE gaps later (how much of the time hangs on their lead?)
+                    if (gap >= 12 + W42_LATE && gap <= 17 + W42_LATE) load_raw(gap - 12 - W42_LATE);
+                    if (gap == 18 + W42_LATE) px_advance();
+#else
                     if (gap >= 12 && gap <= 17) load_raw(gap - 12);
                     if (gap == 18) px_advance();
+#endif
                     if (LAST && has_res && gap < 16) { load_res(2 * gap); load_res(2 * gap + 1); }
                     __builtin_amdgcn_sched_barrier(0);
                 }
