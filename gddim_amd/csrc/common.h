@@ -159,6 +159,7 @@ int launch_conv3x3_wino2d_splitk(const GemmParams &p, hipStream_t s);
 bool conv3x3_wino42_ok(const GemmParams &p);
 bool conv3x3_wino42_shape_ok(const GemmParams &p);
 const char *conv3x3_wino42_name();
+const char *conv3x3_wino42_name_for(const GemmParams &p);
 int launch_conv3x3_wino42(const GemmParams &p, hipStream_t s);
 int launch_wino42_weights(const float *w, float *u, int N, int Cin, hipStream_t s);
 long long wino42_weight_floats(int N, int Cin);

@@ -444,7 +444,7 @@ static int run_gemm(gd_engine *e, int op_index, const Bind &b, int batch, int i0
     }
     if (e->precision == 0 && z == 1 && op.w_slot >= 0 && e->wwino42 && e->wino42_off[op.w_slot] >= 0 && conv3x3_wino42_ok(g)) {
         g.b_wino = e->wwino42 + e->wino42_off[op.w_slot];
-        ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(conv3x3_wino42_name()), op.flops_per_image * nb, gemm_alg_bytes(g, z));
+        ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(conv3x3_wino42_name_for(g)), op.flops_per_image * nb, gemm_alg_bytes(g, z));
         return launch_conv3x3_wino42(g, s);
     }
     if (e->precision == 0 && z == 1 && op.w_slot >= 0 && e->wwino2 && e->wino2_off[op.w_slot] >= 0 && conv3x3_wino2d_ok(g)) {
@@ -1434,6 +1434,28 @@ int gd_conv3x3_winograd42(const float *x_dev, const float *w_dev, float *u_scrat
     g.rows_per_image = H * W;
     g.alpha = alpha; g.out_scale = out_scale;
     GD_CHECK(conv3x3_wino42_shape_ok(g), "conv3x3_winograd42: shape not eligible (B=%d H=%d W=%d Cin=%d Cout=%d)", batch, H, W, Cin, Cout);
+    GD_TRY(launch_wino42_weights(w_dev, u_scratch_dev, Cout, Cin, (hipStream_t)stream));
+    g.b_wino = u_scratch_dev;
+    return launch_conv3x3_wino42(g, (hipStream_t)stream);
+}
+
+int gd_conv3x3_winograd42_gn(const float *x_dev, const float *w_dev, float *u_scratch_dev, const float *bias_dev, const float *res_dev,
+                             float *out_dev, const float *gamma_dev, const float *beta_dev, float *gn_out_dev, int groups, int act,
+                             int batch, int H, int W, int Cin, int Cout, float alpha, float out_scale, void *stream) {
+    GD_CHECK(x_dev && w_dev && u_scratch_dev && gamma_dev && beta_dev && gn_out_dev, "null pointer");
+    GD_CHECK(groups >= 1 && Cout % groups == 0, "conv3x3_winograd42_gn: %d channels do not split into %d groups", Cout, groups);
+    GemmParams g{};
+    g.a0 = x_dev; g.C0 = Cin; g.lda0 = Cin; g.lda1 = 4;
+    g.H = H; g.W = W; g.KH = 3; g.KW = 3; g.stride = 1; g.pad = 1; g.OH = H; g.OW = W;
+    g.M = batch * H * W; g.N = Cout; g.K = 9 * Cin;
+    g.b = w_dev; g.ldb = g.K;
+    g.out = out_dev ? out_dev : gn_out_dev; g.ldc = Cout; g.bias = bias_dev; g.res = res_dev; g.ldres = Cout;
+    g.rows_per_image = H * W;
+    g.alpha = alpha; g.out_scale = out_scale;
+    g.egn_out = gn_out_dev; g.egn_gamma = gamma_dev; g.egn_beta = beta_dev; g.egn_cpg = Cout / groups; g.egn_act = act;
+    g.egn_skip_raw = out_dev ? 0 : 1;
+    GD_CHECK(conv3x3_wino42_shape_ok(g), "conv3x3_winograd42_gn: shape not eligible (B=%d H=%d W=%d Cin=%d Cout=%d groups=%d)", batch, H, W, Cin,
+             Cout, groups);
     GD_TRY(launch_wino42_weights(w_dev, u_scratch_dev, Cout, Cin, (hipStream_t)stream));
     g.b_wino = u_scratch_dev;
     return launch_conv3x3_wino42(g, (hipStream_t)stream);

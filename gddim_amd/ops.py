@@ -155,6 +155,24 @@ def conv3x3_winograd42(x, w_packed, bias=None, res=None, alpha=1.0, out_scale=1.
     return out
 
 
+def conv3x3_winograd42_gn(x, w_packed, gamma, beta, groups, act=True, bias=None, res=None, out_scale=1.0, keep_raw=True):
+    """conv3x3_winograd42 followed by GroupNorm (+ swish) in the kernel's epilogue (gd_conv3x3_winograd42_gn): returns (raw, normalised),
+    raw = None with keep_raw=False (the engine's sole-reader case: the convolution output itself is never stored)."""
+    import torch
+    _need_gpu(x)
+    x, w_packed, gamma, beta = _f32c(x), _f32c(w_packed), _f32c(gamma), _f32c(beta)
+    B, H, W, Cin = x.shape
+    Cout = w_packed.shape[0]
+    raw = torch.empty((B, H, W, Cout), dtype=torch.float32, device=x.device) if keep_raw else None
+    gn = torch.empty((B, H, W, Cout), dtype=torch.float32, device=x.device)
+    u = torch.empty(24 * ((Cout + 31) // 32 * 32) * Cin, dtype=torch.float32, device=x.device)
+    bias = _f32c(bias) if bias is not None else None
+    res = _f32c(res) if res is not None else None
+    check(_abi.lib().gd_conv3x3_winograd42_gn(_ptr(x), _ptr(w_packed), _ptr(u), _ptr(bias), _ptr(res), _ptr(raw), _ptr(gamma), _ptr(beta), _ptr(gn),
+                                              int(groups), int(bool(act)), B, H, W, Cin, Cout, 1.0, float(out_scale), _stream(x)))
+    return raw, gn
+
+
 def group_norm(x, scale, bias, groups, act=False):
     """flax nn.GroupNorm(eps=1e-6) (+swish) on NHWC."""
     import torch

@@ -273,6 +273,13 @@ int gd_conv3x3_winograd2d(const float *x_dev, const float *w_dev, float *u_scrat
 int gd_conv3x3_winograd42(const float *x_dev, const float *w_dev, float *u_scratch_dev, const float *bias_dev,
                           const float *res_dev, float *out_dev, int batch, int H, int W, int Cin, int Cout, float alpha,
                           float out_scale, void *stream);
+/* ... with the GroupNorm (+ swish) that follows the convolution computed in its epilogue (the engine's Op::egn_peer path): gn_out_dev
+ * (B,H,W,Cout) = act(GroupNorm_groups(conv output)) with flax's epsilon 1e-6; out_dev receives the convolution output itself, or is
+ * null when nothing else reads it.  Images of 8x8, 16x16 (one workgroup tile) and 32x32 pixels (four tiles walked by one persistent
+ * workgroup, Cin >= 64).  Replaces: nn.GroupNorm + swish after conv3x3 (cld_jax/models/layerspp.py:196-220). */
+int gd_conv3x3_winograd42_gn(const float *x_dev, const float *w_dev, float *u_scratch_dev, const float *bias_dev, const float *res_dev,
+                             float *out_dev, const float *gamma_dev, const float *beta_dev, float *gn_out_dev, int groups, int act,
+                             int batch, int H, int W, int Cin, int Cout, float alpha, float out_scale, void *stream);
 /* flax GroupNorm(num_groups, eps=1e-6) (+ swish when act != 0) on NHWC (B,H,W,C).
  * Replaces: nn.GroupNorm + nn.swish call sites (cld_jax/models/layerspp.py:69,196,218). */
 int gd_group_norm(const float *x_dev, const float *scale_dev, const float *bias_dev, float *out_dev, int batch,

@@ -18,7 +18,8 @@ from oracle import ncsnpp as onet  # noqa: E402
 
 def main():
     from gddim_amd.engine import Engine
-    cfg = tiny_config("cld", nf=32, num_res_blocks=2, image_size=32, ch_mult=(1, 2, 2), attn=(16,))
+    nf = int(os.environ.get("EGN_WORKER_NF", "32"))  # 64: the 32x32 level has Cin = 64, the persistent form of the hybrid kernel
+    cfg = tiny_config("cld", nf=nf, num_res_blocks=2, image_size=32, ch_mult=(1, 2, 2), attn=(16,))
     B, in_ch = 5, 6
     params = onet.random_params(cfg, in_ch, seed=21)
     eng = Engine(cfg, in_ch, max_batch=B, device=0)

@@ -283,6 +283,45 @@ WINO42_CASES = [
 ]
 
 
+@pytest.mark.parametrize("case", [
+    (3, 8, 8, 64, 64, 16, True, None),       # one image = one wave unit
+    (3, 16, 16, 64, 128, 32, True, None),    # one image = one workgroup tile
+    (5, 32, 32, 64, 64, 16, True, None),     # one image = FOUR tiles walked by one persistent workgroup (round 3), raw output kept
+    (5, 32, 32, 128, 128, 32, False, None),  # ... sole reader: the raw output is never stored; two N tiles
+    (5, 32, 32, 64, 32, 8, True, 2),         # ... half an N tile, two workgroups walking 3 + 2 images
+    (2, 32, 32, 256, 128, 32, False, 1),     # ... two-chunk sources, ONE workgroup walking 2 images x 2 N tiles
+])
+def test_conv3x3_winograd42_epilogue_groupnorm(dev, case, monkeypatch):
+    """gd_conv3x3_winograd42_gn: the GroupNorm (+ swish) that follows a 3x3 convolution, computed in the hybrid Winograd kernel's epilogue
+    (the engine's Op::egn_peer path), against float64 -- bias, residual and scale in front of the normalisation as in a residual block."""
+    from gddim_amd import ops
+    B, H, W, Cin, Cout, groups, keep_raw, grid = case
+    monkeypatch.setenv("GDDIM_EGN32", "1")  # (the 32x32 form is opt-in)
+    if grid:
+        monkeypatch.setenv("GDDIM_WINO42_GRID", str(grid))
+    g = torch.Generator().manual_seed(sum(case[:6]))
+    x = torch.randn(B, H, W, Cin, generator=g)
+    w = torch.randn(3, 3, Cin, Cout, generator=g) / math.sqrt(9 * Cin)
+    bias = torch.randn(Cout, generator=g)
+    res = torch.randn(B, H, W, Cout, generator=g)
+    gamma = 1 + 0.3 * torch.randn(Cout, generator=g)
+    beta = 0.3 * torch.randn(Cout, generator=g)
+    wp = w.permute(3, 0, 1, 2).reshape(Cout, 9 * Cin).contiguous()
+    raw, gn = ops.conv3x3_winograd42_gn(x.to(dev), wp.to(dev), gamma.to(dev), beta.to(dev), groups, act=True, bias=bias.to(dev), res=res.to(dev),
+                                        out_scale=0.7, keep_raw=keep_raw)
+    y = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(3, 2, 0, 1), padding=1).permute(0, 2, 3, 1)
+    y = (y + bias.double() + res.double()) * 0.7
+    yg = y.reshape(B, H * W, groups, Cout // groups)
+    mean = yg.mean(dim=(1, 3), keepdim=True)
+    var = (yg * yg).mean(dim=(1, 3), keepdim=True) - mean * mean
+    t = ((yg - mean) * torch.rsqrt(var + 1e-6)).reshape(B, H, W, Cout) * gamma.double() + beta.double()
+    want = t * torch.sigmoid(t)
+    err = (gn.cpu().double() - want).abs().max().item()
+    eraw = (raw.cpu().double() - y).abs().max().item() if keep_raw else 0.0
+    print("wino42 + GroupNorm %s: max|d| %.2e (raw %.2e)" % (case, err, eraw))
+    assert err < 5e-5 and eraw < 5e-5
+
+
 @pytest.mark.parametrize("case", WINO42_CASES)
 def test_conv3x3_winograd42_matches_torch_fp64(dev, case):
     """gd_conv3x3_winograd42 (hybrid F(2,3)_y x F(4,3)_x: 24 products per 2 x 4 output tile) against the float64 direct convolution.
