@@ -208,7 +208,11 @@ static int fill_gemm(gd_engine *e, const Op &op, const Bind &b, int batch, GemmP
     g.ldb = op.ldb; g.b_kmajor = op.b_kmajor;
     g.out = tptr_at(e, b, op.out, batch, i0); g.ldc = op.ldc;
     g.bias = op.bias_slot >= 0 ? slot_ptr(e, op.bias_slot) + op.bias_off : nullptr;
-    g.rowbias = tptr_at(e, b, op.rowbias, batch, i0); g.ld_rowbias = op.ld_rowbias; g.rows_per_image = op.m_per_image;
+    // the per-image bias rows are the time-embedding projections: inside the fused samplers every image of the batch carries the same
+    // label (b.labels == nullptr: 999 t of the step), one row is computed (run_op) and every image reads it (row stride 0)
+    const bool one_label = b.labels == nullptr && op.rowbias.t >= 0;
+    g.rowbias = one_label ? tptr(e, b, op.rowbias, batch) : tptr_at(e, b, op.rowbias, batch, i0);
+    g.ld_rowbias = one_label ? 0 : op.ld_rowbias; g.rows_per_image = op.m_per_image;
     g.res = tptr_at(e, b, op.res, batch, i0); g.ldres = op.ldres; g.sR = op.sR; g.sQ = op.sQ;
     g.alpha = op.alpha; g.out_scale = op.out_scale; g.in_act = op.in_act;
     g.qstats = tptr_at(e, b, op.qstats, batch, i0); g.qs_slices = op.qs_slices;
@@ -483,10 +487,11 @@ static int run_op(gd_engine *e, int op_index, const Bind &b, int batch, hipStrea
     switch (op.kind) {
         case OP_FOURIER: {
             ProfScope ps(e, s, "fourier", 0, 0);
-            return launch_fourier(b.labels, e->ts_dev, b.step, slot_ptr(e, op.w_slot), tptr(e, b, op.out, batch), batch,
+            return launch_fourier(b.labels, e->ts_dev, b.step, slot_ptr(e, op.w_slot), tptr(e, b, op.out, batch), b.labels ? batch : 1,
                                   op.N, op.act, s);
         }
         case OP_GEMM: {
+            if (op.temb && b.labels == nullptr) return run_gemm(e, op_index, b, batch, 0, 1, true, s);  // one label: one row (see fill_gemm)
             if (attn_core_at(e, op_index)) {  // q k^T, softmax and p v in one launch; the next two ops return at once
                 const Op &av = P.ops[op_index + 2];
                 ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(attn_fused_name()),

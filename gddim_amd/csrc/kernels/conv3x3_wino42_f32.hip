@@ -1182,7 +1182,7 @@ bool conv3x3_wino42_shape_ok(const GemmParams &p) {
     if (p.rows_per_image != p.H * p.W || p.M % (p.H * p.W) != 0 || p.N < 1) return false;
     if ((p.N % 4 != 0 || p.N < 32) && (p.qstats || p.egn_out)) return false;  // (a narrow or ragged N only without the column-quad statistics)
     if (p.qstats && p.qs_slices != p.rows_per_image / 32) return false;
-    if (p.rowbias && p.ld_rowbias <= 0) return false;
+    if (p.rowbias && p.ld_rowbias < 0) return false;  // (0: one row for every image)
     if ((long long)p.M * p.ldc * 4 + 64 >= (1LL << 31) || (p.res && (long long)p.M * p.ldres * 4 + 64 >= (1LL << 31))) return false;
     const long long ldmax = p.lda0 > p.lda1 ? p.lda0 : p.lda1;
     const long long a_bytes = ((long long)p.M + 3 * p.W + 8) * ldmax * 4 + Cin * 4 + 64;

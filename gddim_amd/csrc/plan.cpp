@@ -577,6 +577,7 @@ int Plan::build(const gd_model_desc &d) {
         Op f;
         f.kind = OP_FOURIER; f.label = "temb.fourier"; f.a0 = {t_labels, 0}; f.w_slot = wf; f.N = E; f.out = {t0, 0};
         f.act = d.positional_embedding ? 1 : 0;
+        f.temb = 1;
         ops.push_back(f);
         auto dense = [&](const std::string &label, const std::string &pname, int in_t, int in_c, int out_c, int act_in) {
             int ws = new_slot(pname + "/kernel", out_c, in_c), bs = new_slot(pname + "/bias", 1, out_c);
@@ -587,6 +588,7 @@ int Plan::build(const gd_model_desc &d) {
             g.kind = OP_GEMM; g.label = label; g.a0 = {in_t, 0}; g.C0 = in_c; g.lda0 = in_c; g.m_per_image = 1;
             g.N = out_c; g.K = in_c; g.w_slot = ws; g.ldb = in_c; g.bias_slot = bs; g.out = {o, 0}; g.ldc = out_c;
             g.in_act = act_in; g.flops_per_image = 2.0 * out_c * in_c;
+            g.temb = 1;
             ops.push_back(g);
             return o;
         };
@@ -602,6 +604,7 @@ int Plan::build(const gd_model_desc &d) {
         g.kind = OP_GEMM; g.label = "temb.proj"; g.a0 = {temb_t_, 0}; g.C0 = 4 * nf; g.lda0 = 4 * nf; g.m_per_image = 1;
         g.N = sum_cout_; g.K = 4 * nf; g.w_slot = tproj_slot_w_; g.ldb = 4 * nf; g.bias_slot = tproj_slot_b_;
         g.out = {tproj_t_, 0}; g.ldc = sum_cout_; g.in_act = 1; g.flops_per_image = 2.0 * sum_cout_ * 4 * nf;
+        g.temb = 1;
         ops.push_back(g);
         release(temb_t_);
     }
@@ -930,7 +933,7 @@ std::string Plan::json() const {
           << ",\"ldb\":" << p.ldb << ",\"b_kmajor\":" << p.b_kmajor << ",\"sA\":" << p.sA << ",\"sB\":" << p.sB
           << ",\"sC\":" << p.sC << ",\"sR\":" << p.sR << ",\"sQ\":" << p.sQ << ",\"bias_slot\":" << p.bias_slot << ",\"bias_off\":" << p.bias_off
           << ",\"ld_rowbias\":" << p.ld_rowbias << ",\"ldres\":" << p.ldres << ",\"ldc\":" << p.ldc << ",\"alpha\":" << p.alpha
-          << ",\"out_scale\":" << p.out_scale << ",\"in_act\":" << p.in_act << ",\"qs_slices\":" << p.qs_slices << ",\"S0\":" << p.S0 << ",\"S1\":" << p.S1 << ",\"groups\":" << p.groups
+          << ",\"out_scale\":" << p.out_scale << ",\"in_act\":" << p.in_act << ",\"temb\":" << p.temb << ",\"qs_slices\":" << p.qs_slices << ",\"S0\":" << p.S0 << ",\"S1\":" << p.S1 << ",\"groups\":" << p.groups
           << ",\"act\":" << p.act << ",\"gamma_slot\":" << p.gamma_slot << ",\"beta_slot\":" << p.beta_slot
           << ",\"rows_per_image\":" << p.rows_per_image << ",\"cols\":" << p.cols << ",\"cin\":" << p.cin
           << ",\"cpad\":" << p.cpad << ",\"mul\":" << p.mul << ",\"add\":" << p.add << ",\"flops_per_image\":" << p.flops_per_image

@@ -76,6 +76,7 @@ struct Op {
     int ldc = 0;
     float alpha = 1.f, out_scale = 1.f;
     int in_act = 0;
+    int temb = 0;  // part of the time-embedding path: depends on the label only (the engine computes one row when the batch shares one label)
     // split precision (bf16x3 mode only): GN_APPLY writes its output as bf16 hi|lo rows (split_out) when every consumer is
     // a weight GEMM that can read them (a_split); decided by Plan::mark_split at build time
     int split_out = 0, a_split = 0;
