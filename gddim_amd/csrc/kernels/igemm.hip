@@ -840,6 +840,11 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_pers_kernel(const Gemm
     };
 
     f32x4 ra[AJ], rb[BJ];
+    // gn_side_out: the affine pair of the thread's four channels travels WITH the chunk (requested behind its last A piece, consumed
+    // when the chunk is staged) instead of being fetched at staging time, where the wave sat out its L2 round trip; a 128-row tile lies
+    // inside one image when rows_per_image is a multiple of 128 (igemm_gn_side_ok), so one pair serves both of the thread's rows
+    f32x4 tsc = {0.f, 0.f, 0.f, 0.f}, tsh = {0.f, 0.f, 0.f, 0.f};
+    const bool side_any = p.gn_side_out != nullptr && ntile == 0;
     auto load_piece = [&](int pc) __attribute__((always_inline)) {
         if (pc < AJ) {
             const int j = pc;
@@ -850,6 +855,12 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_pers_kernel(const Gemm
             } else {
                 const int soff = ((s_ty * p.W + s_tx) * p.lda1 + (s_c0 - p.C0)) * 4;
                 ra[j] = buf_load16(srd_a1, rb1[j] | (bad & OOB), soff);
+            }
+            if (side_any && pc == AJ - 1 && ld_m0 >= 0) {
+                const unsigned img = fast_div((unsigned)ld_m0, (unsigned)p.rows_per_image, p.mg_rpi, p.sh_rpi);
+                const float *tb = p.gn_table + (size_t)img * 2 * Cin + s_c0 + kcol;
+                tsc = *reinterpret_cast<const f32x4 *>(tb);
+                tsh = *reinterpret_cast<const f32x4 *>(tb + Cin);
             }
         } else {
             const int j = pc - AJ;
@@ -863,10 +874,8 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_pers_kernel(const Gemm
             if (side) {  // the GroupNorm (+ swish) of the raw element, as gn_apply_kernel computes it
                 const int m = st_m0 + arow + RPP * pc;
                 if (st_m0 >= 0 && m < p.M) {
-                    const unsigned img = fast_div((unsigned)m, (unsigned)p.rows_per_image, p.mg_rpi, p.sh_rpi);
                     const int c = st_c0 + kcol;
-                    const float *tb = p.gn_table + (size_t)img * 2 * Cin + c;
-                    const f32x4 sc = *reinterpret_cast<const f32x4 *>(tb), sh = *reinterpret_cast<const f32x4 *>(tb + Cin);
+                    const f32x4 sc = tsc, sh = tsh;
                     f32x4 y;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
@@ -1109,7 +1118,7 @@ static void pick_tiles(const GemmParams &p, int batch_z, int &bm, int &bn);
 
 bool igemm_gn_side_ok(const GemmParams &p, int batch_z) {
     if (batch_z != 1 || p.KH != 1 || p.KW != 1 || p.stride != 1 || p.pad != 0 || p.OH != p.H || p.OW != p.W) return false;
-    if (!p.gn_table || !p.gn_side_out || p.rows_per_image <= 0 || p.lda0 != p.C0 || (p.C1 > 0 && p.lda1 != p.C1)) return false;
+    if (!p.gn_table || !p.gn_side_out || p.rows_per_image <= 0 || p.rows_per_image % 128 != 0 || p.lda0 != p.C0 || (p.C1 > 0 && p.lda1 != p.C1)) return false;
     int bm, bn;
     pick_tiles(p, batch_z, bm, bn);
     return pers_ok(p, batch_z, bm, bn);
