@@ -199,6 +199,21 @@ __global__ __launch_bounds__(512, 2) void attn256_f32_kernel(const AttnParams p)
     load_b(2);
     __syncthreads();
 
+    // the block's residual tile (32 values per lane) and the bias travel during phase B: one workgroup per CU leaves the registers for it
+    float rv[2][16], bvv[2] = {0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int col = wn * 64 + c * 32 + li;
+        if (p.bias) bvv[c] = p.bias[col];
+        if (p.res) {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int row = wm * 32 + 8 * (v >> 2) + (v & 3) + 4 * lh;
+                rv[c][v] = p.res[((size_t)img * AT_N + q0 + row) * p.ld_res + col];
+            }
+        }
+    }
+
     // ---- phase B: O = P V over 8 chunks of 32 keys ----
 #pragma unroll
     for (int c = 0; c < 2; ++c)
@@ -234,22 +249,10 @@ __global__ __launch_bounds__(512, 2) void attn256_f32_kernel(const AttnParams p)
     }
 
     // ---- epilogue: row = query, column = channel.  Element v of lane (li, lh): row 8 (v >> 2) + (v & 3) + 4 lh of the wave's 32 ----
-    float rv[2][16];
-    if (p.res) {  // all 32 residual values requested before any is consumed
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const int col = wn * 64 + c * 32 + li;
-#pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const int row = wm * 32 + 8 * (v >> 2) + (v & 3) + 4 * lh;
-                rv[c][v] = p.res[((size_t)img * AT_N + q0 + row) * p.ld_res + col];
-            }
-        }
-    }
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         const int col = wn * 64 + c * 32 + li;
-        const float bv = p.bias ? p.bias[col] : 0.f;
+        const float bv = bvv[c];
         float s = 0.f, q = 0.f;
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
