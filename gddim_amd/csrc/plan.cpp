@@ -245,6 +245,7 @@ int Plan::resblock(int idx, int xa, int Ca, int xb, int Cb, int H, int W, int O,
         }
     }
     int xs_src = xa;  // shortcut source (single tensor unless concat)
+    int up_b2 = -1;   // Conv_2's bias slot when the up-sampling shortcut runs before the FIR
     int H2 = H, W2 = W;
     int xr = -1;  // resampled x
     if (up || down) {
@@ -259,11 +260,28 @@ int Plan::resblock(int idx, int xa, int Ca, int xb, int Cb, int H, int W, int O,
         ops.push_back(f);
         release(h0);
         h0 = h0r;
-        xr = new_tensor(n + ".x_resampled", H2, W2, C);
-        f.label = n + (up ? ".fir_up_x" : ".fir_down_x");
-        f.a0 = {xa, 0}; f.out = {xr, 0};
-        ops.push_back(f);
-        xs_src = xr;
+        // the shortcut of a resampling block is Conv_2(FIR(x)) (layerspp.py:198-222).  The FIR acts per channel and Conv_2 per pixel: they
+        // commute up to Conv_2's bias (the FIR's zero boundary does not pass a constant through unchanged).  Down: FIR first, the 1x1
+        // convolution at the low resolution, as written.  Up: the 1x1 convolution WITHOUT its bias at the low resolution -- a quarter of
+        // the rows --, then the FIR on its output; the bias joins Conv_1's, which adds the shortcut as its residual (Plan::bias_folds).
+        static const bool no_swap = getenv("GDDIM_NO_UPSWAP") && atoi(getenv("GDDIM_NO_UPSWAP")) != 0;
+        if (up && !no_swap) {
+            const int xlo = conv(n + ".conv2", n + "/Conv_2", xa, C, -1, 0, H, W, 1, O, -1, 1.f, -1, 0);
+            up_b2 = ops.back().bias_slot;
+            ops.back().bias_slot = -1;
+            folded_flops_per_image += 2.0 * ((double)H2 * W2 - (double)H * W) * O * C;  // (the reference multiplies at the high resolution)
+            xs = new_tensor(n + ".shortcut_resampled", H2, W2, O);
+            f.label = n + ".fir_up_shortcut";
+            f.a0 = {xlo, 0}; f.C0 = O; f.out = {xs, 0};
+            ops.push_back(f);
+            release(xlo);
+        } else {
+            xr = new_tensor(n + ".x_resampled", H2, W2, C);
+            f.label = n + (up ? ".fir_up_x" : ".fir_down_x");
+            f.a0 = {xa, 0}; f.out = {xr, 0};
+            ops.push_back(f);
+            xs_src = xr;
+        }
     }
     // h = Conv_0(h) + Dense_0(act(temb))[:, None, None, :]
     const int tcol = tproj_t_ >= 0 ? rb_tproj_off_[idx] : 0;
@@ -279,13 +297,20 @@ int Plan::resblock(int idx, int xa, int Ca, int xb, int Cb, int H, int W, int O,
     // the shortcut of a resampling block reads the resampled input
     int res_t;
     if (C != O || up || down) {
-        if (up || down) xs = conv(n + ".conv2", n + "/Conv_2", xs_src, C, -1, 0, H2, W2, 1, O, -1, 1.f, -1, 0);
+        if ((up || down) && xs < 0) xs = conv(n + ".conv2", n + "/Conv_2", xs_src, C, -1, 0, H2, W2, 1, O, -1, 1.f, -1, 0);
         res_t = xs;
     } else {
         res_t = xa;
     }
     // (x + Conv_1(h)) / sqrt(2)
     int out = conv(n + ".conv1", n + "/Conv_1", h2, O, -1, 0, H2, W2, 3, O, res_t, scale, -1, 0, -1, true);
+    if (up_b2 >= 0) {
+        BiasFold bf;
+        bf.a = ops.back().bias_slot; bf.b = up_b2;
+        bf.dst = new_slot(n + "/Conv_1/bias+Conv_2/bias", 1, O);
+        ops.back().bias_slot = bf.dst;
+        bias_folds.push_back(bf);
+    }
     link_fused_gn(h2);
     release(h1);
     release(h2);
@@ -390,6 +415,8 @@ int Plan::attn(int idx, int x, int H, int W, int C) {
 }
 
 void Plan::fold_params() {
+    for (const BiasFold &f : bias_folds)
+        for (size_t i = 0; i < slots[f.dst].host.size(); ++i) slots[f.dst].host[i] = slots[f.a].host[i] + slots[f.b].host[i];
     for (const AttnFold &f : attn_folds) {
         const int C = f.C;
         const std::vector<float> &w = slots[f.raw_w].host, &b = slots[f.raw_b].host, &wo = slots[f.raw_wo].host, &bo = slots[f.raw_bo].host;

@@ -149,6 +149,10 @@ struct AttnFold {
     int fold_w = -1, fold_b = -1;  // [2C][C]: rows 0..C-1 of W_q W_k^T (row c' = column c'), rows C..2C-1 of (W_v W_3)^T ; [2C] biases
 };
 
+// A bias slot that is the sum of two loaded ones (Plan::resblock: the shortcut convolution of an up-sampling block runs BEFORE the FIR, its
+// bias is added after it -- folded into Conv_1's).
+struct BiasFold { int dst = -1, a = -1, b = -1; };
+
 struct Plan {
     gd_model_desc desc{};
     int CP = 0;  // U-Net input channels padded to a multiple of 4
@@ -164,6 +168,7 @@ struct Plan {
     // (Plan::attn).  flops_per_image (what bench.py prices) includes them; the ops' own flops_per_image are what they really multiply.
     double folded_flops_per_image = 0;
     std::vector<AttnFold> attn_folds;
+    std::vector<BiasFold> bias_folds;
     void fold_params();  // derived weight slots from the loaded ones (float64 on the host); call once all parameters are loaded
 
     int build(const gd_model_desc &d);  // 0 ok
