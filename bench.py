@@ -3,9 +3,10 @@
 synthetic batches -- BASELINE.json `metric`, config[1] at N=1 and config[3] (batch sharded, one process per
 GPU, RCCL all-gather of the uint8 images at the end of each round) at N>1.
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: re-executes itself under torch.distributed.run)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
       bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus 2 --dry-run                     (CPU, gloo: the launch / shard / barrier / gather / report path without a GPU)
 
 A "step" is one full sampler call on this rank's batch: 49 x (NCSN++ forward + fused AB update) + the
 denoising evaluation + inverse scaling (prior sampling excluded, inputs resident in HBM), then uint8
@@ -100,6 +101,70 @@ def cpu_baseline(cfg, params, nfe_full, cpu_batch, cpu_nfe):
                       "scaled linearly to NFE=%d" % (cpu_batch, cpu_nfe, dt, nfe_full)}
 
 
+def self_launch(n, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher in the environment: run the same command line as N ranks of one node under
+    torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1 at a free port) and hand its exit code back.  The reference needs
+    no launcher either -- jax.pmap drives the local devices from one process (cld_jax/sampling.py:232-237)."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args):
+    """--dry-run: everything around the sampler -- rank / world from the environment, the process group (gloo on CPU), the per-rank
+    seed, the timed region with its barriers and max-over-ranks, the uint8 conversion, the equal-shard all-gather and rank 0's ONE JSON
+    line -- with a stand-in for the sampler call (uniform noise of the image shape).  No GPU, no native library: a plumbing check
+    (tests/test_distributed_cpu.py), never a measurement; the line says so."""
+    import torch
+    from gddim_amd import distributed
+    rank, world, _ = distributed.init_from_env(backend="gloo", single_rank_group=True)
+    grouped = torch.distributed.is_available() and torch.distributed.is_initialized()
+    assert world == args.gpus, "launch with --nproc-per-node equal to --gpus (WORLD_SIZE=%d, --gpus=%d)" % (world, args.gpus)
+    B = args.batch
+    g = torch.Generator()
+    g.manual_seed(distributed.rank_seed(42, 0, rank))
+
+    def step():
+        xs = torch.rand((B, args.image_size, args.image_size, 3), generator=g)
+        return distributed.all_gather_samples(distributed.to_uint8(xs), equal_shards=True, force=grouped)
+
+    def fence():
+        if grouped:
+            torch.distributed.barrier()
+
+    for _ in range(args.warmup):
+        out = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if grouped:
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+    dt = float(tt.item())
+    assert out.shape[0] == B * world and out.dtype == torch.uint8
+    if rank == 0:
+        print(json.dumps({"metric": METRIC, "value": None, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": 1e3 * dt / max(1, args.steps), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "dtype": "f32", "data": "dry run: no sampler, no GPU -- launch / shard / gather plumbing only",
+                          "dry_run": True, "gathered_images": int(out.shape[0]),
+                          "config": {"workload": "dry run of the N-rank harness", "global_batch": B * world,
+                                     "parallelism": "dp%d (one process per rank, gloo)" % world}}))
+    if grouped:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -120,7 +185,13 @@ def main():
     ap.add_argument("--no-alt", action="store_true", help="skip the secondary bf16x3 measurement")
     ap.add_argument("--cpu-batch", type=int, default=16)
     ap.add_argument("--cpu-nfe", type=int, default=10)
+    ap.add_argument("--dry-run", action="store_true", help="CPU / gloo plumbing check of the N-rank harness (no sampler, no GPU)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
+    if args.dry_run:
+        return dry_run(args)
 
     os.environ["GDDIM_PRECISION"] = args.precision  # read at engine creation
     import torch

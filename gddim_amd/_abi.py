@@ -56,6 +56,7 @@ SIGNATURES = {
     "gd_version": (_I, []),
     "gd_device_count": (_I, []),
     "gd_cld_r_table": (_I, [_D, _D, _D, _D, _D, _I, _D, _SZ, _P]),
+    "gd_cld_r_table_f32": (_I, [_D, _D, _D, _D, _D, _I, _D, _SZ, _P]),
     "gd_cld_psi2_table": (_I, [_D, _D, _D, _D, _SZ, _P]),
     "gd_cld_lambda_hat_psi_table": (_I, [_D, _D, _D, _D, _P, _P, _SZ, _D, _SZ, _P]),
     "gd_cld_lambda_cond_rev_cov": (_I, [_D, _D, _D, _D, _P, _P, _SZ, _D, _D, _I, _P]),

@@ -65,8 +65,22 @@ def get_denoising_step(sde, model, t, denoising_eps):
 
 
 def get_rev_ts(sde, ts_order, num_step):
-    return np.power(np.linspace(np.power(sde.T, 1.0 / ts_order), np.power(sde.sampling_eps, 1.0 / ts_order), num_step + 1),
-                    ts_order)
+    """cld_jax/sampling.py:241-249 in the SDE's dtype (float32 for config.model.x64=False): jnp.power of the two Python-float
+    end points, jnp.linspace between them, jnp.power(., ts_order) -- which for a Python int exponent is lax.integer_pow, a chain
+    of multiplications (jax/_src/numpy/lax_numpy.py `power`, from memory), and libm pow otherwise."""
+    from .sde_lib import linspace
+    ft = np.dtype(getattr(sde, '_ft', np.float64)).type
+    lin = linspace(np.power(ft(sde.T), ft(1.0 / ts_order)), np.power(ft(sde.sampling_eps), ft(1.0 / ts_order)), num_step + 1, ft=ft)
+    if isinstance(ts_order, (int, np.integer)) and ts_order >= 0:
+        acc, base, y = None, lin, int(ts_order)  # binary exponentiation, as integer_pow lowers
+        while y:
+            if y & 1:
+                acc = base if acc is None else acc * base
+            y >>= 1
+            if y:
+                base = base * base
+        return np.ones_like(lin) if acc is None else acc
+    return np.power(lin, ft(ts_order))
 
 
 def _denoise_mats(sde, t):
@@ -189,7 +203,9 @@ def get_hyd_deis_sampler(sde, model, data_shape, nfe, inverse_scaler, deis_order
     mid_t = sde.T * img_t_ratio
     noise_nfe = int(num_step * noise_nfe_ratio)
     img_nfe = num_step - noise_nfe
-    noise_ts = np.linspace(sde.T, mid_t, noise_nfe, endpoint=False)
+    from .sde_lib import linspace
+    ft = np.dtype(getattr(sde, '_ft', np.float64)).type
+    noise_ts = linspace(sde.T, mid_t, noise_nfe, endpoint=False, ft=ft)
     # reference: get_rev_ts(sde, ts_order, img_nfe) restarts at sde.T (cld_jax/sampling.py:264) -- kept as is
     img_ts = get_rev_ts(sde, ts_order, img_nfe)
     rev_ts = np.concatenate([noise_ts, img_ts])
@@ -221,8 +237,7 @@ def get_mldeis_sampler(sde, model, data_shape, nfe, inverse_scaler, deis_order, 
     the y-frame state with the x-frame formula, and the final change of frame uses psi1(sampling_eps / 2)."""
     from .sde_lib import MLCLD
     num_step = nfe - 1 if denoising else nfe
-    rev_ts = np.power(np.linspace(np.power(sde.T, 1.0 / ts_order), np.power(sde.sampling_eps, 1.0 / ts_order), num_step + 1),
-                      ts_order)
+    rev_ts = get_rev_ts(sde, ts_order, num_step)
     mlsde = MLCLD(sde)
     deis_coef = mlsde.get_deis_coef(deis_order, rev_ts)
     pre = np.stack([mlsde.y2x_matrix(t) for t in rev_ts[:num_step]])
@@ -293,7 +308,9 @@ def noise_factor(cov):
 
 def sscs_ou(sde, s_t, s_t_next):
     """Mean matrix and covariance of the analytic Ornstein-Uhlenbeck half step (cld_jax/sampling.py:542-561)."""
-    beta_int = -1 * (sde.beta_int(1 - s_t_next) - sde.beta_int(1 - s_t))
+    # (the closed forms below cancel: formed in float64 whatever precision the SDE's tables are in)
+    s_t, s_t_next = float(s_t), float(s_t_next)
+    beta_int = -1 * (sde.beta_0 * ((1 - s_t_next) - (1 - s_t)) + 0.5 * sde.beta_1 * ((1 - s_t_next) ** 2 - (1 - s_t) ** 2))
     G_ = sde.Gamma
     coeff = np.exp(-2. * beta_int / G_)
     mean_matrix = np.array([[1 + 2 * beta_int / G_, -4 * beta_int / G_ / G_], [beta_int, 1 - 2 * beta_int / G_]]) * coeff

@@ -1,10 +1,15 @@
-"""Critically-damped Langevin diffusion: SDE algebra for the sampler (host side, float64 numpy).
+"""Critically-damped Langevin diffusion: SDE algebra for the sampler (host side, numpy).
 
-Replaces the sampling members of cld_jax/sde_lib.py:45-331 (class CLD, from_config).  Closed forms are
-evaluated directly; R(t) comes from the native float64 scan `gd_cld_r_table` (the reference's 1e6-step
-lax.scan + pickle cache, :93-118) and is interpolated exactly as get_interp_fn does (:32-43: 100 000 knots,
-searchsorted side='right', linear).  The reference computes all of this in float32; float64 here differs
-from it by <= 6e-5 absolute on the DEIS table (tests/test_oracle_cld.py), far inside the 1e-3 parity bar.
+Replaces the sampling members of cld_jax/sde_lib.py:45-331 (class CLD, from_config).
+
+Arithmetic.  The reference computes every table in the dtype jax is configured with and asserts that it matches
+`config.model.x64` (sde_lib.py:112,314): float32 unless x64 is set -- and x64=False is its default
+(configs/default_cifar10_config.py).  `CLD(x64=...)` is honoured the same way: with x64=False the R(t) scan (native
+`gd_cld_r_table_f32`), its interpolation, Psi, the epsilon integrand, the time grids and the 10 000-term Riemann sums of the
+DEIS table are evaluated in float32, operation by operation in the order the reference's expressions are written; with
+x64=True the same code runs in float64.  What cannot be reproduced is XLA's summation order inside `jnp.sum` (here: numpy's
+pairwise sum) and its libm (exp, sqrt, pow): DESIGN.md section 2 prices both.  The sampler variants further down (LSDE,
+MLCLD, LambdaSDE) read R(t) from this class in the configured precision and build their own tables in float64.
 """
 import ctypes
 
@@ -22,6 +27,26 @@ def inv_2x2(m):
     return out
 
 
+def linspace(start, stop, num, endpoint=True, ft=np.float64):
+    """jnp.linspace for a floating dtype as jax 0.2.8 evaluates it (jax/_src/numpy/lax_numpy.py, from memory: the form that
+    "recovers the endpoints"): start * (1 - step) + stop * step with step = iota / div, all in the computation dtype."""
+    ft = np.dtype(ft).type
+    div = (num - 1) if endpoint else num
+    if num == 1:
+        return np.asarray([start], dtype=ft)
+    step = np.arange(num, dtype=ft) / ft(div)
+    return ft(start) * (ft(1) - step) + ft(stop) * step
+
+
+def linspace_int(start, stop, num, ft=np.float64):
+    """jnp.linspace(..., dtype=int): floor(start + iota * delta) with delta = (stop - start) / (num - 1) in the floating
+    computation dtype (float32 unless x64) -- in float32 some products round up across an integer (i = 9 999 of the
+    R-table knots: 99 991 instead of 99 990), so the knot rows are the reference's only if the same arithmetic picks them."""
+    ft = np.dtype(ft).type
+    delta = (ft(stop) - ft(start)) / ft(num - 1)
+    return np.floor(ft(start) + np.arange(num).astype(ft) * delta).astype(np.int64)
+
+
 _R_CACHE = {}
 
 
@@ -30,14 +55,16 @@ class CLD(object):
                  used_cache=True, x64=False, is_R_rk=False, R_dt=1e-5):
         self.mixed_score = mixed_score
         self.used_cache = used_cache
-        self.x64 = x64
+        self.x64 = bool(x64)
+        self._ft = np.float64 if self.x64 else np.float32  # the dtype jax would compute in (sde_lib.py:112)
         self.m_inv = float(m_inv)
         self.Gamma = 2.0 / np.sqrt(m_inv)
         self.beta_0 = float(beta_0)
         self.beta_1 = float(beta_1)
         self.vv_gamma = float(vv_gamma)
         self.numerical_eps = float(numerical_eps)
-        self.R_0 = np.array([[np.sqrt(numerical_eps), 0.0], [0.0, np.sqrt(vv_gamma / m_inv + numerical_eps)]])
+        ft = self._ft
+        self.R_0 = np.array([[np.sqrt(ft(numerical_eps)), 0.0], [0.0, np.sqrt(ft(vv_gamma / m_inv + numerical_eps))]], dtype=ft)
         self.is_R_rk = bool(is_R_rk)
         self.R_dt = float(R_dt)
         self._xp, self._fp = self._r_knots()
@@ -46,26 +73,30 @@ class CLD(object):
 
     # ---- R(t) ----
     def _r_knots(self):
-        key = (self.m_inv, self.beta_0, self.beta_1, self.vv_gamma, self.numerical_eps, self.is_R_rk, self.R_dt)
+        key = (self.m_inv, self.beta_0, self.beta_1, self.vv_gamma, self.numerical_eps, self.is_R_rk, self.R_dt, self.x64)
         if self.used_cache and key in _R_CACHE:
             return _R_CACHE[key]
+        ft = self._ft
         n = int(1.0 / self.R_dt) + 1  # sde_lib.py:114 (note int(1/1e-5) == 99999)
-        table = np.empty((n, 2, 2))
-        _abi.check(_abi.lib().gd_cld_r_table(self.m_inv, self.beta_0, self.beta_1, self.vv_gamma, self.numerical_eps,
-                                             int(self.is_R_rk), self.R_dt, n, table.ctypes.data_as(ctypes.c_void_p)))
-        ts = np.linspace(0, 1.0 + self.R_dt, n, endpoint=False)
-        idx = np.linspace(0, n - 1, 100_000).astype(int)
+        table = np.empty((n, 2, 2), dtype=ft)
+        scan = _abi.lib().gd_cld_r_table if self.x64 else _abi.lib().gd_cld_r_table_f32
+        _abi.check(scan(self.m_inv, self.beta_0, self.beta_1, self.vv_gamma, self.numerical_eps, int(self.is_R_rk), self.R_dt, n,
+                        table.ctypes.data_as(ctypes.c_void_p)))
+        ts = linspace(0, 1.0 + self.R_dt, n, endpoint=False, ft=ft)  # :116
+        idx = linspace_int(0, n - 1, 100_000, ft=ft)  # :117
         _R_CACHE[key] = (ts[idx], table[idx])
         return _R_CACHE[key]
 
     def v_R(self, t):
-        """R at a vector of times, (n, 2, 2)."""
-        t = np.atleast_1d(np.asarray(t, dtype=np.float64))
+        """R at a vector of times, (n, 2, 2): get_interp_fn (sde_lib.py:32-43) in the configured dtype."""
+        t = np.atleast_1d(np.asarray(t)).astype(self._ft)
         xp, fp = self._xp, self._fp
         i = np.clip(np.searchsorted(xp, t, side='right'), 1, len(xp) - 1)
+        df = fp[i] - fp[i - 1]
         dx = xp[i] - xp[i - 1]
-        w = np.where(dx == 0, 1.0, (t - xp[i - 1]) / np.where(dx == 0, 1.0, dx))
-        return fp[i - 1] + w[:, None, None] * (fp[i] - fp[i - 1])
+        delta = t - xp[i - 1]
+        w = delta / np.where(dx == 0, self._ft(1), dx)
+        return np.where((dx == 0)[:, None, None], fp[i], fp[i - 1] + w[:, None, None] * df)
 
     def s_R(self, t):
         return self.v_R(t)[0]
@@ -82,44 +113,52 @@ class CLD(object):
 
     # ---- schedule / drift / diffusion ----
     def beta(self, t):
-        return self.beta_0 + self.beta_1 * np.asarray(t, dtype=np.float64)
+        ft = self._ft
+        return ft(self.beta_0) + ft(self.beta_1) * np.asarray(t).astype(ft)
 
     def beta_int(self, t):
-        t = np.asarray(t, dtype=np.float64)
-        return self.beta_0 * t + 0.5 * self.beta_1 * t ** 2
+        ft = self._ft
+        t = np.asarray(t).astype(ft)
+        return ft(self.beta_0) * t + ft(0.5 * self.beta_1) * t ** 2  # :84-85, `0.5 * self.beta_1` is a Python product
 
     def s_F(self, t):
-        b = float(self.beta(t))
-        return np.array([[0.0, b * self.m_inv], [-b, -self.Gamma * b * self.m_inv]])
+        ft = self._ft
+        b = ft(self.beta(t))
+        return np.array([[0.0, b * ft(self.m_inv)], [-b, -ft(self.Gamma) * b * ft(self.m_inv)]], dtype=ft)
 
     def s_G(self, t):
-        b = float(self.beta(t))
-        return np.array([[0.0, 0.0], [0.0, np.sqrt(2 * self.Gamma * b)]])
+        ft = self._ft
+        b = ft(self.beta(t))
+        return np.array([[0.0, 0.0], [0.0, np.sqrt(ft(2 * self.Gamma) * b)]], dtype=ft)
 
     def vs_psi(self, s_vec, t):
-        """Psi(s_n, t) = expm(int_s^t F): e^{-ab/2} [[1+ab/2, a^2 b/4], [-b, 1-ab/2]], a = 2 sqrt(m_inv)."""
+        """Psi(s_n, t) = expm(int_s^t F): e^{-ab/2} [[1+ab/2, a^2 b/4], [-b, 1-ab/2]], a = 2 sqrt(m_inv) (sde_lib.py:182-205)."""
+        ft = self._ft
         b = self.beta_int(t) - self.beta_int(s_vec)
-        a = 2 * np.sqrt(self.m_inv)
-        e = np.exp(-a * b / 2)
-        out = np.empty(np.shape(b) + (2, 2))
-        out[..., 0, 0] = (1 + a * b / 2) * e
-        out[..., 0, 1] = 0.25 * a * a * b * e
+        a = ft(2) * np.sqrt(ft(self.m_inv))
+        e = np.exp(-a * b / ft(2))
+        out = np.empty(np.shape(b) + (2, 2), dtype=ft)
+        out[..., 0, 0] = (ft(1) + a * b / ft(2)) * e
+        out[..., 0, 1] = (ft(0.25) * a * a * b) * e
         out[..., 1, 0] = -b * e
-        out[..., 1, 1] = (1 - a * b / 2) * e
+        out[..., 1, 1] = (ft(1) - a * b / ft(2)) * e
         return out
 
     def s_psi(self, s, t):
-        return self.vs_psi(np.float64(s), t)
+        return self.vs_psi(self._ft(s), t)
 
     def vv_psi(self, s_vec, t_vec):
-        return self.vs_psi(np.asarray(s_vec, dtype=np.float64), np.asarray(t_vec, dtype=np.float64))
+        return self.vs_psi(np.asarray(s_vec), np.asarray(t_vec))
 
     def v_eps_integrand(self, t_vec):
-        """1/2 G G R^-T at a vector of times (G G^T has the single entry 2 Gamma beta at [1,1])."""
-        t_vec = np.atleast_1d(np.asarray(t_vec, dtype=np.float64))
+        """0.5 * G @ G @ inv_2x2(R).T at a vector of times (sde_lib.py:207-212): G = diag(0, g), so only row 1 is non-zero and
+        its factor is (0.5 g) g, formed left to right."""
+        ft = self._ft
+        t_vec = np.atleast_1d(np.asarray(t_vec)).astype(ft)
         invT = np.swapaxes(inv_2x2(self.v_R(t_vec)), -1, -2)
+        g = np.sqrt(ft(2 * self.Gamma) * self.beta(t_vec))
         out = np.zeros_like(invT)
-        out[:, 1, :] = (self.Gamma * self.beta(t_vec))[:, None] * invT[:, 1, :]
+        out[:, 1, :] = ((ft(0.5) * g) * g)[:, None] * invT[:, 1, :]
         return out
 
     def s_eps_integrand(self, t):
@@ -128,7 +167,7 @@ class CLD(object):
     # ---- F = F1 + F2 split of the rotated-frame sampler (sde_lib.py:121-180) ----
     def s_f1_psi(self, s, t):
         """expm(int_s^t F1): a rotation-like matrix, F1 = [[0, beta m_inv], [-beta, 0]]."""
-        b = float(self.beta_int(t) - self.beta_int(s))
+        b = float(self.beta_int(t)) - float(self.beta_int(s))
         sqrt_m, inv_sqrt_m = np.sqrt(1.0 / self.m_inv), np.sqrt(self.m_inv)
         c, sn = np.cos(b * inv_sqrt_m), np.sin(b * inv_sqrt_m)
         return np.array([[c, inv_sqrt_m * sn], [-sqrt_m * sn, c]])
@@ -175,28 +214,28 @@ class CLD(object):
 
     # ---- sampler coefficient tables ----
     def prepare_order0_coef(self, rev_ts, num_item=1000):
-        """sde_lib.py:289-306: Psi_i and a 1000-point left Riemann epsilon matrix per step."""
-        ts = np.asarray(rev_ts, dtype=np.float64)
+        """sde_lib.py:289-306: Psi_i and a 1000-point left Riemann epsilon matrix per step (`integrand * dt` before the sum)."""
+        ts = np.asarray(rev_ts).astype(self._ft)
         mean = self.vv_psi(ts[:-1], ts[1:])
-        eps = deis.get_ab_eps_coef(self, 0, ts, 0, num_item=num_item)[:, 0]
+        eps = deis.get_order0_eps_coef(self, ts, num_item=num_item)
         return mean, eps
 
     def prepare_naive_coef(self, rev_ts):
         """sde_lib.py:276-287 (`get_order0_sampler(is_em=True)`): the Euler step of the probability-flow ODE in the
-        [mean, eps] form -- Psi_i = I + F(t_i) dt and C_i = 1/2 G(t_i) G(t_i) R(t_i)^-T dt, dt = t_{i+1} - t_i < 0."""
-        ts = np.asarray(rev_ts, dtype=np.float64)
+        [mean, eps] form -- Psi_i = I + F(t_i) dt and C_i = 0.5 * G @ G @ inv(R(t_i)).T * dt, dt = t_{i+1} - t_i < 0."""
+        ft = self._ft
+        ts = np.asarray(rev_ts).astype(ft)
         n = ts.shape[0] - 1
-        mean, eps = np.empty((n, 2, 2)), np.empty((n, 2, 2))
+        mean, eps = np.empty((n, 2, 2), dtype=ft), np.empty((n, 2, 2), dtype=ft)
         for i in range(n):
             dt = ts[i + 1] - ts[i]
-            G = self.s_G(ts[i])
-            mean[i] = np.eye(2) + self.s_F(ts[i]) * dt
-            eps[i] = 0.5 * G @ G @ self.s_invR(ts[i]).T * dt
+            mean[i] = np.eye(2, dtype=ft) + self.s_F(ts[i]) * dt
+            eps[i] = self.s_eps_integrand(ts[i]) * dt
         return mean, eps
 
     def get_deis_coef(self, order, rev_timesteps, used_cache=True):
         """(N, order+3, 2, 2) = [Psi_i, C_i0 .. C_i(order+1)] (sde_lib.py:308-319; highest_order = order+1)."""
-        ts = np.asarray(rev_timesteps, dtype=np.float64)
+        ts = np.asarray(rev_timesteps).astype(self._ft)
         x_coef = self.vv_psi(ts[:-1], ts[1:])
         eps_coef = deis.get_ab_eps_coef(self, order + 1, ts, order)
         return np.concatenate([x_coef[:, None], eps_coef], axis=1)

@@ -42,36 +42,99 @@ struct Cld {
 
 }  // namespace
 
-extern "C" int gd_cld_r_table(double m_inv, double beta_0, double beta_1, double vv_gamma, double numerical_eps, int is_rk,
-                              double R_dt, size_t n, double *out_host) {
-    GD_CHECK(out_host && n > 0 && R_dt > 0 && m_inv > 0, "gd_cld_r_table: bad argument");
-    Cld s{m_inv, 2.0 / std::sqrt(m_inv), beta_0, beta_1};
-    M2 x{std::sqrt(numerical_eps), 0.0, 0.0, std::sqrt(vv_gamma / m_inv + numerical_eps)};
-    // grid of the scan: linspace(0, 1 + R_dt, n, endpoint=False)
-    const double h = (1.0 + R_dt) / (double)n;
+// ---- R(t) scan, in the arithmetic the configuration asks for ------------------------------------------------------------------
+// The reference runs the scan in the dtype jax is configured with: float32 when config.model.x64 is False (its default,
+// cld_jax/configs/default_cifar10_config.py; asserted at cld_jax/sde_lib.py:112), float64 otherwise.  A 10^6-step float32
+// recurrence is only reproducible if the operations happen in the order the expressions are written, so the body below follows
+//   _ode_fn        cld_jax/sde_lib.py:94-97    cur_F @ _x + 0.5 * cur_G @ cur_G.T @ inv_2x2(_x).T     (left to right)
+//   runge_kutta    cld_jax/deis.py:5-17        x + grad * dt / 2 ; t + dt / 2 ; x + dt / 6 * (g1 + 2 g2 + 2 g3 + g4)
+//   mid-point step cld_jax/sde_lib.py:103-107  carry + R_dt * (F_m @ carry + 0.5 * G_m @ G_m @ inv(carry).T)
+//   inv_2x2        cld_jax/sde_lib.py:17-26    [[d, -b], [-c, a]] * (1 / (a d - b c))
+// term by term in T, with no fused multiply-add (a 2-term dot product is commutative, so only contraction could change it).
+#pragma clang fp contract(off)
+namespace {
+
+template <class T>
+struct Mat2 {
+    T a, b, c, d;  // [[a, b], [c, d]]
+};
+
+template <class T>
+inline Mat2<T> matmul(const Mat2<T> &x, const Mat2<T> &y) {
+    return {x.a * y.a + x.b * y.c, x.a * y.b + x.b * y.d, x.c * y.a + x.d * y.c, x.c * y.b + x.d * y.d};
+}
+
+template <class T>
+inline Mat2<T> inv_t(const Mat2<T> &m) {  // inv_2x2(m).T
+    const T coef = (T)1 / (m.a * m.d - m.b * m.c);
+    return {m.d * coef, -m.c * coef, -m.b * coef, m.a * coef};
+}
+
+template <class T>
+struct CldT {
+    T m_inv, Gamma, beta_0, beta_1;
+    T beta(T t) const { return beta_0 + beta_1 * t; }
+    Mat2<T> F(T t) const {
+        const T b = beta(t);
+        return {(T)0, b * m_inv, -b, -Gamma * b * m_inv};
+    }
+    T g(T t) const { return std::sqrt((T)2 * Gamma * beta(t)); }  // s_G = diag(0, sqrt(2 Gamma beta))
+    Mat2<T> drift(const Mat2<T> &F, T g0, const Mat2<T> &x) const {
+        const Mat2<T> halfGG{(T)0, (T)0, (T)0, ((T)0.5 * g0) * g0};  // (0.5 * G) @ G.T, G diagonal
+        const Mat2<T> fx = matmul(F, x), gx = matmul(halfGG, inv_t(x));
+        return {fx.a + gx.a, fx.b + gx.b, fx.c + gx.c, fx.d + gx.d};
+    }
+    Mat2<T> ode(const Mat2<T> &x, T t) const { return drift(F(t), g(t), x); }
+};
+
+template <class T>
+inline Mat2<T> step_to(const Mat2<T> &x, const Mat2<T> &g, T h, T div) {  // x + g * h / div
+    return {x.a + g.a * h / div, x.b + g.b * h / div, x.c + g.c * h / div, x.d + g.d * h / div};
+}
+
+template <class T>
+int r_table(double m_inv, double beta_0, double beta_1, double vv_gamma, double numerical_eps, int is_rk, double R_dt, size_t n,
+            T *out) {
+    const CldT<T> s{(T)m_inv, (T)(2.0 / std::sqrt(m_inv)), (T)beta_0, (T)beta_1};  // Gamma = 2 / np.sqrt(m_inv): a Python float
+    // R_0 (sde_lib.py:61-66): jnp.sqrt of Python floats -- the sums are formed in double, rounded to T, then rooted in T
+    Mat2<T> x{std::sqrt((T)numerical_eps), (T)0, (T)0, std::sqrt((T)(vv_gamma / m_inv + numerical_eps))};
+    // grid jnp.linspace(0, 1 + R_dt, n, endpoint=False) = start * (1 - step) + stop * step with step = iota / n (jax 0.2.8)
+    const T stop = (T)(1.0 + R_dt), dt = (T)R_dt;
     for (size_t i = 0; i < n; ++i) {
-        const double t = h * (double)i;
-        out_host[4 * i + 0] = x.a; out_host[4 * i + 1] = x.b; out_host[4 * i + 2] = x.c; out_host[4 * i + 3] = x.d;
+        const T step = (T)i / (T)n;
+        const T t = (T)0 * ((T)1 - step) + stop * step;
+        out[4 * i + 0] = x.a; out[4 * i + 1] = x.b; out[4 * i + 2] = x.c; out[4 * i + 3] = x.d;
         if (is_rk) {
-            const M2 g1 = s.ode(x, t);
-            const M2 g2 = s.ode(axpy(x, R_dt / 2, g1), t + R_dt / 2);
-            const M2 g3 = s.ode(axpy(x, R_dt / 2, g2), t + R_dt / 2);
-            const M2 g4 = s.ode(axpy(x, R_dt, g3), t + R_dt);
-            x = {x.a + R_dt / 6 * (g1.a + 2 * g2.a + 2 * g3.a + g4.a), x.b + R_dt / 6 * (g1.b + 2 * g2.b + 2 * g3.b + g4.b),
-                 x.c + R_dt / 6 * (g1.c + 2 * g2.c + 2 * g3.c + g4.c), x.d + R_dt / 6 * (g1.d + 2 * g2.d + 2 * g3.d + g4.d)};
+            const Mat2<T> g1 = s.ode(x, t);
+            const Mat2<T> g2 = s.ode(step_to(x, g1, dt, (T)2), t + dt / (T)2);
+            const Mat2<T> g3 = s.ode(step_to(x, g2, dt, (T)2), t + dt / (T)2);
+            const Mat2<T> g4 = s.ode(step_to(x, g3, dt, (T)1), t + dt);
+            const T w = dt / (T)6;
+            x = {x.a + w * (g1.a + (T)2 * g2.a + (T)2 * g3.a + g4.a), x.b + w * (g1.b + (T)2 * g2.b + (T)2 * g3.b + g4.b),
+                 x.c + w * (g1.c + (T)2 * g2.c + (T)2 * g3.c + g4.c), x.d + w * (g1.d + (T)2 * g2.d + (T)2 * g3.d + g4.d)};
         } else {
-            // "mid point" Euler of the reference: coefficients averaged over [t, t + R_dt]
-            const M2 F0 = s.F(t), F1 = s.F(t + R_dt);
-            const M2 Fm{(F0.a + F1.a) / 2, (F0.b + F1.b) / 2, (F0.c + F1.c) / 2, (F0.d + F1.d) / 2};
-            const double gm = (s.g(t) + s.g(t + R_dt)) / 2;
-            const double det = x.a * x.d - x.b * x.c;
-            M2 r = mul(Fm, x);
-            r.c += 0.5 * gm * gm * (-x.b / det);
-            r.d += 0.5 * gm * gm * (x.a / det);
-            x = axpy(x, R_dt, r);
+            const Mat2<T> F0 = s.F(t), F1 = s.F(t + dt);
+            const Mat2<T> Fm{(F0.a + F1.a) / (T)2, (F0.b + F1.b) / (T)2, (F0.c + F1.c) / (T)2, (F0.d + F1.d) / (T)2};
+            const T gm = (s.g(t) + s.g(t + dt)) / (T)2;
+            const Mat2<T> r = s.drift(Fm, gm, x);
+            x = {x.a + dt * r.a, x.b + dt * r.b, x.c + dt * r.c, x.d + dt * r.d};
         }
     }
     return 0;
+}
+
+}  // namespace
+
+extern "C" int gd_cld_r_table(double m_inv, double beta_0, double beta_1, double vv_gamma, double numerical_eps, int is_rk,
+                              double R_dt, size_t n, double *out_host) {
+    GD_CHECK(out_host && n > 0 && R_dt > 0 && m_inv > 0, "gd_cld_r_table: bad argument");
+    return r_table<double>(m_inv, beta_0, beta_1, vv_gamma, numerical_eps, is_rk, R_dt, n, out_host);
+}
+
+extern "C" int gd_cld_r_table_f32(double m_inv, double beta_0, double beta_1, double vv_gamma, double numerical_eps, int is_rk,
+                                  double R_dt, size_t n, float *out_host) {
+    GD_CHECK(out_host && n > 0 && R_dt > 0 && m_inv > 0, "gd_cld_r_table_f32: bad argument");
+    return r_table<float>(m_inv, beta_0, beta_1, vv_gamma, numerical_eps, is_rk, R_dt, n, out_host);
 }
 
 // psi2 table of the rotated-frame sampler (cld_jax/sampling.py:272-285): d psi2/dt = psi1(t)^-1 F2(t) psi1(t) psi2.

@@ -264,8 +264,7 @@ int Plan::resblock(int idx, int xa, int Ca, int xb, int Cb, int H, int W, int O,
         // commute up to Conv_2's bias (the FIR's zero boundary does not pass a constant through unchanged).  Down: FIR first, the 1x1
         // convolution at the low resolution, as written.  Up: the 1x1 convolution WITHOUT its bias at the low resolution -- a quarter of
         // the rows --, then the FIR on its output; the bias joins Conv_1's, which adds the shortcut as its residual (Plan::bias_folds).
-        static const bool no_swap = getenv("GDDIM_NO_UPSWAP") && atoi(getenv("GDDIM_NO_UPSWAP")) != 0;
-        if (up && !no_swap) {
+        if (up && !no_upswap) {
             const int xlo = conv(n + ".conv2", n + "/Conv_2", xa, C, -1, 0, H, W, 1, O, -1, 1.f, -1, 0);
             up_b2 = ops.back().bias_slot;
             ops.back().bias_slot = -1;
@@ -328,8 +327,7 @@ int Plan::resblock(int idx, int xa, int Ca, int xb, int Cb, int H, int W, int O,
 // disappears: residual, 1/sqrt(2) and the fused statistics move to the P v'' epilogue.  The products W_q W_k^T and W_v W_3 are formed
 // once per parameter load in float64 (Plan::fold_params) and rounded once.
 int Plan::attn(int idx, int x, int H, int W, int C) {
-    static const bool no_fold = getenv("GDDIM_NO_ATTN_FOLD") && atoi(getenv("GDDIM_NO_ATTN_FOLD")) != 0;
-    if (no_fold) return attn_unfolded(idx, x, H, W, C);
+    if (no_attn_fold) return attn_unfolded(idx, x, H, W, C);
     const std::string n = "AttnBlockpp_" + std::to_string(idx);
     const int HW = H * W;
     const float scale = desc.skip_rescale ? (float)(1.0 / std::sqrt(2.0)) : 1.f;
@@ -386,11 +384,13 @@ int Plan::attn(int idx, int x, int H, int W, int C) {
         sm.kind = OP_SOFTMAX; sm.label = n + ".softmax"; sm.out = {S, 0}; sm.rows_per_image = HW; sm.cols = HW;
         ops.push_back(sm);
     }
-    release(qp);
-    release(hn);
-    // (x + w v'' + (b_v W_3 + b_3)) / sqrt(2), with the statistics of the block output
+    // (x + w v'' + (b_v W_3 + b_3)) / sqrt(2), with the statistics of the block output.  The fused core (attn256_f32_kernel) runs qk,
+    // softmax and av as ONE launch whose workgroups store rows of `out` while others still read q' and h: `out` is allocated while
+    // both are live, so first-fit cannot lay it over them at a shifted offset (64x64 configurations did: out 2 rows below q').
     int out = new_tensor(n + ".out", H, W, C);
     attach_stats(out, HW);
+    release(qp);
+    release(hn);
     {
         Op g;
         g.kind = OP_GEMM; g.label = n + ".av";
@@ -508,9 +508,9 @@ int Plan::attn_unfolded(int idx, int x, int H, int W, int C) {
         sm.kind = OP_SOFTMAX; sm.label = n + ".softmax"; sm.out = {S, 0}; sm.rows_per_image = HW; sm.cols = HW;
         ops.push_back(sm);
     }
-    release(qk);
-    // h = w v (+ b_v)
+    // h = w v (+ b_v); allocated while q, k are live: one fused launch reads them and writes this (see Plan::attn)
     int ho = new_tensor(n + ".av", H, W, C);
+    release(qk);
     {
         Op g;
         g.kind = OP_GEMM; g.label = n + ".av";
@@ -548,6 +548,9 @@ int Plan::attn_unfolded(int idx, int x, int H, int W, int C) {
 // ---------------------------------------------------------------- NCSNpp.__call__
 int Plan::build(const gd_model_desc &d) {
     desc = d;
+    // A/B switches of the lowering, read per plan (a second engine in the process, or a test, may build the other form)
+    no_attn_fold = getenv("GDDIM_NO_ATTN_FOLD") && atoi(getenv("GDDIM_NO_ATTN_FOLD")) != 0;
+    no_upswap = getenv("GDDIM_NO_UPSWAP") && atoi(getenv("GDDIM_NO_UPSWAP")) != 0;
     GD_CHECK(d.num_levels >= 1 && d.num_levels <= GD_MAX_LEVELS, "num_levels out of range");
     GD_CHECK(d.nf >= 16 && d.nf % 16 == 0, "nf must be a multiple of 16 (GroupNorm groups of >= 4 channels), got %d", d.nf);
     GD_CHECK(d.in_channels >= 1 && d.image_size >= (1 << (d.num_levels - 1)), "bad in_channels / image_size");

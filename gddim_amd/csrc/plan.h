@@ -169,6 +169,7 @@ struct Plan {
     double folded_flops_per_image = 0;
     std::vector<AttnFold> attn_folds;
     std::vector<BiasFold> bias_folds;
+    bool no_attn_fold = false, no_upswap = false;  // GDDIM_NO_ATTN_FOLD / GDDIM_NO_UPSWAP at build(): the written forms (A/B, tests)
     void fold_params();  // derived weight slots from the loaded ones (float64 on the host); call once all parameters are loaded
 
     int build(const gd_model_desc &d);  // 0 ok

@@ -69,10 +69,17 @@ int gd_device_count(void);
  * R_0 = diag(sqrt(numerical_eps), sqrt(vv_gamma/m_inv + numerical_eps)), emitting the state
  * before each of n steps (out: n x 4 doubles, row-major 2x2).
  * Replaces: cld_jax/sde_lib.py:93-118 (_get_s_R_fn: lax.scan over scan_body_fn) and
- * cld_jax/deis.py:5-17 (runge_kutta).  Computed in float64 (the reference runs float32,
- * DESIGN.md "precision" explains why float64 is within parity). */
+ * cld_jax/deis.py:5-17 (runge_kutta).  Two instantiations of one body that performs the reference's
+ * operations in the order its expressions are written, without fused multiply-add:
+ *   gd_cld_r_table      float64 -- config.model.x64 = True  (jax_enable_x64, cld_jax/sde_lib.py:112)
+ *   gd_cld_r_table_f32  float32 -- config.model.x64 = False, the reference's default
+ *                       (cld_jax/configs/default_cifar10_config.py); out: n x 4 floats.
+ * The mid-point Euler branch (is_rk = 0, sde_lib.py:103-107) inverts with the closed 2x2 form where the
+ * reference calls jnp.linalg.inv (an LU solve). */
 int gd_cld_r_table(double m_inv, double beta_0, double beta_1, double vv_gamma, double numerical_eps,
                    int is_rk, double R_dt, size_t n, double *out_host);
+int gd_cld_r_table_f32(double m_inv, double beta_0, double beta_1, double vv_gamma, double numerical_eps,
+                       int is_rk, double R_dt, size_t n, float *out_host);
 
 /* psi2(t) table of the rotated-frame ("ML") CLD sampler: RK4 scan of d psi2/dt = psi1(t)^-1 F2(t) psi1(t) psi2 from
  * psi2(0) = I with step dt, emitting the state before each of n steps (out: n x 4 doubles).  psi1(t) = expm(int_0^t F1),

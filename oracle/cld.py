@@ -53,6 +53,27 @@ def inv_2x2(m):
     return np.asarray([[d, -b], [-c, a]], dtype=m.dtype) * m.dtype.type(coef)
 
 
+def jnp_linspace(start, stop, num, endpoint=True, dtype=np.float64):
+    """jnp.linspace of jax 0.2.8 (the reference's pin, Dockerfile:1-15) for a floating dtype, restated from memory of
+    jax/_src/numpy/lax_numpy.py: `step = iota / div; out = start * (1 - step) + stop * step` in the computation dtype ("recovers
+    the endpoints with float32 arithmetic").  In float32 this differs from numpy's float64-then-round grid by an ulp per point,
+    which is 0.6 % of the 1e-5 knot spacing of the R table near t = 1 -- it matters to get_interp_fn's weights."""
+    T = np.dtype(dtype).type
+    div = (num - 1) if endpoint else num
+    if num == 1:
+        return np.asarray([start], dtype=T)
+    step = np.arange(num, dtype=T) / T(div)
+    return T(start) * (T(1) - step) + T(stop) * step
+
+
+def jnp_linspace_int(start, stop, num, dtype=np.float64):
+    """jnp.linspace(start, stop, num, dtype=int): floor(start + iota * delta), delta = (stop - start) / (num - 1), evaluated in
+    the floating computation dtype (`dtype`: float32 when x64 is off) and then converted."""
+    T = np.dtype(dtype).type
+    delta = (T(stop) - T(start)) / T(num - 1)
+    return np.floor(T(start) + np.arange(num).astype(T) * delta).astype(np.int64)
+
+
 def get_interp_fn(xp, fp):
     # sde_lib.py:32-43  (searchsorted side='right', clipped to [1, len-1], linear)
     def _fn(x):
@@ -73,7 +94,13 @@ class CLD:
     """sde_lib.py:45-331 restated.  ``dtype`` plays the role of the jax x64 switch."""
 
     def __init__(self, m_inv=4.0, beta_0=4.0, beta_1=0.0, vv_gamma=0.04, numerical_eps=1e-6,
-                 mixed_score=False, is_R_rk=False, R_dt=1e-5, dtype=np.float64):
+                 mixed_score=False, is_R_rk=False, R_dt=1e-5, dtype=np.float64, sum_order="pairwise"):
+        # sum_order: how the 10 000-term `jnp.sum(..., axis=0)` of deis.py:46 / sde_lib.py:296 is accumulated in `dtype`.  XLA's
+        # order is not defined by the reference's source: a tree on the GPU backend ("pairwise": numpy's pairwise sum along a
+        # contiguous axis), a running loop on the CPU backend ("sequential").  In float32 the two differ by ~2e-6 of the table
+        # scale -- as much as float32 differs from float64 (tests/test_oracle_cld.py holds both numbers).
+        assert sum_order in ("pairwise", "sequential")
+        self.sum_order = sum_order
         self.dtype = np.dtype(dtype)
         T = self.dtype.type
         self.mixed_score = mixed_score
@@ -81,8 +108,9 @@ class CLD:
         self.Gamma = T(2.0 / np.sqrt(m_inv))  # :57
         self.beta_0 = T(beta_0)
         self.beta_1 = T(beta_1)
+        # :61-66: jnp.sqrt of Python floats -- `vv_gamma / self.m_inv + numerical_eps` is a Python (double) expression
         self.R_0 = np.asarray([[np.sqrt(T(numerical_eps)), 0],
-                               [0, np.sqrt(T(vv_gamma) / self.m_inv + T(numerical_eps))]], dtype=self.dtype)  # :61-66
+                               [0, np.sqrt(T(vv_gamma / m_inv + numerical_eps))]], dtype=self.dtype)
         self.is_R_rk = bool(is_R_rk)
         self.R_dt = float(R_dt)
         self.sampling_eps = 1e-3  # :76
@@ -100,7 +128,7 @@ class CLD:
     def _get_s_R_fn(self, is_rk, R_dt):
         # :93-118.  n = int(1/R_dt) + 1 grid points on linspace(0, 1 + R_dt, n, endpoint=False).
         n = int(1.0 / R_dt) + 1
-        ts = np.linspace(0, 1.0 + R_dt, n, endpoint=False).astype(self.dtype)
+        ts = jnp_linspace(0, 1.0 + R_dt, n, endpoint=False, dtype=self.dtype)
         out = np.empty((n, 2, 2), dtype=self.dtype)
         lib = _lib()
         if self.dtype == np.float32:
@@ -114,7 +142,7 @@ class CLD:
         fn(R0.ctypes.data, cT(self.m_inv), cT(self.Gamma), cT(self.beta_0), cT(self.beta_1),
            cT(R_dt), ts.ctypes.data, n, int(is_rk), out.ctypes.data)
         self.R_table_ts, self.R_table = ts, out
-        idx = np.linspace(0, n - 1, 100_000).astype(int)  # :117 (dtype=int truncates)
+        idx = jnp_linspace_int(0, n - 1, 100_000, dtype=self.dtype)  # :117
         return get_interp_fn(ts[idx], out[idx])
 
     def v_R(self, ts):
@@ -168,10 +196,10 @@ class CLD:
         for i in range(N):
             cur_t, next_t = rev_ts[i], rev_ts[i + 1]
             dt = (next_t - cur_t) / num_item
-            t_inter = np.linspace(cur_t, next_t, num_item, endpoint=False).astype(self.dtype)
+            t_inter = jnp_linspace(cur_t, next_t, num_item, endpoint=False, dtype=self.dtype)
             psi_coef = vs_psi(self, t_inter, next_t)
             integrand = v_eps_integrand(self, t_inter)
-            eps[i] = np.einsum("bij,bjk->bik", psi_coef, integrand * dt).sum(axis=0)
+            eps[i] = reduce0(np.einsum("bij,bjk->bik", psi_coef, integrand * dt).astype(self.dtype), self.sum_order)
         return mean, eps
 
     # ---- DEIS coefficients (sde_lib.py:308-319 + deis.py:19-95) ----
@@ -191,6 +219,16 @@ class CLD:
         return np.concatenate([x_coef[:, None], eps_coef], axis=1)
 
 
+def reduce0(a, order):
+    """jnp.sum(a, axis=0) in a's dtype with a stated accumulation order (see CLD.__init__)."""
+    if order == "sequential":
+        acc = np.zeros(a.shape[1:], dtype=a.dtype)
+        for row in a:  # a running sum, one row at a time
+            acc = acc + row
+        return acc
+    return np.sum(np.ascontiguousarray(np.moveaxis(a, 0, -1)), axis=-1)
+
+
 def single_poly_coef(t_val, ts_poly, coef_idx):
     # deis.py:29-36  Lagrange basis l_j(tau) on nodes ts_poly
     num = t_val - ts_poly
@@ -206,14 +244,14 @@ def _eps_single_coef(sde, t_start, t_end, ts_poly, coef_idx, num_item=10000):
     # deis.py:19-27 + 41-47: left Riemann sum, num_item points, endpoint=False
     T = sde.dtype.type
     dt = (t_end - t_start) / T(num_item)
-    t_inter = np.linspace(t_start, t_end, num_item, endpoint=False).astype(sde.dtype)
+    t_inter = jnp_linspace(t_start, t_end, num_item, endpoint=False, dtype=sde.dtype)
     # sde.vs_psi(t_inter, t_end) / sde.v_eps_integrand(t_inter): the LSDE / MLCLD restatements (oracle/cld_ext.py) bring
     # their own, the plain CLD uses the closed forms below
     psi_coef = sde.vs_psi(t_inter, t_end) if hasattr(sde, "vs_psi") else vs_psi(sde, t_inter, t_end)                    # (n,2,2)
     integrand = sde.v_eps_integrand(t_inter) if hasattr(sde, "v_eps_integrand") else v_eps_integrand(sde, t_inter)      # (n,2,2)
     prod = np.einsum("bij,bjk->bik", psi_coef, integrand)
     poly = vec_poly_coef(t_inter, ts_poly, coef_idx)   # (n,)
-    acc = np.sum(prod * poly[:, None, None], axis=0)   # summation order is XLA's, not reproducible
+    acc = reduce0((prod * poly[:, None, None]).astype(sde.dtype), getattr(sde, "sum_order", "pairwise"))  # XLA's order: unknowable
     return (acc * dt).astype(sde.dtype)
 
 
@@ -308,8 +346,10 @@ def get_rev_ts(sde, ts_order, num_step, dtype=None):
     # sampling.py:241-249
     dtype = np.dtype(dtype or sde.dtype)
     T = dtype.type
-    lin = np.linspace(np.power(T(sde.T), T(1.0 / ts_order)), np.power(T(sde.sampling_eps), T(1.0 / ts_order)),
-                      num_step + 1).astype(dtype)
+    lin = jnp_linspace(np.power(T(sde.T), T(1.0 / ts_order)), np.power(T(sde.sampling_eps), T(1.0 / ts_order)),
+                       num_step + 1, dtype=dtype)
+    if isinstance(ts_order, (int, np.integer)) and ts_order == 2:
+        return lin * lin  # jnp.power with a Python int exponent is lax.integer_pow (a multiplication chain)
     return np.power(lin, T(ts_order)).astype(dtype)
 
 

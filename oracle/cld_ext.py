@@ -185,7 +185,7 @@ def hyd_rev_ts(sde, nfe, noise_nfe_ratio=0.3, img_t_ratio=0.3, ts_order=2.0, den
     mid_t = sde.T * img_t_ratio
     noise_nfe = int(num_step * noise_nfe_ratio)
     img_nfe = num_step - noise_nfe
-    noise_ts = np.linspace(sde.T, mid_t, noise_nfe, endpoint=False)
+    noise_ts = ocld.jnp_linspace(sde.T, mid_t, noise_nfe, endpoint=False, dtype=sde.dtype)
     img_ts = ocld.get_rev_ts(sde, ts_order, img_nfe)
     rev_ts = np.concatenate([noise_ts, img_ts])
     assert rev_ts.shape[0] == num_step + 1  # :268
@@ -222,8 +222,7 @@ def mldeis_sampler(sde, eps_fn, u, nfe, deis_order, ts_order=2, denoising=False,
                    mlsde=None):
     """get_mldeis_sampler (sampling.py:322-378), non-pmapped."""
     num_step = nfe - 1 if denoising else nfe
-    rev_ts = np.power(np.linspace(np.power(sde.T, 1.0 / ts_order), np.power(sde.sampling_eps, 1.0 / ts_order), num_step + 1),
-                      ts_order)
+    rev_ts = ocld.get_rev_ts(sde, ts_order, num_step)  # sampling.py:330-337 repeats get_rev_ts inline
     mlsde = MLCLD(sde) if mlsde is None else mlsde
     if deis_coef is None:
         deis_coef = mlsde.get_deis_coef(deis_order, rev_ts)

@@ -15,6 +15,9 @@
  */
 #include <stddef.h>
 
+#define SQRT_float(x) __builtin_sqrtf(x)
+#define SQRT_double(x) __builtin_sqrt(x)
+
 #define DEFINE_SCAN(NAME, T)                                                                   \
     static void NAME##_inv2(const T m[4], T o[4]) {                                            \
         /* sde_lib.py:17-26: coef = 1/(a d - b c); [[d,-b],[-c,a]] * coef */                   \
@@ -30,7 +33,8 @@
         T b = beta0 + beta1 * t;                                                               \
         F[0] = 0; F[1] = b * m_inv; F[2] = -b; F[3] = -Gamma * b * m_inv;                      \
         (void)gt;                                                                              \
-        GG[0] = 0; GG[1] = 0; GG[2] = 0; GG[3] = (T)2.0 * Gamma * b; /* G G^T (G diagonal) */  \
+        /* (0.5 * cur_G) @ cur_G.T as written at :96 (left to right; G diagonal): (0.5 g) g, g = sqrt(2 Gamma b) in T */ \
+        { T g = (T)SQRT_##T((T)2.0 * Gamma * b); GG[0] = 0; GG[1] = 0; GG[2] = 0; GG[3] = ((T)0.5 * g) * g; } \
     }                                                                                          \
     static void NAME##_ode(const T x[4], T t, T m_inv, T Gamma, T b0, T b1, T g[4]) {          \
         /* sde_lib.py:94-97: F @ x + 0.5 * G @ G.T @ inv_2x2(x).T */                           \
@@ -40,7 +44,7 @@
         invT[0] = inv[0]; invT[1] = inv[2]; invT[2] = inv[1]; invT[3] = inv[3];                \
         NAME##_mm(F, x, a);                                                                    \
         NAME##_mm(GG, invT, c);                                                                \
-        for (int i = 0; i < 4; ++i) g[i] = a[i] + (T)0.5 * c[i];                               \
+        for (int i = 0; i < 4; ++i) g[i] = a[i] + c[i];                                        \
     }                                                                                          \
     /* out: n x 4 row-major 2x2 matrices. is_rk: RK4 (deis.py:5-17) else the "mid point"     */ \
     /* Euler variant (sde_lib.py:103-107).                                                    */ \
@@ -69,16 +73,16 @@
                 /* cur_G = (G(t)+G(t+dt))/2 then cur_G @ cur_G: with beta_1 = 0 both equal */  \
                 {                                                                              \
                     T b_a = beta0 + beta1 * t, b_b = beta0 + beta1 * (t + R_dt);               \
-                    T ga = (T)__builtin_sqrt((double)((T)2.0 * Gamma * b_a));                  \
-                    T gb = (T)__builtin_sqrt((double)((T)2.0 * Gamma * b_b));                  \
+                    T ga = (T)SQRT_##T((T)2.0 * Gamma * b_a);                                  \
+                    T gb = (T)SQRT_##T((T)2.0 * Gamma * b_b);                                  \
                     T g = (ga + gb) / (T)2;                                                    \
-                    GG[0] = 0; GG[1] = 0; GG[2] = 0; GG[3] = g * g;                            \
+                    GG[0] = 0; GG[1] = 0; GG[2] = 0; GG[3] = ((T)0.5 * g) * g;                 \
                 }                                                                              \
                 NAME##_inv2(x, inv);                                                           \
                 invT[0] = inv[0]; invT[1] = inv[2]; invT[2] = inv[1]; invT[3] = inv[3];        \
                 NAME##_mm(F, x, a);                                                            \
                 NAME##_mm(GG, invT, c);                                                        \
-                for (int k = 0; k < 4; ++k) x[k] = x[k] + R_dt * (a[k] + (T)0.5 * c[k]);       \
+                for (int k = 0; k < 4; ++k) x[k] = x[k] + R_dt * (a[k] + c[k]);                \
             }                                                                                  \
         }                                                                                      \
     }

@@ -49,3 +49,13 @@ def tiny_config(kind="cld", nf=16, num_res_blocks=1, image_size=16, ch_mult=(1, 
     cfg.data.image_size = image_size
     cfg.data.centered = centered
     return cfg
+
+
+def oracle_cld_like(sde, **kw):
+    """The oracle's CLD in the arithmetic the product object is configured for: float32 tables for config.model.x64=False (the
+    reference's default), float64 for x64=True -- so that a comparison measures the HIP path, not the tables' precision (that term is
+    held by tests/test_oracle_cld.py::test_parity_budget_float32_tables_end_to_end)."""
+    import numpy as np
+    from oracle import cld as ocld
+    return ocld.CLD(m_inv=sde.m_inv, beta_0=sde.beta_0, beta_1=sde.beta_1, vv_gamma=sde.vv_gamma, numerical_eps=sde.numerical_eps,
+                    is_R_rk=sde.is_R_rk, R_dt=sde.R_dt, dtype=np.float64 if sde.x64 else np.float32, **kw)

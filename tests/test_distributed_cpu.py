@@ -117,3 +117,29 @@ def test_sample_data_uneven_round_keeps_every_image(tmp_path):
     mp.spawn(_round_worker, args=(2, _free_port(), str(tmp_path), 7), nprocs=2, join=True)
     info = np.load(os.path.join(str(tmp_path), "samples_0.npz"))
     assert info["samples"].shape == (7, 4, 4, 3) and info["samples_x"].shape == (1, 7, 4, 4, 3)
+
+
+def test_bench_self_launches_for_n_gt_1(tmp_path):
+    """`python bench.py --gpus 2` with NO launcher in the environment (how the driver calls it for N = 1) must start its own two ranks
+    (it used to die on `assert world == args.gpus`).  --dry-run keeps the GPU and the sampler out of it: gloo ranks, the
+    timed region with its barriers, the uint8 all-gather and rank 0's single JSON line."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "2"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "2", "--warmup", "1",
+                        "--batch", "8"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=str(tmp_path))
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines  # ONE line, from rank 0
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["dry_run"] is True and d["value"] is None and d["steps"] == 2 and d["warmup"] == 1
+    assert d["gathered_images"] == 16 and d["config"]["global_batch"] == 16 and d["scaling"] == "weak"
+    # under an external launcher the same file still works (the driver's N > 1 form): torch.distributed.run sets RANK, no re-exec
+    port = _free_port()
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "1", "--warmup", "0",
+                        "--batch", "4"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=str(tmp_path))
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    d = json.loads([l for l in p.stdout.decode().splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["gathered_images"] == 8

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import tiny_config
+from conftest import oracle_cld_like, tiny_config
 from oracle import cld as ocld
 from oracle import ncsnpp as onet
 
@@ -49,7 +49,7 @@ def test_bf16x3_sampler_matches_oracle(native_lib):
     cfg = tiny_config("cld", nf=32, num_res_blocks=1, image_size=16, ch_mult=(1, 2, 2), attn=(8,))  # channels % 32 == 0
     params = onet.random_params(cfg, 6, seed=21)
     sde = sde_lib.from_config(cfg)
-    osde = ocld.CLD(is_R_rk=True, R_dt=1e-6, dtype=np.float64)
+    osde = oracle_cld_like(sde)
     model = mutils.get_model(cfg.model.name)(config=cfg)
     state = mutils.State(params_ema=params, model_state={})
     rng = np.random.default_rng(0)

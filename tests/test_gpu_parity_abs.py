@@ -23,6 +23,7 @@ import numpy as np
 import pytest
 import torch
 
+from conftest import oracle_cld_like
 from oracle import blur as oblur
 from oracle import cld as ocld
 from oracle import ncsnpp as onet
@@ -48,12 +49,13 @@ def _scaled_head(params, gain):
     return p
 
 
-def _cld_case(native_lib, cfg_mod, image_size, B, n_ref, nfe, gain, seed, method="deis", **samp):
+def _cld_case(native_lib, cfg_mod, image_size, B, n_ref, nfe, gain, seed, method="deis", x64=False, **samp):
     from gddim_amd.cld import sampling, sde_lib
     from gddim_amd.datasets import get_data_inverse_scaler
     from gddim_amd.models import utils as mutils
     cfg = cfg_mod.get_config()
     cfg.data.image_size = image_size
+    cfg.model.x64 = x64  # False = the reference's default: float32 tables on both sides (conftest.oracle_cld_like)
     params = _scaled_head(onet.random_params(cfg, 6, seed=seed), gain)
 
     class NearDenoiserCLD(sde_lib.CLD):
@@ -63,7 +65,7 @@ def _cld_case(native_lib, cfg_mod, image_size, B, n_ref, nfe, gain, seed, method
     sde = sde_lib.from_config(cfg)
     sde.__class__ = NearDenoiserCLD
     sde.mixed_score = True
-    osde = ocld.CLD(is_R_rk=cfg.model.is_R_rk, R_dt=cfg.model.R_dt, dtype=np.float64)
+    osde = oracle_cld_like(sde)
     model = mutils.get_model(cfg.model.name)(config=cfg)
     state = mutils.State(params_ema=params, model_state={})
     rng = np.random.default_rng(seed + 100)
@@ -97,15 +99,19 @@ def _report(tag, x, v, wx, wv, lx, n_ref, trace=None):
     return ex, ev, moved
 
 
-def test_cld_nfe50_b256_absolute_parity(native_lib):
-    """BASELINE config 2: CLD gDDIM deis_order=2, NFE=50 (49 AB steps + denoising), 256 images, full accr U-Net, hipGraph."""
+@pytest.mark.parametrize("x64", [False, True], ids=["x64=False", "x64=True"])
+def test_cld_nfe50_b256_absolute_parity(native_lib, x64):
+    """BASELINE config 2: CLD gDDIM deis_order=2, NFE=50 (49 AB steps + denoising), 256 images, full accr U-Net, hipGraph -- with the
+    coefficient tables in the reference's default arithmetic (config.model.x64=False: float32) and in float64, the oracle's tables in
+    the same arithmetic each time."""
     from gddim_amd.configs import cld_accr_dcifar10
-    n_ref, nfe, gain = 2, 50, 0.3
-    cfg, osde, eps64, lin64, u_ref, x, v, n, model = _cld_case(native_lib, cld_accr_dcifar10, 32, 256, n_ref, nfe, gain, seed=0)
+    n_ref, nfe, gain = (1 if x64 else 2), 50, 0.3
+    cfg, osde, eps64, lin64, u_ref, x, v, n, model = _cld_case(native_lib, cld_accr_dcifar10, 32, 256, n_ref, nfe, gain, seed=0, x64=x64)
+    assert osde.dtype == (np.float64 if x64 else np.float32)
     trace = []
     wx, wv, _ = ocld.deis_sampler(osde, eps64, u_ref, nfe, 2, ts_order=2, denoising=True, inverse_scaler=ocld.inverse_scaler_centered, trace=trace)
     lx, _, _ = ocld.deis_sampler(osde, lin64, u_ref, nfe, 2, ts_order=2, denoising=True, inverse_scaler=ocld.inverse_scaler_centered)
-    ex, ev, moved = _report("CLD NFE=50 B=256", x, v, wx, wv, lx, n_ref, trace)
+    ex, ev, moved = _report("CLD NFE=50 B=256 x64=%s" % x64, x, v, wx, wv, lx, n_ref, trace)
     # the kernels of the benchmark ran (hybrid Winograd kernel, persistent short-K GEMM), not a small-batch fallback
     names = _profile_names(model, 6, 256)
     assert any("conv3x3_wino42_f32_kernel" in k for k in names) and any("igemm_f32_pers_kernel" in k for k in names), names
@@ -221,7 +227,7 @@ def test_hybdeis_absolute_parity(native_lib):
     cfg = tiny_config("cld", nf=16, num_res_blocks=1, image_size=16, ch_mult=(1, 2, 2), attn=(8,))
     params = _scaled_head(onet.random_params(cfg, 6, seed=3), 0.3)
     sde = sde_lib.from_config(cfg)
-    osde = ocld.CLD(is_R_rk=cfg.model.is_R_rk, R_dt=cfg.model.R_dt, dtype=np.float64)
+    osde = oracle_cld_like(sde)
     model = mutils.get_model(cfg.model.name)(config=cfg)
     state = mutils.State(params_ema=params, model_state={})
     rng = np.random.default_rng(4)
@@ -252,7 +258,7 @@ def test_order0_is_em_matches_oracle(native_lib):
     cfg = tiny_config("cld", nf=16, num_res_blocks=1, image_size=16, ch_mult=(1, 2, 2), attn=(8,))
     params = onet.random_params(cfg, 6, seed=5)
     sde = sde_lib.from_config(cfg)
-    osde = ocld.CLD(is_R_rk=cfg.model.is_R_rk, R_dt=cfg.model.R_dt, dtype=np.float64)
+    osde = oracle_cld_like(sde)
     model = mutils.get_model(cfg.model.name)(config=cfg)
     state = mutils.State(params_ema=params, model_state={})
     rng = np.random.default_rng(6)

@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import tiny_config
+from conftest import oracle_cld_like, tiny_config
 from oracle import blur as oblur
 from oracle import cld as ocld
 from oracle import ncsnpp as onet
@@ -28,14 +28,14 @@ def _tol(want):
     return REL_TOL * max(1.0, float(np.abs(want).max()))
 
 
-@pytest.fixture(scope="module")
-def cld_setup(native_lib):
+def _cld_setup(x64):
     from gddim_amd.cld import sde_lib
     from gddim_amd.models import utils as mutils
     cfg = tiny_config("cld", nf=16, num_res_blocks=1, image_size=16, ch_mult=(1, 2, 2), attn=(8,))
+    cfg.model.x64 = x64
     params = onet.random_params(cfg, 6, seed=2)
     sde = sde_lib.from_config(cfg)
-    osde = ocld.CLD(is_R_rk=cfg.model.is_R_rk, R_dt=cfg.model.R_dt, dtype=np.float64)
+    osde = oracle_cld_like(sde)
     model = mutils.get_model(cfg.model.name)(config=cfg)
     state = mutils.State(params_ema=params, model_state={})
     rng = np.random.default_rng(0)
@@ -44,11 +44,26 @@ def cld_setup(native_lib):
     return cfg, params, sde, osde, model, state, u
 
 
+@pytest.fixture(scope="module")
+def cld_setup(native_lib):
+    """The sampler variants (ldeis, mldeis, em, sscs, sdeis, ode: SURVEY section 8f N3) build their own tables in float64 on top of
+    R(t); their oracles (oracle/cld_ext.py) are float64 restatements, so this fixture sets config.model.x64 = True on both sides."""
+    return _cld_setup(True)
+
+
+@pytest.fixture(scope="module", params=[False, True], ids=["x64=False", "x64=True"])
+def cld_setup_ref(request, native_lib):
+    """The reference path proper (deis / order0, BASELINE configs 1, 2, 4, 5) in both arithmetic modes of its tables: x64=False (the
+    reference's default: float32 scan, grids and Riemann sums) and x64=True; the oracle's tables follow (conftest.oracle_cld_like)."""
+    return _cld_setup(request.param)
+
+
 @pytest.mark.parametrize("nfe,order,denoise", [(10, 2, True), (6, 1, False), (5, 0, True), (8, 3, True)])
-def test_deis_sampler_matches_oracle(cld_setup, nfe, order, denoise):
+def test_deis_sampler_matches_oracle(cld_setup_ref, nfe, order, denoise):
     from gddim_amd.cld import sampling
     from gddim_amd.datasets import get_data_inverse_scaler
-    cfg, params, sde, osde, model, state, u = cld_setup
+    cfg, params, sde, osde, model, state, u = cld_setup_ref
+    assert sde._fp.dtype == osde.R_table.dtype == (np.float64 if cfg.model.x64 else np.float32)
     inv = get_data_inverse_scaler(cfg)
     fn = sampling.get_deis_sampler(sde, model, (16, 16, 3), nfe, inv, deis_order=order, ts_order=2, denoising=denoise, is_p=False)
     x, v, n = fn(0, state, u.shape[0], torch.as_tensor(u, device="cuda:0"))
@@ -73,10 +88,10 @@ def test_deis_sampler_matches_oracle(cld_setup, nfe, order, denoise):
     assert torch.equal(x5, x[:2])
 
 
-def test_order0_sampler_and_factory(cld_setup):
+def test_order0_sampler_and_factory(cld_setup_ref):
     from gddim_amd.cld import sampling
     from gddim_amd.datasets import get_data_inverse_scaler
-    cfg, params, sde, osde, model, state, u = cld_setup
+    cfg, params, sde, osde, model, state, u = cld_setup_ref
     cfg = cfg.copy_and_resolve_references()
     cfg.sampling.method = 'order0'
     cfg.sampling.nfe = 6
@@ -123,7 +138,7 @@ def test_dirac_data_known_answer(native_lib):
     left-Riemann quadrature error)."""
     from gddim_amd import ops
     from gddim_amd.cld import sampling, sde_lib
-    sde = sde_lib.CLD(is_R_rk=True, R_dt=1e-6)
+    sde = sde_lib.CLD(is_R_rk=True, R_dt=1e-6, x64=True)
     c = 0.3
     rng = np.random.default_rng(5)
     z = rng.standard_normal((64, 2))
@@ -404,7 +419,7 @@ def test_deis_sampler_on_a_ddpmpp_style_network(native_lib):
     cfg.model.embedding_type = 'positional'
     params = onet.random_params(cfg, 6, seed=8)
     sde = sde_lib.from_config(cfg)
-    osde = ocld.CLD(is_R_rk=cfg.model.is_R_rk, R_dt=cfg.model.R_dt, dtype=np.float64)
+    osde = oracle_cld_like(sde)
     model = mutils.get_model(cfg.model.name)(config=cfg)
     state = mutils.State(params_ema=params, model_state={})
     rng = np.random.default_rng(3)
@@ -426,7 +441,7 @@ def test_production_batch_sampler_matches_oracle(native_lib):
     cfg = cld_accr_dcifar10.get_config()
     params = onet.random_params(cfg, 6, seed=0)
     sde = sde_lib.from_config(cfg)
-    osde = ocld.CLD(is_R_rk=cfg.model.is_R_rk, R_dt=cfg.model.R_dt, dtype=np.float64)
+    osde = oracle_cld_like(sde)
     model = mutils.get_model(cfg.model.name)(config=cfg)
     state = mutils.State(params_ema=params, model_state={})
     rng = np.random.default_rng(2)

@@ -53,7 +53,7 @@ def test_cholesky_parametrisation(osde):
 
 def test_product_host_math_matches_oracle(native_lib, osde):
     from gddim_amd.cld import sde_lib
-    sde = sde_lib.CLD(is_R_rk=True, R_dt=1e-5)
+    sde = sde_lib.CLD(is_R_rk=True, R_dt=1e-5, x64=True)
     rev = ocld.get_rev_ts(osde, 2, 5)
     pl, ol = sde_lib.LSDE(sde), ox.LSDE(osde)
     cl, co = pl.get_deis_coef(2, rev), ol.get_deis_coef(2, rev)
@@ -146,7 +146,7 @@ def test_sscs_ou_half_step_is_the_exact_ou_transition(osde):
 
 def test_product_sscs_and_em_maps_match_oracle(native_lib, osde):
     from gddim_amd.cld import sampling, sde_lib
-    sde = sde_lib.CLD(is_R_rk=True, R_dt=1e-5)
+    sde = sde_lib.CLD(is_R_rk=True, R_dt=1e-5, x64=True)
     M, cov = sampling.sscs_ou(sde, 0.3, 0.35)
     _, ocov = ox.sscs_ou(osde, np.zeros((1, 1, 2)), 0.3, 0.35, np.zeros((1, 1, 2)))
     assert np.abs(cov - ocov).max() < 1e-15
@@ -191,7 +191,7 @@ def test_lambda_sde_reverse_transition_keeps_the_marginal(osde, olam):
 
 def test_product_lambda_sde_matches_oracle(native_lib, osde, olam):
     from gddim_amd.cld import sampling, sde_lib
-    sde = sde_lib.CLD(is_R_rk=True, R_dt=1e-5)
+    sde = sde_lib.CLD(is_R_rk=True, R_dt=1e-5, x64=True)
     pl = sde_lib.LambdaSDE(sde, 1.0, use_order0=True)
     for s, t in ((1.0, 0.7), (0.3, 0.1), (0.01, 0.001)):
         assert np.abs(pl.s_hat_psi(s, t) - olam.s_hat_psi(s, t)).max() < 1e-6 * max(1.0, np.abs(olam.s_hat_psi(s, t)).max())
@@ -219,7 +219,7 @@ def test_hybdeis_grid_and_table(native_lib, osde):
     rev = ox.hyd_rev_ts(osde, 11, 0.3, 0.3, 2.0, denoising=True)  # num_step 10: 3 noise knots + 8 image knots
     assert rev.shape == (11,) and np.allclose(rev[:3], [1.0, 1.0 - 0.7 / 3, 1.0 - 1.4 / 3]) and rev[3] == 1.0 and abs(rev[-1] - 1e-3) < 1e-15
     assert np.all(np.diff(rev[3:]) < 0) and rev[2] < rev[3]  # the restart
-    sde = sde_lib.CLD(is_R_rk=True, R_dt=1e-5)
+    sde = sde_lib.CLD(is_R_rk=True, R_dt=1e-5, x64=True)
     seen = {}
     orig = sampling._impl_deis_sampler
     try:
@@ -236,7 +236,7 @@ def test_naive_coef_is_the_euler_step(native_lib, osde):
     """prepare_naive_coef (cld_jax/sde_lib.py:276-287, `order0` with is_em=True): product == oracle, and both are the first-order
     expansion of the exponential-integrator coefficients (gap O(dt^2))."""
     from gddim_amd.cld import sde_lib
-    sde = sde_lib.CLD(is_R_rk=True, R_dt=1e-5)
+    sde = sde_lib.CLD(is_R_rk=True, R_dt=1e-5, x64=True)
     rev = ocld.get_rev_ts(osde, 2, 200)
     pm, pe = sde.prepare_naive_coef(rev)
     om, oe = osde.prepare_naive_coef(rev)
@@ -247,3 +247,25 @@ def test_naive_coef_is_the_euler_step(native_lib, osde):
     i = 150  # a short step
     h = abs(rev[i + 1] - rev[i])
     assert np.abs(pm[i] - em[i]).max() < 200 * h * h and np.abs(pe[i] - ee[i]).max() < 0.1 * np.abs(ee[i]).max()
+
+
+def test_variants_run_on_the_float32_base(native_lib):
+    """With config.model.x64=False the base CLD's members are float32 (the reference's arithmetic); the variant wrappers read R(t) from it
+    and build their own tables in float64.  They must construct and stay within the float32-vs-float64 spread of the base tables."""
+    from gddim_amd.cld import sampling, sde_lib
+    s32, s64 = sde_lib.CLD(is_R_rk=True, R_dt=1e-5), sde_lib.CLD(is_R_rk=True, R_dt=1e-5, x64=True)
+    assert s32.s_R(0.3).dtype == np.float32 and s64.s_R(0.3).dtype == np.float64
+    rev32, rev64 = sampling.get_rev_ts(s32, 2, 5), sampling.get_rev_ts(s64, 2, 5)
+    assert rev32.dtype == np.float32 and np.abs(rev32 - rev64).max() < 1e-6
+
+    def close(a, b, rel):
+        return np.isfinite(a).all() and np.abs(a - b).max() <= rel * max(1.0, np.abs(b).max())
+
+    for make, order, rel in ((sde_lib.LSDE, 1, 1e-3), (sde_lib.MLCLD, 1, 1e-3), (lambda s: sde_lib.LambdaSDE(s, 1.0, True), 0, 1e-3),
+                             (lambda s: sde_lib.LambdaSDE(s, 1.0, True), 1, 1e-3)):
+        a, b = make(s32).get_deis_coef(order, rev32), make(s64).get_deis_coef(order, rev64)
+        assert a.shape == b.shape and close(np.asarray(a, dtype=np.float64), b, rel), (order, np.abs(a - b).max())
+    c32, n32 = sampling._em_coef(s32, rev32, 1.0)
+    c64, n64 = sampling._em_coef(s64, rev64, 1.0)
+    assert close(c32, c64, 1e-3) and close(n32, n64, 1e-3)
+    assert close(sampling.sscs_ou(s32, 0.3, 0.35)[1], sampling.sscs_ou(s64, 0.3, 0.35)[1], 1e-12)  # formed in float64 in both modes
