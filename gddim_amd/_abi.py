@@ -55,6 +55,7 @@ SIGNATURES = {
     "gd_last_error": (ctypes.c_char_p, []),
     "gd_version": (_I, []),
     "gd_device_count": (_I, []),
+    "gd_options_reload": (_I, []),
     "gd_cld_r_table": (_I, [_D, _D, _D, _D, _D, _I, _D, _SZ, _P]),
     "gd_cld_r_table_f32": (_I, [_D, _D, _D, _D, _D, _I, _D, _SZ, _P]),
     "gd_cld_psi2_table": (_I, [_D, _D, _D, _D, _SZ, _P]),
@@ -135,6 +136,11 @@ def lib():
 def check(rc):
     if rc != 0:
         raise GddimError(lib().gd_last_error().decode(errors="replace"))
+
+
+def reload_options():
+    """Re-read the GDDIM_* / GD_* environment into the library's option table (csrc/options.h); engines re-read it when they are created."""
+    check(lib().gd_options_reload())
 
 
 def device_count():

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "common.h"
+#include "options.h"
 #include "plan.h"
 
 namespace gd {
@@ -172,6 +173,17 @@ static std::string label_class(const Op &op) {
     return r + buf;
 }
 
+// The key of a profile entry: the kernel's name (default), the op's label class (GD_PROF_BY_LABEL=1), or both, "class|kernel"
+// (GD_PROF_BY_LABEL=2: which kernel every level of the network ran on, tools/batch_sweep.py).  Empty when the profiler is off.
+static std::string pkey(const gd_engine *e, const Op &op, const std::string &kernel, const char *class_prefix = "") {
+    if (!e->prof) return std::string();
+    switch (opts().prof_key) {
+        case 1: return class_prefix + label_class(op);
+        case 2: return class_prefix + label_class(op) + "|" + kernel;
+        default: return kernel;
+    }
+}
+
 // pointer of a tensor reference advanced to image i0 of the batch (tensors are stored image after image, per_image floats each)
 static float *tptr_at(gd_engine *e, const Bind &b, const TRef &r, int batch, int i0) {
     float *p = tptr(e, b, r, batch);
@@ -293,8 +305,7 @@ static void fill_egn(gd_engine *e, const Op &op, const Bind &b, int batch, GemmP
 }
 
 static bool egn_fused(gd_engine *e, const Bind &b, int batch, int gemm_index) {
-    static const bool off = getenv("GDDIM_NO_EGN") != nullptr;
-    if (off || e->precision != 0 || gemm_index < 0) return false;
+    if (opts().no_egn || e->precision != 0 || gemm_index < 0) return false;
     auto it = e->egn_ok.find(batch);
     if (it == e->egn_ok.end()) {
         std::vector<char> ok(e->plan.ops.size(), 0);
@@ -328,8 +339,7 @@ static void fill_side(gd_engine *e, const Op &op, const Bind &b, int batch, Gemm
 }
 
 static bool side_fused(gd_engine *e, const Bind &b, int batch, int gemm_index) {
-    static const bool off = getenv("GDDIM_NO_SIDE_GN") != nullptr;
-    if (off || e->precision != 0 || gemm_index < 0) return false;
+    if (opts().no_side_gn || e->precision != 0 || gemm_index < 0) return false;
     auto it = e->side_ok.find(batch);
     if (it == e->side_ok.end()) {
         std::vector<char> ok(e->plan.ops.size(), 0);
@@ -396,8 +406,7 @@ static bool attn_core_at(const gd_engine *e, int i) {
 static int launch_apply_op(gd_engine *e, const Op &op, const Bind &b, int batch, bool table_only, hipStream_t s) {
     const int HW = op.H * op.W;
     const int rt = gn_slices(batch, HW);
-    static const bool by_label = getenv("GD_PROF_BY_LABEL") != nullptr;
-    ProfScope ps(e, s, !e->prof ? std::string() : by_label ? std::string(table_only ? "gn_table:" : "gn_apply:") + label_class(op) : std::string(table_only ? "gn_table" : "gn_apply"), 0,
+    ProfScope ps(e, s, pkey(e, op, std::string(table_only ? "gn_table" : "gn_apply"), table_only ? "gn_table:" : "gn_apply:"), 0,
                  table_only ? 0.0 : 8.0 * batch * HW * (op.C0 + op.C1));
     return launch_gn_apply(tptr(e, b, op.a0, batch), op.C0, tptr(e, b, op.a1, batch), op.C1, tptr(e, b, op.stats, batch),
                            op.S0 > 0 ? op.S0 : rt, tptr(e, b, op.stats1, batch), op.S1 > 0 ? op.S1 : rt,
@@ -412,7 +421,6 @@ static int launch_apply_op(gd_engine *e, const Op &op, const Bind &b, int batch,
 static int run_gemm(gd_engine *e, int op_index, const Bind &b, int batch, int i0, int nb, bool first, hipStream_t s) {
     const Op &op = e->plan.ops[op_index];
     const Plan &P = e->plan;
-    static const bool by_label = getenv("GD_PROF_BY_LABEL") != nullptr;
     GemmParams g{};
     const int z = fill_gemm(e, op, b, batch, g, i0, nb);
     if (e->precision == 1 && op.w_slot >= 0 && e->wsplit_valid) {
@@ -427,15 +435,15 @@ static int run_gemm(gd_engine *e, int op_index, const Bind &b, int batch, int i0
             g.a_presplit = 0;
             g.gn_table = tptr(e, b, op.gn_table, batch);
             g.gn_act = e->plan.ops[op.fuse_peer].act;
-            ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(conv3x3_halo_fused_name()), op.flops_per_image * nb, gemm_alg_bytes(g, z));
+            ProfScope ps(e, s, pkey(e, op, std::string(conv3x3_halo_fused_name())), op.flops_per_image * nb, gemm_alg_bytes(g, z));
             return launch_conv3x3_halo(g, s);
         }
         if (z == 1 && conv3x3_halo_ok(g)) {
-            ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(conv3x3_halo_name()), op.flops_per_image * nb, gemm_alg_bytes(g, z));
+            ProfScope ps(e, s, pkey(e, op, std::string(conv3x3_halo_name())), op.flops_per_image * nb, gemm_alg_bytes(g, z));
             return launch_conv3x3_halo(g, s);
         }
         if (igemm_bf16x3_ok(g, z)) {
-            ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(igemm_bf16x3_name(g)), op.flops_per_image * nb, gemm_alg_bytes(g, z));
+            ProfScope ps(e, s, pkey(e, op, std::string(igemm_bf16x3_name(g))), op.flops_per_image * nb, gemm_alg_bytes(g, z));
             return launch_igemm_bf16x3(g, s);
         }
         g.b_hi = g.b_lo = nullptr;
@@ -443,17 +451,17 @@ static int run_gemm(gd_engine *e, int op_index, const Bind &b, int batch, int i0
     GD_CHECK(!g.a_presplit, "%s: pre-split input without a split-precision kernel", op.label.c_str());
     if (op.egn_peer >= 0 && egn_fused(e, b, batch, op_index)) fill_egn(e, op, b, batch, g, i0);
     if (e->precision == 1 && op.w_slot < 0 && igemm_bf16x3_act_ok(g, z)) {  // attention products: activation x activation
-        ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string("igemm_bf16x3_kernel<256,128,4,2,act>"), op.flops_per_image * nb, gemm_alg_bytes(g, z));
+        ProfScope ps(e, s, pkey(e, op, std::string("igemm_bf16x3_kernel<256,128,4,2,act>")), op.flops_per_image * nb, gemm_alg_bytes(g, z));
         return launch_igemm_bf16x3_act(g, z, s);
     }
     if (e->precision == 0 && z == 1 && op.w_slot >= 0 && e->wwino42 && e->wino42_off[op.w_slot] >= 0 && conv3x3_wino42_ok(g)) {
         g.b_wino = e->wwino42 + e->wino42_off[op.w_slot];
-        ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(conv3x3_wino42_name_for(g)), op.flops_per_image * nb, gemm_alg_bytes(g, z));
+        ProfScope ps(e, s, pkey(e, op, std::string(conv3x3_wino42_name_for(g))), op.flops_per_image * nb, gemm_alg_bytes(g, z));
         return launch_conv3x3_wino42(g, s);
     }
     if (e->precision == 0 && z == 1 && op.w_slot >= 0 && e->wwino2 && e->wino2_off[op.w_slot] >= 0 && conv3x3_wino2d_ok(g)) {
         g.b_wino = e->wwino2 + e->wino2_off[op.w_slot];
-        ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(conv3x3_wino2d_name()), op.flops_per_image * nb, gemm_alg_bytes(g, z));
+        ProfScope ps(e, s, pkey(e, op, std::string(conv3x3_wino2d_name())), op.flops_per_image * nb, gemm_alg_bytes(g, z));
         return launch_conv3x3_wino2d(g, s);
     }
     if (e->precision == 0 && z == 1 && op.w_slot >= 0 && e->wwino2 && e->wino2_off[op.w_slot] >= 0 && e->splitk_ws &&
@@ -463,19 +471,19 @@ static int run_gemm(gd_engine *e, int op_index, const Bind &b, int batch, int i0
         g.wk_partial = e->splitk_ws + img0 * e->splitk_per_image;
         GD_CHECK(img0 * e->splitk_per_image + (long long)conv3x3_wino2d_splitk_factor(g) * g.M * g.N <= e->splitk_ws_floats,
                  "%s: split-K scratch too small", op.label.c_str());
-        ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(conv3x3_wino2d_splitk_name()), op.flops_per_image * nb, gemm_alg_bytes(g, z));
+        ProfScope ps(e, s, pkey(e, op, std::string(conv3x3_wino2d_splitk_name())), op.flops_per_image * nb, gemm_alg_bytes(g, z));
         return launch_conv3x3_wino2d_splitk(g, s);
     }
     if (e->precision == 0 && z == 1 && op.w_slot >= 0 && e->wwino && e->wino_off[op.w_slot] >= 0 && conv3x3_wino_ok(g)) {
         g.b_wino = e->wwino + e->wino_off[op.w_slot];
-        ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(conv3x3_wino_name(g)), op.flops_per_image * nb, gemm_alg_bytes(g, z));
+        ProfScope ps(e, s, pkey(e, op, std::string(conv3x3_wino_name(g))), op.flops_per_image * nb, gemm_alg_bytes(g, z));
         return launch_conv3x3_wino(g, s);
     }
     if (op.side_peer >= 0 && side_fused(e, b, batch, op_index)) {  // the per-image affine table first, then the GEMM whose loader applies it
         if (first) GD_TRY(launch_apply_op(e, P.ops[op.side_peer], b, batch, true, s));  // (the table of the whole batch)
         fill_side(e, op, b, batch, g, i0);
     }
-    ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(igemm_variant_name(g, z)) + (g.gn_side_out ? "+gn" : ""),
+    ProfScope ps(e, s, pkey(e, op, std::string(igemm_variant_name(g, z)) + (g.gn_side_out ? "+gn" : "")),
                  op.flops_per_image * nb, gemm_alg_bytes(g, z));
     return launch_igemm(g, z, s);
 }
@@ -483,7 +491,6 @@ static int run_gemm(gd_engine *e, int op_index, const Bind &b, int batch, int i0
 static int run_op(gd_engine *e, int op_index, const Bind &b, int batch, hipStream_t s) {
     const Op &op = e->plan.ops[op_index];
     const Plan &P = e->plan;
-    static const bool by_label = getenv("GD_PROF_BY_LABEL") != nullptr;
     switch (op.kind) {
         case OP_FOURIER: {
             ProfScope ps(e, s, "fourier", 0, 0);
@@ -494,7 +501,7 @@ static int run_op(gd_engine *e, int op_index, const Bind &b, int batch, hipStrea
             if (op.temb && b.labels == nullptr) return run_gemm(e, op_index, b, batch, 0, 1, true, s);  // one label: one row (see fill_gemm)
             if (attn_core_at(e, op_index)) {  // q k^T, softmax and p v in one launch; the next two ops return at once
                 const Op &av = P.ops[op_index + 2];
-                ProfScope ps(e, s, !e->prof ? std::string() : by_label ? label_class(op) : std::string(attn_fused_name()),
+                ProfScope ps(e, s, pkey(e, op, std::string(attn_fused_name())),
                              (op.flops_per_image + av.flops_per_image) * batch, 4.0 * batch * (av.res.t >= 0 ? 5.0 : 4.0) * op.N * op.C0);  // q, k, v^T, out (, residual) once each
                 return launch_attn_fused(tptr(e, b, op.a0, batch), op.lda0, tptr(e, b, op.bten, batch), op.ldb, tptr(e, b, av.bten, batch),
                                          av.bias_slot >= 0 ? slot_ptr(e, av.bias_slot) + av.bias_off : nullptr, tptr(e, b, av.res, batch), av.ldres,
@@ -590,6 +597,7 @@ int gd_device_count(void) {
 int gd_engine_create(const gd_model_desc *desc, int device, gd_engine **out) {
     GD_CHECK(desc && out, "null argument");
     gd_engine *e = new gd_engine();
+    options_reload();  // an engine is built under the environment of its creation (options.h)
     if (e->plan.build(*desc)) { delete e; return 1; }
     e->device = device;
     e->plan_only = device < 0;
@@ -630,8 +638,8 @@ int gd_engine_create(const gd_model_desc *desc, int device, gd_engine **out) {
         GD_ALLOC(e->step_dev, gd_engine::MAX_LANES);
 #undef GD_ALLOC
         (void)hipMemset(e->step_dev, 0, sizeof(int) * gd_engine::MAX_LANES);
-        if (const char *pm = getenv("GDDIM_PRECISION")) e->precision = (strcmp(pm, "bf16x3") == 0) ? 1 : 0;
-        if (const char *ln = getenv("GD_LANES")) e->lanes = std::max(1, std::min((int)gd_engine::MAX_LANES, atoi(ln)));
+        e->precision = opts().precision;
+        e->lanes = std::max(1, std::min((int)gd_engine::MAX_LANES, opts().lanes));
         if (!igemm_zero_buffer()) return fail("zero buffer", hipErrorOutOfMemory);  // never allocate inside a graph capture
         if ((err = hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming)) != hipSuccess) return fail("hipEventCreate", err);
         for (int i = 0; i < gd_engine::MAX_LANES; ++i) {

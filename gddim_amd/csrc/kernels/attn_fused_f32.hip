@@ -17,6 +17,7 @@
 #include <cstdlib>
 
 #include "../common.h"
+#include "../options.h"
 
 namespace gd {
 
@@ -275,8 +276,7 @@ __global__ __launch_bounds__(512, 2) void attn256_f32_kernel(const AttnParams p)
 }
 
 bool attn_fused_ok(int N, int C) {
-    static const int off = getenv("GDDIM_NO_FUSED_ATTN") ? atoi(getenv("GDDIM_NO_FUSED_ATTN")) : 0;
-    return !off && N == AT_N && C == AT_C;
+    return !opts().no_fused_attn && N == AT_N && C == AT_C;
 }
 
 const char *attn_fused_name() { return "attn256_f32_kernel"; }

@@ -17,6 +17,7 @@
 #include <cstdlib>
 
 #include "../common.h"
+#include "../options.h"
 #include "act.h"
 #include "epilogue.h"
 
@@ -304,11 +305,10 @@ static bool halo_shape_ok(const GemmParams &p);
 
 // fused-GroupNorm variant: same shapes, raw fp32 input (GDDIM_X3_NOFUSE=1 keeps the separate gn_apply pass)
 bool conv3x3_halo_fused_ok(const GemmParams &p) {
-    static const int off = (getenv("GDDIM_X3_NOHALO") ? atoi(getenv("GDDIM_X3_NOHALO")) : 0) |
-                           (getenv("GDDIM_X3_NOFUSE") ? atoi(getenv("GDDIM_X3_NOFUSE")) : 0);
+    const int off = opts().x3_nohalo | opts().x3_nofuse;
     // every N tile of a row block stages (and therefore normalises) the halo again; measured (tools/variants_x3.sh): fusing the
     // 256-output layers too still wins (+3.2 % all fused, +2.7 % only N <= 128), so there is no limit by default
-    static const int max_n = getenv("GDDIM_X3_FUSE_MAXN") ? atoi(getenv("GDDIM_X3_FUSE_MAXN")) : (1 << 30);
+    const int max_n = opts().x3_fuse_maxn;
     if (off || !p.b_hi || !p.b_lo || p.N > max_n) return false;
     GemmParams q = p;
     q.a_presplit = 0;  // igemm_bf16x3_ok then applies the concat-aware addressing limits of a 4-byte-per-element source
@@ -317,8 +317,7 @@ bool conv3x3_halo_fused_ok(const GemmParams &p) {
 }
 
 bool conv3x3_halo_ok(const GemmParams &p) {
-    static const int off = getenv("GDDIM_X3_NOHALO") ? atoi(getenv("GDDIM_X3_NOHALO")) : 0;
-    if (off || !p.a_presplit || !p.b_hi || !p.b_lo) return false;
+    if (opts().x3_nohalo || !p.a_presplit || !p.b_hi || !p.b_lo) return false;
     return halo_shape_ok(p);
 }
 
@@ -350,7 +349,7 @@ int launch_conv3x3_halo(const GemmParams &p_in, hipStream_t s) {
     p.n_tiles = (p.N + HBN_ - 1) / HBN_;
     p.flat_tiles = p.m_tiles < 16;
     const int total = p.flat_tiles ? p.m_tiles * p.n_tiles : ((p.m_tiles + 7) / 8) * 8 * p.n_tiles;
-    static const int one_per_tile = getenv("GDDIM_X3_NOPERSIST") ? atoi(getenv("GDDIM_X3_NOPERSIST")) : 0;  // A/B only
+    const int one_per_tile = opts().x3_nopersist;  // A/B only
     static int cus = 0;
     if (!cus) {
         int dev = 0;

@@ -39,6 +39,7 @@
 #include <type_traits>
 
 #include "../common.h"
+#include "../options.h"
 #include "act.h"
 #include "epilogue.h"
 
@@ -599,10 +600,8 @@ bool conv3x3_wino2d_shape_ok(const GemmParams &p) {
 // what the engine sends to it: an eligible shape with at least two workgroups per CU.  GDDIM_NOWINO2=1 routes everything back to the
 // one-dimensional kernel; GDDIM_WINO2_MINBLOCKS overrides the fill criterion (A/B).
 bool conv3x3_wino2d_ok(const GemmParams &p) {
-    static const int off = getenv("GDDIM_NOWINO2") ? atoi(getenv("GDDIM_NOWINO2")) : (getenv("GDDIM_NOWINO") ? atoi(getenv("GDDIM_NOWINO")) : 0);
-    static const int min_blocks = getenv("GDDIM_WINO2_MINBLOCKS") ? atoi(getenv("GDDIM_WINO2_MINBLOCKS")) : 256;
-    if (off || !conv3x3_wino2d_shape_ok(p)) return false;
-    return (long long)((p.M / 4 + 63) / 64) * ((p.N + 63) / 64) >= min_blocks;
+    if (opts().no_wino2 || !conv3x3_wino2d_shape_ok(p)) return false;
+    return (long long)((p.M / 4 + 63) / 64) * ((p.N + 63) / 64) >= opts().wino2_min_blocks;
 }
 
 const char *conv3x3_wino2d_name() { return "conv3x3_wino2d_f32_kernel"; }
@@ -707,9 +706,7 @@ __global__ __launch_bounds__(256) void wino2d_splitk_finish_kernel(const GemmPar
 
 // The number of splits for this problem, 0 when the split path does not take it.  GDDIM_NOWINO2_SPLITK=1 switches it off (A/B).
 int conv3x3_wino2d_splitk_factor(const GemmParams &p) {
-    static const int off = getenv("GDDIM_NOWINO2_SPLITK") ? atoi(getenv("GDDIM_NOWINO2_SPLITK"))
-                                                          : (getenv("GDDIM_NOWINO2") ? atoi(getenv("GDDIM_NOWINO2")) : (getenv("GDDIM_NOWINO") ? atoi(getenv("GDDIM_NOWINO")) : 0));
-    if (off || p.H != 4 || p.W != 4 || p.rows_per_image != 16 || p.M % 16 != 0 || p.N % 4 != 0 || p.N < 32 || p.ldc % 4 != 0) return 0;
+    if (opts().no_wino2_splitk || p.H != 4 || p.W != 4 || p.rows_per_image != 16 || p.M % 16 != 0 || p.N % 4 != 0 || p.N < 32 || p.ldc % 4 != 0) return 0;
     if (p.res && p.ldres % 4 != 0) return 0;
     if (p.rowbias && p.ld_rowbias % 4 != 0) return 0;
     if (p.qstats && p.qs_slices != 1) return 0;

@@ -42,6 +42,7 @@
 #include <type_traits>
 
 #include "../common.h"
+#include "../options.h"
 #include "act.h"
 #include "epilogue.h"
 
@@ -1172,8 +1173,7 @@ bool conv3x3_wino42_shape_ok(const GemmParams &p) {
     // (GDDIM_EGN32=1, read per call): measured in round 3 it costs the convolution as much as the stand-alone pass it removes (one
     // workgroup per CU keeps too few bytes in flight for the re-read: profiles/r03_notes.md)
     if (p.egn_out && p.rows_per_image == 1024) {
-        const char *on32 = getenv("GDDIM_EGN32");
-        if (!on32 || atoi(on32) == 0 || p.W != 32 || p.H != 32 || p.C0 + p.C1 < 64 || p.M % 1024 != 0) return false;
+        if (!opts().egn32 || p.W != 32 || p.H != 32 || p.C0 + p.C1 < 64 || p.M % 1024 != 0) return false;
     }
     if (p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1 || p.OH != p.H || p.OW != p.W) return false;
     const int Cin = p.C0 + p.C1;
@@ -1192,11 +1192,8 @@ bool conv3x3_wino42_shape_ok(const GemmParams &p) {
 // what the engine sends to it: an eligible shape with at least one workgroup per CU.  GDDIM_NOWINO42=1 routes everything back to the
 // F(2x2,3x3) kernel; GDDIM_WINO42_MINBLOCKS overrides the fill criterion (A/B).
 bool conv3x3_wino42_ok(const GemmParams &p) {
-    static const int off = getenv("GDDIM_NOWINO42") ? atoi(getenv("GDDIM_NOWINO42"))
-                                                    : (getenv("GDDIM_NOWINO2") ? atoi(getenv("GDDIM_NOWINO2")) : (getenv("GDDIM_NOWINO") ? atoi(getenv("GDDIM_NOWINO")) : 0));
-    static const int min_blocks = getenv("GDDIM_WINO42_MINBLOCKS") ? atoi(getenv("GDDIM_WINO42_MINBLOCKS")) : 256;
-    if (off || !conv3x3_wino42_shape_ok(p)) return false;
-    return (long long)((p.M / 8 + 31) / 32) * ((p.N + 63) / 64) >= min_blocks;
+    if (opts().no_wino42 || !conv3x3_wino42_shape_ok(p)) return false;
+    return (long long)((p.M / 8 + 31) / 32) * ((p.N + 63) / 64) >= opts().wino42_min_blocks;
 }
 
 const char *conv3x3_wino42_name() { return "conv3x3_wino42_f32_kernel"; }
@@ -1230,8 +1227,7 @@ int launch_conv3x3_wino42(const GemmParams &p_in, hipStream_t s) {
             cus = cus / 8 * 8 > 0 ? cus / 8 * 8 : 8;
         }
         int grid = gx < cus ? gx : cus;
-        if (const char *e = getenv("GDDIM_WINO42_GRID")) {
-            const int g = atoi(e);
+        if (const int g = opts().wino42_grid) {
             if (g > 0 && g < grid) grid = g;
         }
         if (p.egn_out && p.rows_per_image == 1024) hipLaunchKernelGGL(conv3x3_wino42_gn32_f32_kernel, dim3(grid), dim3(512), 0, s, p);

@@ -26,6 +26,7 @@
 #include <type_traits>
 
 #include "../common.h"
+#include "../options.h"
 #include "act.h"
 #include "epilogue.h"
 
@@ -524,8 +525,7 @@ static void wfill_div(unsigned d, unsigned &magic, unsigned &shift) {
 // Tile choice: 64 pairs x 128 outputs when that gives every CU two workgroups, 64 x 64 (half the accumulators, up to four
 // workgroups per CU) for the 8x8 level; 0 = neither fills the chip (the direct kernel's smaller tiles take the problem).
 static int wino_bn(const GemmParams &p) {
-    static const int min_blocks = getenv("GDDIM_WINO_MINBLOCKS") ? atoi(getenv("GDDIM_WINO_MINBLOCKS")) : 512;
-    static const int no_small = getenv("GDDIM_WINO_NOSMALL") ? atoi(getenv("GDDIM_WINO_NOSMALL")) : 0;  // A/B only
+    const int min_blocks = opts().wino_min_blocks, no_small = opts().wino_nosmall;
     const long long mt = (p.M / 2 + 63) / 64;
     if (mt * ((p.N + 127) / 128) >= min_blocks) return 128;
     if (!no_small && mt * ((p.N + 63) / 64) >= min_blocks) return 64;
@@ -550,15 +550,13 @@ bool conv3x3_wino_shape_ok(const GemmParams &p) {
 
 // what the engine sends to it: an eligible shape that fills the chip; GDDIM_NOWINO=1 routes everything back to the direct kernel
 bool conv3x3_wino_ok(const GemmParams &p) {
-    static const int off = getenv("GDDIM_NOWINO") ? atoi(getenv("GDDIM_NOWINO")) : 0;
-    return !off && conv3x3_wino_shape_ok(p) && wino_bn(p) != 0;
+    return !opts().no_wino && conv3x3_wino_shape_ok(p) && wino_bn(p) != 0;
 }
 
 // 128 pairs x 128 outputs, eight waves, ONE workgroup per CU: a third less staging traffic per MAC (the weight chunk is shared by
 // twice as many pairs); taken when it still gives every CU two tiles.  GDDIM_WINO_NOBIG=1 (A/B) keeps the 64-pair tiles.
 static bool wino_big(const GemmParams &p) {
-    static const int nobig = getenv("GDDIM_WINO_NOBIG") ? atoi(getenv("GDDIM_WINO_NOBIG")) : 0;
-    return !nobig && wino_bn(p) == 128 && (long long)((p.M / 2 + 127) / 128) * ((p.N + 127) / 128) >= 512;
+    return !opts().wino_nobig && wino_bn(p) == 128 && (long long)((p.M / 2 + 127) / 128) * ((p.N + 127) / 128) >= 512;
 }
 
 // the engine would send this problem to a 64-pair Winograd tile and that tile can normalise its output (p.egn_* set)
@@ -590,7 +588,7 @@ int launch_conv3x3_wino(const GemmParams &p_in, hipStream_t s) {
     const int gx = p.flat_tiles ? p.m_tiles * p.n_tiles : ((p.m_tiles + 7) / 8) * 8 * p.n_tiles;
     if (use_big) {
         // persistent: one workgroup per CU walks tile ids with a stride that is a multiple of 8 * n_tiles (same N tile, same XCD)
-        static const int one_per_tile = getenv("GDDIM_WINO_NOPERSIST") ? atoi(getenv("GDDIM_WINO_NOPERSIST")) : 0;  // A/B only
+        const int one_per_tile = opts().wino_nopersist;  // A/B only
         static int cus = 0;
         if (!cus) {
             int dev = 0;

@@ -31,6 +31,7 @@
 #include <cstdlib>
 
 #include "../common.h"
+#include "../options.h"
 #include "act.h"
 #include "qstats.h"
 
@@ -1027,12 +1028,8 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_pers_kernel(const Gemm
 // GDDIM_IGEMM_VARIANT (env, read once) overrides the large-tile kernel for A/B measurements:
 //   0: 128x128, 8 waves (2x4)  [default]     1: 128x128, 4 waves (2x2)     2: 256x128, 8 waves (4x2) when M is large
 static int big_variant() {
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("GDDIM_IGEMM_VARIANT");
-        v = e ? atoi(e) : 0;
-        if (v < 0 || v > 2) v = 0;
-    }
+    int v = opts().igemm_variant;
+    if (v < 0 || v > 2) v = 0;
     return v;
 }
 
@@ -1042,8 +1039,7 @@ static void pick_tiles(const GemmParams &p, int batch_z, int &bm, int &bn) {
     };
     // Largest tile that still gives every CU of the 256 at least ~1.5 blocks; the small spatial
     // levels (8x8, 4x4) of the U-Net otherwise leave most of the chip idle.
-    static const long long big_min = getenv("GDDIM_IGEMM_BIGMIN") ? atoll(getenv("GDDIM_IGEMM_BIGMIN")) : 384;  // A/B only
-    static const long long mid_min = getenv("GDDIM_IGEMM_MIDMIN") ? atoll(getenv("GDDIM_IGEMM_MIDMIN")) : 384;
+    const long long big_min = opts().igemm_bigmin, mid_min = opts().igemm_midmin;  // A/B only
     if (p.N > 64 && blocks(128, 128) >= big_min) { bm = 128; bn = 128; return; }
     if (blocks(128, 64) >= mid_min) { bm = 128; bn = 64; return; }
     bm = 64; bn = 64;
@@ -1054,7 +1050,7 @@ static bool fast_ok(const GemmParams &p);
 // Intra-workgroup split-K factor of the 64x64 tile (igemm_f32_fast_kernel<..., KS>): when a launch has fewer than two tiles per
 // CU and K is long, KS wave groups share a tile.  GDDIM_IGEMM_KS=1/2/4 overrides (A/B).
 static int pick_ksplit(const GemmParams &p, int batch_z, int bm, int bn) {
-    static const int forced = getenv("GDDIM_IGEMM_KS") ? atoi(getenv("GDDIM_IGEMM_KS")) : 0;
+    const int forced = opts().igemm_ks;
     if (bm != 64 || bn != 64 || !fast_ok(p) || p.b_kmajor || p.KH * p.KW > 32) return 1;
     const long long blocks = (long long)((p.M + 63) / 64) * ((p.N + 63) / 64) * batch_z;
     const int nk = p.K / KC;
@@ -1078,8 +1074,7 @@ static int device_cus() {
 }
 
 static bool pers_ok(const GemmParams &p, int batch_z, int bm, int bn) {
-    static const int off = getenv("GDDIM_IGEMM_NOPERSIST") ? atoi(getenv("GDDIM_IGEMM_NOPERSIST")) : 0;
-    static const int maxk = getenv("GDDIM_IGEMM_PERS_MAXK") ? atoi(getenv("GDDIM_IGEMM_PERS_MAXK")) : 1024;
+    const int off = opts().igemm_nopersist, maxk = opts().igemm_pers_maxk;
     if (off || bm != 128 || bn != 128 || big_variant() != 0 || !fast_ok(p) || p.b_kmajor || p.KH * p.KW > 32) return false;
     if (p.K < 3 * KC || p.K > maxk || p.diag) return false;
     const long long tiles = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) * batch_z;
@@ -1096,7 +1091,7 @@ const char *igemm_variant_name(const GemmParams &p, int batch_z) {
         if (big_variant() == 2 && (long long)((p.M + 255) / 256) * ((p.N + bn - 1) / bn) * batch_z >= 512) { bm = 256; wmm = 4; wnn = 2; }
         else if (big_variant() != 1) { wmm = 2; wnn = 4; }
     }
-    if (bm == 128 && bn == 64 && !getenv("GDDIM_IGEMM_SMALL4")) { wmm = 4; wnn = 2; }
+    if (bm == 128 && bn == 64 && !opts().igemm_small4) { wmm = 4; wnn = 2; }
     const int ksp = pick_ksplit(p, batch_z, bm, bn);
     if (pers_ok(p, batch_z, bm, bn)) snprintf(buf, sizeof buf, "igemm_f32_pers_kernel<128,128,2,4>");
     else if (ksp > 1) snprintf(buf, sizeof buf, "igemm_f32_fast_kernel<64,64,2,2,false,false,%d>", ksp);
@@ -1125,8 +1120,7 @@ bool igemm_gn_side_ok(const GemmParams &p, int batch_z) {
 }
 
 static bool fast_ok(const GemmParams &p) {
-    static const int off = getenv("GDDIM_IGEMM_NOFAST") ? atoi(getenv("GDDIM_IGEMM_NOFAST")) : 0;
-    if (off || p.in_act) return false;
+    if (opts().igemm_nofast || p.in_act) return false;
     const int Cin = p.C0 + p.C1;
     if (Cin % 32 != 0 || (p.C1 > 0 && p.C0 % 32 != 0) || p.KH * p.KW > 64 || (p.KH * p.KW > 32 && p.b_kmajor) || p.K % 32 != 0) return false;
     if (p.rowbias && p.rows_per_image % 8 != 0) return false;
@@ -1193,8 +1187,7 @@ int launch_igemm(const GemmParams &p_in, int batch_z, hipStream_t s) {
         const long long b_elems = (long long)(p.b_kmajor ? p.K : p.N) * p.ldb;
         GD_CHECK(a_elems < (1LL << 31) && b_elems < (1LL << 31), "igemm: operand larger than 2^31 elements per z-slice");
     }
-    static const int diag = getenv("GDDIM_IGEMM_DIAG") ? atoi(getenv("GDDIM_IGEMM_DIAG")) : 0;
-    p.diag = diag;
+    p.diag = opts().igemm_diag;
     GD_CHECK(!p.egn_out || igemm_egn_ok(p, batch_z), "igemm: epilogue GroupNorm requested for a launch that cannot compute it");
     fill_div((unsigned)(p.OH * p.OW), p.mg_ohw, p.sh_ohw);
     fill_div((unsigned)p.OW, p.mg_ow, p.sh_ow);
@@ -1224,7 +1217,7 @@ int launch_igemm(const GemmParams &p_in, int batch_z, hipStream_t s) {
         if (big_variant() == 1) launch_variant<128, 128, 2, 2>(p, dim3(gx, 1, batch_z), s);
         else launch_variant<128, 128, 2, 4>(p, dim3(gx, 1, batch_z), s);
     } else if (bm == 128) {
-        if (getenv("GDDIM_IGEMM_SMALL4")) launch_variant<128, 64, 2, 2>(p, dim3(gx, 1, batch_z), s);
+        if (opts().igemm_small4) launch_variant<128, 64, 2, 2>(p, dim3(gx, 1, batch_z), s);
         else launch_variant<128, 64, 4, 2>(p, dim3(gx, 1, batch_z), s);
     } else {
         const int ksp = pick_ksplit(p, batch_z, bm, bn);

@@ -20,6 +20,7 @@
 #include <cstdlib>
 
 #include "../common.h"
+#include "../options.h"
 #include "epilogue.h"
 
 namespace gd {
@@ -340,8 +341,7 @@ bool igemm_bf16x3_ok(const GemmParams &p, int batch_z) {
 
 // batched activation x activation products (attention QK^T, PV, V^T): both operands fp32, split in the kernel
 bool igemm_bf16x3_act_ok(const GemmParams &p, int batch_z) {
-    static const int off = getenv("GDDIM_X3_NOATTN") ? atoi(getenv("GDDIM_X3_NOATTN")) : 0;
-    if (off || batch_z < 1 || p.b_kmajor || p.in_act || !p.b || p.a_presplit || p.C1 != 0 || p.KH != 1 || p.KW != 1) return false;
+    if (opts().x3_noattn || batch_z < 1 || p.b_kmajor || p.in_act || !p.b || p.a_presplit || p.C1 != 0 || p.KH != 1 || p.KW != 1) return false;
     if (p.C0 % 32 != 0 || p.K != p.C0 || p.ldb % 4 != 0 || p.lda0 % 4 != 0 || p.rowbias) return false;
     if (p.res && (long long)p.M * p.ldres * 4 + 64 >= (1LL << 31)) return false;
     if ((long long)((p.M + 255) / 256) * ((p.N + 127) / 128) * batch_z < 256) return false;  // only the 256x128 tile is instantiated
@@ -406,17 +406,16 @@ int launch_igemm_bf16x3(const GemmParams &p_in, hipStream_t s) {
     p.n_tiles = (p.N + bn - 1) / bn;
     p.flat_tiles = p.m_tiles < 16;
     const int gx = p.flat_tiles ? p.m_tiles * p.n_tiles : ((p.m_tiles + 7) / 8) * 8 * p.n_tiles;
-    static const int diag = getenv("GDDIM_IGEMM_DIAG") ? atoi(getenv("GDDIM_IGEMM_DIAG")) : 0;
-    p.diag = diag;
-    static const int variant = getenv("GDDIM_X3_VARIANT") ? atoi(getenv("GDDIM_X3_VARIANT")) : 0;  // A/B measurements only
+    p.diag = opts().igemm_diag;
+    const int variant = opts().x3_variant;  // A/B measurements only
     if (variant == 1 && bm == 256 && p.a_presplit) {  // 128x128 tiles, 4 waves, 80 KB LDS: two workgroups per CU
         p.m_tiles = (p.M + 127) / 128;
         p.flat_tiles = p.m_tiles < 16;
         const int gx1 = p.flat_tiles ? p.m_tiles * p.n_tiles : ((p.m_tiles + 7) / 8) * 8 * p.n_tiles;
         hipLaunchKernelGGL((igemm_bf16x3_kernel<128, 128, 2, 2, true>), dim3(gx1), dim3(256), 0, s, p);
     } else
-    if (bm == 256 && diag && p.a_presplit) hipLaunchKernelGGL((igemm_bf16x3_kernel<256, 128, 4, 2, true, true>), dim3(gx), dim3(512), 0, s, p);
-    else if (bm == 256 && diag) hipLaunchKernelGGL((igemm_bf16x3_kernel<256, 128, 4, 2, false, true>), dim3(gx), dim3(512), 0, s, p);
+    if (bm == 256 && p.diag && p.a_presplit) hipLaunchKernelGGL((igemm_bf16x3_kernel<256, 128, 4, 2, true, true>), dim3(gx), dim3(512), 0, s, p);
+    else if (bm == 256 && p.diag) hipLaunchKernelGGL((igemm_bf16x3_kernel<256, 128, 4, 2, false, true>), dim3(gx), dim3(512), 0, s, p);
     else if (bm == 256 && p.a_presplit) hipLaunchKernelGGL((igemm_bf16x3_kernel<256, 128, 4, 2, true>), dim3(gx), dim3(512), 0, s, p);
     else if (bm == 256) hipLaunchKernelGGL((igemm_bf16x3_kernel<256, 128, 4, 2>), dim3(gx), dim3(512), 0, s, p);
     else if (bm == 128 && p.a_presplit) hipLaunchKernelGGL((igemm_bf16x3_kernel<128, 128, 2, 4, true>), dim3(gx), dim3(512), 0, s, p);

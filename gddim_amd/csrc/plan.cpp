@@ -13,6 +13,7 @@
 #include <sstream>
 
 #include "common.h"
+#include "options.h"
 
 namespace gd {
 
@@ -174,8 +175,7 @@ int Plan::gn(const std::string &label, const std::string &pname, int xa, int Ca,
     // 16, 64, 256 or -- with GDDIM_EGN32=1 -- 1024 pixels (256: one workgroup tile of the two-dimensional Winograd kernels; 1024: four
     // tiles that the hybrid kernel's persistent workgroup walks back to back), groups of 4..32 channels that divide a 32-column tile
     const int cpg = C / G;
-    const char *on32 = getenv("GDDIM_EGN32");  // (opt-in, read per plan: see conv3x3_wino42_shape_ok)
-    const bool egn32 = on32 && atoi(on32) != 0;
+    const bool egn32 = opts().egn32 != 0;  // (opt-in: see conv3x3_wino42_shape_ok)
     const bool egn_candidate = Cb == 0 && (H * W == 16 || H * W == 64 || (H == 16 && W == 16) || (egn32 && H == 32 && W == 32)) && tensors[xa].stats_t >= 0 && tensors[xa].C == C &&
                                (cpg == 4 || cpg == 8 || cpg == 16 || cpg == 32) && C % 32 == 0;
     fresh_producer_ = -1;
@@ -549,8 +549,9 @@ int Plan::attn_unfolded(int idx, int x, int H, int W, int C) {
 int Plan::build(const gd_model_desc &d) {
     desc = d;
     // A/B switches of the lowering, read per plan (a second engine in the process, or a test, may build the other form)
-    no_attn_fold = getenv("GDDIM_NO_ATTN_FOLD") && atoi(getenv("GDDIM_NO_ATTN_FOLD")) != 0;
-    no_upswap = getenv("GDDIM_NO_UPSWAP") && atoi(getenv("GDDIM_NO_UPSWAP")) != 0;
+    no_attn_fold = opts().no_attn_fold != 0;
+    no_upswap = opts().no_upswap != 0;
+    options_at_build = options_json();
     GD_CHECK(d.num_levels >= 1 && d.num_levels <= GD_MAX_LEVELS, "num_levels out of range");
     GD_CHECK(d.nf >= 16 && d.nf % 16 == 0, "nf must be a multiple of 16 (GroupNorm groups of >= 4 channels), got %d", d.nf);
     GD_CHECK(d.in_channels >= 1 && d.image_size >= (1 << (d.num_levels - 1)), "bad in_channels / image_size");
@@ -937,7 +938,7 @@ static void jref(std::ostringstream &o, const char *k, const TRef &r) { o << "\"
 std::string Plan::json() const {
     std::ostringstream o;
     o.precision(9);
-    o << "{\"CP\":" << CP << ",\"arena_per_image\":" << arena_per_image << ",\"flops_per_image\":" << flops_per_image
+    o << "{\"options\":" << (options_at_build.empty() ? std::string("{}") : options_at_build) << ",\"CP\":" << CP << ",\"arena_per_image\":" << arena_per_image << ",\"flops_per_image\":" << flops_per_image
       << ",\"conv3x3_flops_per_image\":" << conv3x3_flops_per_image << ",\"folded_flops_per_image\":" << folded_flops_per_image << ",\"gn_max_slices\":" << GN_MAX_SLICES
       << ",\"tensors\":[";
     for (size_t i = 0; i < tensors.size(); ++i) {

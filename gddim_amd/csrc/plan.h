@@ -170,6 +170,7 @@ struct Plan {
     std::vector<AttnFold> attn_folds;
     std::vector<BiasFold> bias_folds;
     bool no_attn_fold = false, no_upswap = false;  // GDDIM_NO_ATTN_FOLD / GDDIM_NO_UPSWAP at build(): the written forms (A/B, tests)
+    std::string options_at_build;                  // options_json() when build() ran: printed by json()
     void fold_params();  // derived weight slots from the loaded ones (float64 on the host); call once all parameters are loaded
 
     int build(const gd_model_desc &d);  // 0 ok

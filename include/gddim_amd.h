@@ -64,6 +64,11 @@ int gd_version(void);
 /* Number of visible HIP devices (0 when there is no GPU / driver). */
 int gd_device_count(void);
 
+/* The library's run-time switches (GDDIM_* / GD_* environment variables: A/B measurements and tests, none needed in normal use) live in
+ * one table (csrc/options.h), parsed when first needed, at every gd_engine_create, and here.  gd_engine_plan_json prints the table an
+ * engine was built under ("options").  No reference counterpart. */
+int gd_options_reload(void);
+
 /* ---- host-side SDE math (no GPU) -------------------------------------------------------- */
 /* R(t) table of the CLD SDE: fixed-step integration of dR/dt = F R + 1/2 G G^T R^-T from
  * R_0 = diag(sqrt(numerical_eps), sqrt(vv_gamma/m_inv + numerical_eps)), emitting the state

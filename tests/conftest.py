@@ -33,6 +33,25 @@ def native_lib():
     return _abi.lib()
 
 
+@pytest.fixture
+def gd_env(monkeypatch):
+    """Switches of the native library for ONE test: gd_env(GDDIM_X="1", ...) writes the environment and has the library parse it again
+    (csrc/options.h: one table, read when the library first needs it, at engine creation and on gd_options_reload); undone afterwards."""
+    from gddim_amd import _abi
+
+    def set_(**kw):
+        for k, v in kw.items():
+            if v is None:
+                monkeypatch.delenv(k, raising=False)
+            else:
+                monkeypatch.setenv(k, str(v))
+        _abi.reload_options()
+
+    yield set_
+    monkeypatch.undo()
+    _abi.reload_options()
+
+
 def tiny_config(kind="cld", nf=16, num_res_blocks=1, image_size=16, ch_mult=(1, 2, 2), attn=(8,), centered=True,
                 progressive_input='residual'):
     """A small NCSN++ of the benchmarked family (biggan blocks, fir, fourier, skip_rescale)."""

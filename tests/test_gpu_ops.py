@@ -291,14 +291,12 @@ WINO42_CASES = [
     (5, 32, 32, 64, 32, 8, True, 2),         # ... half an N tile, two workgroups walking 3 + 2 images
     (2, 32, 32, 256, 128, 32, False, 1),     # ... two-chunk sources, ONE workgroup walking 2 images x 2 N tiles
 ])
-def test_conv3x3_winograd42_epilogue_groupnorm(dev, case, monkeypatch):
+def test_conv3x3_winograd42_epilogue_groupnorm(dev, case, gd_env):
     """gd_conv3x3_winograd42_gn: the GroupNorm (+ swish) that follows a 3x3 convolution, computed in the hybrid Winograd kernel's epilogue
     (the engine's Op::egn_peer path), against float64 -- bias, residual and scale in front of the normalisation as in a residual block."""
     from gddim_amd import ops
     B, H, W, Cin, Cout, groups, keep_raw, grid = case
-    monkeypatch.setenv("GDDIM_EGN32", "1")  # (the 32x32 form is opt-in)
-    if grid:
-        monkeypatch.setenv("GDDIM_WINO42_GRID", str(grid))
+    gd_env(GDDIM_EGN32="1", GDDIM_WINO42_GRID=grid if grid else None)  # (the 32x32 form is opt-in)
     g = torch.Generator().manual_seed(sum(case[:6]))
     x = torch.randn(B, H, W, Cin, generator=g)
     w = torch.randn(3, 3, Cin, Cout, generator=g) / math.sqrt(9 * Cin)
@@ -353,7 +351,7 @@ def test_conv3x3_winograd42_matches_torch_fp64(dev, case):
 @pytest.mark.parametrize("grid", [1, 3, 8])
 @pytest.mark.parametrize("case", [(2, 32, 32, 128, 128, True, True), (5, 32, 32, 64, 132, True, True), (6, 8, 8, 64, 96, True, False),
                                   (3, 16, 16, 256, 256, False, True)])
-def test_conv3x3_winograd42_persistent_walk(dev, case, grid):
+def test_conv3x3_winograd42_persistent_walk(dev, case, grid, gd_env):
     """The hybrid kernel is persistent (Cin >= 64): a workgroup walks over tiles and its K-loop pipeline runs across them (the last two
     chunks of a tile stage the first two of the next).  Unit-test problems have fewer tiles than CUs, so GDDIM_WINO42_GRID forces a small
     grid: every workgroup then takes several tiles -- including the XCD-grouped mapping's padding ids (20 M tiles: ids 20..23 of the last
@@ -370,11 +368,8 @@ def test_conv3x3_winograd42_persistent_walk(dev, case, grid):
     wp = w.permute(3, 0, 1, 2).reshape(Cout, 9 * Cin).contiguous()
     args = (x.to(dev), wp.to(dev), None if bias is None else bias.to(dev), None if res is None else res.to(dev))
     ref = ops.conv3x3_winograd42(*args, alpha=1.25, out_scale=0.7).cpu()
-    os.environ["GDDIM_WINO42_GRID"] = str(grid)
-    try:
-        got = ops.conv3x3_winograd42(*args, alpha=1.25, out_scale=0.7).cpu()
-    finally:
-        del os.environ["GDDIM_WINO42_GRID"]
+    gd_env(GDDIM_WINO42_GRID=grid)
+    got = ops.conv3x3_winograd42(*args, alpha=1.25, out_scale=0.7).cpu()
     assert torch.equal(got, ref), (case, grid, (got - ref).abs().max().item())
     want = 1.25 * F.conv2d(x.permute(0, 3, 1, 2).double(), w.permute(3, 2, 0, 1).double(), padding=1).permute(0, 2, 3, 1)
     if bias is not None:
