@@ -526,11 +526,9 @@ __device__ __forceinline__ void wino42_tile(const GemmParams &p, float *smem) {
 // already holds the successor's first chunk); a wave keeps the z values of its own unit in registers, so the area is 96 KB, not 128.
 constexpr int W4P_EXB = W4_STAGE;                       // exchange area base (floats)
 constexpr int W4P_EXW = 48 * 64;                        // floats per wave in it (48 registers x 64 lanes)
-constexpr int W4P_RED = W4P_EXB + 8 * W4P_EXW;          // GroupNorm scratch: [tile of the image][wn][unit][32 columns] (sum, sum of squares)
-constexpr int W4P_SMEM = W4P_RED + 4 * 512 + 128;       // 156 672 bytes (+ the affine table of the 32x32 GroupNorm)
+constexpr int W4P_RED = W4P_EXB + 8 * W4P_EXW;          // GroupNorm scratch: [wn][unit][32 columns] (sum, sum of squares)
+constexpr int W4P_SMEM = W4P_RED + 512;                 // 149 504 bytes
 
-// MI (compile time, a kernel symbol each: the image walk costs the plain form six spilled registers when it is a run-time choice): 1 or 4, below
-template <int MI>
 __device__ __forceinline__ void wino42_persistent(const GemmParams &p, float *smem) {
     constexpr int OOB = (int)0x80000000u;
 
@@ -581,14 +579,9 @@ __device__ __forceinline__ void wino42_persistent(const GemmParams &p, float *sm
         }
         return vb;
     };
-    // MI: M tiles walked back to back by one workgroup before it moves on by gridDim.x units.  1: the unit is an M tile.  4 (launched when
-    // p.egn_out && p.rows_per_image == 1024): the unit is a
-    // 32x32 IMAGE (128 Winograd tiles = 4 M tiles, p.m_tiles counts images): after the fourth tile the workgroup holds the statistics of
-    // its 64 output channels over the whole image and normalises what it has written (the epilogue GroupNorm, rows_per_image == 1024).
-    int cur_vb, cur_q = 0, cur_mt = 0, cur_nt = 0;
+    int cur_vb, cur_mt = 0, cur_nt = 0;
     cur_vb = next_valid((int)blockIdx.x, cur_mt, cur_nt);
     if (cur_vb >= nvb) return;
-    cur_mt *= MI;
 #ifdef W42_TRACE  // in-kernel timeline (tools/wino42_trace.py): thread 0 of workgroups 0 and 100 stamps the 100 MHz wall clock and the shader
                   // clock at five points of its first four tiles into the tail of the residual tensor
     int trn = 0;
@@ -603,15 +596,9 @@ __device__ __forceinline__ void wino42_persistent(const GemmParams &p, float *sm
         ++trn;
     };
 #endif
-    // the tile after (vb, q): the unit's next M tile, or the first one of the workgroup's next unit (vb >= nvb: none)
-    auto next_tile = [&](int vb, int q, int mt, int ntl, int &vb2, int &q2, int &mt2, int &nt2) __attribute__((always_inline)) {
-        if (q + 1 < MI) { vb2 = vb; q2 = q + 1; mt2 = mt + 1; nt2 = ntl; return; }
-        q2 = 0;
-        vb2 = next_valid(vb + (int)gridDim.x, mt2, nt2);
-        mt2 *= MI;
-    };
-    int nx_vb, nx_q = 0, nx_mt = 0, nx_nt = 0;
-    next_tile(cur_vb, cur_q, cur_mt, cur_nt, nx_vb, nx_q, nx_mt, nx_nt);
+    // the workgroup's next tile (nx_vb >= nvb: none)
+    int nx_vb, nx_mt = 0, nx_nt = 0;
+    nx_vb = next_valid(cur_vb + (int)gridDim.x, nx_mt, nx_nt);
 
     // ---- staging role: (tile tl, channel quad chq, patch row r), see wino42_tile ----
     const int tl = tid >> 4, chq = (tid >> 2) & 3, sr = tid & 3;
@@ -965,72 +952,7 @@ __device__ __forceinline__ void wino42_persistent(const GemmParams &p, float *sm
                         ps[a] += val;
                         pq[a] += val * val;
                     }
-            if (p.egn_out && MI == 4) {
-                // GroupNorm (+ swish) of a 32x32 image = FOUR M tiles of this workgroup (plan.h: Op::egn_peer).  Every tile leaves its column
-                // sums in LDS and its finished values RAW in memory (in the output, or -- when nobody else reads it -- in the normalised
-                // tensor's own memory).  After tile 3 the statistics of the workgroup's 64 channels are complete: one affine pair per channel
-                // goes to LDS and the workgroup passes over its slab of the image (1024 pixels x 64 channels, 35-100 us old at most: L2) in
-                // 16-byte pieces -- 32 loads and 32 stores per lane where the accumulator layout would need 128 of each.
-                float gsum = ps[0] + ps[1], gsq = pq[0] + pq[1];
-                gsum += __shfl_xor(gsum, 32); gsq += __shfl_xor(gsq, 32);
-                float2 *red = reinterpret_cast<float2 *>(smem + W4P_RED);  // [tile][wn][unit][32 columns]
-                if (lh == 0) red[((cur_q * 2 + wn) * 4 + f) * 32 + li] = make_float2(gsum, gsq);
-                const __amdgpu_buffer_rsrc_t srd_g =
-                    __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(p.egn_out), 0, p.M * p.ldc * 4, 0x00020000);
-                if (p.egn_skip_raw) {
-#pragma unroll
-                    for (int a = 0; a < 2; ++a)
-#pragma unroll
-                        for (int b = 0; b < 4; ++b)
-#pragma unroll
-                            for (int vv = 0; vv < 4; ++vv)
-                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vals[a][b][vv]), srd_g, vo_o, pix_off(vv, a, b) * p.ldc * 4, 0);
-                }
-                if (cur_q == 3) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this tile's raw values have reached L2
-                    __syncthreads();                                  // (whole images: every wave of the workgroup is here)
-                    float2 *tab = reinterpret_cast<float2 *>(smem + W4P_RED + 4 * 512);  // [64 channels] (scale, shift)
-                    if (f == 0) {
-                        gsum = 0.f; gsq = 0.f;
-#pragma unroll
-                        for (int u = 0; u < 16; ++u) {
-                            const float2 v = red[((u >> 2) * 2 + wn) * 128 + (u & 3) * 32 + li];
-                            gsum += v.x; gsq += v.y;
-                        }
-                        for (int o = 1; o < p.egn_cpg; o <<= 1) { gsum += __shfl_xor(gsum, o); gsq += __shfl_xor(gsq, o); }
-                        const float inv_n = 1.0f / (1024.0f * (float)p.egn_cpg);
-                        const float mean = gsum * inv_n;
-                        const float rstd = rsqrtf(gsq * inv_n - mean * mean + 1e-6f);
-                        const float ga = nok ? p.egn_gamma[n] : 0.f, be = nok ? p.egn_beta[n] : 0.f;
-                        if (lh == 0) tab[wn * 32 + li] = make_float2(rstd * ga, be - mean * rstd * ga);
-                    }
-                    __syncthreads();
-                    const __amdgpu_buffer_rsrc_t srd_s = p.egn_skip_raw ? srd_g : srd_o;  // where the tiles left their raw values
-                    // every wave passes over what IT wrote: the two pixel rows of its unit in each of the four tiles x its 32 channels, as 16-byte
-                    // pieces (lane -> pixel lane / 8 + 8 k of the 64, channel quad lane % 8)
-                    const int q8 = lane & 7, n4 = cur_nt * 64 + wn * 32 + q8 * 4;
-                    const w4f32x4 t0 = *reinterpret_cast<const w4f32x4 *>(tab + wn * 32 + q8 * 4), t1 = *reinterpret_cast<const w4f32x4 *>(tab + wn * 32 + q8 * 4 + 2);
-                    const float sc4[4] = {t0[0], t0[2], t1[0], t1[2]}, sh4[4] = {t0[1], t0[3], t1[1], t1[3]};
-                    const int vo_s = n4 < p.N ? ((img * 1024 + 2 * f * 32 + (lane >> 3)) * p.ldc + n4) * 4 : OOB;  // + tile q: 256 pixels, + step k: 8 pixels
-#pragma unroll 1  // (fully unrolled -- 32 scalar offsets more in a kernel that already spills SGPRs into VGPR lanes -- hipcc 7.2 produced
-                  // a loop that stored other registers' contents in single dwords of some lanes: profiles/r03_notes.md)
-                    for (int q = 0; q < 4; ++q) {
-                        w4f32x4 xr[8];
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) xr[k] = w4_load16<1>(srd_s, vo_s, (q * 256 + k * 8) * p.ldc * 4);
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) {
-                            w4f32x4 y4;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const float t = xr[k][e] * sc4[e] + sh4[e];
-                                y4[e] = p.egn_act ? swish_e(t) : t;
-                            }
-                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(w4u32x4, y4), srd_g, vo_s, (q * 256 + k * 8) * p.ldc * 4, 0);
-                        }
-                    }
-                }
-            } else if (p.egn_out) {
+            if (p.egn_out) {
                 // GroupNorm (+ swish) of the output (plan.h: Op::egn_peer), see wino42_tile.  rows_per_image == 256: every wave of the
                 // workgroup is here (whole images: no unit is past the batch), the scratch is rewritten only after the next tile's barriers
                 float gsum = ps[0] + ps[1], gsq = pq[0] + pq[1];
@@ -1096,20 +1018,14 @@ __device__ __forceinline__ void wino42_persistent(const GemmParams &p, float *sm
         trace();
 #endif
         if (nx_vb >= nvb) break;
-        cur_vb = nx_vb; cur_q = nx_q; cur_mt = nx_mt; cur_nt = nx_nt;
-        next_tile(cur_vb, cur_q, cur_mt, cur_nt, nx_vb, nx_q, nx_mt, nx_nt);
+        cur_vb = nx_vb; cur_mt = nx_mt; cur_nt = nx_nt;
+        nx_vb = next_valid(cur_vb + (int)gridDim.x, nx_mt, nx_nt);
     }
 }
 
 __global__ __launch_bounds__(512, 2) void conv3x3_wino42_f32_kernel(const GemmParams p) {
     __shared__ __attribute__((aligned(16))) float smem[W4P_SMEM];
-    wino42_persistent<1>(p, smem);
-}
-
-// ... with the GroupNorm of 32x32 images in the epilogue (a workgroup walks the four M tiles of an image)
-__global__ __launch_bounds__(512, 2) void conv3x3_wino42_gn32_f32_kernel(const GemmParams p) {
-    __shared__ __attribute__((aligned(16))) float smem[W4P_SMEM];
-    wino42_persistent<4>(p, smem);
+    wino42_persistent(p, smem);
 }
 
 __global__ __launch_bounds__(512, 2) void conv3x3_wino42_k32_f32_kernel(const GemmParams p) {
@@ -1167,14 +1083,11 @@ static void w4fill_div(unsigned d, unsigned &magic, unsigned &shift) {
 // what the kernel can compute at all (p.b_wino is not looked at)
 bool conv3x3_wino42_shape_ok(const GemmParams &p) {
     if (p.in_act || p.b_kmajor || p.a_presplit || p.gn_table || p.wk_split > 1) return false;
-    if (p.egn_out && ((p.rows_per_image != 64 && p.rows_per_image != 256 && p.rows_per_image != 1024) || p.N % p.egn_cpg != 0 ||
+    // epilogue GroupNorm: images that are one unit (8x8) or one workgroup tile (16x16).  (A 32x32 image spans four M tiles; normalising it
+    // in this kernel was built and measured in round 3 -- it costs the convolution what the stand-alone pass costs, profiles/r03_notes.md --
+    // and removed in round 4.)
+    if (p.egn_out && ((p.rows_per_image != 64 && p.rows_per_image != 256) || p.N % p.egn_cpg != 0 ||
                       (p.egn_cpg != 4 && p.egn_cpg != 8 && p.egn_cpg != 16 && p.egn_cpg != 32))) return false;
-    // 32x32 images: the persistent form walks the four M tiles of an image with one workgroup (W = H = 32, Cin >= 64).  OPT-IN
-    // (GDDIM_EGN32=1, read per call): measured in round 3 it costs the convolution as much as the stand-alone pass it removes (one
-    // workgroup per CU keeps too few bytes in flight for the re-read: profiles/r03_notes.md)
-    if (p.egn_out && p.rows_per_image == 1024) {
-        if (!opts().egn32 || p.W != 32 || p.H != 32 || p.C0 + p.C1 < 64 || p.M % 1024 != 0) return false;
-    }
     if (p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1 || p.OH != p.H || p.OW != p.W) return false;
     const int Cin = p.C0 + p.C1;
     if (Cin % 32 != 0 || (p.C1 > 0 && (p.C0 % 32 != 0 || !p.a1)) || p.K != 9 * Cin) return false;
@@ -1200,7 +1113,7 @@ const char *conv3x3_wino42_name() { return "conv3x3_wino42_f32_kernel"; }
 // the kernel symbol launch_conv3x3_wino42 would pick for this problem (as rocprofv3 prints it)
 const char *conv3x3_wino42_name_for(const GemmParams &p) {
     if (p.C0 + p.C1 == 32) return "conv3x3_wino42_k32_f32_kernel";
-    return (p.egn_out && p.rows_per_image == 1024) ? "conv3x3_wino42_gn32_f32_kernel" : "conv3x3_wino42_f32_kernel";
+    return "conv3x3_wino42_f32_kernel";
 }
 
 int launch_conv3x3_wino42(const GemmParams &p_in, hipStream_t s) {
@@ -1210,7 +1123,6 @@ int launch_conv3x3_wino42(const GemmParams &p_in, hipStream_t s) {
     w4fill_div((unsigned)(p.H * p.W / 8), p.mg_ohw, p.sh_ohw);  // tiles per image
     p.sh_ow = p.W == 8 ? 1 : p.W == 16 ? 2 : p.W == 32 ? 3 : 4;  // log2(W / 4)
     p.m_tiles = (p.M / 8 + 31) / 32;
-    if (p.egn_out && p.rows_per_image == 1024) p.m_tiles /= 4;  // the walk's unit is an image (wino42_persistent: MI)
     p.n_tiles = (p.N + 63) / 64;
     p.flat_tiles = p.m_tiles < 16;
     const int gx = p.flat_tiles ? p.m_tiles * p.n_tiles : ((p.m_tiles + 7) / 8) * 8 * p.n_tiles;
@@ -1230,8 +1142,7 @@ int launch_conv3x3_wino42(const GemmParams &p_in, hipStream_t s) {
         if (const int g = opts().wino42_grid) {
             if (g > 0 && g < grid) grid = g;
         }
-        if (p.egn_out && p.rows_per_image == 1024) hipLaunchKernelGGL(conv3x3_wino42_gn32_f32_kernel, dim3(grid), dim3(512), 0, s, p);
-        else hipLaunchKernelGGL(conv3x3_wino42_f32_kernel, dim3(grid), dim3(512), 0, s, p);
+        hipLaunchKernelGGL(conv3x3_wino42_f32_kernel, dim3(grid), dim3(512), 0, s, p);
     }
     GD_HIP(hipGetLastError());
     return 0;

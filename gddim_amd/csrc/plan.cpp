@@ -172,11 +172,10 @@ int Plan::gn(const std::string &label, const std::string &pname, int xa, int Ca,
         }
     }
     // candidate for normalisation in the producer's epilogue (Op::egn_peer): one source that carries fused statistics, an image of
-    // 16, 64, 256 or -- with GDDIM_EGN32=1 -- 1024 pixels (256: one workgroup tile of the two-dimensional Winograd kernels; 1024: four
-    // tiles that the hybrid kernel's persistent workgroup walks back to back), groups of 4..32 channels that divide a 32-column tile
+    // 16, 64 or 256 pixels (256: one workgroup tile of the two-dimensional Winograd kernels), groups of 4..32 channels that divide a
+    // 32-column tile
     const int cpg = C / G;
-    const bool egn32 = opts().egn32 != 0;  // (opt-in: see conv3x3_wino42_shape_ok)
-    const bool egn_candidate = Cb == 0 && (H * W == 16 || H * W == 64 || (H == 16 && W == 16) || (egn32 && H == 32 && W == 32)) && tensors[xa].stats_t >= 0 && tensors[xa].C == C &&
+    const bool egn_candidate = Cb == 0 && (H * W == 16 || H * W == 64 || (H == 16 && W == 16)) && tensors[xa].stats_t >= 0 && tensors[xa].C == C &&
                                (cpg == 4 || cpg == 8 || cpg == 16 || cpg == 32) && C % 32 == 0;
     fresh_producer_ = -1;
     if (egn_candidate)

@@ -286,17 +286,16 @@ WINO42_CASES = [
 @pytest.mark.parametrize("case", [
     (3, 8, 8, 64, 64, 16, True, None),       # one image = one wave unit
     (3, 16, 16, 64, 128, 32, True, None),    # one image = one workgroup tile
-    (5, 32, 32, 64, 64, 16, True, None),     # one image = FOUR tiles walked by one persistent workgroup (round 3), raw output kept
-    (5, 32, 32, 128, 128, 32, False, None),  # ... sole reader: the raw output is never stored; two N tiles
-    (5, 32, 32, 64, 32, 8, True, 2),         # ... half an N tile, two workgroups walking 3 + 2 images
-    (2, 32, 32, 256, 128, 32, False, 1),     # ... two-chunk sources, ONE workgroup walking 2 images x 2 N tiles
+    (5, 16, 16, 128, 128, 32, False, None),  # ... sole reader: the raw output is never stored; two N tiles
+    (5, 8, 8, 64, 32, 8, True, 2),           # half an N tile, two workgroups walking the tiles of 5 images
+    (6, 16, 16, 256, 128, 32, False, 1),     # two-chunk sources, ONE workgroup walking 6 images x 2 N tiles
 ])
 def test_conv3x3_winograd42_epilogue_groupnorm(dev, case, gd_env):
     """gd_conv3x3_winograd42_gn: the GroupNorm (+ swish) that follows a 3x3 convolution, computed in the hybrid Winograd kernel's epilogue
     (the engine's Op::egn_peer path), against float64 -- bias, residual and scale in front of the normalisation as in a residual block."""
     from gddim_amd import ops
     B, H, W, Cin, Cout, groups, keep_raw, grid = case
-    gd_env(GDDIM_EGN32="1", GDDIM_WINO42_GRID=grid if grid else None)  # (the 32x32 form is opt-in)
+    gd_env(GDDIM_WINO42_GRID=grid if grid else None)
     g = torch.Generator().manual_seed(sum(case[:6]))
     x = torch.randn(B, H, W, Cin, generator=g)
     w = torch.randn(3, 3, Cin, Cout, generator=g) / math.sqrt(9 * Cin)
