@@ -529,7 +529,13 @@ constexpr int W4P_EXW = 48 * 64;                        // floats per wave in it
 constexpr int W4P_RED = W4P_EXB + 8 * W4P_EXW;          // GroupNorm scratch: [wn][unit][32 columns] (sum, sum of squares)
 constexpr int W4P_SMEM = W4P_RED + 512;                 // 149 504 bytes
 
+// NW: output blocks (32 columns) per workgroup tile.  2: 512 threads, 32 tiles x 64 outputs -- the production tile.  1: 256 threads = the four
+// component-row waves of ONE output block, 32 tiles x 32 outputs, for launches that would leave CUs idle with the larger tile (small
+// batches, the 8x8 level at the reference's per-device batch of 128): twice the workgroups, and every thread stages TWO tiles' patch rows
+// (slots u = 0, 1: tiles tl and tl + 16) -- one wave per SIMD may hold 512 registers, so the second register set costs nothing here.
+template <int NW>
 __device__ __forceinline__ void wino42_persistent(const GemmParams &p, float *smem) {
+    constexpr int S = 2 / NW;  // staging slots per thread
     constexpr int OOB = (int)0x80000000u;
 
     const int tid = threadIdx.x;
@@ -600,40 +606,45 @@ __device__ __forceinline__ void wino42_persistent(const GemmParams &p, float *sm
     int nx_vb, nx_mt = 0, nx_nt = 0;
     nx_vb = next_valid(cur_vb + (int)gridDim.x, nx_mt, nx_nt);
 
-    // ---- staging role: (tile tl, channel quad chq, patch row r), see wino42_tile ----
+    // ---- staging role: (tile tl, channel quad chq, patch row r), see wino42_tile; NW = 1: slot u stages tile tl + 16 u ----
     const int tl = tid >> 4, chq = (tid >> 2) & 3, sr = tid & 3;
     const float sb = sr == 1 ? 1.f : -1.f;
-    int pix = 0;
-    unsigned bad = 0x3Fu;
-    int vo[6];
+    int pix[S];
+    unsigned bad[S];
+    int vo[S][6];
     auto set_vo = [&](int lda, int biasb) __attribute__((always_inline)) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            int off = (pix + sr * W + k) * lda * 4 + biasb + chq * 16;
-            if (W42_ABL & 128) off = (pix + sr * W + k) * 64 + biasb + chq * 16;  // timing ablation: a channel-blocked layout [C/16][pixel][16]
-            vo[k] = ((bad >> k) & 1u) ? OOB : off;
-        }
+        for (int u = 0; u < S; ++u)
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                int off = (pix[u] + sr * W + k) * lda * 4 + biasb + chq * 16;
+                if (W42_ABL & 128) off = (pix[u] + sr * W + k) * 64 + biasb + chq * 16;  // timing ablation: a channel-blocked layout [C/16][pixel][16]
+                vo[u][k] = ((bad[u] >> k) & 1u) ? OOB : off;
+            }
     };
     // pixel-loading state -> M tile mt (mt < 0: no tile, every load out of bounds)
     auto setup_pix = [&](int mt) __attribute__((always_inline)) {
-        pix = 0;
-        bad = 0x3Fu;
-        const int t = mt * 32 + tl;
-        if (mt >= 0 && t < T) {
-            const int img = (int)epi_div((unsigned)t, (unsigned)TI, p.mg_ohw, p.sh_ohw);
-            const int tr = t - img * TI;
-            const int ty = tr >> wts;
-            const int tx = tr - (ty << wts);
-            const int y0 = 2 * ty - 1, x0 = 4 * tx - 1;
-            pix = (img * H + y0) * W + x0;
-            unsigned xb = 0;
 #pragma unroll
-            for (int s = 0; s < 6; ++s) xb |= ((unsigned)(x0 + s) < (unsigned)W ? 0u : 1u) << s;
-            bad = (unsigned)(y0 + sr) < (unsigned)H ? xb : 0x3Fu;
+        for (int u = 0; u < S; ++u) {
+            pix[u] = 0;
+            bad[u] = 0x3Fu;
+            const int t = mt * 32 + tl + 16 * u;
+            if (mt >= 0 && t < T) {
+                const int img = (int)epi_div((unsigned)t, (unsigned)TI, p.mg_ohw, p.sh_ohw);
+                const int tr = t - img * TI;
+                const int ty = tr >> wts;
+                const int tx = tr - (ty << wts);
+                const int y0 = 2 * ty - 1, x0 = 4 * tx - 1;
+                pix[u] = (img * H + y0) * W + x0;
+                unsigned xb = 0;
+#pragma unroll
+                for (int s = 0; s < 6; ++s) xb |= ((unsigned)(x0 + s) < (unsigned)W ? 0u : 1u) << s;
+                bad[u] = (unsigned)(y0 + sr) < (unsigned)H ? xb : 0x3Fu;
+            }
         }
         set_vo(p.lda0, bias0);
     };
-    const int v_lds = tl * W4_LD + sr * 16 + chq * 4;  // + j * 64 (+ 2 for the quad's second channel pair)
+    const int v_lds = tl * W4_LD + sr * 16 + chq * 4;  // + u * 16 tiles + j * 64 (+ 2 for the quad's second channel pair)
 
     int s_c = 0;
     bool s_first = true;
@@ -649,22 +660,22 @@ __device__ __forceinline__ void wino42_persistent(const GemmParams &p, float *sm
         }
     };
 
-    w4f32x4 rr[6];
-    w4f32x2 vv6[6];
+    w4f32x4 rr[S][6];
+    w4f32x2 vv6[S][6];  // (a slot of its own each: the second slot's last stores run beside the first slot's first transform)
     bool steady = false;  // (timing ablations only: set after the prologue)
-    auto load_raw_to = [&](w4f32x4 *dst, int k) __attribute__((always_inline)) {
+    auto load_raw_to = [&](w4f32x4 *dst, int k, int u) __attribute__((always_inline)) {
         if ((W42_ABL & 1) && steady) return;
         if ((W42_ABL & 64) && steady) { dst[k] = w4_load16<W42_PX_AUX>(srd_a0, bias0 + (lane & 3) * 16, 0); return; }  // every pixel load from ONE L1-resident line
         if ((W42_ABL & 256) && steady && k >= 3) { dst[k] = w4_load16<W42_PX_AUX>(srd_a0, bias0 + (lane & 3) * 16, 0); return; }  // ... half of them
         if (W42_ABL & 128) {  // (whole 128-byte lines per request: pixels x 64 B contiguous inside a 16-channel block of a_imgs HW pixels)
-            if (s_first) dst[k] = w4_load16<W42_PX_AUX>(srd_a0, vo[k], (s_c >> 4) * a_imgs * HW * 64);
-            else dst[k] = w4_load16<W42_PX_AUX>(srd_a1, vo[k], ((s_c - p.C0) >> 4) * a_imgs * HW * 64);
+            if (s_first) dst[k] = w4_load16<W42_PX_AUX>(srd_a0, vo[u][k], (s_c >> 4) * a_imgs * HW * 64);
+            else dst[k] = w4_load16<W42_PX_AUX>(srd_a1, vo[u][k], ((s_c - p.C0) >> 4) * a_imgs * HW * 64);
             return;
         }
-        if (s_first) dst[k] = w4_load16<W42_PX_AUX>(srd_a0, vo[k], s_c * 4);
-        else dst[k] = w4_load16<W42_PX_AUX>(srd_a1, vo[k], (s_c - p.C0) * 4);
+        if (s_first) dst[k] = w4_load16<W42_PX_AUX>(srd_a0, vo[u][k], s_c * 4);
+        else dst[k] = w4_load16<W42_PX_AUX>(srd_a1, vo[u][k], (s_c - p.C0) * 4);
     };
-    auto load_raw = [&](int k) __attribute__((always_inline)) { load_raw_to(rr, k); };
+    auto load_raw = [&](int k, int u) __attribute__((always_inline)) { load_raw_to(rr[u], k, u); };
     auto combine_in = [&](w4f32x4 *x) __attribute__((always_inline)) {
         if (W42_ABL & 16) return;
 #pragma unroll
@@ -680,38 +691,38 @@ __device__ __forceinline__ void wino42_persistent(const GemmParams &p, float *sm
             }
         }
     };
-    auto xform = [&](const w4f32x4 *cm, int h) __attribute__((always_inline)) {
+    auto xform = [&](const w4f32x4 *cm, int h, int u) __attribute__((always_inline)) {
         w4f32x2 d[6];
 #pragma unroll
         for (int s = 0; s < 6; ++s) d[s] = w4f32x2{cm[s][2 * h], cm[s][2 * h + 1]};
         if (W42_ABL & 16) {
 #pragma unroll
-            for (int j = 0; j < 6; ++j) vv6[j] = d[j];
+            for (int j = 0; j < 6; ++j) vv6[u][j] = d[j];
             return;
         }
         const w4f32x2 t3 = pk_sub(d[4], d[2]);
         const w4f32x2 t4 = pk_sub(d[3], d[1]);
         const w4f32x2 u0 = pk_sub(d[0], d[2]);
-        vv6[0] = pk_fma_p4(u0, t3);
+        vv6[u][0] = pk_fma_p4(u0, t3);
         const w4f32x2 t1 = pk_fma_m4(d[2], d[4]);
         const w4f32x2 t2 = pk_fma_m4(d[1], d[3]);
-        vv6[1] = pk_add(t1, t2);
-        vv6[2] = pk_sub(t1, t2);
-        vv6[3] = pk_fma_p2(t4, t3);
-        vv6[4] = pk_fma_m2(t4, t3);
+        vv6[u][1] = pk_add(t1, t2);
+        vv6[u][2] = pk_sub(t1, t2);
+        vv6[u][3] = pk_fma_p2(t4, t3);
+        vv6[u][4] = pk_fma_m2(t4, t3);
         const w4f32x2 u5 = pk_sub(d[5], d[3]);
-        vv6[5] = pk_fma_m4(t4, u5);
+        vv6[u][5] = pk_fma_m4(t4, u5);
     };
-    auto store_v = [&](int j, int par, int h) __attribute__((always_inline)) {
-        if (W42_ABL & 2) { asm volatile("" ::"v"(vv6[j])); return; }
-        *reinterpret_cast<w4f32x2 *>(&smem[v_lds + par * W4_STAGE + j * 64 + 2 * h]) = vv6[j];
+    auto store_v = [&](int j, int par, int h, int u) __attribute__((always_inline)) {
+        if (W42_ABL & 2) { asm volatile("" ::"v"(vv6[u][j])); return; }
+        *reinterpret_cast<w4f32x2 *>(&smem[v_lds + u * 16 * W4_LD + par * W4_STAGE + j * 64 + 2 * h]) = vv6[u][j];
     };
 
     // ---- weight-fragment loading state (one chunk ahead) ----
     w4f32x4 bf[6][2];
     int s_ub = 0, u_vo = OOB, ukc = 0;
     auto setup_u = [&](int ntl) __attribute__((always_inline)) {  // ntl < 0: no tile
-        const int nb = ntl * 2 + wn;
+        const int nb = ntl * NW + wn;
         s_ub = ((nb * NK8) * 24 + wi * 6) * 1024;
         u_vo = (ntl >= 0 && nb < nblk) ? lane * 16 : OOB;
         ukc = 0;
@@ -732,22 +743,29 @@ __device__ __forceinline__ void wino42_persistent(const GemmParams &p, float *sm
     setup_pix(cur_mt);
     setup_u(cur_nt);
     {
-        w4f32x4 r0[6];
+        w4f32x4 r0[S][6];
 #pragma unroll
         for (int j = 0; j < 6; ++j) { load_u(j, 0); load_u(j, 1); }
         u_advance();
 #pragma unroll
-        for (int k = 0; k < 6; ++k) load_raw_to(r0, k);
+        for (int u = 0; u < S; ++u)
+#pragma unroll
+            for (int k = 0; k < 6; ++k) load_raw_to(r0[u], k, u);
         px_advance();
 #pragma unroll
-        for (int k = 0; k < 6; ++k) load_raw(k);
+        for (int u = 0; u < S; ++u)
+#pragma unroll
+            for (int k = 0; k < 6; ++k) load_raw(k, u);
         px_advance();
-        combine_in(r0);
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            xform(r0, h);
+        for (int u = 0; u < S; ++u) {
+            combine_in(r0[u]);
 #pragma unroll
-            for (int j = 0; j < 6; ++j) store_v(j, 0, h);
+            for (int h = 0; h < 2; ++h) {
+                xform(r0[u], h, u);
+#pragma unroll
+                for (int j = 0; j < 6; ++j) store_v(j, 0, h, u);
+            }
         }
     }
     __syncthreads();
@@ -765,7 +783,7 @@ __device__ __forceinline__ void wino42_persistent(const GemmParams &p, float *sm
         const int tru = tuc - img * TI;
         const int tyu = tru >> wts, txu = tru - (tyu << wts);
         mu = img * HW + 2 * tyu * W + 4 * txu;
-        n = cur_nt * 64 + wn * 32 + li;
+        n = cur_nt * (32 * NW) + wn * 32 + li;
         nok = n < p.N && tu < T;
         lane_px = Wt >= 8 ? lh * 16 : Wt == 4 ? lh * 2 * W : lh * 4 * W;
         vo_r = nok ? (lane_px * p.ldres + n) * 4 : OOB;
@@ -819,16 +837,24 @@ __device__ __forceinline__ void wino42_persistent(const GemmParams &p, float *sm
                         load_u(2 * jp, g);
                         load_u(2 * jp + 1, g);
                     }
-                    if (gap == 6) combine_in(rr);
-                    if (gap == 7) xform(rr, 0);
-                    if (gap >= 8 && gap <= 10) { store_v(2 * (gap - 8), nxt, 0); store_v(2 * (gap - 8) + 1, nxt, 0); }
-                    if (gap == 11) xform(rr, 1);
-                    if (gap >= 12 && gap <= 14) { store_v(2 * (gap - 12), nxt, 1); store_v(2 * (gap - 12) + 1, nxt, 1); }
+                    if (S == 2) {  // the second slot, six gaps ahead of the first: transformed in gaps 0-8, its next pixels requested in 6-11
+                        if (gap == 0) combine_in(rr[S - 1]);
+                        if (gap == 1) xform(rr[S - 1], 0, S - 1);
+                        if (gap >= 2 && gap <= 4) { store_v(2 * (gap - 2), nxt, 0, S - 1); store_v(2 * (gap - 2) + 1, nxt, 0, S - 1); }
+                        if (gap == 5) xform(rr[S - 1], 1, S - 1);
+                        if (gap >= 6 && gap <= 8) { store_v(2 * (gap - 6), nxt, 1, S - 1); store_v(2 * (gap - 6) + 1, nxt, 1, S - 1); }
+                        if (gap >= 6 && gap <= 11) load_raw(gap - 6, S - 1);
+                    }
+                    if (gap == 6) combine_in(rr[0]);
+                    if (gap == 7) xform(rr[0], 0, 0);
+                    if (gap >= 8 && gap <= 10) { store_v(2 * (gap - 8), nxt, 0, 0); store_v(2 * (gap - 8) + 1, nxt, 0, 0); }
+                    if (gap == 11) xform(rr[0], 1, 0);
+                    if (gap >= 12 && gap <= 14) { store_v(2 * (gap - 12), nxt, 1, 0); store_v(2 * (gap - 12) + 1, nxt, 1, 0); }
 #ifdef W42_LATE  // timing experiment: the pixel requests W42_LATE gaps later (how much of the time hangs on their lead?)
-                    if (gap >= 12 + W42_LATE && gap <= 17 + W42_LATE) load_raw(gap - 12 - W42_LATE);
+                    if (gap >= 12 + W42_LATE && gap <= 17 + W42_LATE) load_raw(gap - 12 - W42_LATE, 0);
                     if (gap == 18 + W42_LATE) px_advance();
 #else
-                    if (gap >= 12 && gap <= 17) load_raw(gap - 12);
+                    if (gap >= 12 && gap <= 17) load_raw(gap - 12, 0);
                     if (gap == 18) px_advance();
 #endif
                     if (LAST && has_res && gap < 16) { load_res(2 * gap); load_res(2 * gap + 1); }
@@ -1025,7 +1051,13 @@ __device__ __forceinline__ void wino42_persistent(const GemmParams &p, float *sm
 
 __global__ __launch_bounds__(512, 2) void conv3x3_wino42_f32_kernel(const GemmParams p) {
     __shared__ __attribute__((aligned(16))) float smem[W4P_SMEM];
-    wino42_persistent(p, smem);
+    wino42_persistent<2>(p, smem);
+}
+
+// ... 32 tiles x 32 outputs, four waves (one per SIMD, up to 512 registers each): the tile of launches the 64-output tile cannot fill the chip with
+__global__ __launch_bounds__(256, 1) void conv3x3_wino42_n32_f32_kernel(const GemmParams p) {
+    __shared__ __attribute__((aligned(16))) float smem[W4P_SMEM];
+    wino42_persistent<1>(p, smem);
 }
 
 __global__ __launch_bounds__(512, 2) void conv3x3_wino42_k32_f32_kernel(const GemmParams p) {
@@ -1102,18 +1134,30 @@ bool conv3x3_wino42_shape_ok(const GemmParams &p) {
     return a_bytes < (1LL << 31) && wino42_weight_floats(p.N, Cin) * 4 + 64 < (1LL << 31);
 }
 
-// what the engine sends to it: an eligible shape with at least one workgroup per CU.  GDDIM_NOWINO42=1 routes everything back to the
-// F(2x2,3x3) kernel; GDDIM_WINO42_MINBLOCKS overrides the fill criterion (A/B).
-bool conv3x3_wino42_ok(const GemmParams &p) {
-    if (opts().no_wino42 || !conv3x3_wino42_shape_ok(p)) return false;
-    return (long long)((p.M / 8 + 31) / 32) * ((p.N + 63) / 64) >= opts().wino42_min_blocks;
+// The workgroup tile of a launch: 2 = 32 tiles x 64 outputs (eight waves), 1 = 32 tiles x 32 outputs (four waves), 0 = not this kernel.
+// A persistent launch takes ceil(tiles / CUs) rounds; a 32-output tile costs W42_N32_COST of a 64-output one (measured:
+// profiles/r04_notes.md -- half the products, all of the pixel staging), so the narrow tile wins exactly where the wide one leaves CUs
+// idle: the 8x8 level below a batch of 256, the 16x16 level below 64, every level of a small batch.  GDDIM_WINO42_NW=1 / 2 forces a tile,
+// GDDIM_WINO42_MINBLOCKS is the least number of wide tiles a launch without a narrow alternative (Cin = 32) must have.
+constexpr double W42_N32_COST = 0.6;
+static int wino42_nw(const GemmParams &p) {
+    if (opts().no_wino42 || !conv3x3_wino42_shape_ok(p)) return 0;
+    const long long mt = (p.M / 8 + 31) / 32, t64 = mt * ((p.N + 63) / 64), t32 = mt * ((p.N + 31) / 32);
+    if (p.C0 + p.C1 == 32) return t64 >= opts().wino42_min_blocks ? 2 : 0;  // (the two-chunk form has the wide tile only)
+    if (opts().wino42_nw == 1 || opts().wino42_nw == 2) return opts().wino42_nw;
+    const long long cus = 256;
+    const double c64 = (double)((t64 + cus - 1) / cus), c32 = W42_N32_COST * (double)((t32 + cus - 1) / cus);
+    return c32 < c64 ? 1 : 2;
 }
+
+// what the engine sends to it: an eligible shape (GDDIM_NOWINO42=1 routes everything back to the F(2x2,3x3) kernel)
+bool conv3x3_wino42_ok(const GemmParams &p) { return wino42_nw(p) != 0; }
 
 const char *conv3x3_wino42_name() { return "conv3x3_wino42_f32_kernel"; }
 // the kernel symbol launch_conv3x3_wino42 would pick for this problem (as rocprofv3 prints it)
 const char *conv3x3_wino42_name_for(const GemmParams &p) {
     if (p.C0 + p.C1 == 32) return "conv3x3_wino42_k32_f32_kernel";
-    return "conv3x3_wino42_f32_kernel";
+    return wino42_nw(p) == 1 ? "conv3x3_wino42_n32_f32_kernel" : "conv3x3_wino42_f32_kernel";
 }
 
 int launch_conv3x3_wino42(const GemmParams &p_in, hipStream_t s) {
@@ -1122,8 +1166,9 @@ int launch_conv3x3_wino42(const GemmParams &p_in, hipStream_t s) {
     if (p.C1 == 0) p.lda1 = 4;
     w4fill_div((unsigned)(p.H * p.W / 8), p.mg_ohw, p.sh_ohw);  // tiles per image
     p.sh_ow = p.W == 8 ? 1 : p.W == 16 ? 2 : p.W == 32 ? 3 : 4;  // log2(W / 4)
+    const int nw = p.C0 + p.C1 == 32 ? 2 : (wino42_nw(p) == 1 ? 1 : 2);  // (a direct call with a shape the engine would not send: the wide tile)
     p.m_tiles = (p.M / 8 + 31) / 32;
-    p.n_tiles = (p.N + 63) / 64;
+    p.n_tiles = (p.N + 32 * nw - 1) / (32 * nw);
     p.flat_tiles = p.m_tiles < 16;
     const int gx = p.flat_tiles ? p.m_tiles * p.n_tiles : ((p.m_tiles + 7) / 8) * 8 * p.n_tiles;
     if (p.C0 + p.C1 == 32) {
@@ -1142,7 +1187,8 @@ int launch_conv3x3_wino42(const GemmParams &p_in, hipStream_t s) {
         if (const int g = opts().wino42_grid) {
             if (g > 0 && g < grid) grid = g;
         }
-        hipLaunchKernelGGL(conv3x3_wino42_f32_kernel, dim3(grid), dim3(512), 0, s, p);
+        if (nw == 1) hipLaunchKernelGGL(conv3x3_wino42_n32_f32_kernel, dim3(grid), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL(conv3x3_wino42_f32_kernel, dim3(grid), dim3(512), 0, s, p);
     }
     GD_HIP(hipGetLastError());
     return 0;

@@ -33,6 +33,7 @@ const Entry kEntries[] = {
     {"GDDIM_WINO2_MINBLOCKS", &Options::wino2_min_blocks, nullptr},
     {"GDDIM_WINO42_MINBLOCKS", &Options::wino42_min_blocks, nullptr},
     {"GDDIM_WINO42_GRID", &Options::wino42_grid, nullptr},
+    {"GDDIM_WINO42_NW", &Options::wino42_nw, nullptr},
     {"GDDIM_WINO_MINBLOCKS", &Options::wino_min_blocks, nullptr},
     {"GDDIM_WINO_NOSMALL", &Options::wino_nosmall, nullptr},
     {"GDDIM_WINO_NOBIG", &Options::wino_nobig, nullptr},

@@ -290,12 +290,14 @@ WINO42_CASES = [
     (5, 8, 8, 64, 32, 8, True, 2),           # half an N tile, two workgroups walking the tiles of 5 images
     (6, 16, 16, 256, 128, 32, False, 1),     # two-chunk sources, ONE workgroup walking 6 images x 2 N tiles
 ])
-def test_conv3x3_winograd42_epilogue_groupnorm(dev, case, gd_env):
+@pytest.mark.parametrize("nw", [2, 1])
+def test_conv3x3_winograd42_epilogue_groupnorm(dev, case, nw, gd_env):
     """gd_conv3x3_winograd42_gn: the GroupNorm (+ swish) that follows a 3x3 convolution, computed in the hybrid Winograd kernel's epilogue
-    (the engine's Op::egn_peer path), against float64 -- bias, residual and scale in front of the normalisation as in a residual block."""
+    (the engine's Op::egn_peer path), against float64 -- bias, residual and scale in front of the normalisation as in a residual block.
+    nw: the 64-output (eight waves) and the 32-output (four waves, round 4) workgroup tile."""
     from gddim_amd import ops
     B, H, W, Cin, Cout, groups, keep_raw, grid = case
-    gd_env(GDDIM_WINO42_GRID=grid if grid else None)
+    gd_env(GDDIM_WINO42_GRID=grid if grid else None, GDDIM_WINO42_NW=nw)
     g = torch.Generator().manual_seed(sum(case[:6]))
     x = torch.randn(B, H, W, Cin, generator=g)
     w = torch.randn(3, 3, Cin, Cout, generator=g) / math.sqrt(9 * Cin)
@@ -320,12 +322,16 @@ def test_conv3x3_winograd42_epilogue_groupnorm(dev, case, gd_env):
 
 
 @pytest.mark.parametrize("case", WINO42_CASES)
-def test_conv3x3_winograd42_matches_torch_fp64(dev, case):
+@pytest.mark.parametrize("nw", [2, 1])
+def test_conv3x3_winograd42_matches_torch_fp64(dev, case, nw, gd_env):
     """gd_conv3x3_winograd42 (hybrid F(2,3)_y x F(4,3)_x: 24 products per 2 x 4 output tile) against the float64 direct convolution.
     F(4,3) has transform constants up to 8 (A^T) and 5 (B^T): the bar is 4e-5 absolute on outputs of scale ~3 and at most 6x the
-    direct fp32 kernel's error (measured 1.5-2.5x; CPU emulation in profiles/r03_winograd_error_study.md)."""
+    direct fp32 kernel's error (measured 1.5-2.5x; CPU emulation in profiles/r03_winograd_error_study.md).  nw: the workgroup tile --
+    32 tiles x 64 outputs (eight waves, the production tile) or 32 tiles x 32 outputs (four waves staging two tiles' patch rows each, the
+    tile of launches that cannot fill the chip: round 4); Cin = 32 has the wide two-chunk form only."""
     from gddim_amd import ops
     B, H, W, Cin, Cout, use_bias, use_res = case
+    gd_env(GDDIM_WINO42_NW=nw)
     g = torch.Generator().manual_seed(sum(case[:5]) + 2)
     x = torch.randn(B, H, W, Cin, generator=g)
     w = torch.randn(3, 3, Cin, Cout, generator=g) / math.sqrt(9 * Cin)
@@ -350,7 +356,8 @@ def test_conv3x3_winograd42_matches_torch_fp64(dev, case):
 @pytest.mark.parametrize("grid", [1, 3, 8])
 @pytest.mark.parametrize("case", [(2, 32, 32, 128, 128, True, True), (5, 32, 32, 64, 132, True, True), (6, 8, 8, 64, 96, True, False),
                                   (3, 16, 16, 256, 256, False, True)])
-def test_conv3x3_winograd42_persistent_walk(dev, case, grid, gd_env):
+@pytest.mark.parametrize("nw", [2, 1])
+def test_conv3x3_winograd42_persistent_walk(dev, case, grid, nw, gd_env):
     """The hybrid kernel is persistent (Cin >= 64): a workgroup walks over tiles and its K-loop pipeline runs across them (the last two
     chunks of a tile stage the first two of the next).  Unit-test problems have fewer tiles than CUs, so GDDIM_WINO42_GRID forces a small
     grid: every workgroup then takes several tiles -- including the XCD-grouped mapping's padding ids (20 M tiles: ids 20..23 of the last
@@ -366,8 +373,9 @@ def test_conv3x3_winograd42_persistent_walk(dev, case, grid, gd_env):
     res = torch.randn(B, H, W, Cout, generator=g) if use_res else None
     wp = w.permute(3, 0, 1, 2).reshape(Cout, 9 * Cin).contiguous()
     args = (x.to(dev), wp.to(dev), None if bias is None else bias.to(dev), None if res is None else res.to(dev))
-    ref = ops.conv3x3_winograd42(*args, alpha=1.25, out_scale=0.7).cpu()
-    gd_env(GDDIM_WINO42_GRID=grid)
+    gd_env(GDDIM_WINO42_NW=2)
+    ref = ops.conv3x3_winograd42(*args, alpha=1.25, out_scale=0.7).cpu()  # the wide tile, default grid: every output's arithmetic is the same in both tiles
+    gd_env(GDDIM_WINO42_GRID=grid, GDDIM_WINO42_NW=nw)
     got = ops.conv3x3_winograd42(*args, alpha=1.25, out_scale=0.7).cpu()
     assert torch.equal(got, ref), (case, grid, (got - ref).abs().max().item())
     want = 1.25 * F.conv2d(x.permute(0, 3, 1, 2).double(), w.permute(3, 2, 0, 1).double(), padding=1).permute(0, 2, 3, 1)
