@@ -66,8 +66,6 @@ def issued_ratio(name):
         return 1.0 / 3.0   # F(2,3)y x F(4,3)x: 24 products per 8 outputs instead of 72
     if "wino2d" in name:
         return 4.0 / 9.0   # F(2x2,3x3): 16 per 4 outputs instead of 36
-    if "wino" in name:
-        return 2.0 / 3.0   # F(2,3) along x
     if "bf16x3" in name:
         return 3.0
     return 1.0
@@ -176,7 +174,7 @@ def main():
     ap.add_argument("--image-size", type=int, default=32)
     ap.add_argument("--workload", choices=["cld", "blur"], default="cld", help="cld = BASELINE configs 2/4/5, blur = config 3")
     ap.add_argument("--precision", choices=["fp32", "bf16x3"], default="fp32",
-                    help="fp32 = fp32 operands on the fp32 matrix core, 3x3 convolutions through Winograd F(2x2,3x3) / F(2,3) (headline); bf16x3 = split-precision weight contractions on the bf16 matrix core")
+                    help="fp32 = fp32 operands on the fp32 matrix core, 3x3 convolutions through the hybrid Winograd transform F(2,3)y x F(4,3)x (headline); bf16x3 = split-precision weight contractions on the bf16 matrix core")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--graph", choices=["step", "loop", "none"], default="step",
                     help="step: one captured hipGraph per NFE step, replayed (default); loop: ONE graph for the whole sampler call; none: eager launches")
@@ -289,7 +287,8 @@ def main():
         "config": {"workload": "%s, batch=%d per GPU, %dx%dx3 synthetic noise, random-init NCSN++ "
                                "(nf=128, ch_mult=(1,2,2,2), 8 res blocks, attn@16)" % (desc, B, cfg.data.image_size, cfg.data.image_size),
                    "global_batch": B * world, "parallelism": "dp%d (one process per GPU, uint8 all-gather per round%s)" % (world, ", RCCL" if grouped else ""),
-                   "hipgraph": {True: "per-step graph replayed NFE-1 times + denoise graph", "loop": "one graph per sampler call", False: False}[graph_mode], "tflop_per_image": flops_img / 1e12},
+                   "hipgraph": {True: "per-step graph replayed NFE-1 times + denoise graph", "loop": "one graph per sampler call", False: False}[graph_mode],
+                   "tflop_per_image": flops_img / 1e12, "tflop_per_image_is": "the reference's algorithmic count (direct convolutions, four attention projections)"},
         "e2e_tflops_per_gpu": B * args.steps * flops_img / dt / 1e12,
     }
 
@@ -306,7 +305,7 @@ def main():
         # bf16x3 issues 3 bf16 MFMAs per algorithmic product: achieved stays ALGORITHMIC flops, the peak is the bf16 one
         peak = BF16_MFMA_PEAK_TFLOPS if "bf16x3" in dom["name"] else FP32_MFMA_PEAK_TFLOPS
         # `achieved` = ALGORITHMIC flops of the direct algorithm / time.  `frac` = fraction of the matrix
-        # pipe the kernel keeps busy = ISSUED MFMA flops / time / peak (<= 1): Winograd F(2,3) issues 2/3 of the algorithmic
+        # pipe the kernel keeps busy = ISSUED MFMA flops / time / peak (<= 1): the hybrid Winograd kernel issues 1/3 of the algorithmic
         # products, bf16x3 issues 3 bf16 MFMAs per algorithmic product.  `algorithmic_frac` = achieved / peak (may exceed 1
         # for Winograd: the kernel does less work than the direct algorithm).
         issue_ratio = issued_ratio(dom["name"])
@@ -319,7 +318,17 @@ def main():
                               "launches": dom["launches"], "avg_launch_ms": dom["ms"] / max(1, dom["launches"]),
                               "flops_per_launch": dom["flops"] / max(1, dom["launches"]),
                               "share_of_gpu_time": dom["ms"] / tot_ms if tot_ms else None,
-                              "traffic_source": "committed rocprofv3 --pmc passes of this command (profiles/), not this run"}
+                              "traffic_source": "committed rocprofv3 --pmc passes of this command (profiles/), not this run",
+                              "timing_source": "one extra EAGER sampler call under the engine's hipEvent profiler (events around every launch on "
+                                               "the launch stream) -- not the hipGraph replay that `value` times; rocprofv3's average for the "
+                                               "same kernel in the replayed run is in profiles/"}
+        # what the matrix pipe really multiplies per step (Winograd kernels issue 1/3 or 4/9 of the direct algorithm's products, the folded
+        # attention projections and the up-sampling shortcuts' high-resolution share are not multiplied at all): next to the headline's
+        # reference-algorithmic TFLOP/s (`e2e_tflops_per_gpu` prices the reference's 37.2 GFLOP per image and evaluation)
+        issued = sum(p["flops"] * issued_ratio(p["name"]) for p in prof if p["flops"] and "bf16x3" not in p["name"])
+        result["e2e_issued_fp32_tflops_per_gpu"] = issued / (dt / max(1, args.steps)) / 1e12
+        result["e2e_issued_frac_of_fp32_mfma_peak"] = result["e2e_issued_fp32_tflops_per_gpu"] / FP32_MFMA_PEAK_TFLOPS
+        result["kernel_breakdown_source"] = "the same eager profiling pass (its sum exceeds ms_per_step by the launch gaps the graph replay hides)"
         if "wino42" in dom["name"]:
             result["roofline"]["note"] = ("hybrid Winograd F(2,3)y x F(4,3)x: achieved = algorithmic flops of the direct convolution / time; the kernel "
                                           "issues 24 products per 2x4 output tile instead of 72, i.e. 1/3 of that; frac = issued / dense fp32 MFMA peak "
@@ -329,9 +338,6 @@ def main():
                                           "issues 16 products per 2x2 output quad instead of 36, i.e. 4/9 of that; frac = issued / dense fp32 MFMA peak (nominal, 2.4 GHz); "
                                           "the in-kernel timeline (profiles/r02_notes.md, tools/wino2d_trace.py) shows the shader clock at 1.9-2.1 GHz under this "
                                           "kernel (power-limited) and its K loop at 82-88 % of the MFMA issue bound in shader cycles")
-        elif "wino" in dom["name"]:
-            result["roofline"]["note"] = ("Winograd F(2,3) along x: achieved = algorithmic flops of the direct convolution / time; "
-                                          "issued MFMA flops are 2/3 of that; frac = issued / dense fp32 MFMA peak")
         result["kernel_breakdown"] = [
             {"name": p["name"], "ms": round(p["ms"], 3), "launches": p["launches"],
              "tflops": (p["flops"] / (p["ms"] * 1e-3) / 1e12) if p["flops"] and p["ms"] else None,

@@ -39,7 +39,7 @@ class ModelDesc(ctypes.Structure):
 
 
 class ProfEntry(ctypes.Structure):
-    _fields_ = [("name", ctypes.c_char * 48), ("ms", ctypes.c_double), ("flops", ctypes.c_double),
+    _fields_ = [("name", ctypes.c_char * 128), ("ms", ctypes.c_double), ("flops", ctypes.c_double),
                 ("bytes", ctypes.c_double), ("launches", ctypes.c_longlong)]
 
 
@@ -70,6 +70,7 @@ SIGNATURES = {
     "gd_engine_load_param": (_I, [_P, ctypes.c_char_p, _P, ctypes.POINTER(ctypes.c_int64), _I]),
     "gd_engine_params_ready": (_I, [_P]),
     "gd_engine_packed_weight": (_I, [_P, ctypes.c_char_p, _P, _SZ, ctypes.POINTER(_SZ)]),
+    "gd_engine_weight_bytes": (_I, [_P, ctypes.POINTER(ctypes.c_longlong)]),
     "gd_engine_set_precision": (_I, [_P, _I]),
     "gd_unet_forward": (_I, [_P, _P, _P, _P, _I, _P]),
     "gd_cld_eps": (_I, [_P, _P, _P, _P, _I, _P]),
@@ -90,7 +91,6 @@ SIGNATURES = {
     "gd_bmm2x2": (_I, [_P, _P, _P, _LL, _I, _LL, _P]),
     "gd_dct2d_32": (_I, [_P, _P, _I, _I, _I, _P]),
     "gd_conv2d": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _P]),
-    "gd_conv3x3_winograd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _P]),
     "gd_conv3x3_winograd2d": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _P]),
     "gd_conv3x3_winograd42": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _P]),
     "gd_conv3x3_winograd42_gn": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _F, _P]),

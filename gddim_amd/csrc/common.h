@@ -95,10 +95,10 @@ struct GemmParams {
     float *egn_out;
     const float *egn_gamma, *egn_beta;
     int egn_cpg, egn_act, egn_skip_raw;
-    // fp32 Winograd F(2,3) path (kernels/conv3x3_wino_f32.hip): the 3x3 weights pre-transformed to
-    // U[n][ky][Cin/8][component][8] by launch_wino_weights (row stride ldb_wino = 12 Cin); null = direct kernel
+    // fp32 Winograd kernels (conv3x3_wino2d_f32.hip, conv3x3_wino42_f32.hip): the 3x3 weights pre-transformed by launch_wino2d_weights /
+    // launch_wino42_weights into the layout the kernel reads; null = direct kernel
     const float *b_wino;
-    int ldb_wino;
+    int ldb_wino;  // F(2x2,3x3): row stride of U (16 Cin floats; set by its launcher)
     // two-dimensional Winograd kernel with the channel range split over wk_split workgroups per tile (4x4 images, whose few tiles would
     // leave most CUs idle): split s multiplies channels [s, s + 1) * Cin / wk_split and stores its partial outputs -- after the output
     // transform, before bias / residual / scale -- to wk_partial[s][m][n] (row stride N); wino2d_splitk_finish_kernel adds the
@@ -132,17 +132,9 @@ bool conv3x3_halo_fused_ok(const GemmParams &p);  // shape test of the fused-Gro
 const char *conv3x3_halo_name();
 const char *conv3x3_halo_fused_name();
 int launch_conv3x3_halo(const GemmParams &p, hipStream_t s);
-// fp32 3x3 stride-1 convolutions through the 1-D Winograd transform F(2,3) (x 1.5 fewer matrix-core flops);
-// GDDIM_NOWINO=1 routes them back to igemm_f32_fast_kernel
-bool conv3x3_wino_ok(const GemmParams &p);
-bool conv3x3_wino_shape_ok(const GemmParams &p);  // without the fill-the-chip criterion (stand-alone entry)
-bool conv3x3_wino_egn_ok(const GemmParams &p);    // ... and its tile implements the epilogue GroupNorm (p.egn_* set)
-const char *conv3x3_wino_name(const GemmParams &p);
-int launch_conv3x3_wino(const GemmParams &p, hipStream_t s);
-int launch_wino_weights(const float *w, float *u, int N, int Cin, hipStream_t s);
 // fp32 3x3 stride-1 convolutions through the two-dimensional Winograd transform F(2x2, 3x3) (x 2.25 fewer matrix-core flops than
 // the direct sum, kernels/conv3x3_wino2d_f32.hip); p.b_wino = U[n][Cin/8][16][8] from launch_wino2d_weights (16 N Cin floats);
-// GDDIM_NOWINO2=1 routes them back to the one-dimensional kernel
+// GDDIM_NOWINO2=1 routes them back to the direct implicit-GEMM kernel
 bool conv3x3_wino2d_ok(const GemmParams &p);
 bool conv3x3_wino2d_shape_ok(const GemmParams &p);
 const char *conv3x3_wino2d_name();

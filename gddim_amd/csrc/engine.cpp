@@ -56,10 +56,6 @@ struct gd_engine {
     int precision = 0;
     unsigned short *wsplit_hi = nullptr, *wsplit_lo = nullptr;  // bf16 hi / lo of wbuf, same element offsets
     bool wsplit_valid = false;
-    // fp32 mode: Winograd F(2,3) copies of the 3x3 stride-1 convolution weights (kernels/conv3x3_wino_f32.hip), one region per
-    // eligible weight slot (float offset into wwino, -1 = none); built on the device from wbuf when the parameters are uploaded
-    float *wwino = nullptr;
-    std::vector<long long> wino_off;
     // ... and their two-dimensional F(2x2, 3x3) copies (kernels/conv3x3_wino2d_f32.hip), 16 N Cin floats per eligible slot
     float *wwino2 = nullptr;
     float *splitk_ws = nullptr;  // partial outputs of the channel-split 2-D Winograd launches (4x4 level): 8 * max_batch * 16 * max N floats
@@ -74,6 +70,7 @@ struct gd_engine {
     std::map<int, std::vector<char>> presplit_ok;  // batch size -> per tensor: may be stored pre-split (see presplit_allowed)
     std::vector<long long> slot_off;  // floats into wbuf
     long long wbuf_floats = 0;
+    long long wwino2_floats = 0, wwino42_floats = 0;
     float *xin = nullptr, *epsb = nullptr, *labels = nullptr, *eps_planar = nullptr;
     // sampler state
     float *u8 = nullptr, *ring = nullptr, *ystate = nullptr;
@@ -292,8 +289,8 @@ static bool gn_fused(gd_engine *e, const Bind &b, int batch, int gemm_index) {
 }
 
 // Epilogue GroupNorm (plan.h: Op::egn_peer), fp32 mode: taken when, at this batch size, the kernel the GEMM runs on implements it
-// (the two-dimensional Winograd kernel on 16x16 / 8x8 images, a 64-pair one-dimensional tile on 8x8 images, igemm_f32_fast_kernel on 4x4 images).  Fills the egn_* fields of g.  Decided once per
-// batch size; GDDIM_NO_EGN=1 switches it off (A/B).
+// (the Winograd kernels on 16x16 / 8x8 images, the finishing pass of the channel-split launch and igemm_f32_fast_kernel on 4x4 images).
+// Fills the egn_* fields of g.  Decided once per batch size; GDDIM_NO_EGN=1 switches it off (A/B).
 static void fill_egn(gd_engine *e, const Op &op, const Bind &b, int batch, GemmParams &g, int i0 = 0) {
     const Op &a = e->plan.ops[op.egn_peer];
     g.egn_out = tptr_at(e, b, a.out, batch, i0);
@@ -318,10 +315,9 @@ static bool egn_fused(gd_engine *e, const Bind &b, int batch, int gemm_index) {
             const bool wino2 = z == 1 && op.w_slot >= 0 && e->wwino2 && e->wino2_off[op.w_slot] >= 0;
             const bool wino42 = z == 1 && op.w_slot >= 0 && e->wwino42 && e->wino42_off[op.w_slot] >= 0;
             if (wino42 && conv3x3_wino42_ok(g)) { ok[i] = 1; continue; }  // (its shape test covers the egn_* fields)
-            const bool wino = z == 1 && op.w_slot >= 0 && e->wwino && e->wino_off[op.w_slot] >= 0 && conv3x3_wino_ok(g);
             if (wino2 && conv3x3_wino2d_ok(g)) ok[i] = 1;  // (its shape test covers the egn_* fields)
             else if (wino2 && e->splitk_ws && conv3x3_wino2d_splitk_factor(g) > 1) ok[i] = 1;  // (the finishing pass normalises)
-            else ok[i] = (wino ? conv3x3_wino_egn_ok(g) : igemm_egn_ok(g, z)) ? 1 : 0;
+            else ok[i] = igemm_egn_ok(g, z) ? 1 : 0;
         }
         it = e->egn_ok.emplace(batch, std::move(ok)).first;
     }
@@ -473,11 +469,6 @@ static int run_gemm(gd_engine *e, int op_index, const Bind &b, int batch, int i0
                  "%s: split-K scratch too small", op.label.c_str());
         ProfScope ps(e, s, pkey(e, op, std::string(conv3x3_wino2d_splitk_name())), op.flops_per_image * nb, gemm_alg_bytes(g, z));
         return launch_conv3x3_wino2d_splitk(g, s);
-    }
-    if (e->precision == 0 && z == 1 && op.w_slot >= 0 && e->wwino && e->wino_off[op.w_slot] >= 0 && conv3x3_wino_ok(g)) {
-        g.b_wino = e->wwino + e->wino_off[op.w_slot];
-        ProfScope ps(e, s, pkey(e, op, std::string(conv3x3_wino_name(g))), op.flops_per_image * nb, gemm_alg_bytes(g, z));
-        return launch_conv3x3_wino(g, s);
     }
     if (op.side_peer >= 0 && side_fused(e, b, batch, op_index)) {  // the per-image affine table first, then the GEMM whose loader applies it
         if (first) GD_TRY(launch_apply_op(e, P.ops[op.side_peer], b, batch, true, s));  // (the table of the whole batch)
@@ -658,7 +649,6 @@ int gd_engine_destroy(gd_engine *e) {
         (void)hipDeviceSynchronize();
         drop_graphs(e);
         for (auto &p : e->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
-        if (e->wwino) (void)hipFree(e->wwino);
         if (e->wwino2) (void)hipFree(e->wwino2);
         if (e->wwino42) (void)hipFree(e->wwino42);
         if (e->splitk_ws) (void)hipFree(e->splitk_ws);
@@ -749,31 +739,18 @@ static int upload_split_weights(gd_engine *e) {
     return 0;
 }
 
-// U = G g for every weight slot read by a 3x3 / stride 1 / pad 1 convolution whose channel counts fit the Winograd kernel
-// (the per-launch shape test conv3x3_wino_ok decides whether a given batch size actually uses it)
+// The Winograd-domain copies of the 3x3 / stride 1 / pad 1 convolution weights, built on the device from wbuf when the parameters are
+// uploaded (allocated once: the plan fixes their sizes, and captured graphs keep pointing into them when parameters are loaded again).
+// Which launches use a copy is decided per batch size by the kernels' *_ok tests.  A slot the hybrid kernel can take gets the hybrid copy
+// only -- the F(2x2,3x3) copy is for what the hybrid kernel cannot tile (the 4x4 level) and, under GDDIM_NOWINO42=1, for the A/B of the
+// older kernel: 1.4 GB of weights for the benchmarked network instead of round 3's 2.8 GB (gd_engine_weight_bytes).
 static int build_wino_weights(gd_engine *e) {
     const Plan &P = e->plan;
-    e->wino_off.assign(P.slots.size(), -1);
-    long long total = 0;
     std::vector<std::pair<int, int>> dims(P.slots.size(), {0, 0});  // (N, Cin) per slot
-    for (const Op &op : P.ops) {
-        if (op.kind != OP_GEMM || op.w_slot < 0 || op.a_slot >= 0 || op.z_per_image) continue;
-        const int Cin = op.C0 + op.C1;
-        if (op.KH != 3 || op.KW != 3 || op.stride != 1 || op.pad != 1 || Cin % 32 != 0 || op.K != 9 * Cin || op.ldb != op.K) continue;
-        if (op.N % 4 != 0 || op.N < 64 || e->wino_off[op.w_slot] >= 0) continue;
-        if (P.slots[op.w_slot].rows != op.N || P.slots[op.w_slot].cols != op.K) continue;
-        e->wino_off[op.w_slot] = total;
-        dims[op.w_slot] = {op.N, Cin};
-        total += (long long)op.N * 12 * Cin;
-    }
-    if (total == 0) return 0;
-    // allocated once (the plan fixes its size): captured graphs keep pointing into it when parameters are loaded again
-    if (!e->wwino) GD_HIP(hipMalloc((void **)&e->wwino, (size_t)total * sizeof(float)));
-    for (size_t i = 0; i < P.slots.size(); ++i)
-        if (e->wino_off[i] >= 0)
-            GD_TRY(launch_wino_weights(e->wbuf + e->slot_off[i], e->wwino + e->wino_off[i], dims[i].first, dims[i].second, nullptr));
-    // the two-dimensional form (which launches use it is decided per batch size by conv3x3_wino2d_ok) for the same slots and for
-    // those only the 2-D kernel takes (any N without fused statistics: the 6-channel head convolution), on images it can tile
+    auto hybrid_takes = [&](const Op &op) {
+        return !opts().no_wino42 && (op.W == 8 || op.W == 16 || op.W == 32 || op.W == 64) && op.H % 2 == 0 && (op.H * op.W / 8) % 8 == 0;
+    };
+    // the two-dimensional form F(2x2,3x3)
     e->wino2_off.assign(P.slots.size(), -1);
     long long total2 = 0, need_ws = 0;
     for (const Op &op : P.ops) {
@@ -784,6 +761,7 @@ static int build_wino_weights(gd_engine *e) {
         if ((op.N % 4 != 0 || op.N < 32) && (op.qstats.t >= 0 || op.egn_peer >= 0)) continue;
         const bool img4 = op.H == 4 && op.W == 4;  // the channel-split launch (conv3x3_wino2d_splitk_factor)
         if (!img4 && ((op.W != 8 && op.W != 16 && op.W != 32 && op.W != 64) || op.H % 2 != 0 || (op.H * op.W / 4) % 16 != 0)) continue;
+        if (!img4 && hybrid_takes(op)) continue;
         if (img4) need_ws = std::max(need_ws, 8LL * e->plan.desc.max_batch * 16 * op.N);
         if (img4) e->splitk_per_image = std::max(e->splitk_per_image, 8LL * 16 * op.N);
         e->wino2_off[op.w_slot] = total2;
@@ -795,8 +773,10 @@ static int build_wino_weights(gd_engine *e) {
         GD_HIP(hipMalloc((void **)&e->splitk_ws, (size_t)need_ws * sizeof(float)));
         e->splitk_ws_floats = need_ws;
     }
+    GD_CHECK(!e->wwino2 || total2 == e->wwino2_floats, "the option table changed between two parameter loads of one engine (GDDIM_NOWINO42)");
     if (total2 > 0) {
         if (!e->wwino2) GD_HIP(hipMalloc((void **)&e->wwino2, (size_t)total2 * sizeof(float)));
+        e->wwino2_floats = total2;
         for (size_t i = 0; i < P.slots.size(); ++i)
             if (e->wino2_off[i] >= 0)
                 GD_TRY(launch_wino2d_weights(e->wbuf + e->slot_off[i], e->wwino2 + e->wino2_off[i], dims[i].first, dims[i].second, nullptr));
@@ -811,13 +791,15 @@ static int build_wino_weights(gd_engine *e) {
         if (op.KH != 3 || op.KW != 3 || op.stride != 1 || op.pad != 1 || Cin % 32 != 0 || op.K != 9 * Cin || op.ldb != op.K) continue;
         if (P.slots[op.w_slot].rows != op.N || P.slots[op.w_slot].cols != op.K) continue;
         if ((op.N % 4 != 0 || op.N < 32) && (op.qstats.t >= 0 || op.egn_peer >= 0)) continue;
-        if ((op.W != 8 && op.W != 16 && op.W != 32 && op.W != 64) || op.H % 2 != 0 || (op.H * op.W / 8) % 8 != 0) continue;
+        if (!hybrid_takes(op)) continue;
         e->wino42_off[op.w_slot] = total42;
         dims[op.w_slot] = {op.N, Cin};
         total42 += wino42_weight_floats(op.N, Cin);
     }
+    GD_CHECK(!e->wwino42 || total42 == e->wwino42_floats, "the option table changed between two parameter loads of one engine (GDDIM_NOWINO42)");
     if (total42 > 0) {
         if (!e->wwino42) GD_HIP(hipMalloc((void **)&e->wwino42, (size_t)total42 * sizeof(float)));
+        e->wwino42_floats = total42;
         for (size_t i = 0; i < P.slots.size(); ++i)
             if (e->wino42_off[i] >= 0)
                 GD_TRY(launch_wino42_weights(e->wbuf + e->slot_off[i], e->wwino42 + e->wino42_off[i], dims[i].first, dims[i].second, nullptr));
@@ -866,6 +848,15 @@ int gd_engine_params_ready(gd_engine *e) {
         GD_TRY(build_wino_weights(e));
         if (e->precision == 1) GD_TRY(upload_split_weights(e));
     }
+    return 0;
+}
+
+int gd_engine_weight_bytes(gd_engine *e, long long out4[4]) {
+    GD_CHECK(e && out4, "null argument");
+    out4[0] = e->wbuf_floats * 4;
+    out4[1] = e->wwino2_floats * 4;
+    out4[2] = e->wwino42_floats * 4;
+    out4[3] = e->wsplit_hi ? e->wbuf_floats * 4 : 0;  // bf16 hi + lo
     return 0;
 }
 
@@ -1385,23 +1376,6 @@ int gd_conv2d(const float *x_dev, const float *w_dev, const float *bias_dev, con
     g.rows_per_image = g.OH * g.OW;
     g.alpha = alpha; g.out_scale = out_scale;
     return launch_igemm(g, 1, (hipStream_t)stream);
-}
-
-int gd_conv3x3_winograd(const float *x_dev, const float *w_dev, float *u_scratch_dev, const float *bias_dev, const float *res_dev,
-                        float *out_dev, int batch, int H, int W, int Cin, int Cout, float alpha, float out_scale, void *stream) {
-    GD_CHECK(x_dev && w_dev && u_scratch_dev && out_dev, "null pointer");
-    GemmParams g{};
-    g.a0 = x_dev; g.C0 = Cin; g.lda0 = Cin; g.lda1 = 4;
-    g.H = H; g.W = W; g.KH = 3; g.KW = 3; g.stride = 1; g.pad = 1; g.OH = H; g.OW = W;
-    g.M = batch * H * W; g.N = Cout; g.K = 9 * Cin;
-    g.b = w_dev; g.ldb = g.K;
-    g.out = out_dev; g.ldc = Cout; g.bias = bias_dev; g.res = res_dev; g.ldres = Cout;
-    g.rows_per_image = H * W;
-    g.alpha = alpha; g.out_scale = out_scale;
-    GD_CHECK(conv3x3_wino_shape_ok(g), "conv3x3_winograd: shape not eligible (B=%d H=%d W=%d Cin=%d Cout=%d)", batch, H, W, Cin, Cout);
-    GD_TRY(launch_wino_weights(w_dev, u_scratch_dev, Cout, Cin, (hipStream_t)stream));
-    g.b_wino = u_scratch_dev;
-    return launch_conv3x3_wino(g, (hipStream_t)stream);
 }
 
 int gd_conv3x3_winograd2d(const float *x_dev, const float *w_dev, float *u_scratch_dev, const float *bias_dev, const float *res_dev,

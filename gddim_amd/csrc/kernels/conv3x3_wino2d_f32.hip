@@ -1,23 +1,23 @@
 // 3x3 / stride 1 / pad 1 convolution in fp32 with the TWO-dimensional Winograd transform F(2x2, 3x3).
 //
-// conv3x3_wino_f32.hip transforms along x only: 4 products per output pair and kernel row, 12 M N Cin flops instead of 18.  With
-// the matrix pipe saturated at the clock the chip sustains the only way further is fewer products again:
-// transforming along y as well needs 16 products per 2 x 2 output quad instead of 36, 8 M N Cin flops -- x 2.25 fewer than the direct
-// sum, x 1.5 fewer than the one-dimensional kernel.  For the quad with top-left output pixel (2 qy, 2 qx), its 4 x 4 input patch
+// Round 1's kernel transformed along x only, F(2,3): 4 products per output pair and kernel row, 12 M N Cin flops instead of 18 (removed
+// in round 4: the hybrid kernel's 32-output tile covers the small launches it was kept for).  With the matrix pipe saturated at the clock
+// the chip sustains the only way further is fewer products again: transforming along y as well needs 16 products
+// per 2 x 2 output quad instead of 36, 8 M N Cin flops -- x 2.25 fewer than the direct sum.  Since round 3 the production path of the
+// 64x64 .. 8x8 levels is the hybrid F(2,3)y x F(4,3)x kernel (conv3x3_wino42_f32.hip); this one runs the 4x4 level (channel-split launch)
+// and is the A/B fallback behind GDDIM_NOWINO42=1.  For the quad with top-left output pixel (2 qy, 2 qx), its 4 x 4 input patch
 // d[r][s] = in[2 qy - 1 + r][2 qx - 1 + s] and the kernel g[ky][kx]:
 //     V = B^T d B,   U = G g G^T,   M_ij[quad][n] = sum_c V_ij[quad][c] U_ij[n][c],   Y = A^T M A   (2 x 2 outputs)
 //     B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1],  G = [1 0 0; 1/2 1/2 1/2; 1/2 -1/2 1/2; 0 0 1],  A^T = [1 1 1 0; 0 1 -1 -1]
-// i.e. the same one-dimensional F(2,3) of conv3x3_wino_f32.hip applied to rows and to columns.  Both activation-side transforms are
+// i.e. the one-dimensional F(2,3) applied to rows and to columns.  Both activation-side transforms are
 // additions only; the 1/2 and 1/4 live in the pre-transformed weights (computed in double, rounded once): the benign Winograd size.
 //
 // Sixteen components x 32 x 32 accumulators do not fit one wave, so the components are split over the waves of a workgroup:
 // 512 threads = 8 wave64; workgroup tile 64 quads (256 pixels) x 64 outputs x 16 components; wave (wi, wq) owns component row i = wi
-// (its four components j = 0..3) of quad block wq (32 quads) x 64 outputs = eight 32x32x2 fp32 accumulators, exactly the register
-// budget of the one-dimensional kernel's wave.  K = Cin is consumed in chunks of 8 channels: LDS rows [quad or n][16 components x 8
+// (its four components j = 0..3) of quad block wq (32 quads) x 64 outputs = eight 32x32x2 fp32 accumulators.  K = Cin is consumed in chunks of 8 channels: LDS rows [quad or n][16 components x 8
 // channels + 4 pad] (132 floats = an odd number of 16-byte units: the ds_read_b128 of 16 consecutive rows cover all banks), two stages
 // of 66 KB (V stage 0 | V stage 1 | U stage 0 | U stage 1: the stage is an immediate offset, the K loop is unrolled by two), one
-// workgroup per CU.  One ds_read_b128 per (fragment, component) feeds four MFMAs, 32 MFMAs per wave between barriers -- the same
-// K-loop shape as the one-dimensional kernel -- while a chunk now carries 1.5 x the output work.
+// workgroup per CU.  One ds_read_b128 per (fragment, component) feeds four MFMAs, 32 MFMAs per wave between barriers.
 // Staging: thread (quad, 4-channel half, patch row i) loads ONE row of the quad's 4 x 4 patch (4 pixels x 16 B, out-of-image pixels
 // pushed out of the buffer bounds -> zero padding); the row B^T row i combines it with lives in a neighbouring lane and comes in
 // through a DPP operand (16 v_fmac_f32_dpp); the x-direction transform is 8 packed-fp32 additions; four component float4s go to
@@ -597,8 +597,8 @@ bool conv3x3_wino2d_shape_ok(const GemmParams &p) {
     return a_bytes < (1LL << 31) && (long long)p.N * 16 * Cin * 4 + 64 < (1LL << 31);
 }
 
-// what the engine sends to it: an eligible shape with at least two workgroups per CU.  GDDIM_NOWINO2=1 routes everything back to the
-// one-dimensional kernel; GDDIM_WINO2_MINBLOCKS overrides the fill criterion (A/B).
+// what the engine sends to it: an eligible shape with at least one workgroup per CU.  GDDIM_NOWINO2=1 routes everything back to the
+// direct implicit-GEMM kernel; GDDIM_WINO2_MINBLOCKS overrides the fill criterion (A/B).
 bool conv3x3_wino2d_ok(const GemmParams &p) {
     if (opts().no_wino2 || !conv3x3_wino2d_shape_ok(p)) return false;
     return (long long)((p.M / 4 + 63) / 64) * ((p.N + 63) / 64) >= opts().wino2_min_blocks;

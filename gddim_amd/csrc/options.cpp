@@ -34,10 +34,6 @@ const Entry kEntries[] = {
     {"GDDIM_WINO42_MINBLOCKS", &Options::wino42_min_blocks, nullptr},
     {"GDDIM_WINO42_GRID", &Options::wino42_grid, nullptr},
     {"GDDIM_WINO42_NW", &Options::wino42_nw, nullptr},
-    {"GDDIM_WINO_MINBLOCKS", &Options::wino_min_blocks, nullptr},
-    {"GDDIM_WINO_NOSMALL", &Options::wino_nosmall, nullptr},
-    {"GDDIM_WINO_NOBIG", &Options::wino_nobig, nullptr},
-    {"GDDIM_WINO_NOPERSIST", &Options::wino_nopersist, nullptr},
     {"GDDIM_IGEMM_VARIANT", &Options::igemm_variant, nullptr},
     {"GDDIM_IGEMM_BIGMIN", nullptr, &Options::igemm_bigmin},
     {"GDDIM_IGEMM_MIDMIN", nullptr, &Options::igemm_midmin},

@@ -21,14 +21,13 @@ struct Options {
     int no_upswap = 0;          // GDDIM_NO_UPSWAP: up-sampling blocks multiply their 1x1 shortcut after the FIR
     // ---- fp32 3x3 convolutions ----
     int no_wino = 0;            // GDDIM_NOWINO: every 3x3 convolution on the direct implicit-GEMM kernel
-    int no_wino2 = 0;           // GDDIM_NOWINO2: no F(2x2,3x3) kernel (and no hybrid kernel)
+    int no_wino2 = 0;           // GDDIM_NOWINO2: no F(2x2,3x3) kernel (and no hybrid kernel): the same as GDDIM_NOWINO since round 4
     int no_wino42 = 0;          // GDDIM_NOWINO42: no hybrid F(2,3)y x F(4,3)x kernel
     int no_wino2_splitk = 0;    // GDDIM_NOWINO2_SPLITK: 4x4 level back on the direct split-K tile
     int wino2_min_blocks = 256; // GDDIM_WINO2_MINBLOCKS: workgroup tiles a launch must have for the F(2x2,3x3) kernel
     int wino42_min_blocks = 256;  // GDDIM_WINO42_MINBLOCKS: ... for the hybrid kernel
     int wino42_grid = 0;        // GDDIM_WINO42_GRID: persistent workgroups per launch (tests: several tiles per workgroup)
     int wino42_nw = 0;          // GDDIM_WINO42_NW: 0 the launcher's choice, 1 / 2 force the 32- / 64-output workgroup tile
-    int wino_min_blocks = 512, wino_nosmall = 0, wino_nobig = 0, wino_nopersist = 0;  // GDDIM_WINO_*: the one-dimensional F(2,3) kernel
     // ---- fp32 implicit GEMM ----
     int igemm_variant = 0;      // GDDIM_IGEMM_VARIANT: 0 128x128 / 8 waves, 1 128x128 / 4 waves, 2 256x128
     long long igemm_bigmin = 384, igemm_midmin = 384;  // GDDIM_IGEMM_BIGMIN / _MIDMIN: workgroups needed for 128x128 / 128x64 tiles

@@ -129,6 +129,12 @@ class Engine(object):
             out[name.value.decode()] = tuple(int(shape[j]) for j in range(nd.value))
         return out
 
+    def weight_bytes(self):
+        """Device bytes of the weights: packed GEMM layout, F(2x2,3x3) copies, hybrid Winograd copies, bf16 hi + lo copies."""
+        out = (ctypes.c_longlong * 4)()
+        check(self._lib.gd_engine_weight_bytes(self._h, out))
+        return {"packed": out[0], "wino2d": out[1], "wino42": out[2], "bf16_split": out[3]}
+
     def packed_weight(self, slot):
         n = ctypes.c_size_t()
         check(self._lib.gd_engine_packed_weight(self._h, slot.encode(), None, 0, ctypes.byref(n)))
@@ -155,7 +161,7 @@ class Engine(object):
         return self
 
     def set_precision(self, mode):
-        """'fp32' (fp32 MFMA, 3x3 convolutions through Winograd F(2,3) at production batch sizes; default) or 'bf16x3' (split-precision weight contractions on the bf16 matrix core)."""
+        """'fp32' (fp32 MFMA, 3x3 convolutions through the hybrid Winograd transform F(2,3)y x F(4,3)x; default) or 'bf16x3' (split-precision weight contractions on the bf16 matrix core)."""
         code = {"fp32": 0, "f32": 0, 0: 0, "bf16x3": 1, 1: 1}[mode]
         check(self._lib.gd_engine_set_precision(self._h, code))
         self._schedule_token = None

@@ -104,23 +104,6 @@ def conv2d(x, w_packed, bias=None, res=None, KH=3, KW=3, stride=1, pad=1, alpha=
     return out
 
 
-def conv3x3_winograd(x, w_packed, bias=None, res=None, alpha=1.0, out_scale=1.0, u_scratch=None):
-    """3x3 / stride 1 / pad 1 NHWC conv through the fp32 Winograd F(2,3) kernel (same packed weights as conv2d)."""
-    import torch
-    _need_gpu(x)
-    x, w_packed = _f32c(x), _f32c(w_packed)
-    B, H, W, Cin = x.shape
-    Cout = w_packed.shape[0]
-    out = torch.empty((B, H, W, Cout), dtype=torch.float32, device=x.device)
-    if u_scratch is None:
-        u_scratch = torch.empty(Cout * 12 * Cin, dtype=torch.float32, device=x.device)
-    bias = _f32c(bias) if bias is not None else None
-    res = _f32c(res) if res is not None else None
-    check(_abi.lib().gd_conv3x3_winograd(_ptr(x), _ptr(w_packed), _ptr(u_scratch), _ptr(bias), _ptr(res), _ptr(out), B, H, W, Cin,
-                                         Cout, float(alpha), float(out_scale), _stream(x)))
-    return out
-
-
 def conv3x3_winograd2d(x, w_packed, bias=None, res=None, alpha=1.0, out_scale=1.0, u_scratch=None):
     """3x3 / stride 1 / pad 1 NHWC conv through the fp32 two-dimensional Winograd F(2x2,3x3) kernel (same packed weights as conv2d)."""
     import torch

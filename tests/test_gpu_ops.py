@@ -141,64 +141,7 @@ def test_conv2d_transpose_detecting(dev):
     assert (got.double() - want).abs().max() < 1e-5
 
 
-# ---- fp32 Winograd F(2,3) kernel (what the engine runs for the 3x3 stride-1 convolutions at production batch sizes) --------
-WINO_CASES = [
-    # B, H, W, Cin, Cout, bias, res
-    (2, 32, 32, 128, 128, True, True),    # 64 x 128 tile, the dominant layer shape
-    (3, 16, 16, 256, 256, True, True),    # two N tiles
-    (2, 8, 8, 64, 64, True, False),       # 64 x 64 tile variant (N <= 64)
-    (1, 32, 32, 32, 68, False, True),     # ragged N tile (68 = 64 + 4), K of one slab
-    (5, 8, 16, 96, 132, True, True),      # non-square image, Cin = 3 slabs, ragged N, ragged M tile (5 * 64 pairs)
-    (4, 4, 16, 32, 64, False, False),     # H*W = 64: one wave tile per image
-]
-
-
-@pytest.mark.parametrize("case", WINO_CASES)
-def test_conv3x3_winograd_matches_torch_fp64(dev, case):
-    """gd_conv3x3_winograd against the float64 direct convolution; the bar is the direct fp32 kernel's (2e-5): F(2,3) adds a few
-    roundings (transforms are additions, the 1/2 of the weight transform is exact), not a conditioning problem."""
-    from gddim_amd import ops
-    B, H, W, Cin, Cout, use_bias, use_res = case
-    g = torch.Generator().manual_seed(sum(case[:5]))
-    x = torch.randn(B, H, W, Cin, generator=g)
-    w = torch.randn(3, 3, Cin, Cout, generator=g) / math.sqrt(9 * Cin)
-    bias = torch.randn(Cout, generator=g) if use_bias else None
-    res = torch.randn(B, H, W, Cout, generator=g) if use_res else None
-    wp = w.permute(3, 0, 1, 2).reshape(Cout, 9 * Cin).contiguous()
-    got = ops.conv3x3_winograd(x.to(dev), wp.to(dev), None if bias is None else bias.to(dev), None if res is None else res.to(dev),
-                               alpha=1.25, out_scale=0.7).cpu().double()
-    want = 1.25 * F.conv2d(x.permute(0, 3, 1, 2).double(), w.permute(3, 2, 0, 1).double(), padding=1).permute(0, 2, 3, 1)
-    if bias is not None:
-        want = want + bias.double()
-    if res is not None:
-        want = want + res.double()
-    want = want * 0.7
-    direct = ops.conv2d(x.to(dev), wp.to(dev), None if bias is None else bias.to(dev), None if res is None else res.to(dev),
-                        alpha=1.25, out_scale=0.7).cpu().double()
-    err, err_direct = (got - want).abs().max().item(), (direct - want).abs().max().item()
-    assert err < 2e-5 and err < 4 * err_direct + 1e-6, (case, err, err_direct)
-
-
-def test_conv3x3_winograd_big_tile(dev):
-    """Problems with >= 512 tiles of 128 pairs x 128 outputs take the eight-wave 128 x 128 tile (one workgroup per CU): batch 128 of
-    the dominant layer shape, and a 256-output layer whose last N tile is ragged.  Whole output against the direct fp32 kernel, the
-    first two images against float64."""
-    from gddim_amd import ops
-    for (B, H, Cin, Cout) in [(128, 32, 128, 128), (128, 16, 64, 260)]:
-        g = torch.Generator().manual_seed(B + Cout)
-        x = torch.randn(B, H, H, Cin, generator=g)
-        w = torch.randn(3, 3, Cin, Cout, generator=g) / math.sqrt(9 * Cin)
-        bias = torch.randn(Cout, generator=g)
-        res = torch.randn(B, H, H, Cout, generator=g)
-        wp = w.permute(3, 0, 1, 2).reshape(Cout, 9 * Cin).contiguous()
-        got = ops.conv3x3_winograd(x.to(dev), wp.to(dev), bias.to(dev), res.to(dev), out_scale=0.7).cpu()
-        direct = ops.conv2d(x.to(dev), wp.to(dev), bias.to(dev), res.to(dev), out_scale=0.7).cpu()
-        want = (F.conv2d(x[:2].permute(0, 3, 1, 2).double(), w.permute(3, 2, 0, 1).double(), padding=1).permute(0, 2, 3, 1)
-                + bias.double() + res[:2].double()) * 0.7
-        assert (got - direct).abs().max().item() < 2e-5, (B, H, Cin, Cout)
-        assert (got[:2].double() - want).abs().max().item() < 2e-5, (B, H, Cin, Cout)
-
-
+# ---- fp32 Winograd kernels: F(2x2,3x3) (round 2; the 4x4 level and the A/B fallback) and the hybrid F(2,3)y x F(4,3)x (production) ----
 WINO2D_CASES = [
     # B, H, W, Cin, Cout, bias, res
     (2, 32, 32, 128, 128, True, True),    # the dominant layer shape: 4 tiles per image, 2 N tiles
@@ -221,7 +164,7 @@ WINO2D_CASES = [
 @pytest.mark.parametrize("case", WINO2D_CASES)
 def test_conv3x3_winograd2d_matches_torch_fp64(dev, case):
     """gd_conv3x3_winograd2d (F(2x2,3x3): 16 products per 2x2 output quad) against the float64 direct convolution; same bar as the
-    one-dimensional kernel: both transforms are additions, the 1/2 and 1/4 of the weight transform are exact."""
+    direct kernel: both transforms are additions, the 1/2 and 1/4 of the weight transform are exact."""
     from gddim_amd import ops
     B, H, W, Cin, Cout, use_bias, use_res = case
     g = torch.Generator().manual_seed(sum(case[:5]) + 1)
@@ -405,26 +348,6 @@ def test_conv3x3_winograd42_impulse_and_rejects(dev):
         b_, h_, w_, ci, co = shape
         with pytest.raises(GddimError):
             ops.conv3x3_winograd42(torch.zeros(b_, h_, w_, ci, device=dev), torch.zeros(co, 9 * ci, device=dev))
-
-
-def test_conv3x3_winograd_impulse_and_rejects(dev):
-    """An impulse input with an asymmetric kernel (catches a swapped tap, pixel-parity or component order), at an image corner and
-    at an odd column; shapes the kernel cannot take (odd W, Cin % 32 != 0) are refused loudly."""
-    from gddim_amd import ops
-    from gddim_amd._abi import GddimError
-    B, H, W, Cin, Cout = 1, 8, 8, 32, 64
-    w = torch.arange(3 * 3 * Cin * Cout, dtype=torch.float32).reshape(3, 3, Cin, Cout) / 1000.0
-    wp = w.permute(3, 0, 1, 2).reshape(Cout, 9 * Cin).contiguous()
-    for (y, xx, c) in [(0, 0, 5), (3, 5, 17), (7, 7, 31), (4, 2, 0)]:
-        x = torch.zeros(B, H, W, Cin)
-        x[0, y, xx, c] = 1.0
-        got = ops.conv3x3_winograd(x.to(dev), wp.to(dev)).cpu().double()
-        want = F.conv2d(x.permute(0, 3, 1, 2).double(), w.permute(3, 2, 0, 1).double(), padding=1).permute(0, 2, 3, 1)
-        assert (got - want).abs().max() < 1e-4 * want.abs().max(), (y, xx, c)
-    with pytest.raises(GddimError):
-        ops.conv3x3_winograd(torch.zeros(1, 8, 7, 32, device=dev), wp.to(dev))
-    with pytest.raises(GddimError):
-        ops.conv3x3_winograd(torch.zeros(1, 8, 8, 16, device=dev), torch.zeros(64, 9 * 16, device=dev))
 
 
 # ---- GroupNorm / FIR / attention -----------------------------------------------------------------------------

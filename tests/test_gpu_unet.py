@@ -68,6 +68,12 @@ def test_unet_full_architecture_matches_oracle(native_lib):
     eps = eng.cld_eps(torch.as_tensor(u, device="cuda:0"), torch.as_tensor(t, device="cuda:0")).cpu().numpy()
     want_eps = onet.cld_eps_fn(params, cfg, dtype=torch.float64)(u.astype(np.float64), t.astype(np.float64))
     assert np.abs(eps - want_eps).max() < max(4 * e_f32, 2e-5) * scale
+    # weight footprint in HBM: the packed GEMM layout (430 MB) + ONE Winograd copy per 3x3 slot -- hybrid fragment order for the 64x64 .. 8x8
+    # levels, F(2x2,3x3) for the 4x4 level -- 2.8 GB in round 3, when every slot also carried an F(2,3) and an F(2x2,3x3) copy (<= 2.2 GB)
+    wb = eng.weight_bytes()
+    print("weights in HBM: %s -> %.2f GB" % (wb, sum(wb.values()) / 1e9))
+    assert 4.2e8 < wb["packed"] < 4.5e8 and wb["bf16_split"] == 0
+    assert 0 < wb["wino2d"] < 0.3e9 and 0.6e9 < wb["wino42"] < 1.0e9 and sum(wb.values()) < 2.2e9
     eng.close()
 
 
@@ -142,11 +148,11 @@ def test_unet_64x64_winograd_levels_match_oracle(native_lib):
     assert np.abs(got[:1] - alone).max() / scale < 2e-5
 
 
-@pytest.mark.parametrize("kernel", ["wino42", "wino2d"])
+@pytest.mark.parametrize("kernel", ["wino42", "wino42_n32", "wino2d"])
 def test_epilogue_groupnorm_16x16_level(native_lib, tmp_path, kernel):
     """GroupNorm in the producer's epilogue (plan.h: Op::egn_peer) on 16x16 images, where the image is one workgroup tile of the
-    Winograd kernel -- the hybrid F(2,3)y x F(4,3)x kernel of round 3 (persistent form for Cin = 64, one-tile form for Cin = 32) and the
-    F(2x2,3x3) kernel it replaced (kept as the fallback) -- and the column sums of its waves are added through LDS: a three-level network
+    Winograd kernel -- the hybrid F(2,3)y x F(4,3)x kernel of round 3 (persistent form for Cin = 64 with its 64-output and, round 4, its
+    32-output workgroup tile; one-tile form for Cin = 32) and the F(2x2,3x3) kernel it replaced (kept as the fallback) -- and the column sums of its waves are added through LDS: a three-level network
     run with the kernel forced on at a small batch (the switches are read once per process, hence the worker), with and without the
     fusion.  Both runs match the float64 oracle, the fused one launches fewer GroupNorm passes, and the two agree with each other."""
     import os
@@ -156,7 +162,8 @@ def test_epilogue_groupnorm_16x16_level(native_lib, tmp_path, kernel):
     res = {}
     for tag, extra in (("egn", {}), ("noegn", {"GDDIM_NO_EGN": "1"})):
         out = str(tmp_path / (tag + ".npz"))
-        force = {"GDDIM_WINO42_MINBLOCKS": "1"} if kernel == "wino42" else {"GDDIM_NOWINO42": "1", "GDDIM_WINO2_MINBLOCKS": "1"}
+        force = {"wino42": {"GDDIM_WINO42_MINBLOCKS": "1", "GDDIM_WINO42_NW": "2"}, "wino42_n32": {"GDDIM_WINO42_MINBLOCKS": "1", "GDDIM_WINO42_NW": "1"},
+                 "wino2d": {"GDDIM_NOWINO42": "1", "GDDIM_WINO2_MINBLOCKS": "1"}}[kernel]
         env = dict(os.environ, **force, **extra)
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "egn_worker.py"), out], cwd=ROOT, env=env, capture_output=True,
                            text=True, timeout=900)
