@@ -216,6 +216,22 @@ def test_cld_64x64_b512_full_size_absolute_parity(native_lib):
     model.close()  # 35 GB of arena
 
 
+def test_cld_64x64_b512_nfe20_absolute_parity(native_lib):
+    """BASELINE config 5 at its stated size on a SECOND schedule: 64x64x3, B = 512, full accr U-Net, NFE = 20 (19 AB steps + denoising:
+    other step sizes, other DEIS rows, twice the error-growth horizon of the NFE 10 check above), hipGraph, through get_sampling_fn; image 0
+    against the float64 oracle loop.  (NFE 20 / 50 / 100 at this size existed as bench lines only.)"""
+    from gddim_amd.configs import cld_accr_dcifar10
+    B, n_ref, nfe, gain = 512, 1, 20, 0.3
+    cfg, osde, eps64, lin64, u_ref, x, v, n, model = _cld_case(native_lib, cld_accr_dcifar10, 64, B, n_ref, nfe, gain, seed=5)
+    assert n == nfe and np.isfinite(x).all() and np.isfinite(v).all()
+    wx, wv, _ = ocld.deis_sampler(osde, eps64, u_ref, nfe, 2, ts_order=2, denoising=True, inverse_scaler=ocld.inverse_scaler_centered)
+    lx, _, _ = ocld.deis_sampler(osde, lin64, u_ref, nfe, 2, ts_order=2, denoising=True, inverse_scaler=ocld.inverse_scaler_centered)
+    ex, ev, moved = _report("CLD 64x64 NFE=20 B=512", x, v, wx, wv, lx, n_ref)
+    assert moved > 20 * ABS_TOL
+    assert ex <= ABS_TOL and ev <= ABS_TOL * max(1.0, float(np.abs(wv).max()))
+    model.close()  # 35 GB of arena
+
+
 def test_hybdeis_absolute_parity(native_lib):
     """`hybdeis` (cld_jax/sampling.py:255-269) through get_sampling_fn against the oracle's restatement of its two-phase grid,
     on a small network, bounded trajectory."""
