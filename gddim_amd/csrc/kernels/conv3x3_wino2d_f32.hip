@@ -722,7 +722,7 @@ int conv3x3_wino2d_splitk_factor(const GemmParams &p) {
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
     }
     for (int ks = 8; ks >= 2; ks >>= 1) {
-        if (tiles * ks > cus) continue;  // at most one workgroup per CU
+        if (opts().wino2_ks ? ks != opts().wino2_ks : tiles * ks > cus) continue;  // at most one workgroup per CU (GDDIM_WINO2_KS forces a factor: A/B)
         GemmParams q = p;
         q.wk_split = ks;
         q.wk_partial = reinterpret_cast<float *>(16);  // (only tested for null)

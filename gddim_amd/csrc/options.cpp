@@ -30,6 +30,7 @@ const Entry kEntries[] = {
     {"GDDIM_NOWINO2", &Options::no_wino2, nullptr},
     {"GDDIM_NOWINO42", &Options::no_wino42, nullptr},
     {"GDDIM_NOWINO2_SPLITK", &Options::no_wino2_splitk, nullptr},
+    {"GDDIM_WINO2_KS", &Options::wino2_ks, nullptr},
     {"GDDIM_WINO2_MINBLOCKS", &Options::wino2_min_blocks, nullptr},
     {"GDDIM_WINO42_MINBLOCKS", &Options::wino42_min_blocks, nullptr},
     {"GDDIM_WINO42_GRID", &Options::wino42_grid, nullptr},
