@@ -1,10 +1,12 @@
 #!/bin/bash
-# Round-3 evidence, run on the GPU box (via gpurun) from the repo root.  rocprofv3 kernel-trace statistics of the default bench
+# Per-round evidence, run on the GPU box (via gpurun) from the repo root:  bash tools/collect_profiles.sh 4   (-> gpurun_out/prof4).  rocprofv3 kernel-trace statistics of the default bench
 # command, separate PMC passes (never combined with trace domains other than --kernel-trace), and warmed bench lines (+ rocprofv3
-# statistics) of BASELINE configs 3 and 5.  Summaries land under gpurun_out/prof3; tools/update_profiles.py r02 copies them.
+# statistics) of BASELINE configs 3 and 5, the batch-size curve and the full-size parity log.  Summaries land under gpurun_out/prof<N>;
+# `python tools/update_profiles.py r0<N>` copies them to profiles/.
 set -u
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$REPO/gpurun_out/prof3
+ROUND=${1:-4}
+OUT=$REPO/gpurun_out/prof$ROUND
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 PY="python $REPO/bench.py"
@@ -47,4 +49,7 @@ stats config5_nfe10 --image-size 64 --batch 512 --nfe 10 --steps 1 --warmup 1 --
 for g in none step loop; do
     $PY --batch 16 --nfe 10 --steps 20 --warmup 3 --graph $g --no-alt --no-cpu-baseline --no-profile 2>/dev/null | tail -1 > $OUT/small_b16_nfe10_graph_$g.json
 done
+# ---- the batch-size curve (per-level kernels) and the full-size parity checks with their printed errors
+python $REPO/tools/batch_sweep.py --out $OUT/batch_sweep.json > $OUT/batch_sweep.log 2>&1
+(cd $REPO && python -m pytest tests/test_gpu_parity_abs.py -m gpu -q -s 2>&1 | grep -a -E "max\|dx\||passed|failed|share of the flops" > $OUT/parity_abs_tests.log)
 find $OUT -type f -size +3M -delete 2>/dev/null; du -sh $OUT; ls $OUT
