@@ -1189,6 +1189,9 @@ int launch_igemm(const GemmParams &p_in, int batch_z, hipStream_t s) {
     }
     p.diag = opts().igemm_diag;
     GD_CHECK(!p.egn_out || igemm_egn_ok(p, batch_z), "igemm: epilogue GroupNorm requested for a launch that cannot compute it");
+    // (the engine decides these fusions once per batch size on the launch that covers the first image; a later image sub-range, or an
+    // option table re-read in between, must not silently land on a kernel that ignores them: the stand-alone pass has been skipped)
+    GD_CHECK(!p.gn_side_out || igemm_gn_side_ok(p, batch_z), "igemm: GroupNorm side output requested for a launch that cannot write it");
     fill_div((unsigned)(p.OH * p.OW), p.mg_ohw, p.sh_ohw);
     fill_div((unsigned)p.OW, p.mg_ow, p.sh_ow);
     fill_div((unsigned)(p.rows_per_image > 0 ? p.rows_per_image : 1), p.mg_rpi, p.sh_rpi);

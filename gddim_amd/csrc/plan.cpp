@@ -780,6 +780,22 @@ int Plan::build(const gd_model_desc &d) {
 
     mark_split();
     link_epilogue_gn();
+    // The engine computes the time-embedding ops (Op::temb) on ONE row when the whole batch carries one label and lets every image read
+    // that row with stride 0 (engine.cpp: fill_gemm).  That is only right while the tensors those ops produce are read as per-image bias
+    // rows or by other time-embedding ops, and while every per-image bias row comes from them: rows 1.. of such a tensor are stale.
+    {
+        std::vector<char> from_temb(tensors.size(), 0);
+        for (const Op &o : ops)
+            if (o.temb && o.out.t >= 0) from_temb[o.out.t] = 1;
+        for (const Op &o : ops) {
+            GD_CHECK(o.rowbias.t < 0 || from_temb[o.rowbias.t], "internal: %s reads a per-image bias row that no time-embedding op produces",
+                     o.label.c_str());
+            if (o.temb) continue;
+            for (const TRef *r : {&o.a0, &o.a1, &o.bten, &o.res})
+                GD_CHECK(r->t < 0 || !from_temb[r->t], "internal: %s reads a time-embedding tensor as an operand (only its first row is "
+                         "computed when the batch shares one label)", o.label.c_str());
+        }
+    }
     flops_per_image = conv3x3_flops_per_image = 0;
     for (const Op &o : ops) {
         flops_per_image += o.flops_per_image;

@@ -258,3 +258,30 @@ def test_no_live_tensors_alias_including_early_epilogue_writes(native_lib, which
         # 4.51 M floats per image in round 2 (every early-written block fresh), 2.79 M before the epilogue GroupNorm existed, 3.70 M with
         # recycled early blocks
         assert plan["arena_per_image"] < 3.8e6, plan["arena_per_image"]
+
+
+@pytest.mark.parametrize("switch", ["GDDIM_NO_ATTN_FOLD", "GDDIM_NO_UPSWAP"])
+def test_written_forms_behind_the_lowering_switches_match_oracle(native_lib, gd_env, switch):
+    """The planner's two algebraic rewrites -- attention blocks with two of their four projections folded away (Plan::attn), up-sampling
+    blocks multiplying their 1x1 shortcut before the FIR (Plan::resblock) -- have the written forms behind switches that are read per
+    plan (csrc/options.h; ADVICE r3: they used to be latched in function-local statics on the first plan of the process, and nothing ran
+    them).  Both forms of both rewrites, built in ONE process, executed by the float64 plan interpreter on the engine's packed weights,
+    against the oracle's literal blocks; the switch changes the program (op counts) and not the function."""
+    from gddim_amd.engine import Engine
+    cfg = tiny_config("cld", nf=16, num_res_blocks=2, image_size=16, ch_mult=(1, 2, 2), attn=(8,))
+    counts = {}
+    for on in (False, True):
+        gd_env(**{switch: "1" if on else None})
+        eng = Engine(cfg, 6, max_batch=1, plan_only=True)
+        plan = eng.plan()
+        eng.close()
+        assert plan["options"][switch] == (1 if on else 0)
+        labels = [op["label"] for op in plan["ops"]]
+        counts[on] = {"ops": len(labels), "q_proj": sum(l.endswith(".q_proj") for l in labels), "qk_proj": sum(l.endswith(".qk_proj") for l in labels),
+                      "proj": sum(l.startswith("AttnBlockpp") and l.endswith(".proj") for l in labels)}
+        got, want = _run(cfg, 6, B=2, seed=11)
+        err = (got - want).abs().max().item()
+        assert torch.isfinite(got).all() and err < 2e-5 * max(1.0, want.abs().max().item()), (switch, on, err)
+    if switch == "GDDIM_NO_ATTN_FOLD":
+        assert counts[False]["q_proj"] > 0 and counts[False]["proj"] == 0 and counts[True]["qk_proj"] == counts[False]["q_proj"] and counts[True]["proj"] > 0
+    assert counts[True]["ops"] != counts[False]["ops"] or switch == "GDDIM_NO_UPSWAP"
