@@ -203,3 +203,46 @@ def test_unet_agrees_across_batch_sizes(native_lib):
         err = np.abs(out[:n] - ref[:n]).max() / scale
         assert np.isfinite(out).all() and err < 2e-5, (B, err)
     eng.close()
+
+
+def test_3x3_levels_stay_on_the_hybrid_kernel_across_batch_sizes(native_lib, gd_env):
+    """at the reference's own per-device batch (eval.batch_size / 8 = 128, cld_jax/run_lib.py:721) the 8x8 level has 128
+    wide workgroup tiles and used to fall off the hybrid Winograd kernel onto the direct one (105 instead of ~300 TFLOP/s algorithmic), the
+    16x16 level likewise below B = 64.  With the 32-output tile the 3x3 stride-1 convolutions of the 32x32 .. 8x8 levels run the hybrid kernel
+    at EVERY batch size -- the narrow tile where the wide one would leave CUs idle, the wide one at the production batch -- and the 4x4 level
+    its channel-split F(2x2,3x3) launch.  Kernel per level from the engine's profile ("label class|kernel" keys)."""
+    import re
+    from gddim_amd.configs import cld_accr_dcifar10
+    from gddim_amd.engine import Engine
+    gd_env(GD_PROF_BY_LABEL="2")
+    cfg = cld_accr_dcifar10.get_config()
+    params = onet.random_params(cfg, 6, seed=3)
+    eng = Engine(cfg, 6, max_batch=256, device=0)
+    eng.load_params(params)
+    rng = np.random.default_rng(6)
+    x = torch.as_tensor(rng.standard_normal((256, 32, 32, 6)).astype(np.float32), device="cuda:0")
+    lab = torch.full((256,), 500.0, device="cuda:0")
+    want = {16: {32: "n32", 16: "n32", 8: "n32"}, 64: {32: "wide", 16: "wide", 8: "n32"}, 128: {32: "wide", 16: "wide", 8: "n32"},
+            256: {32: "wide", 16: "wide", 8: "wide"}}
+    for B, levels in want.items():
+        eng.profile(True)
+        eng.unet(x[:B], lab[:B])
+        prof = eng.profile_read()
+        eng.profile(False)
+        seen = {}
+        for p in prof:
+            # label classes have their digits removed: Conv_0 / Conv_1 (3x3) and the 1x1 shortcut Conv_2 of a residual block all read
+            # "ResnetBlockBigGANpp_.conv@HxW:Cin>Cout"; the 3x3 ones are those on a conv3x3_* kernel -- or, if the dispatch regressed, the
+            # launches missing from the per-level counts below (SURVEY A.3: 36 / 38 / 38 / 40 at 32x32 / 16x16 / 8x8 / 4x4)
+            m = re.match(r"ResnetBlockBigGANpp_\.conv@(\d+)x\d+:\d+>\d+\|(conv3x3_\w+)", p["name"])
+            if m:
+                d = seen.setdefault(int(m.group(1)), {})
+                d[m.group(2)] = d.get(m.group(2), 0) + p["launches"]
+        counts = {32: 36, 16: 38, 8: 38, 4: 40}
+        for H, tile in levels.items():
+            kern = "conv3x3_wino42_n32_f32_kernel" if tile == "n32" else "conv3x3_wino42_f32_kernel"
+            got = seen.get(H, {})
+            assert all(k.startswith("conv3x3_wino42") for k in got) and sum(got.values()) == counts[H], (B, H, got)
+            assert max(got, key=got.get) == kern, (B, H, got)
+        assert seen.get(4) == {"conv3x3_wino2d_splitk_f32_kernel": counts[4]}, (B, seen.get(4))
+    eng.close()
