@@ -184,7 +184,7 @@ int launch_softmax_rows(float *x, long long rows, int cols, hipStream_t s);
 // none), qstats (null: none) = the fused GroupNorm statistics of out, 8 slices per image (kernels/qstats.h);
 // GDDIM_NO_FUSED_ATTN=1 keeps the three-launch path
 bool attn_fused_ok(int N, int C);
-const char *attn_fused_name();
+const char *attn_fused_name(int batch);
 int launch_attn_fused(const float *q, int ld_q, const float *k, int ld_k, const float *vT, const float *bias, const float *res, int ld_res,
                       float out_scale, float *qstats, float *out, int ld_o, int batch, int N, int C, hipStream_t s);
 int launch_swish(const float *x, float *out, long long n, hipStream_t s);

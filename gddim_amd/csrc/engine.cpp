@@ -492,7 +492,7 @@ static int run_op(gd_engine *e, int op_index, const Bind &b, int batch, hipStrea
             if (op.temb && b.labels == nullptr) return run_gemm(e, op_index, b, batch, 0, 1, true, s);  // one label: one row (see fill_gemm)
             if (attn_core_at(e, op_index)) {  // q k^T, softmax and p v in one launch; the next two ops return at once
                 const Op &av = P.ops[op_index + 2];
-                ProfScope ps(e, s, pkey(e, op, std::string(attn_fused_name())),
+                ProfScope ps(e, s, pkey(e, op, std::string(attn_fused_name(batch))),
                              (op.flops_per_image + av.flops_per_image) * batch, 4.0 * batch * (av.res.t >= 0 ? 5.0 : 4.0) * op.N * op.C0);  // q, k, v^T, out (, residual) once each
                 return launch_attn_fused(tptr(e, b, op.a0, batch), op.lda0, tptr(e, b, op.bten, batch), op.ldb, tptr(e, b, av.bten, batch),
                                          av.bias_slot >= 0 ? slot_ptr(e, av.bias_slot) + av.bias_off : nullptr, tptr(e, b, av.res, batch), av.ldres,

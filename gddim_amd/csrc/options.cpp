@@ -24,6 +24,7 @@ const Entry kEntries[] = {
     {"GDDIM_NO_EGN", &Options::no_egn, nullptr},
     {"GDDIM_NO_SIDE_GN", &Options::no_side_gn, nullptr},
     {"GDDIM_NO_FUSED_ATTN", &Options::no_fused_attn, nullptr},
+    {"GDDIM_ATTN_Q", &Options::attn_q, nullptr},
     {"GDDIM_NO_ATTN_FOLD", &Options::no_attn_fold, nullptr},
     {"GDDIM_NO_UPSWAP", &Options::no_upswap, nullptr},
     {"GDDIM_NOWINO", &Options::no_wino, nullptr},

@@ -16,6 +16,7 @@ struct Options {
     int no_egn = 0;             // GDDIM_NO_EGN: no GroupNorm in the producer's epilogue
     int no_side_gn = 0;         // GDDIM_NO_SIDE_GN: no GroupNorm as a side output of the shortcut convolution's loader
     int no_fused_attn = 0;      // GDDIM_NO_FUSED_ATTN: attention core as three launches
+    int attn_q = 0;             // GDDIM_ATTN_Q: 0 the launcher's choice, 32 / 64 force the fused attention kernel's query block (A/B)
     // ---- lowering (Plan::build) ----
     int no_attn_fold = 0;       // GDDIM_NO_ATTN_FOLD: attention blocks keep their four projections
     int no_upswap = 0;          // GDDIM_NO_UPSWAP: up-sampling blocks multiply their 1x1 shortcut after the FIR

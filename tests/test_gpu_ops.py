@@ -437,12 +437,15 @@ def test_naive_resample_matches_oracle(dev, up):
         assert np.array_equal(got, np.repeat(np.repeat(x, 2, axis=1), 2, axis=2))  # exact: pure replication
 
 
-def test_attention_fused_matches_float64(dev):
+@pytest.mark.parametrize("qblock", [64, 32])
+def test_attention_fused_matches_float64(dev, qblock, gd_env):
     """gd_attention_fused (q k^T -> softmax -> p v in one launch, N = C = 256, operands in the engine's layout: q|k packed, v transposed per
     image, value bias in the epilogue) against float64 and against the three-launch path; scores of very different magnitude per row
-    (the row maximum matters), other sizes refused."""
+    (the row maximum matters), other sizes refused.  qblock: the 64-query form (one workgroup per CU) and the 32-query form (two per CU,
+    round 4: what the launcher takes when 4 B workgroups cannot fill the chip)."""
     from gddim_amd import ops
     from gddim_amd._abi import GddimError
+    gd_env(GDDIM_ATTN_Q=qblock)
     B, N, C = 3, 256, 256
     g = torch.Generator().manual_seed(7)
     q = torch.randn(B, N, C, generator=g) * torch.linspace(0.2, 6.0, N).view(1, N, 1)  # rows with flat and with peaked distributions
@@ -462,11 +465,13 @@ def test_attention_fused_matches_float64(dev):
         ops.attention_fused(torch.zeros(1, 64, 512, device=dev), torch.zeros(1, 256, 64, device=dev))
 
 
-def test_attention_block_fused_epilogue(dev):
+@pytest.mark.parametrize("qblock", [64, 32])
+def test_attention_block_fused_epilogue(dev, qblock, gd_env):
     """gd_attention_block_fused: the fused core with separate q / k tensors and the block tail in its epilogue -- bias, residual,
     1/sqrt(2) and the GroupNorm quad statistics of the result (kernels/qstats.h layout) -- against float64; a batch that is not a
-    multiple of the 8 images one XCD round holds."""
+    multiple of the 8 images one XCD round holds.  Both query blocks; the two forms agree bit for bit (same k order in every row)."""
     from gddim_amd import ops
+    gd_env(GDDIM_ATTN_Q=qblock)
     B, N, C = 11, 256, 256
     g = torch.Generator().manual_seed(11)
     q = torch.randn(B, N, C, generator=g) * 1.5
@@ -487,3 +492,6 @@ def test_attention_block_fused_epilogue(dev):
     assert err < 2e-5 and es < 2e-3 and eq < 1e-5
     plain = ops.attention_block_fused(q.to(dev), k.to(dev), v.transpose(1, 2).contiguous().to(dev))  # no bias, residual, statistics
     assert (plain.cpu().double() - torch.einsum("bij,bjc->bic", w, v.double())).abs().max().item() < 2e-5
+    gd_env(GDDIM_ATTN_Q=96 - qblock)
+    other, qs2 = ops.attention_block_fused(q.to(dev), k.to(dev), v.transpose(1, 2).contiguous().to(dev), bias.to(dev), res.to(dev), sc, want_stats=True)
+    assert torch.equal(other, out) and torch.equal(qs2, qs)
