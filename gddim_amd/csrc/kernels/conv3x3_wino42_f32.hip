@@ -533,17 +533,8 @@ constexpr int W4P_SMEM = W4P_RED + 512;                 // 149 504 bytes
 // component-row waves of ONE output block, 32 tiles x 32 outputs, for launches that would leave CUs idle with the larger tile (small
 // batches, the 8x8 level at the reference's per-device batch of 128): twice the workgroups, and every thread stages TWO tiles' patch rows
 // (slots u = 0, 1: tiles tl and tl + 16) -- one wave per SIMD may hold 512 registers, so the second register set costs nothing here.
-// RAW (NW = 2 only; round 4): the tile's PIXEL REGION is loaded once per chunk -- not once per overlapping 4 x 6 patch
-// -- by LDS-DMA (buffer_load_dwordx4 ... lds: no registers held while the request is in flight) into a raw LDS stage, two chunks ahead and
-// at the HEAD of an iteration; every thread then reads the six pixels of its patch row from that stage right before it transforms them.
-// The 24 pixel registers of the plain form live for five gaps instead of a chunk, a request has 22-24 gaps to land instead of 13-18, and
-// L2 -> L1 carries every pixel of the region once per N tile instead of 2.25 times.  LDS: V stage 0 | V stage 1 | two raw stages; the
-// epilogue's exchange area shrinks to V stage 1 by exchanging the z values in two passes (b = 0, 1 then b = 2, 3).
-// Region of an M tile (32 consecutive tiles = RT tile rows of one image, or NI whole images): per part (2 RT + 2) rows x (W + 2) pixels of
-// 64 B, row stride W + 3 pixels (16-byte slots of the four patch rows a ds_read_b128 lane group reads then differ: 12 mod 16 per row).
-template <int NW, bool RAW = false>
-__device__ __forceinline__ void wino42_persistent(const GemmParams &p, float *smem, float *raw0 = nullptr, float *raw1 = nullptr) {
-    static_assert(!RAW || NW == 2, "the raw-stage form exists for the 64-output tile");
+template <int NW>
+__device__ __forceinline__ void wino42_persistent(const GemmParams &p, float *smem) {
     constexpr int S = 2 / NW;  // staging slots per thread
     constexpr int OOB = (int)0x80000000u;
 
@@ -618,47 +609,10 @@ __device__ __forceinline__ void wino42_persistent(const GemmParams &p, float *sm
     // ---- staging role: (tile tl, channel quad chq, patch row r), see wino42_tile; NW = 1: slot u stages tile tl + 16 u ----
     const int tl = tid >> 4, chq = (tid >> 2) & 3, sr = tid & 3;
     const float sb = sr == 1 ? 1.f : -1.f;
-    // ---- RAW: geometry of an M tile's pixel region (the same for every M tile), this wave's DMA slots, this thread's read offset ----
-    const int HT = H >> 1;                                 // tile rows per image
-    const int NI = TI >= 32 ? 1 : 32 / TI;                 // image parts of an M tile
-    const int RT = TI >= 32 ? 32 >> wts : HT;              // tile rows per part
-    const int NR = 2 * RT + 2, NC = W + 2;                 // region rows / pixels per row
-    const int RSf = (W + 3) * 16, PSf = NR * RSf;          // row / part stride in floats (16 channels per pixel)
-    const int G = (NC + 15) >> 4;                          // 16-pixel groups per region row: one DMA instruction (1 KB) each
-    const int NS = NI * NR * G;                            // DMA instructions per chunk (30 .. 40): wave w issues slots w, w + 8, ..
-    int sl_lds[5], sl_geo[5];                              // per slot (wave-uniform): LDS float offset of its 1 KB; part << 16 | region row << 8 | column group
-    unsigned dmask = 0;                                    // bit i: this lane takes part in slot i (the slot exists and the lane's pixel is inside the row)
-    int dpx[5], dvo[5];                                    // this lane's pixel index (-1: nothing to load) / byte offset in the current source
-    __amdgpu_buffer_rsrc_t d_srd = srd_a0;                 // descriptor and first channel of the source the load side stands in
-    int d_cbase = 0;
-    if (RAW) {
-#pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const int sidx = wave + 8 * i;
-            const int part = sidx / (NR * G), rem = sidx - part * (NR * G);
-            const int rr_ = rem / G, cg = rem - rr_ * G;
-            sl_geo[i] = (part << 16) | (rr_ << 8) | cg;
-            sl_lds[i] = part * PSf + rr_ * RSf + cg * 256;
-            if (sidx < NS && cg * 16 + (lane >> 2) < NC) dmask |= 1u << i;
-            dpx[i] = -1; dvo[i] = OOB;
-        }
-    }
-    int roff = 0;  // float offset of pixel 0 of this thread's patch row (channel quad chq) in a raw stage
-    if (RAW) {
-        const int tpp = 32 / NI;                           // tiles per part
-        const int part = tl / tpp, tr = tl - part * tpp;
-        const int tyr = tr >> wts, txr = tr - (tyr << wts);
-        roff = part * PSf + (2 * tyr + sr) * RSf + (4 * txr) * 16 + chq * 4;
-    }
     int pix[S];
     unsigned bad[S];
     int vo[S][6];
     auto set_vo = [&](int lda, int biasb) __attribute__((always_inline)) {
-        if (RAW) {  // byte offsets of this lane's DMA pixels in the source the next chunk comes from (set_vo(lda1, ..) = the second source)
-#pragma unroll
-            for (int i = 0; i < 5; ++i) dvo[i] = dpx[i] < 0 ? OOB : dpx[i] * lda * 4 + biasb + (lane & 3) * 16;
-            return;
-        }
 #pragma unroll
         for (int u = 0; u < S; ++u)
 #pragma unroll
@@ -670,19 +624,6 @@ __device__ __forceinline__ void wino42_persistent(const GemmParams &p, float *sm
     };
     // pixel-loading state -> M tile mt (mt < 0: no tile, every load out of bounds)
     auto setup_pix = [&](int mt) __attribute__((always_inline)) {
-        if (RAW) {
-            const int t0 = mt * 32;
-            const int img0 = mt >= 0 ? (int)epi_div((unsigned)t0, (unsigned)TI, p.mg_ohw, p.sh_ohw) : 0;
-            const int ty0 = NI > 1 ? 0 : (t0 - img0 * TI) >> wts;
-#pragma unroll
-            for (int i = 0; i < 5; ++i) {
-                const int img = img0 + (sl_geo[i] >> 16), y = 2 * ty0 + ((sl_geo[i] >> 8) & 255) - 1, x = (sl_geo[i] & 255) * 16 + (lane >> 2) - 1;
-                const bool ok = mt >= 0 && ((dmask >> i) & 1u) && img < a_imgs && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
-                dpx[i] = ok ? (img * H + y) * W + x : -1;
-            }
-            d_srd = srd_a0; d_cbase = 0; set_vo(p.lda0, bias0);
-            return;
-        }
 #pragma unroll
         for (int u = 0; u < S; ++u) {
             pix[u] = 0;
@@ -709,15 +650,13 @@ __device__ __forceinline__ void wino42_persistent(const GemmParams &p, float *sm
     bool s_first = true;
     auto px_advance = [&]() __attribute__((always_inline)) {
         s_c += 16;
-        if (RAW) s_c = __builtin_amdgcn_readfirstlane(s_c);  // (the raw-stage form: the compiler's uniformity analysis loses this counter otherwise,
-                                                              // and every branch on it, hence the DMA descriptor, becomes per-lane: waterfall loops)
         if (s_c >= Cin) {  // the tile has no channels left: on to the next tile of this workgroup (or to nothing)
             s_c = 0;
             s_first = true;
             setup_pix(nx_vb < nvb ? nx_mt : -1);
         } else if (s_first && s_c >= p.C0 && p.C1 > 0) {  // on to the second source of a channel concat
             s_first = false;
-            if (RAW) { d_srd = srd_a1; d_cbase = p.C0; } set_vo(p.lda1, bias1);
+            set_vo(p.lda1, bias1);
         }
     };
 
@@ -737,24 +676,6 @@ __device__ __forceinline__ void wino42_persistent(const GemmParams &p, float *sm
         else dst[k] = w4_load16<W42_PX_AUX>(srd_a1, vo[u][k], (s_c - p.C0) * 4);
     };
     auto load_raw = [&](int k, int u) __attribute__((always_inline)) { load_raw_to(rr[u], k, u); };
-    // RAW: DMA slot i of the chunk the load side stands at -> raw stage `dst` (1 KB per instruction: 16 pixels x 64 B; lanes past the region's
-    // last pixel are masked: their bytes would be the next row's); and the thread's six pixels out of a landed stage
-    auto dma_slot = [&](int i, float *dst) __attribute__((always_inline)) {
-        if ((W42_ABL & 1) && steady) return;
-        // (ONE call on the descriptor of the current source, d_srd: with a call per source the compiler sinks the two into one whose
-        // descriptor is a per-lane select, and wraps it in a waterfall loop.  Lanes past the row's last pixel, and slots past the region,
-        // stay out: their bytes would be another row's)
-        __attribute__((address_space(3))) void *l = (__attribute__((address_space(3))) void *)(dst + sl_lds[i]);
-        const bool on = (dmask >> i) & 1u;
-        const int so = __builtin_amdgcn_readfirstlane((s_c - d_cbase) * 4);  // (an SGPR by construction: no waterfall on the scalar offset)
-        const int f0 = __builtin_amdgcn_readfirstlane(d_cbase == 0 ? 1 : 0);  // (likewise the choice of source)
-        const __amdgpu_buffer_rsrc_t d = f0 ? srd_a0 : srd_a1;
-        if (on) __builtin_amdgcn_raw_ptr_buffer_load_lds(d, l, 16, dvo[i], so, 0, W42_PX_AUX);
-    };
-    auto read_raw_to = [&](w4f32x4 *dst, const float *src) __attribute__((always_inline)) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) dst[k] = *reinterpret_cast<const w4f32x4 *>(src + roff + k * 16);
-    };
     auto combine_in = [&](w4f32x4 *x) __attribute__((always_inline)) {
         if (W42_ABL & 16) return;
 #pragma unroll
@@ -821,29 +742,7 @@ __device__ __forceinline__ void wino42_persistent(const GemmParams &p, float *sm
     // ---- prologue (first tile of the workgroup only) ----
     setup_pix(cur_mt);
     setup_u(cur_nt);
-    if (RAW) {
-        // chunk 0 -> raw stage 0, chunk 1 -> raw stage 1 (chunk c of every tile lives in stage c & 1: NK is even); the barrier publishes
-        // them (the compiler waits for a wave's own LDS-DMA in front of it); chunk 0 -> V stage 0
-#pragma unroll
-        for (int j = 0; j < 6; ++j) { load_u(j, 0); load_u(j, 1); }
-        u_advance();
-#pragma unroll
-        for (int i = 0; i < 5; ++i) dma_slot(i, raw0);
-        px_advance();
-#pragma unroll
-        for (int i = 0; i < 5; ++i) dma_slot(i, raw1);
-        px_advance();
-        __syncthreads();
-        w4f32x4 r0[6];
-        read_raw_to(r0, raw0);
-        combine_in(r0);
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            xform(r0, h, 0);
-#pragma unroll
-            for (int j = 0; j < 6; ++j) store_v(j, 0, h, 0);
-        }
-    } else {
+    {
         w4f32x4 r0[S][6];
 #pragma unroll
         for (int j = 0; j < 6; ++j) { load_u(j, 0); load_u(j, 1); }
@@ -946,14 +845,6 @@ __device__ __forceinline__ void wino42_persistent(const GemmParams &p, float *sm
                         if (gap >= 6 && gap <= 8) { store_v(2 * (gap - 6), nxt, 1, S - 1); store_v(2 * (gap - 6) + 1, nxt, 1, S - 1); }
                         if (gap >= 6 && gap <= 11) load_raw(gap - 6, S - 1);
                     }
-                    if (RAW) {  // the head of the iteration requests the chunk two ahead (raw stage PAR: its pixels were consumed an iteration ago)
-                        float *rnxt = PAR ? raw1 : raw0;
-                        if (gap == 0) { dma_slot(0, rnxt); dma_slot(1, rnxt); }
-                        if (gap == 1) { dma_slot(2, rnxt); dma_slot(3, rnxt); }
-                        if (gap == 2) dma_slot(4, rnxt);
-                        if (gap == 3) px_advance();
-                        if (gap == 5) read_raw_to(rr[0], PAR ? raw0 : raw1);  // the next chunk's pixels, landed before the last barrier
-                    }
                     if (gap == 6) combine_in(rr[0]);
                     if (gap == 7) xform(rr[0], 0, 0);
                     if (gap >= 8 && gap <= 10) { store_v(2 * (gap - 8), nxt, 0, 0); store_v(2 * (gap - 8) + 1, nxt, 0, 0); }
@@ -963,10 +854,8 @@ __device__ __forceinline__ void wino42_persistent(const GemmParams &p, float *sm
                     if (gap >= 12 + W42_LATE && gap <= 17 + W42_LATE) load_raw(gap - 12 - W42_LATE, 0);
                     if (gap == 18 + W42_LATE) px_advance();
 #else
-                    if (!RAW) {
-                        if (gap >= 12 && gap <= 17) load_raw(gap - 12, 0);
-                        if (gap == 18) px_advance();
-                    }
+                    if (gap >= 12 && gap <= 17) load_raw(gap - 12, 0);
+                    if (gap == 18) px_advance();
 #endif
                     if (LAST && has_res && gap < 16) { load_res(2 * gap); load_res(2 * gap + 1); }
                     __builtin_amdgcn_sched_barrier(0);
@@ -1002,118 +891,65 @@ __device__ __forceinline__ void wino42_persistent(const GemmParams &p, float *sm
         // the four component-row waves of an output block through LDS: wave i keeps the z of its own unit (v >> 2 == i) and writes the
         // three other units' to its 48-register slab ----
         float zo[4][4];  // [b][vv]: own unit
-        float y[2][4][4];  // [a][b][vv]: output pixel (2 ty + a, 4 tx + b) of tile 4 lh + vv of the unit
-        if (RAW) {
-            // the same exchange in TWO passes over the output columns (b = 0, 1 then b = 2, 3): 24 instead of 48 values per wave in flight,
-            // so the area fits V stage 1 (the raw stages hold the successor's pixels, stage 0 its first transformed chunk)
-            constexpr int EXW = 24 * 64;
-            float *mine = smem + W4P_EXB + (wn * 4 + wi) * EXW + lane;
-            const float *slab = smem + W4P_EXB + (wn * 4) * EXW + lane;
-            auto pass = [&](auto f_tag, auto ph_tag) __attribute__((always_inline)) {
-                constexpr int F = decltype(f_tag)::value;    // == wi == f
-                constexpr int PH = decltype(ph_tag)::value;  // columns b = 2 PH, 2 PH + 1
+        {
+            float *mine = smem + W4P_EXB + (wn * 4 + wi) * W4P_EXW + lane;
+            auto emit = [&](auto f_tag) __attribute__((always_inline)) {
+                constexpr int F = decltype(f_tag)::value;  // == wi
 #pragma unroll
                 for (int v = 0; v < 16; ++v) {
                     const float m0 = acc[0][v], m1 = acc[1][v], m2 = acc[2][v], m3 = acc[3][v], m4 = acc[4][v], m5 = acc[5][v];
                     const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
-                    const float za = PH == 0 ? (m0 + s1) + s2 : s1 + 4.f * s2;           // z[2 PH]
-                    const float zb = PH == 0 ? d1 + 2.f * d2 : (d1 + 8.f * d2) + m5;     // z[2 PH + 1]
+                    const float z0 = (m0 + s1) + s2, z1 = d1 + 2.f * d2, z2 = s1 + 4.f * s2, z3 = (d1 + 8.f * d2) + m5;
                     const int fu = v >> 2, vv = v & 3;
                     if (fu == F) {
-                        zo[2 * PH][vv] = za; zo[2 * PH + 1][vv] = zb;
+                        zo[0][vv] = z0; zo[1][vv] = z1; zo[2][vv] = z2; zo[3][vv] = z3;
                     } else {
-                        const int r = fu < F ? fu : fu - 1;
-                        mine[((0 * 3 + r) * 4 + vv) * 64] = za;
-                        mine[((1 * 3 + r) * 4 + vv) * 64] = zb;
+                        const int r = fu < F ? fu : fu - 1;  // rank of unit fu among the three foreign ones
+                        mine[((0 * 3 + r) * 4 + vv) * 64] = z0;
+                        mine[((1 * 3 + r) * 4 + vv) * 64] = z1;
+                        mine[((2 * 3 + r) * 4 + vv) * 64] = z2;
+                        mine[((3 * 3 + r) * 4 + vv) * 64] = z3;
                     }
                 }
-                __syncthreads();
+            };
+            if (wi == 0) emit(std::integral_constant<int, 0>{});
+            else if (wi == 1) emit(std::integral_constant<int, 1>{});
+            else if (wi == 2) emit(std::integral_constant<int, 2>{});
+            else emit(std::integral_constant<int, 3>{});
+        }
+        __syncthreads();
+#ifdef W42_TRACE
+        trace();
+#endif
+        float y[2][4][4];  // [a][b][vv]: output pixel (2 ty + a, 4 tx + b) of tile 4 lh + vv of the unit
+        {
+            // component row k of my unit: from wave k's slab at rank (f < k ? f : f - 1), or my own registers (k == f)
+            const float *slab = smem + W4P_EXB + (wn * 4) * W4P_EXW + lane;
+            auto gather = [&](auto f_tag) __attribute__((always_inline)) {
+                constexpr int F = decltype(f_tag)::value;  // == f == wi
 #pragma unroll
-                for (int bb = 0; bb < 2; ++bb)
+                for (int b = 0; b < 4; ++b)
 #pragma unroll
                     for (int vv = 0; vv < 4; ++vv) {
                         float z[4];
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
-                            if (k == F) z[k] = zo[2 * PH + bb][vv];
+                            if (k == F) z[k] = zo[b][vv];
                             else {
                                 const int r = F < k ? F : F - 1;
-                                z[k] = slab[k * EXW + ((bb * 3 + r) * 4 + vv) * 64];
+                                z[k] = slab[k * W4P_EXW + ((b * 3 + r) * 4 + vv) * 64];
                             }
                         }
-                        y[0][2 * PH + bb][vv] = z[0] + z[1] + z[2];
-                        y[1][2 * PH + bb][vv] = z[1] - z[2] - z[3];
+                        y[0][b][vv] = z[0] + z[1] + z[2];
+                        y[1][b][vv] = z[1] - z[2] - z[3];
                     }
-                __syncthreads();  // (pass 1 rewrites the slabs; after pass 1: the successor's first chunk writes stage 1)
             };
-            auto both = [&](auto f_tag) __attribute__((always_inline)) {
-                pass(f_tag, std::integral_constant<int, 0>{});
-                pass(f_tag, std::integral_constant<int, 1>{});
-            };
-            if (wi == 0) both(std::integral_constant<int, 0>{});
-            else if (wi == 1) both(std::integral_constant<int, 1>{});
-            else if (wi == 2) both(std::integral_constant<int, 2>{});
-            else both(std::integral_constant<int, 3>{});
-        } else {
-            {
-                float *mine = smem + W4P_EXB + (wn * 4 + wi) * W4P_EXW + lane;
-                auto emit = [&](auto f_tag) __attribute__((always_inline)) {
-                    constexpr int F = decltype(f_tag)::value;  // == wi
-#pragma unroll
-                    for (int v = 0; v < 16; ++v) {
-                        const float m0 = acc[0][v], m1 = acc[1][v], m2 = acc[2][v], m3 = acc[3][v], m4 = acc[4][v], m5 = acc[5][v];
-                        const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
-                        const float z0 = (m0 + s1) + s2, z1 = d1 + 2.f * d2, z2 = s1 + 4.f * s2, z3 = (d1 + 8.f * d2) + m5;
-                        const int fu = v >> 2, vv = v & 3;
-                        if (fu == F) {
-                            zo[0][vv] = z0; zo[1][vv] = z1; zo[2][vv] = z2; zo[3][vv] = z3;
-                        } else {
-                            const int r = fu < F ? fu : fu - 1;  // rank of unit fu among the three foreign ones
-                            mine[((0 * 3 + r) * 4 + vv) * 64] = z0;
-                            mine[((1 * 3 + r) * 4 + vv) * 64] = z1;
-                            mine[((2 * 3 + r) * 4 + vv) * 64] = z2;
-                            mine[((3 * 3 + r) * 4 + vv) * 64] = z3;
-                        }
-                    }
-                };
-                if (wi == 0) emit(std::integral_constant<int, 0>{});
-                else if (wi == 1) emit(std::integral_constant<int, 1>{});
-                else if (wi == 2) emit(std::integral_constant<int, 2>{});
-                else emit(std::integral_constant<int, 3>{});
-            }
-            __syncthreads();
-#ifdef W42_TRACE
-            trace();
-#endif
-            {
-                // component row k of my unit: from wave k's slab at rank (f < k ? f : f - 1), or my own registers (k == f)
-                const float *slab = smem + W4P_EXB + (wn * 4) * W4P_EXW + lane;
-                auto gather = [&](auto f_tag) __attribute__((always_inline)) {
-                    constexpr int F = decltype(f_tag)::value;  // == f == wi
-#pragma unroll
-                    for (int b = 0; b < 4; ++b)
-#pragma unroll
-                        for (int vv = 0; vv < 4; ++vv) {
-                            float z[4];
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) {
-                                if (k == F) z[k] = zo[b][vv];
-                                else {
-                                    const int r = F < k ? F : F - 1;
-                                    z[k] = slab[k * W4P_EXW + ((b * 3 + r) * 4 + vv) * 64];
-                                }
-                            }
-                            y[0][b][vv] = z[0] + z[1] + z[2];
-                            y[1][b][vv] = z[1] - z[2] - z[3];
-                        }
-                };
-                if (wi == 0) gather(std::integral_constant<int, 0>{});
-                else if (wi == 1) gather(std::integral_constant<int, 1>{});
-                else if (wi == 2) gather(std::integral_constant<int, 2>{});
-                else gather(std::integral_constant<int, 3>{});
-            }
-            __syncthreads();  // (the successor's first chunk writes stage 1, which the exchange area covers)
+            if (wi == 0) gather(std::integral_constant<int, 0>{});
+            else if (wi == 1) gather(std::integral_constant<int, 1>{});
+            else if (wi == 2) gather(std::integral_constant<int, 2>{});
+            else gather(std::integral_constant<int, 3>{});
         }
+        __syncthreads();  // (the successor's first chunk writes stage 1, which the exchange area covers)
 #ifdef W42_TRACE
         trace();
 #endif
@@ -1149,7 +985,7 @@ __device__ __forceinline__ void wino42_persistent(const GemmParams &p, float *sm
                 gsum += __shfl_xor(gsum, 32); gsq += __shfl_xor(gsq, 32);
                 float rows = 64.0f;
                 if (p.rows_per_image == 256) {
-                    float2 *red = reinterpret_cast<float2 *>(smem + (RAW ? 2 * W4_STAGE : W4P_RED));  // [wn][unit][32 columns]
+                    float2 *red = reinterpret_cast<float2 *>(smem + W4P_RED);  // [wn][unit][32 columns]
                     if (lh == 0) red[(wn * 4 + f) * 32 + li] = make_float2(gsum, gsq);
                     __syncthreads();
                     gsum = 0.f; gsq = 0.f;
@@ -1216,15 +1052,6 @@ __device__ __forceinline__ void wino42_persistent(const GemmParams &p, float *sm
 __global__ __launch_bounds__(512, 2) void conv3x3_wino42_f32_kernel(const GemmParams p) {
     __shared__ __attribute__((aligned(16))) float smem[W4P_SMEM];
     wino42_persistent<2>(p, smem);
-}
-
-// ... the 64-output tile with the pixel region staged once per chunk through raw LDS stages (LDS-DMA): see wino42_persistent<NW, RAW>
-constexpr int W4R_RAW = 7040;  // floats per raw stage: the largest region (W = 8: four parts of 10 rows x 11 pixels x 16 channels)
-__global__ __launch_bounds__(512, 2) void conv3x3_wino42_raw_f32_kernel(const GemmParams p) {
-    __shared__ __attribute__((aligned(16))) float smem[2 * W4_STAGE + 512];
-    __shared__ __attribute__((aligned(16))) float raw0[W4R_RAW];
-    __shared__ __attribute__((aligned(16))) float raw1[W4R_RAW];
-    wino42_persistent<2, true>(p, smem, raw0, raw1);
 }
 
 // ... 32 tiles x 32 outputs, four waves (one per SIMD, up to 512 registers each): the tile of launches the 64-output tile cannot fill the chip with
@@ -1326,21 +1153,11 @@ static int wino42_nw(const GemmParams &p) {
 // what the engine sends to it: an eligible shape (GDDIM_NOWINO42=1 routes everything back to the F(2x2,3x3) kernel)
 bool conv3x3_wino42_ok(const GemmParams &p) { return wino42_nw(p) != 0; }
 
-// the raw-stage form takes M tiles that are whole tile rows of one image or whole images (power-of-two geometries: the U-Net's)
-static bool wino42_raw_ok(const GemmParams &p) {
-    if (!opts().wino42_raw || p.C0 + p.C1 < 64) return false;
-    const int TI = p.H * p.W / 8, Wt = p.W / 4;
-    if (!(TI % 32 == 0 || 32 % TI == 0) || 32 % Wt != 0) return false;
-    const int NI = TI >= 32 ? 1 : 32 / TI, RT = TI >= 32 ? 32 / Wt : p.H / 2;
-    const int NR = 2 * RT + 2, G = (p.W + 2 + 15) / 16;
-    return NI * NR * (p.W + 3) * 16 <= W4R_RAW && NI * NR * G <= 40;
-}
-
 const char *conv3x3_wino42_name() { return "conv3x3_wino42_f32_kernel"; }
 // the kernel symbol launch_conv3x3_wino42 would pick for this problem (as rocprofv3 prints it)
 const char *conv3x3_wino42_name_for(const GemmParams &p) {
     if (p.C0 + p.C1 == 32) return "conv3x3_wino42_k32_f32_kernel";
-    return wino42_nw(p) == 1 ? "conv3x3_wino42_n32_f32_kernel" : wino42_raw_ok(p) ? "conv3x3_wino42_raw_f32_kernel" : "conv3x3_wino42_f32_kernel";
+    return wino42_nw(p) == 1 ? "conv3x3_wino42_n32_f32_kernel" : "conv3x3_wino42_f32_kernel";
 }
 
 int launch_conv3x3_wino42(const GemmParams &p_in, hipStream_t s) {
@@ -1371,7 +1188,6 @@ int launch_conv3x3_wino42(const GemmParams &p_in, hipStream_t s) {
             if (g > 0 && g < grid) grid = g;
         }
         if (nw == 1) hipLaunchKernelGGL(conv3x3_wino42_n32_f32_kernel, dim3(grid), dim3(256), 0, s, p);
-        else if (wino42_raw_ok(p)) hipLaunchKernelGGL(conv3x3_wino42_raw_f32_kernel, dim3(grid), dim3(512), 0, s, p);
         else hipLaunchKernelGGL(conv3x3_wino42_f32_kernel, dim3(grid), dim3(512), 0, s, p);
     }
     GD_HIP(hipGetLastError());

@@ -36,7 +36,6 @@ const Entry kEntries[] = {
     {"GDDIM_WINO42_MINBLOCKS", &Options::wino42_min_blocks, nullptr},
     {"GDDIM_WINO42_GRID", &Options::wino42_grid, nullptr},
     {"GDDIM_WINO42_NW", &Options::wino42_nw, nullptr},
-    {"GDDIM_WINO42_RAW", &Options::wino42_raw, nullptr},
     {"GDDIM_IGEMM_VARIANT", &Options::igemm_variant, nullptr},
     {"GDDIM_IGEMM_BIGMIN", nullptr, &Options::igemm_bigmin},
     {"GDDIM_IGEMM_MIDMIN", nullptr, &Options::igemm_midmin},

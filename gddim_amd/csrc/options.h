@@ -29,7 +29,6 @@ struct Options {
     int wino2_min_blocks = 256; // GDDIM_WINO2_MINBLOCKS: workgroup tiles a launch must have for the F(2x2,3x3) kernel
     int wino42_min_blocks = 256;  // GDDIM_WINO42_MINBLOCKS: ... for the hybrid kernel
     int wino42_grid = 0;        // GDDIM_WINO42_GRID: persistent workgroups per launch (tests: several tiles per workgroup)
-    int wino42_raw = 0;         // GDDIM_WINO42_RAW: the 64-output tile with its pixel region staged through raw LDS stages by LDS-DMA (A/B)
     int wino42_nw = 0;          // GDDIM_WINO42_NW: 0 the launcher's choice, 1 / 2 force the 32- / 64-output workgroup tile
     // ---- fp32 implicit GEMM ----
     int igemm_variant = 0;      // GDDIM_IGEMM_VARIANT: 0 128x128 / 8 waves, 1 128x128 / 4 waves, 2 256x128
