@@ -58,8 +58,7 @@ typedef unsigned int w4u32x2 __attribute__((ext_vector_type(2)));
 #define W42_ABL 0  // timing ablations (results wrong): 1 no pixel loads in the K loop, 2 no LDS stores, 4 no weight-fragment loads in the K loop,
                    // 8 no barrier, 16 no transform arithmetic, 64 (persistent form) every pixel load from one L1-resident line: the instruction
                    // count stays, the L2 / HBM traffic and latency go, 256 (persistent form) half of them, 128 (persistent form) the pixel
-                   // addresses of a channel-blocked activation layout [C/16][pixel][16]: whole 128-byte lines per request, the same bytes from HBM,
-                   // 512 (persistent form) no epilogue after the exchange's writes (gather, bias / residual, stores, statistics)
+                   // addresses of a channel-blocked activation layout [C/16][pixel][16]: whole 128-byte lines per request, the same bytes from HBM
 #endif
 
 constexpr int W4_LD = 388;               // LDS row stride (floats): 24 components x 16 channels + 4 pad = 97 16-byte units (odd)
@@ -534,9 +533,8 @@ constexpr int W4P_SMEM = W4P_RED + 512;                 // 149 504 bytes
 // component-row waves of ONE output block, 32 tiles x 32 outputs, for launches that would leave CUs idle with the larger tile (small
 // batches, the 8x8 level at the reference's per-device batch of 128): twice the workgroups, and every thread stages TWO tiles' patch rows
 // (slots u = 0, 1: tiles tl and tl + 16) -- one wave per SIMD may hold 512 registers, so the second register set costs nothing here.
-template <int NW, bool DEFER>
+template <int NW>
 __device__ __forceinline__ void wino42_persistent(const GemmParams &p, float *smem) {
-    static_assert(!DEFER || NW == 2, "the deferred epilogue tail belongs to the eight-wave tile");
     constexpr int S = 2 / NW;  // staging slots per thread
     constexpr int OOB = (int)0x80000000u;
 
@@ -591,7 +589,7 @@ __device__ __forceinline__ void wino42_persistent(const GemmParams &p, float *sm
     cur_vb = next_valid((int)blockIdx.x, cur_mt, cur_nt);
     if (cur_vb >= nvb) return;
 #ifdef W42_TRACE  // in-kernel timeline (tools/wino42_trace.py): thread 0 of workgroups 0 and 100 stamps the 100 MHz wall clock and the shader
-                  // clock at five points of its first four tiles into the tail of the residual tensor
+                  // clock at six (-DW42_TRACE=2: eight) points of its first tiles into the tail of the residual tensor
     int trn = 0;
     const int trslot = blockIdx.x == 0 ? 0 : blockIdx.x == 100 ? 1 : -1;
     float *trbuf = const_cast<float *>(p.res) + (size_t)p.M * p.ldres - 128 + (trslot < 0 ? 0 : trslot) * 64;
@@ -773,7 +771,6 @@ __device__ __forceinline__ void wino42_persistent(const GemmParams &p, float *sm
     __syncthreads();
 
     // ---- epilogue geometry of the CURRENT tile (set before its last chunk, which requests the residual) ----
-    const bool has_res = p.res != nullptr;
     const int f = wi;
     int tu = 0, img = 0, mu = 0, n = 0, lane_px = 0, vo_r = OOB;
     bool nok = false;
@@ -789,108 +786,27 @@ __device__ __forceinline__ void wino42_persistent(const GemmParams &p, float *sm
         n = cur_nt * (32 * NW) + wn * 32 + li;
         nok = n < p.N && tu < T;
         lane_px = Wt >= 8 ? lh * 16 : Wt == 4 ? lh * 2 * W : lh * 4 * W;
-        vo_r = (nok && has_res && !(W42_ABL & 4096)) ? (lane_px * p.ldres + n) * 4 : OOB;  // (no residual: the loads still issue, out of bounds -- as a branch
-                                                                      // around them the compiler carries the 32 old values through the K loop)
+        vo_r = nok ? (lane_px * p.ldres + n) * 4 : OOB;
     };
     auto pix_off = [&](int vv, int a, int b) __attribute__((always_inline)) {
         const int base = Wt == 2 ? (vv >> 1) * 2 * W + (vv & 1) * 4 : vv * 4;
         return mu + base + a * W + b;
     };
     float rs[2][4][4];
+    const bool has_res = p.res != nullptr;
     auto load_res = [&](int idx) __attribute__((always_inline)) {  // idx = (a * 4 + b) * 4 + vv
         const int a = idx >> 4, b = (idx >> 2) & 3, vv = idx & 3;
-        if (W42_ABL & 32768) {  // timing ablation: the same bytes by a quarter of the instructions (16 bytes per lane, wrong addresses)
-            if (vv == 0) {
-                const w4u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(srd_r, nok ? vo_r + li * 12 : OOB, pix_off(0, a, b) * p.ldres * 4, 0);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) rs[a][b][e] = __builtin_bit_cast(float, t[e]);
-            }
-            return;
-        }
         rs[a][b][vv] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_r, vo_r, pix_off(vv, a, b) * p.ldres * 4, 0));
-    };
-
-    // ---- the DEFERRED TAIL of a tile's epilogue (NW = 2, tiles with a successor in this workgroup, no epilogue GroupNorm): after the x
-    // transform and the exchange's writes the accumulators are free, and what is left of the epilogue -- the y transform out of the exchange
-    // area, bias / residual / scale, the stores and the quad statistics: 6.5 % of the kernel's time when it runs on its own
-    // (profiles/r04_notes.md) -- runs under the MFMAs of the successor's FIRST chunk, whose gaps 0-7 have no staging work and whose
-    // accumulators 2-5 are not live yet: two (b, vv) pairs per gap, a barrier in gap 8 before the chunk's first V stores (stage 1 lies under
-    // the exchange area), the statistics in gap 9.  The geometry of the finished tile stays in place until the successor's last chunk. ----
-    float zo[4][4];  // [b][vv]: own unit's x-transformed values (set by the epilogue's first phase)
-    float t_add = 0.f, t_ps[2] = {0.f, 0.f}, t_pq[2] = {0.f, 0.f};
-    bool t_live = false;  // a finished tile's tail is pending (its statistics are still to be emitted)
-    int t_vo = OOB;
-    const float *t_base = smem + W4P_EXB + (wn * 4) * W4P_EXW + lane;
-    int t_off[4];  // (wave-uniform: wave k's slab at my rank among its three foreign units; k == wi: never used, any valid address)
-#pragma unroll
-    for (int k = 0; k < 4; ++k) t_off[k] = k * W4P_EXW + (wi < k ? wi : (wi > 0 ? wi - 1 : 0)) * 256;
-    unsigned t_own[4];  // all ones for k == wi (the unit's own component row comes from zo, not from a slab)
-#pragma unroll
-    for (int k = 0; k < 4; ++k) t_own[k] = wi == k ? 0xFFFFFFFFu : 0u;
-    const __amdgpu_buffer_rsrc_t srd_o =
-        __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(p.out), 0, p.M * p.ldc * 4, 0x00020000);
-    auto tail_begin = [&]() __attribute__((always_inline)) {
-        t_vo = (nok && !(W42_ABL & 16384)) ? (lane_px * p.ldc + n) * 4 : OOB;
-        t_add = (p.bias && nok && !(W42_ABL & 8192)) ? p.bias[n] : 0.f;
-        if (p.rowbias && nok && !(W42_ABL & 8192)) t_add += p.rowbias[(size_t)img * p.ld_rowbias + n];
-        t_ps[0] = t_ps[1] = t_pq[0] = t_pq[1] = 0.f;
-    };
-    auto tail_piece = [&](int q) __attribute__((always_inline)) {  // output column b = q >> 2 of tile 4 lh + (q & 3) of the unit, both rows
-        if (W42_ABL & 2048) return;
-        const int b = q >> 2, vv = q & 3;
-        float z[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {  // (a bit select on a wave-uniform mask: as a conditional the compiler branches around every load)
-            const unsigned ld = __builtin_bit_cast(unsigned, t_base[t_off[k] + (b * 12 + vv) * 64]);
-            const unsigned own = __builtin_bit_cast(unsigned, zo[b][vv]);
-            z[k] = __builtin_bit_cast(float, (ld & ~t_own[k]) | (own & t_own[k]));
-        }
-        const float y2[2] = {z[0] + z[1] + z[2], z[1] - z[2] - z[3]};
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            float add = t_add;
-            if (has_res) add += rs[a][b][vv];
-            const float val = (p.alpha * y2[a] + add) * p.out_scale;
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), srd_o, t_vo, pix_off(vv, a, b) * p.ldc * 4, 0);
-            t_ps[a] += val;
-            t_pq[a] += val * val;
-        }
-    };
-    // the GroupNorm quad statistics of the unit from its two row sums (both epilogue paths)
-    auto emit_qstats = [&](const float *ps, const float *pq) __attribute__((always_inline)) {
-        float s0, q0, s1, q1;
-        if (Wt >= 8) {
-            s0 = ps[0] + __shfl_xor(ps[0], 32); q0 = pq[0] + __shfl_xor(pq[0], 32);
-            s1 = ps[1] + __shfl_xor(ps[1], 32); q1 = pq[1] + __shfl_xor(pq[1], 32);
-        } else {
-            const float ts = ps[0] + ps[1], tq = pq[0] + pq[1];
-            const float os = __shfl_xor(ts, 32), oq = __shfl_xor(tq, 32);
-            s0 = lh == 0 ? ts : os; q0 = lh == 0 ? tq : oq;
-            s1 = lh == 0 ? os : ts; q1 = lh == 0 ? oq : tq;
-        }
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            float s = g == 0 ? s0 : s1, q = g == 0 ? q0 : q1;
-            if (!nok) { s = 0.f; q = 0.f; }
-            s += __shfl_xor(s, 1); q += __shfl_xor(q, 1);
-            s += __shfl_xor(s, 2); q += __shfl_xor(q, 2);
-            if ((li & 3) == 0 && lh == 0 && nok) {
-                const int first = (mu - img * HW) + (Wt >= 8 ? g * W : g * 32);
-                float2 *o = reinterpret_cast<float2 *>(p.qstats) + ((size_t)img * p.qs_slices + (first >> 5)) * (p.N >> 2) + (n >> 2);
-                o[0] = make_float2(s, q);
-            }
-        }
     };
 
     // ---- one 16-channel chunk: 48 MFMAs per wave between barriers, in 24 gaps of two.  Every chunk stages the chunk after it (registers
     // -> the other LDS stage), requests the pixels two chunks ahead and the weight fragments one chunk ahead -- of this tile or of the next.
     // FIRST: the tile's first chunk (accumulators start from the constant 0); LAST: its last one (the residual tile is requested) ----
     w4f32x4 af[2][2];
-    auto chunk = [&](auto par_tag, auto first_tag, auto last_tag, auto tail_tag) __attribute__((always_inline)) {
+    auto chunk = [&](auto par_tag, auto first_tag, auto last_tag) __attribute__((always_inline)) {
         constexpr int PAR = decltype(par_tag)::value;
         constexpr bool FIRST = decltype(first_tag)::value != 0;
         constexpr bool LAST = decltype(last_tag)::value != 0;
-        constexpr bool TAIL = decltype(tail_tag)::value != 0;  // (FIRST chunks only: the predecessor's deferred epilogue tail rides along)
         const float *cur = smem + PAR * W4_STAGE;
         constexpr int nxt = PAR ^ 1;
         af[0][0] = *reinterpret_cast<const w4f32x4 *>(cur + a_off);
@@ -902,19 +818,13 @@ __device__ __forceinline__ void wino42_persistent(const GemmParams &p, float *sm
                 const int grp = jp * 2 + g, buf = grp & 1;
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
-                    float a0 = af[buf][0][jj], a1 = af[buf][1][jj];
-                    if (TAIL && grp * 4 + jj >= 1 && grp * 4 + jj <= 9) {
-                        // (the MFMAs are pure to the compiler: without a dependency on something that sits behind the previous gap's tail
-                        // pieces its instruction selection issues the chunk's first dozen up front and the pieces after them, un-overlapped)
-                        asm volatile("" : "+v"(a0), "+v"(a1));
-                    }
                     if (FIRST && g == 0 && jj == 0) {
                         const w4f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                        acc[2 * jp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bf[2 * jp][g][jj], zero, 0, 0, 0);
-                        acc[2 * jp + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bf[2 * jp + 1][g][jj], zero, 0, 0, 0);
+                        acc[2 * jp] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[buf][0][jj], bf[2 * jp][g][jj], zero, 0, 0, 0);
+                        acc[2 * jp + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[buf][1][jj], bf[2 * jp + 1][g][jj], zero, 0, 0, 0);
                     } else {
-                        acc[2 * jp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bf[2 * jp][g][jj], acc[2 * jp], 0, 0, 0);
-                        acc[2 * jp + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bf[2 * jp + 1][g][jj], acc[2 * jp + 1], 0, 0, 0);
+                        acc[2 * jp] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[buf][0][jj], bf[2 * jp][g][jj], acc[2 * jp], 0, 0, 0);
+                        acc[2 * jp + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[buf][1][jj], bf[2 * jp + 1][g][jj], acc[2 * jp + 1], 0, 0, 0);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     const int gap = grp * 4 + jj;
@@ -935,12 +845,6 @@ __device__ __forceinline__ void wino42_persistent(const GemmParams &p, float *sm
                         if (gap >= 6 && gap <= 8) { store_v(2 * (gap - 6), nxt, 1, S - 1); store_v(2 * (gap - 6) + 1, nxt, 1, S - 1); }
                         if (gap >= 6 && gap <= 11) load_raw(gap - 6, S - 1);
                     }
-                    if (TAIL) {
-                        if (gap < 8) { tail_piece(2 * gap); tail_piece(2 * gap + 1); }
-                        if (gap == 8) __syncthreads();  // every wave has read its slabs: the V stores below may overwrite the exchange area
-                        if (gap == 9 && p.qstats && t_live) emit_qstats(t_ps, t_pq);
-                        if (gap == 9) t_live = false;
-                    }
                     if (gap == 6) combine_in(rr[0]);
                     if (gap == 7) xform(rr[0], 0, 0);
                     if (gap >= 8 && gap <= 10) { store_v(2 * (gap - 8), nxt, 0, 0); store_v(2 * (gap - 8) + 1, nxt, 0, 0); }
@@ -953,7 +857,7 @@ __device__ __forceinline__ void wino42_persistent(const GemmParams &p, float *sm
                     if (gap >= 12 && gap <= 17) load_raw(gap - 12, 0);
                     if (gap == 18) px_advance();
 #endif
-                    if (!DEFER && LAST && gap < 16) { load_res(2 * gap); load_res(2 * gap + 1); }  // (DEFER: during the x transform)
+                    if (LAST && has_res && gap < 16) { load_res(2 * gap); load_res(2 * gap + 1); }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -970,19 +874,18 @@ __device__ __forceinline__ void wino42_persistent(const GemmParams &p, float *sm
 #ifdef W42_TRACE
         trace();
 #endif
-        if constexpr (DEFER) chunk(I0{}, I1{}, I0{}, I1{});  // (a workgroup's first tile: a tail of masked stores, t_vo = OOB)
-        else chunk(I0{}, I1{}, I0{}, I0{});
+        chunk(I0{}, I1{}, I0{});
 #ifdef W42_TRACE
-        trace();  // (after the tile's first chunk: six stamps per tile in the form that finishes its epilogue, four in the deferred one)
+        trace();  // (after the tile's first chunk: six stamps per tile, eight with -DW42_TRACE=2)
 #endif
-        chunk(I1{}, I0{}, I0{}, I0{});
+        chunk(I1{}, I0{}, I0{});
         for (int kc = 2; kc < NK - 2; kc += 2) {
-            chunk(I0{}, I0{}, I0{}, I0{});
-            chunk(I1{}, I0{}, I0{}, I0{});
+            chunk(I0{}, I0{}, I0{});
+            chunk(I1{}, I0{}, I0{});
         }
-        chunk(I0{}, I0{}, I0{}, I0{});
+        chunk(I0{}, I0{}, I0{});
         set_geometry();
-        chunk(I1{}, I0{}, I1{}, I0{});
+        chunk(I1{}, I0{}, I1{});
 #ifdef W42_TRACE
         trace();
 #endif
@@ -990,6 +893,7 @@ __device__ __forceinline__ void wino42_persistent(const GemmParams &p, float *sm
         // ---- output transform along x (in-lane): z[b][v] = sum_j Ax^T[b][j] M_ij for tile 4 lh + (v & 3) + 8 (v >> 2); then along y across
         // the four component-row waves of an output block through LDS: wave i keeps the z of its own unit (v >> 2 == i) and writes the
         // three other units' to its 48-register slab ----
+        float zo[4][4];  // [b][vv]: own unit
         {
             float *mine = smem + W4P_EXB + (wn * 4 + wi) * W4P_EXW + lane;
             auto emit = [&](auto f_tag) __attribute__((always_inline)) {
@@ -1000,12 +904,6 @@ __device__ __forceinline__ void wino42_persistent(const GemmParams &p, float *sm
                     const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
                     const float z0 = (m0 + s1) + s2, z1 = d1 + 2.f * d2, z2 = s1 + 4.f * s2, z3 = (d1 + 8.f * d2) + m5;
                     const int fu = v >> 2, vv = v & 3;
-                    if (DEFER && v == 8) {  // the residual tile, into registers the accumulators have just left: wanted from the
-                                                       // successor's first gaps on (requesting it during the last chunk, as the other form
-                                                       // does, holds 32 registers where the loop has none to give)
-#pragma unroll
-                        for (int idx = 0; idx < 32; ++idx) load_res(idx);
-                    }
                     if (fu == F) {
                         zo[0][vv] = z0; zo[1][vv] = z1; zo[2][vv] = z2; zo[3][vv] = z3;
                     } else {
@@ -1026,16 +924,8 @@ __device__ __forceinline__ void wino42_persistent(const GemmParams &p, float *sm
 #ifdef W42_TRACE
         trace();
 #endif
-        if constexpr (DEFER) {  // the rest rides under the successor's first chunk, or runs after the loop
-            tail_begin();
-            t_live = true;
-            if (nx_vb >= nvb) break;
-            cur_vb = nx_vb; cur_mt = nx_mt; cur_nt = nx_nt;
-            nx_vb = next_valid(cur_vb + (int)gridDim.x, nx_mt, nx_nt);
-            continue;
-        }
         float y[2][4][4];  // [a][b][vv]: output pixel (2 ty + a, 4 tx + b) of tile 4 lh + vv of the unit
-        if (!(W42_ABL & 512)) {
+        {
             // component row k of my unit: from wave k's slab at rank (f < k ? f : f - 1), or my own registers (k == f)
             const float *slab = smem + W4P_EXB + (wn * 4) * W4P_EXW + lane;
             auto gather = [&](auto f_tag) __attribute__((always_inline)) {
@@ -1067,15 +957,22 @@ __device__ __forceinline__ void wino42_persistent(const GemmParams &p, float *sm
         trace();
 #endif
 
-        if ((W42_ABL & 512) && has_res) {  // (the residual tile's loads stay)
-#pragma unroll
-            for (int i = 0; i < 32; ++i) asm volatile("" ::"v"(rs[i >> 4][(i >> 2) & 3][i & 3]));
-        }
         // ---- epilogue of the unit ----
-        if (tu < T && !(W42_ABL & 512)) {
-            const int vo_o = (nok && !(W42_ABL & 16384)) ? (lane_px * p.ldc + n) * 4 : OOB;
+        if (tu < T) {
+            const __amdgpu_buffer_rsrc_t srd_o =
+                __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(p.out), 0, p.M * p.ldc * 4, 0x00020000);
+            const int vo_o = nok ? (lane_px * p.ldc + n) * 4 : OOB;
+#if defined(W42_TRACE) && W42_TRACE >= 2  // fine mode: what the epilogue waits for (everything in flight; then the bias)
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            trace();
+#endif
             float addv = (p.bias && nok) ? p.bias[n] : 0.f;
             if (p.rowbias && nok) addv += p.rowbias[(size_t)img * p.ld_rowbias + n];
+#if defined(W42_TRACE) && W42_TRACE >= 2
+            asm volatile("" ::"v"(addv));
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            trace();
+#endif
             float ps[2] = {0.f, 0.f}, pq[2] = {0.f, 0.f};
             float vals[2][4][4];
 #pragma unroll
@@ -1088,12 +985,7 @@ __device__ __forceinline__ void wino42_persistent(const GemmParams &p, float *sm
                         if (has_res) add += rs[a][b][vv];
                         const float val = (p.alpha * y[a][b][vv] + add) * p.out_scale;
                         vals[a][b][vv] = val;
-                        if ((W42_ABL & 32768) && vv == 3) {
-                            const w4u32x4 t = {__builtin_bit_cast(unsigned, vals[a][b][0]), __builtin_bit_cast(unsigned, vals[a][b][1]),
-                                               __builtin_bit_cast(unsigned, vals[a][b][2]), __builtin_bit_cast(unsigned, val)};
-                            __builtin_amdgcn_raw_buffer_store_b128(t, srd_o, nok ? vo_o + li * 12 : OOB, pix_off(0, a, b) * p.ldc * 4, 0);
-                        }
-                        if (!p.egn_skip_raw && !(W42_ABL & 32768))
+                        if (!p.egn_skip_raw)
                             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), srd_o, vo_o, pix_off(vv, a, b) * p.ldc * 4, 0);
                         ps[a] += val;
                         pq[a] += val * val;
@@ -1135,7 +1027,30 @@ __device__ __forceinline__ void wino42_persistent(const GemmParams &p, float *sm
                             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, t), srd_g, vo_o, pix_off(vv, a, b) * p.ldc * 4, 0);
                         }
             }
-            if (p.qstats) emit_qstats(ps, pq);
+            if (p.qstats) {
+                float s0, q0, s1, q1;
+                if (Wt >= 8) {
+                    s0 = ps[0] + __shfl_xor(ps[0], 32); q0 = pq[0] + __shfl_xor(pq[0], 32);
+                    s1 = ps[1] + __shfl_xor(ps[1], 32); q1 = pq[1] + __shfl_xor(pq[1], 32);
+                } else {
+                    const float ts = ps[0] + ps[1], tq = pq[0] + pq[1];
+                    const float os = __shfl_xor(ts, 32), oq = __shfl_xor(tq, 32);
+                    s0 = lh == 0 ? ts : os; q0 = lh == 0 ? tq : oq;
+                    s1 = lh == 0 ? os : ts; q1 = lh == 0 ? oq : tq;
+                }
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    float s = g == 0 ? s0 : s1, q = g == 0 ? q0 : q1;
+                    if (!nok) { s = 0.f; q = 0.f; }
+                    s += __shfl_xor(s, 1); q += __shfl_xor(q, 1);
+                    s += __shfl_xor(s, 2); q += __shfl_xor(q, 2);
+                    if ((li & 3) == 0 && lh == 0 && nok) {
+                        const int first = (mu - img * HW) + (Wt >= 8 ? g * W : g * 32);
+                        float2 *o = reinterpret_cast<float2 *>(p.qstats) + ((size_t)img * p.qs_slices + (first >> 5)) * (p.N >> 2) + (n >> 2);
+                        o[0] = make_float2(s, q);
+                    }
+                }
+            }
         }
 #ifdef W42_TRACE
         trace();
@@ -1144,28 +1059,17 @@ __device__ __forceinline__ void wino42_persistent(const GemmParams &p, float *sm
         cur_vb = nx_vb; cur_mt = nx_mt; cur_nt = nx_nt;
         nx_vb = next_valid(cur_vb + (int)gridDim.x, nx_mt, nx_nt);
     }
-    if constexpr (DEFER) {  // the workgroup's last tile: its tail on its own
-#pragma unroll
-        for (int q = 0; q < 16; ++q) tail_piece(q);
-        if (p.qstats) emit_qstats(t_ps, t_pq);
-    }
 }
 
-// the production tile; and its form with the deferred epilogue tail (GDDIM_WINO42_DEFER=1, launches without the epilogue GroupNorm)
 __global__ __launch_bounds__(512, 2) void conv3x3_wino42_f32_kernel(const GemmParams p) {
     __shared__ __attribute__((aligned(16))) float smem[W4P_SMEM];
-    wino42_persistent<2, false>(p, smem);
-}
-
-__global__ __launch_bounds__(512, 2) void conv3x3_wino42_defer_f32_kernel(const GemmParams p) {
-    __shared__ __attribute__((aligned(16))) float smem[W4P_SMEM];
-    wino42_persistent<2, true>(p, smem);
+    wino42_persistent<2>(p, smem);
 }
 
 // ... 32 tiles x 32 outputs, four waves (one per SIMD, up to 512 registers each): the tile of launches the 64-output tile cannot fill the chip with
 __global__ __launch_bounds__(256, 1) void conv3x3_wino42_n32_f32_kernel(const GemmParams p) {
     __shared__ __attribute__((aligned(16))) float smem[W4P_SMEM];
-    wino42_persistent<1, false>(p, smem);
+    wino42_persistent<1>(p, smem);
 }
 
 __global__ __launch_bounds__(512, 2) void conv3x3_wino42_k32_f32_kernel(const GemmParams p) {
@@ -1265,8 +1169,7 @@ const char *conv3x3_wino42_name() { return "conv3x3_wino42_f32_kernel"; }
 // the kernel symbol launch_conv3x3_wino42 would pick for this problem (as rocprofv3 prints it)
 const char *conv3x3_wino42_name_for(const GemmParams &p) {
     if (p.C0 + p.C1 == 32) return "conv3x3_wino42_k32_f32_kernel";
-    if (wino42_nw(p) == 1) return "conv3x3_wino42_n32_f32_kernel";
-    return (p.egn_out || !opts().wino42_defer) ? "conv3x3_wino42_f32_kernel" : "conv3x3_wino42_defer_f32_kernel";
+    return wino42_nw(p) == 1 ? "conv3x3_wino42_n32_f32_kernel" : "conv3x3_wino42_f32_kernel";
 }
 
 int launch_conv3x3_wino42(const GemmParams &p_in, hipStream_t s) {
@@ -1297,8 +1200,7 @@ int launch_conv3x3_wino42(const GemmParams &p_in, hipStream_t s) {
             if (g > 0 && g < grid) grid = g;
         }
         if (nw == 1) hipLaunchKernelGGL(conv3x3_wino42_n32_f32_kernel, dim3(grid), dim3(256), 0, s, p);
-        else if (p.egn_out || !opts().wino42_defer) hipLaunchKernelGGL(conv3x3_wino42_f32_kernel, dim3(grid), dim3(512), 0, s, p);
-        else hipLaunchKernelGGL(conv3x3_wino42_defer_f32_kernel, dim3(grid), dim3(512), 0, s, p);
+        else hipLaunchKernelGGL(conv3x3_wino42_f32_kernel, dim3(grid), dim3(512), 0, s, p);
     }
     GD_HIP(hipGetLastError());
     return 0;

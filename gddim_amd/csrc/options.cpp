@@ -30,7 +30,6 @@ const Entry kEntries[] = {
     {"GDDIM_NOWINO", &Options::no_wino, nullptr},
     {"GDDIM_NOWINO2", &Options::no_wino2, nullptr},
     {"GDDIM_NOWINO42", &Options::no_wino42, nullptr},
-    {"GDDIM_WINO42_DEFER", &Options::wino42_defer, nullptr},
     {"GDDIM_NOWINO2_SPLITK", &Options::no_wino2_splitk, nullptr},
     {"GDDIM_WINO2_KS", &Options::wino2_ks, nullptr},
     {"GDDIM_WINO2_MINBLOCKS", &Options::wino2_min_blocks, nullptr},

@@ -24,7 +24,6 @@ struct Options {
     int no_wino = 0;            // GDDIM_NOWINO: every 3x3 convolution on the direct implicit-GEMM kernel
     int no_wino2 = 0;           // GDDIM_NOWINO2: no F(2x2,3x3) kernel (and no hybrid kernel): the same as GDDIM_NOWINO since round 4
     int no_wino42 = 0;          // GDDIM_NOWINO42: no hybrid F(2,3)y x F(4,3)x kernel
-    int wino42_defer = 0;       // GDDIM_WINO42_DEFER: launches without the epilogue GroupNorm on the form whose epilogue tail rides under the next tile's first chunk (measured slower: profiles/r04_notes.md)
     int no_wino2_splitk = 0;    // GDDIM_NOWINO2_SPLITK: 4x4 level back on the direct split-K tile
     int wino2_ks = 0;           // GDDIM_WINO2_KS: forced channel-split factor of the 4x4 level's launch (2, 4, 8)
     int wino2_min_blocks = 256; // GDDIM_WINO2_MINBLOCKS: workgroup tiles a launch must have for the F(2x2,3x3) kernel

@@ -1,18 +1,19 @@
 """In-kernel timeline of the persistent hybrid Winograd kernel: build a trace copy of the library
   python tools/build_variant.py w42trace kernels/conv3x3_wino42_f32.hip -DW42_TRACE
-and run  GDDIM_LIB=gddim_amd/libgddim_w42trace.so [GDDIM_WINO42_NODEFER=1] python tools/wino42_trace.py  on the GPU box.  Thread 0 of
+and run  GDDIM_LIB=gddim_amd/libgddim_w42trace.so python tools/wino42_trace.py  on the GPU box.  Thread 0 of
 workgroups 0 and 100 stamps the 100 MHz wall clock and the shader clock into the tail of the residual tensor: at the top of a tile, after
-its first chunk, after its K loop, after the exchange's barrier -- and, in the form that finishes a tile's epilogue before the next tile
-(GDDIM_WINO42_NODEFER=1), after the gather's barrier and after the stores were issued."""
+its first chunk, after its K loop, after the exchange's barrier,
+after the gather's barrier and after the stores were issued (-DW42_TRACE=2 and W42_TRACE_FINE=1: also after a wait for everything in flight
+at the top of the epilogue and after the bias has arrived)."""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from gddim_amd import ops
 dev = torch.device("cuda", 0)
-nodefer = os.environ.get("GDDIM_WINO42_NODEFER", "0") == "1"
-per = 6 if nodefer else 4
-names = ["first chunk", "rest of K loop", "x transform + exchange write"] + (["gather", "epilogue + stores"] if nodefer else [])
+fine = os.environ.get("W42_TRACE_FINE", "0") == "1"  # a library built with -DW42_TRACE=2
+per = 8 if fine else 6
+names = ["first chunk", "rest of K loop", "x transform + exchange write", "gather"] + (["wait for the loads in flight", "bias", "arithmetic + stores"] if fine else ["epilogue + stores"])
 for (H, Cin, Cout) in [(32, 128, 128), (32, 256, 128), (16, 256, 256), (16, 512, 256)]:
     B = 256
     x = torch.randn(B, H, H, Cin, device=dev); w = torch.randn(Cout, 9 * Cin, device=dev) / (9 * Cin) ** 0.5
