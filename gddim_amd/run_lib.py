@@ -1,6 +1,7 @@
-"""Sampling rounds and the FID report: the two evaluation entry points of the reference's run driver.
+"""Sampling rounds and the FID report: the evaluation entry points of the reference's run driver.
 
   sample_data(config, ckpt_file, result_folder, is_continue=False)   cld_jax/run_lib.py:674-731 (blur_jax/run_lib.py:300-345)
+  sampling_from_fn(config, state, sampling_fn, result_folder)        cld_jax/run_lib.py:646-671
   check_fid(config, result_folder, ...)                              cld_jax/run_lib.py:735-791
 
 Same files on disk: `samples_<r>.npz` with keys samples (uint8, clip(x*255, 0, 255) truncated), nfe_cnt, samples_v, samples_x;
@@ -44,6 +45,23 @@ def sample_data(config, ckpt_file, result_folder, is_continue=False, state=None)
         state = checkpoints.restore_checkpoint(ckpt_file, mutils.State(lr=config.optim.lr, ema_rate=config.model.ema_rate))
     if torch.cuda.is_available():
         torch.cuda.set_device(local_rank)
+    return _rounds(config, state, sampling_fn, result_folder, is_continue, rank, world)
+
+
+def sampling_from_fn(config, state, sampling_fn, result_folder):
+    """cld_jax/run_lib.py:646-671: the same rounds with a sampling function the caller built (`sampling.get_sampling_fn(...)` or
+    `get_deis_sampler(..., is_p=True)`) and a `State` already in hand; every round is (re)written."""
+    import torch
+    rank, world, local_rank = distributed.init_from_env()
+    os.makedirs(result_folder, exist_ok=True)
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local_rank)
+    return _rounds(config, state, sampling_fn, result_folder, False, rank, world)
+
+
+def _rounds(config, state, sampling_fn, result_folder, is_continue, rank, world):
+    import torch
+    num_sampling_rounds = config.eval.num_samples // config.eval.batch_size + 1
     # the reference gives every device eval.batch_size // n_dev images (cld_jax/run_lib.py:721) and silently drops the remainder;
     # here the remainder goes to the first ranks so that a round always holds eval.batch_size images
     _, per_rank = distributed.shard_batch(config.eval.batch_size, world, rank)

@@ -40,3 +40,19 @@ def test_sample_data_rounds(native_lib, tmp_path, kind):
     assert run_lib.sample_data(cfg, ckpt, res, is_continue=True) == []
     again = run_lib.sample_data(cfg, ckpt, res)
     assert np.array_equal(np.load(again[0])["samples_x"], info["samples_x"])
+    # sampling_from_fn (cld_jax/run_lib.py:646-671): the caller's own sampling function and state, the same rounds on disk
+    if kind == "cld":
+        from gddim_amd import datasets
+        from gddim_amd.cld import sampling, sde_lib
+        from gddim_amd.models import utils as mutils
+        sde = sde_lib.from_config(cfg)
+        model = mutils.get_model(cfg.model.name)(config=cfg)
+        fn = sampling.get_sampling_fn(cfg, sde, model, None, datasets.get_data_inverse_scaler(cfg))
+        state = checkpoints.restore_checkpoint(ckpt, State())
+        res2 = str(tmp_path / "res2")
+        files2 = run_lib.sampling_from_fn(cfg, state, fn, res2)
+        assert [os.path.basename(f) for f in files2] == ["samples_0.npz", "samples_1.npz"]
+        for a, b in zip(files, files2):
+            fa, fb = np.load(a), np.load(b)
+            assert set(fa.files) == set(fb.files) and all(np.array_equal(fa[k], fb[k]) for k in fa.files)
+
