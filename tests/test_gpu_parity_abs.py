@@ -18,6 +18,7 @@ NCSN++, 256 images per call, NFE 50 / 100, hipGraph replay, the production kerne
 
 The oracle side is the float64 restatement loop on the first images of the batch (images are independent units)."""
 import copy
+import os
 
 import numpy as np
 import pytest
@@ -216,17 +217,19 @@ def test_cld_64x64_b512_full_size_absolute_parity(native_lib):
     model.close()  # 35 GB of arena
 
 
-def test_cld_64x64_b512_nfe20_absolute_parity(native_lib):
+# (GDDIM_PARITY_EXTRA_NFE="50,100" adds the configuration's longer schedules: minutes of float64 oracle each; profiles/r04_parity_config5_long.log)
+@pytest.mark.parametrize("nfe", [20] + [int(v) for v in os.environ.get("GDDIM_PARITY_EXTRA_NFE", "").split(",") if v])
+def test_cld_64x64_b512_nfe20_absolute_parity(native_lib, nfe):
     """BASELINE config 5 at its stated size on a SECOND schedule: 64x64x3, B = 512, full accr U-Net, NFE = 20 (19 AB steps + denoising:
     other step sizes, other DEIS rows, twice the error-growth horizon of the NFE 10 check above), hipGraph, through get_sampling_fn; image 0
     against the float64 oracle loop.  (NFE 20 / 50 / 100 at this size existed as bench lines only.)"""
     from gddim_amd.configs import cld_accr_dcifar10
-    B, n_ref, nfe, gain = 512, 1, 20, 0.3
+    B, n_ref, gain = 512, 1, 0.3
     cfg, osde, eps64, lin64, u_ref, x, v, n, model = _cld_case(native_lib, cld_accr_dcifar10, 64, B, n_ref, nfe, gain, seed=5)
     assert n == nfe and np.isfinite(x).all() and np.isfinite(v).all()
     wx, wv, _ = ocld.deis_sampler(osde, eps64, u_ref, nfe, 2, ts_order=2, denoising=True, inverse_scaler=ocld.inverse_scaler_centered)
     lx, _, _ = ocld.deis_sampler(osde, lin64, u_ref, nfe, 2, ts_order=2, denoising=True, inverse_scaler=ocld.inverse_scaler_centered)
-    ex, ev, moved = _report("CLD 64x64 NFE=20 B=512", x, v, wx, wv, lx, n_ref)
+    ex, ev, moved = _report("CLD 64x64 NFE=%d B=512" % nfe, x, v, wx, wv, lx, n_ref)
     assert moved > 20 * ABS_TOL
     assert ex <= ABS_TOL and ev <= ABS_TOL * max(1.0, float(np.abs(wv).max()))
     model.close()  # 35 GB of arena
