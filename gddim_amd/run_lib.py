@@ -7,7 +7,8 @@
 Same files on disk: `samples_<r>.npz` with keys samples (uint8, clip(x*255, 0, 255) truncated), nfe_cnt, samples_v, samples_x;
 `statistics_<r>.npz` with pool_3, logits, nfe_cnt; `report.npz` with IS, fid, nfe.  The reference shards one round over
 `jax.local_device_count()` devices with pmap; here one process drives one GPU (launch with torchrun), every rank samples
-`eval.batch_size // world_size` images of the round and the shards meet in one all-gather (RCCL) before rank 0 writes the file.
+`eval.batch_size // world_size` images of the round and the shards meet in one all-gather (RCCL) before rank 0 writes the file --
+on writer threads behind pinned staging buffers, so that round r + 1 samples while round r is compressed (`_RoundWriter`).
 Training, logging and the rest of run_lib are out of scope."""
 import os
 
@@ -26,9 +27,10 @@ def _modules(config):
     return sampling, sde_lib
 
 
-def sample_data(config, ckpt_file, result_folder, is_continue=False, state=None):
+def sample_data(config, ckpt_file, result_folder, is_continue=False, state=None, stats=None):
     """Generate eval.num_samples // eval.batch_size + 1 rounds of eval.batch_size images.  `state` overrides the checkpoint
-    (synthetic weights); otherwise a missing `ckpt_file` raises RuntimeError like the reference."""
+    (synthetic weights); otherwise a missing `ckpt_file` raises RuntimeError like the reference.  `stats` (a dict) receives the
+    wall time, per-round device times and image count of the call (tools/run_50k.py)."""
     import torch
     from .models import utils as mutils
     rank, world, local_rank = distributed.init_from_env()
@@ -45,7 +47,10 @@ def sample_data(config, ckpt_file, result_folder, is_continue=False, state=None)
         state = checkpoints.restore_checkpoint(ckpt_file, mutils.State(lr=config.optim.lr, ema_rate=config.model.ema_rate))
     if torch.cuda.is_available():
         torch.cuda.set_device(local_rank)
-    return _rounds(config, state, sampling_fn, result_folder, is_continue, rank, world)
+    try:
+        return _rounds(config, state, sampling_fn, result_folder, is_continue, rank, world, stats)
+    finally:
+        score_model.close()  # this call built the engines (arena + weight copies in HBM); hand them back
 
 
 def sampling_from_fn(config, state, sampling_fn, result_folder):
@@ -59,7 +64,115 @@ def sampling_from_fn(config, state, sampling_fn, result_folder):
     return _rounds(config, state, sampling_fn, result_folder, False, rank, world)
 
 
-def _rounds(config, state, sampling_fn, result_folder, is_continue, rank, world):
+class _RoundWriter:
+    """Takes the host side of a round -- device-to-host copies, zlib, the file -- off the sampler's critical path (rank 0).
+
+    The reference's loop is strictly serial: sample, copy, `np.savez_compressed` (25 MB of incompressible float32 noise per 1 024
+    images: about a second of zlib), next round (cld_jax/run_lib.py:714-731).  Here a finished round is copied into one of
+    `writers + 1` pinned staging slots on a side stream while the next round's sampler call is already queued, and `writers`
+    threads (zlib releases the GIL) wait for their slot's copy event, write `samples_<r>.npz.tmp.npz` and rename it -- the same
+    bytes, keys and atomic-rename resume semantics as the serial form.  A slot is handed back when its file is on disk, so at most
+    `writers + 1` rounds are ever in flight (back-pressure instead of unbounded host memory).  writers = 0 is the serial form."""
+
+    def __init__(self, writers):
+        import queue
+        import threading
+        self.writers = int(writers)
+        self.written = {}
+        self.error = None
+        self._stream = None
+        if self.writers <= 0:
+            return
+        self._free = queue.Queue()
+        self._jobs = queue.Queue()
+        self._slots = [dict() for _ in range(self.writers + 1)]
+        for i in range(len(self._slots)):
+            self._free.put(i)
+        self._threads = [threading.Thread(target=self._work, name="gddim-round-writer-%d" % i, daemon=True) for i in range(self.writers)]
+        for t in self._threads:
+            t.start()
+
+    @staticmethod
+    def _save(f_sample, keys):
+        tmp = f_sample + ".tmp.npz"
+        np.savez_compressed(tmp, **keys)
+        os.replace(tmp, f_sample)
+
+    def _work(self):
+        while True:
+            job = self._jobs.get()
+            if job is None:
+                return
+            r, f_sample, slot, event, views, extra = job
+            try:
+                if event is not None:
+                    event.synchronize()
+                keys = {k: t.numpy().reshape(shape) for k, (t, shape) in views.items()}
+                keys.update(extra)
+                self._save(f_sample, keys)
+                self.written[r] = f_sample
+            except BaseException as e:  # surfaced by the next submit() / close() on the main thread
+                self.error = e
+            finally:
+                self._free.put(slot)
+
+    def submit(self, r, f_sample, tensors, extra):
+        """tensors: {key: (tensor, shape on disk)}; extra: {key: small host value}.  Returns once the copies are QUEUED."""
+        import torch
+        if self.error is not None:
+            raise self.error
+        if self.writers <= 0:
+            keys = {k: t.cpu().numpy().reshape(shape) for k, (t, shape) in tensors.items()}
+            keys.update(extra)
+            self._save(f_sample, keys)
+            self.written[r] = f_sample
+            return
+        slot = self._free.get()  # blocks while writers + 1 rounds are in flight
+        stage = self._slots[slot]
+        on_gpu = any(t.is_cuda for t, _ in tensors.values())
+        event = None
+        views = {}
+        if on_gpu:
+            if self._stream is None:
+                self._stream = torch.cuda.Stream()
+            self._stream.wait_stream(torch.cuda.current_stream())
+        for k, (t, shape) in tensors.items():
+            buf = stage.get(k)
+            if buf is None or buf.shape != t.shape or buf.dtype != t.dtype:
+                buf = stage[k] = torch.empty(t.shape, dtype=t.dtype, device="cpu", pin_memory=on_gpu)
+            if t.is_cuda:
+                with torch.cuda.stream(self._stream):
+                    buf.copy_(t, non_blocking=True)
+                t.record_stream(self._stream)  # the caching allocator must not hand this block out before the copy has run
+            else:
+                buf.copy_(t)
+            views[k] = (buf, shape)
+        if on_gpu:
+            event = torch.cuda.Event()
+            event.record(self._stream)
+        self._jobs.put((r, f_sample, slot, event, views, extra))
+
+    def close(self):
+        if self.writers > 0:
+            for _ in self._threads:
+                self._jobs.put(None)
+            for t in self._threads:
+                t.join()
+        if self.error is not None:
+            raise self.error
+        return [self.written[r] for r in sorted(self.written)]
+
+
+def _writer_threads(config):
+    """`config.eval.writer_threads` if the config carries it, else GDDIM_WRITER_THREADS, else 2 (0 = the reference's serial loop)."""
+    ev = config.eval
+    if 'writer_threads' in ev:
+        return int(ev.writer_threads)
+    return int(os.environ.get("GDDIM_WRITER_THREADS", "2"))
+
+
+def _rounds(config, state, sampling_fn, result_folder, is_continue, rank, world, stats=None):
+    import time
     import torch
     num_sampling_rounds = config.eval.num_samples // config.eval.batch_size + 1
     # the reference gives every device eval.batch_size // n_dev images (cld_jax/run_lib.py:721) and silently drops the remainder;
@@ -68,32 +181,52 @@ def _rounds(config, state, sampling_fn, result_folder, is_continue, rank, world)
     equal = config.eval.batch_size % world == 0
     if config.eval.batch_size < world:
         raise GddimError("eval.batch_size %d is smaller than the number of ranks %d" % (config.eval.batch_size, world))
-    written = []
-    for r in range(num_sampling_rounds):
-        f_sample = os.path.join(result_folder, "samples_%d.npz" % r)
-        if os.path.exists(f_sample) and is_continue:
-            continue
-        out = sampling_fn([distributed.rank_seed(config.seed + 1, r, rank)], state, per_rank)
-        samples_org_x, nfe_cnt = out[0], out[-1]
-        samples_v = out[1] if len(out) == 3 else None
-        x = samples_org_x.reshape((-1,) + tuple(samples_org_x.shape[2:]))
-        u8 = distributed.all_gather_samples(distributed.to_uint8(x), equal_shards=equal)
-        # the float copies the reference also stores (samples_x, samples_v): one more gather, x and v stacked
-        fl = x[..., None] if samples_v is None else torch.stack([x, samples_v.reshape(x.shape)], dim=-1)
-        fl = distributed.all_gather_samples(fl, equal_shards=equal)
-        xf = fl[..., 0]
-        vf = fl[..., 1] if samples_v is not None else None
-        # reference layout of the float arrays: (n_dev, B / n_dev, H, W, C); uneven shards (not possible there) are written as one row
-        lead = (world, config.eval.batch_size // world) if equal else (1, config.eval.batch_size)
-        if rank == 0:
-            keys = dict(samples=u8.cpu().numpy().reshape((-1, config.data.image_size, config.data.image_size, config.data.num_channels)),
-                        nfe_cnt=nfe_cnt, samples_x=xf.cpu().numpy().reshape(lead + tuple(xf.shape[1:])))
-            if vf is not None:
-                keys['samples_v'] = vf.cpu().numpy().reshape(lead + tuple(vf.shape[1:]))
-            tmp = f_sample + ".tmp.npz"
-            np.savez_compressed(tmp, **keys)
-            os.replace(tmp, f_sample)
-            written.append(f_sample)
+    writer = _RoundWriter(_writer_threads(config) if rank == 0 else 0)
+    gpu = torch.cuda.is_available()
+    marks = []
+    t_start = time.perf_counter()
+    try:
+        for r in range(num_sampling_rounds):
+            f_sample = os.path.join(result_folder, "samples_%d.npz" % r)
+            if os.path.exists(f_sample) and is_continue:
+                continue
+            out = sampling_fn([distributed.rank_seed(config.seed + 1, r, rank)], state, per_rank)
+            samples_org_x, nfe_cnt = out[0], out[-1]
+            samples_v = out[1] if len(out) == 3 else None
+            x = samples_org_x.reshape((-1,) + tuple(samples_org_x.shape[2:]))
+            u8 = distributed.all_gather_samples(distributed.to_uint8(x), equal_shards=equal)
+            # the float copies the reference also stores (samples_x, samples_v): one more gather, x and v stacked
+            fl = x[..., None] if samples_v is None else torch.stack([x, samples_v.reshape(x.shape)], dim=-1)
+            fl = distributed.all_gather_samples(fl, equal_shards=equal)
+            # reference layout of the float arrays: (n_dev, B / n_dev, H, W, C); uneven shards (not possible there) are written as one row
+            lead = (world, config.eval.batch_size // world) if equal else (1, config.eval.batch_size)
+            if rank == 0:
+                xf = fl[..., 0].contiguous()
+                tensors = dict(samples=(u8, (-1, config.data.image_size, config.data.image_size, config.data.num_channels)),
+                               samples_x=(xf, lead + tuple(xf.shape[1:])))
+                if samples_v is not None:
+                    vf = fl[..., 1].contiguous()
+                    tensors['samples_v'] = (vf, lead + tuple(vf.shape[1:]))
+                writer.submit(r, f_sample, tensors, dict(nfe_cnt=nfe_cnt))
+            if stats is not None:
+                if gpu:
+                    ev = torch.cuda.Event(enable_timing=True)
+                    ev.record()
+                    marks.append((r, ev, time.perf_counter()))
+                else:
+                    marks.append((r, None, time.perf_counter()))
+    finally:
+        written = writer.close() if rank == 0 else []
+    if stats is not None:
+        if gpu:
+            torch.cuda.synchronize()
+        stats["wall_s"] = time.perf_counter() - t_start
+        stats["rounds"] = [m[0] for m in marks]
+        stats["host_submit_s"] = [m[2] - t_start for m in marks]
+        if gpu and len(marks) > 1:  # GPU time between the ends of consecutive rounds' device work
+            stats["gpu_round_ms"] = [marks[i][1].elapsed_time(marks[i + 1][1]) for i in range(len(marks) - 1)]
+        stats["images"] = len(marks) * config.eval.batch_size
+        stats["writer_threads"] = writer.writers
     return written
 
 

@@ -143,3 +143,76 @@ def test_bench_self_launches_for_n_gt_1(tmp_path):
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     d = json.loads([l for l in p.stdout.decode().splitlines() if l.startswith("{")][0])
     assert d["n_gpus"] == 2 and d["gathered_images"] == 8
+
+
+def _fake_rounds_setup(monkeypatch_target, n_rounds_samples=25, batch=6, size=4):
+    from gddim_amd.cld import sampling
+    from gddim_amd.configs import cld_accr_dcifar10
+    cfg = cld_accr_dcifar10.get_config()
+    cfg.data.image_size = size
+    cfg.eval.num_samples, cfg.eval.batch_size = n_rounds_samples, batch
+
+    def fake_factory(config, sde, model, shape, inverse_scaler):
+        def fn(rng, state, batch_size, u=None):
+            g = torch.Generator().manual_seed(int(rng[0]) % (2 ** 31))
+            x = torch.rand((1, batch_size, size, size, 3), generator=g)
+            return x, -x, 50
+        return fn
+
+    monkeypatch_target.setattr(sampling, "get_sampling_fn", fake_factory)
+    return cfg
+
+
+def test_round_writer_threads_write_the_serial_files(tmp_path, monkeypatch):
+    """run_lib's rounds with the host work (copies, zlib, file) on writer threads against the serial loop the
+    reference has (cld_jax/run_lib.py:714-731): same files, same keys, byte-identical archives; resume (`is_continue`) skips what
+    exists and rewrites what is missing; no `.tmp` file is left behind; a failing write surfaces on the caller's thread."""
+    from gddim_amd import run_lib
+    from gddim_amd.models.utils import State
+    cfg = _fake_rounds_setup(monkeypatch)
+    st = State(params_ema={})
+    outs = {}
+    for writers in (0, 1, 3):
+        monkeypatch.setenv("GDDIM_WRITER_THREADS", str(writers))
+        d = str(tmp_path / ("w%d" % writers))
+        stats = {}
+        files = run_lib.sample_data(cfg, "unused", d, state=st, stats=stats)
+        assert [os.path.basename(f) for f in files] == ["samples_%d.npz" % r for r in range(25 // 6 + 1)]
+        assert sorted(os.listdir(d)) == sorted(os.path.basename(f) for f in files)  # no temporary left
+        assert stats["images"] == 5 * 6 and stats["writer_threads"] == writers and len(stats["host_submit_s"]) == 5
+        outs[writers] = [open(f, "rb").read() for f in files]
+    assert outs[0] == outs[1] == outs[3]
+    info = np.load(os.path.join(str(tmp_path / "w3"), "samples_2.npz"))
+    assert set(info.files) == {"samples", "nfe_cnt", "samples_v", "samples_x"} and info["samples"].shape == (6, 4, 4, 3)
+    assert np.array_equal(info["samples"], np.clip(info["samples_x"][0] * 255.0, 0, 255).astype(np.uint8))
+    # resume: remove two rounds, only those come back, identical
+    d = str(tmp_path / "w3")
+    os.remove(os.path.join(d, "samples_1.npz"))
+    os.remove(os.path.join(d, "samples_4.npz"))
+    again = run_lib.sample_data(cfg, "unused", d, is_continue=True, state=st)
+    assert [os.path.basename(f) for f in again] == ["samples_1.npz", "samples_4.npz"]
+    assert [open(os.path.join(d, "samples_%d.npz" % r), "rb").read() for r in range(5)] == outs[0]
+    # the config's own knob wins over the environment
+    cfg.eval.writer_threads = 0
+    stats = {}
+    run_lib.sample_data(cfg, "unused", str(tmp_path / "cfgknob"), state=st, stats=stats)
+    assert stats["writer_threads"] == 0
+
+
+def test_round_writer_error_reaches_the_caller(tmp_path, monkeypatch):
+    import pytest
+    from gddim_amd import run_lib
+    from gddim_amd.models.utils import State
+    cfg = _fake_rounds_setup(monkeypatch)
+    monkeypatch.setenv("GDDIM_WRITER_THREADS", "2")
+    real = run_lib._RoundWriter._save
+
+    def failing(f_sample, keys):
+        if f_sample.endswith("samples_1.npz"):
+            raise OSError("disk full (test)")
+        real(f_sample, keys)
+
+    monkeypatch.setattr(run_lib._RoundWriter, "_save", staticmethod(failing))
+    with pytest.raises(OSError, match="disk full"):
+        run_lib.sample_data(cfg, "unused", str(tmp_path / "e"), state=State(params_ema={}))
+    assert not os.path.exists(os.path.join(str(tmp_path / "e"), "samples_1.npz"))

@@ -296,6 +296,39 @@ def test_conv3x3_winograd42_matches_torch_fp64(dev, case, nw, gd_env):
     assert err < 4e-5 and err < 6 * err_direct + 1e-6, (case, err, err_direct)
 
 
+@pytest.mark.parametrize("case", [
+    (256, 32, 32, 128, 128),   # the dominant launch of the benchmark: 1 024 M blocks x 2 N tiles = 2 048 workgroup tiles, 8 rounds of the persistent walk
+    (256, 8, 8, 256, 256),     # 8x8 level at B = 256: 64 M blocks x 4 N tiles = 256 workgroup tiles, exactly one round on 256 CUs
+    (320, 16, 16, 256, 256),   # a batch whose walk ends in a partial round (the stream-K tail's case)
+    (128, 8, 8, 512, 256),     # the reference's own per-device batch on the longest K
+])
+def test_conv3x3_winograd42_production_size_every_output(dev, case):
+    """gd_conv3x3_winograd42 at the PRODUCTION launch sizes (default grid, default tile choice, nothing forced), every output against the
+    float64 direct convolution: the persistent walk over thousands of tiles, the XCD-grouped tile ids and the far end of the
+    batch, which the small operator cases above only reach through forced grids.  Besides the global bar the
+    error is reported per image so that a defect confined to mid-batch positions cannot hide behind a max over the batch."""
+    from gddim_amd import ops
+    B, H, W, Cin, Cout = case
+    g = torch.Generator().manual_seed(sum(case) + 11)
+    x = torch.randn(B, H, W, Cin, generator=g)
+    w = torch.randn(3, 3, Cin, Cout, generator=g) / math.sqrt(9 * Cin)
+    bias = torch.randn(Cout, generator=g)
+    res = torch.randn(B, H, W, Cout, generator=g)
+    wp = w.permute(3, 0, 1, 2).reshape(Cout, 9 * Cin).contiguous()
+    got = ops.conv3x3_winograd42(x.to(dev), wp.to(dev), bias.to(dev), res.to(dev), alpha=1.0, out_scale=0.7).cpu()
+    assert torch.isfinite(got).all()
+    wd = w.permute(3, 2, 0, 1).double()
+    per_image = torch.empty(B, dtype=torch.float64)
+    for b0 in range(0, B, 32):   # float64 reference in slabs of 32 images (memory)
+        xs = x[b0:b0 + 32].permute(0, 3, 1, 2).double()
+        want = (F.conv2d(xs, wd, padding=1).permute(0, 2, 3, 1) + bias.double() + res[b0:b0 + 32].double()) * 0.7
+        per_image[b0:b0 + 32] = (got[b0:b0 + 32].double() - want).abs().amax(dim=(1, 2, 3))
+    print("wino42 production size", case, "max|d| %.2e, worst image %d, median over images %.2e" %
+          (per_image.max().item(), int(per_image.argmax()), per_image.median().item()))
+    assert per_image.max().item() < 4e-5, (case, int(per_image.argmax()), per_image.max().item())
+    assert per_image.max().item() < 4 * per_image.median().item() + 1e-6  # no image is an outlier: the error is round-off everywhere
+
+
 @pytest.mark.parametrize("grid", [1, 3, 8])
 @pytest.mark.parametrize("case", [(2, 32, 32, 128, 128, True, True), (5, 32, 32, 64, 132, True, True), (6, 8, 8, 64, 96, True, False),
                                   (3, 16, 16, 256, 256, False, True)])

@@ -16,7 +16,12 @@ NCSN++, 256 images per call, NFE 50 / 100, hipGraph replay, the production kerne
         (y0 ~ N(0, s^2 I)) through the reference's `sde.model2eps` hook (blur_jax/sde_lib.py:150-152), exposed by the product
         in linear form.
 
-The oracle side is the float64 restatement loop on the first images of the batch (images are independent units)."""
+The oracle side is the float64 restatement loop on a few DISTINCT noises (images are independent units); the batch is built from
+those noises laid out over all positions by a seeded random assignment (`_layout`), and every copy of a noise must equal every other
+copy BIT FOR BIT.  Each position of the batch is thereby chained to an oracle-checked image: directly where all distinct noises go
+through the oracle (config 2), through complementary layouts of further GPU runs where the oracle is too slow for that (config 5).
+A defect confined to some batch positions, tile indices or rounds of a persistent walk shows either as a broken copy or -- if it
+mixes images up -- as a changed result wherever the two images involved differ (7 of 8 pairs at 8 distinct noises)."""
 import copy
 import os
 
@@ -50,7 +55,29 @@ def _scaled_head(params, gain):
     return p
 
 
-def _cld_case(native_lib, cfg_mod, image_size, B, n_ref, nfe, gain, seed, method="deis", x64=False, **samp):
+def _layout(B, distinct, seed, shift=0):
+    """Seeded random assignment of `distinct` noises to the B positions of a batch, every noise used B // distinct times
+    (+-1); `shift` rotates the noise ids so that `distinct` shifted layouts put every noise at every position once."""
+    lay = np.arange(B) % distinct
+    np.random.default_rng(1000 + seed).shuffle(lay)
+    return (lay + shift) % distinct
+
+
+def _assert_copies_identical(tag, lay, *arrays):
+    """Every copy of a noise gives the same bits wherever it sits in the batch; returns the position of each noise's first copy."""
+    first = {}
+    for p, j in enumerate(lay):
+        first.setdefault(int(j), p)
+    for a in arrays:
+        bad = [p for p, j in enumerate(lay) if not np.array_equal(a[p], a[first[int(j)]])]
+        assert not bad, "%s: %d of %d positions differ from the first copy of their noise, e.g. position %d (noise %d, first copy at %d): max|d| %.3e" % (
+            tag, len(bad), len(lay), bad[0], lay[bad[0]], first[int(lay[bad[0]])], float(np.abs(a[bad[0]] - a[first[int(lay[bad[0]])]]).max()))
+    return [first[j] for j in sorted(first)]
+
+
+def _cld_case(native_lib, cfg_mod, image_size, B, distinct, nfe, gain, seed, method="deis", x64=False, **samp):
+    """Returns (cfg, osde, eps64, lin64, u_distinct (float64), run, model): `run(layout)` samples the batch whose position p holds
+    noise `layout[p]` and returns (x, v, nfe) as numpy."""
     from gddim_amd.cld import sampling, sde_lib
     from gddim_amd.datasets import get_data_inverse_scaler
     from gddim_amd.models import utils as mutils
@@ -70,14 +97,19 @@ def _cld_case(native_lib, cfg_mod, image_size, B, n_ref, nfe, gain, seed, method
     model = mutils.get_model(cfg.model.name)(config=cfg)
     state = mutils.State(params_ema=params, model_state={})
     rng = np.random.default_rng(seed + 100)
-    shape = (B, image_size, image_size, 3)
-    u = np.stack([rng.standard_normal(shape), rng.standard_normal(shape) / 2], axis=-1).astype(np.float32)
+    shape = (distinct, image_size, image_size, 3)
+    ud = np.stack([rng.standard_normal(shape), rng.standard_normal(shape) / 2], axis=-1).astype(np.float32)
     cfg.sampling.method, cfg.sampling.nfe, cfg.sampling.deis_order, cfg.sampling.noise_removal = method, nfe, 2, True
     for k, v in samp.items():
         setattr(cfg.sampling, k, v)
     fn = sampling.get_sampling_fn(cfg, sde, model, None, get_data_inverse_scaler(cfg))  # the factory: is_p=True, hipGraph replay
-    xs, vs, n = fn([0], state, B, torch.as_tensor(u[None], device="cuda:0"))
-    x, v = xs[0].cpu().numpy(), vs[0].cpu().numpy()
+    ud_dev = torch.as_tensor(ud, device="cuda:0")
+
+    def run(layout):
+        u = ud_dev[torch.as_tensor(np.asarray(layout), device="cuda:0", dtype=torch.long)]
+        xs, vs, n = fn([0], state, len(layout), u[None])
+        return xs[0].cpu().numpy(), vs[0].cpu().numpy(), n
+
     net64 = onet.cld_eps_fn(params, cfg, dtype=torch.float64)
 
     def lin64(uu, t):  # the Gaussian-data model alone: how much of the result is the network's doing
@@ -86,13 +118,12 @@ def _cld_case(native_lib, cfg_mod, image_size, B, n_ref, nfe, gain, seed, method
     def eps64(uu, t):  # NCSNpp(u, t) + X(t) u
         return net64(uu, t) + lin64(uu, t)
 
-    u_ref = u[:n_ref].astype(np.float64)
-    return cfg, osde, eps64, lin64, u_ref, x, v, n, model
+    return cfg, osde, eps64, lin64, ud.astype(np.float64), run, model
 
 
-def _report(tag, x, v, wx, wv, lx, n_ref, trace=None):
-    ex = float(np.abs(x[:n_ref] - wx).max())
-    ev = float(np.abs(v[:n_ref] - wv).max())
+def _report(tag, x, v, wx, wv, lx, trace=None):
+    ex = float(np.abs(x - wx).max())
+    ev = float(np.abs(v - wv).max())
     moved = float(np.abs(wx - lx).max())
     print("%s: max|dx| %.3e (abs, bar %.0e)  max|dv| %.3e  | x in [%.3f, %.3f] std %.3f, |v| <= %.2f, network moved x by %.3f%s"
           % (tag, ex, ABS_TOL, ev, wx.min(), wx.max(), wx.std(), np.abs(wv).max(), moved,
@@ -100,23 +131,57 @@ def _report(tag, x, v, wx, wv, lx, n_ref, trace=None):
     return ex, ev, moved
 
 
+def _oracle(osde, eps64, lin64, u, nfe, trace=None):
+    """The float64 restatement loop (cld_jax/sampling.py:204-230) on noises u, with and without the network."""
+    wx, wv, _ = ocld.deis_sampler(osde, eps64, u, nfe, 2, ts_order=2, denoising=True, inverse_scaler=ocld.inverse_scaler_centered, trace=trace)
+    lx, _, _ = ocld.deis_sampler(osde, lin64, u, nfe, 2, ts_order=2, denoising=True, inverse_scaler=ocld.inverse_scaler_centered)
+    return wx, wv, lx
+
+
+def _chained_runs(tag, run, B, distinct, n_ref, seed):
+    """GPU runs over complementary layouts so that EVERY position of the batch holds an oracle-checked noise (ids < n_ref) in one of
+    them: run r uses the base layout with the noise ids rotated by r * n_ref.  In every run all copies of a noise must agree bit for
+    bit, and a noise must give the same bits in every run (other neighbours, other positions).  Returns the results of the distinct
+    noises (D, ...) and the number of runs."""
+    runs = -(-distinct // n_ref)
+    xd = vd = None
+    covered = np.zeros(B, dtype=bool)
+    nfe = None
+    for r in range(runs):
+        lay = _layout(B, distinct, seed, shift=r * n_ref)
+        x, v, nfe = run(lay)
+        assert np.isfinite(x).all() and np.isfinite(v).all()
+        first = _assert_copies_identical("%s run %d" % (tag, r), lay, x, v)
+        if xd is None:
+            xd, vd = x[first], v[first]
+        else:
+            assert np.array_equal(x[first], xd) and np.array_equal(v[first], vd), "%s: run %d gives other bits for the same noises" % (tag, r)
+        covered |= lay < n_ref
+    assert covered.all()
+    return xd, vd, nfe, runs
+
+
 @pytest.mark.parametrize("x64", [False, True], ids=["x64=False", "x64=True"])
 def test_cld_nfe50_b256_absolute_parity(native_lib, x64):
     """BASELINE config 2: CLD gDDIM deis_order=2, NFE=50 (49 AB steps + denoising), 256 images, full accr U-Net, hipGraph -- with the
     coefficient tables in the reference's default arithmetic (config.model.x64=False: float32) and in float64, the oracle's tables in
-    the same arithmetic each time."""
+    the same arithmetic each time.  The batch is 8 distinct noises over the 256 positions (seeded random assignment, 32 copies each):
+    x64=False sends ALL 8 through the float64 oracle, so every one of the 256 positions is bit-identical to an oracle-checked image;
+    x64=True (same kernels, other tables) checks 2 of them and covers the positions with 4 complementary layouts."""
     from gddim_amd.configs import cld_accr_dcifar10
-    n_ref, nfe, gain = (1 if x64 else 2), 50, 0.3
-    cfg, osde, eps64, lin64, u_ref, x, v, n, model = _cld_case(native_lib, cld_accr_dcifar10, 32, 256, n_ref, nfe, gain, seed=0, x64=x64)
+    B, distinct, nfe, gain = 256, 8, 50, 0.3
+    n_ref = 2 if x64 else 8
+    cfg, osde, eps64, lin64, ud, run, model = _cld_case(native_lib, cld_accr_dcifar10, 32, B, distinct, nfe, gain, seed=0, x64=x64)
     assert osde.dtype == (np.float64 if x64 else np.float32)
+    xd, vd, n, runs = _chained_runs("CLD NFE=50 B=256 x64=%s" % x64, run, B, distinct, n_ref, seed=0)
     trace = []
-    wx, wv, _ = ocld.deis_sampler(osde, eps64, u_ref, nfe, 2, ts_order=2, denoising=True, inverse_scaler=ocld.inverse_scaler_centered, trace=trace)
-    lx, _, _ = ocld.deis_sampler(osde, lin64, u_ref, nfe, 2, ts_order=2, denoising=True, inverse_scaler=ocld.inverse_scaler_centered)
-    ex, ev, moved = _report("CLD NFE=50 B=256 x64=%s" % x64, x, v, wx, wv, lx, n_ref, trace)
+    wx, wv, lx = _oracle(osde, eps64, lin64, ud[:n_ref], nfe, trace)
+    ex, ev, moved = _report("CLD NFE=50 B=256 x64=%s (%d noises vs the oracle, %d layouts, 256/256 positions chained)" % (x64, n_ref, runs),
+                            xd[:n_ref], vd[:n_ref], wx, wv, lx, trace)
     # the kernels of the benchmark ran (hybrid Winograd kernel, persistent short-K GEMM), not a small-batch fallback
     names = _profile_names(model, 6, 256)
     assert any("conv3x3_wino42_f32_kernel" in k for k in names) and any("igemm_f32_pers_kernel" in k for k in names), names
-    assert n == nfe and np.isfinite(x).all() and np.isfinite(v).all()
+    assert n == nfe
     assert moved > 20 * ABS_TOL, "the network must matter for the test to mean anything (moved x by %.3e)" % moved
     assert max(float(np.abs(a).max()) for a in trace) < 100.0
     assert ex <= ABS_TOL and ev <= ABS_TOL * max(1.0, float(np.abs(wv).max()))
@@ -135,14 +200,15 @@ def _profile_names(model, in_ch, B, entries=False):
 
 
 def test_cld_nfe100_b256_absolute_parity(native_lib):
-    """NFE = 100 (BASELINE config 5's longest schedule) on the 32x32 production batch: error growth over 99 AB steps."""
+    """NFE = 100 (BASELINE config 5's longest schedule) on the 32x32 production batch: error growth over 99 AB steps; 4 distinct
+    noises, 2 through the oracle, two complementary layouts."""
     from gddim_amd.configs import cld_accr_dcifar10
-    n_ref, nfe, gain = 1, 100, 0.3
-    cfg, osde, eps64, lin64, u_ref, x, v, n, model = _cld_case(native_lib, cld_accr_dcifar10, 32, 256, n_ref, nfe, gain, seed=1)
-    wx, wv, _ = ocld.deis_sampler(osde, eps64, u_ref, nfe, 2, ts_order=2, denoising=True, inverse_scaler=ocld.inverse_scaler_centered)
-    lx, _, _ = ocld.deis_sampler(osde, lin64, u_ref, nfe, 2, ts_order=2, denoising=True, inverse_scaler=ocld.inverse_scaler_centered)
-    ex, ev, moved = _report("CLD NFE=100 B=256", x, v, wx, wv, lx, n_ref)
-    assert n == nfe and np.isfinite(x).all() and moved > 20 * ABS_TOL
+    B, distinct, n_ref, nfe, gain = 256, 4, 2, 100, 0.3
+    cfg, osde, eps64, lin64, ud, run, model = _cld_case(native_lib, cld_accr_dcifar10, 32, B, distinct, nfe, gain, seed=1)
+    xd, vd, n, runs = _chained_runs("CLD NFE=100 B=256", run, B, distinct, n_ref, seed=1)
+    wx, wv, lx = _oracle(osde, eps64, lin64, ud[:n_ref], nfe)
+    ex, ev, moved = _report("CLD NFE=100 B=256 (%d noises vs the oracle, %d layouts)" % (n_ref, runs), xd[:n_ref], vd[:n_ref], wx, wv, lx)
+    assert n == nfe and moved > 20 * ABS_TOL
     assert ex <= ABS_TOL and ev <= ABS_TOL * max(1.0, float(np.abs(wv).max()))
 
 
@@ -152,29 +218,28 @@ def test_cld_64x64_nfe10_persistent_tile_absolute_parity(native_lib):
     x (the image, [0, 1] units) is the quantity under the absolute 1e-3 bar; the velocity v is not an output of the reference's
     pipeline and is bounded by the bar scaled by max|v| (|v| <= 20 on this trajectory)."""
     from gddim_amd.configs import cld_accr_dcifar10
-    n_ref, nfe, gain = 1, 10, 0.3
-    cfg, osde, eps64, lin64, u_ref, x, v, n, model = _cld_case(native_lib, cld_accr_dcifar10, 64, 32, n_ref, nfe, gain, seed=2)
-    wx, wv, _ = ocld.deis_sampler(osde, eps64, u_ref, nfe, 2, ts_order=2, denoising=True, inverse_scaler=ocld.inverse_scaler_centered)
-    lx, _, _ = ocld.deis_sampler(osde, lin64, u_ref, nfe, 2, ts_order=2, denoising=True, inverse_scaler=ocld.inverse_scaler_centered)
-    ex, ev, moved = _report("CLD 64x64 NFE=10 B=32", x, v, wx, wv, lx, n_ref)
+    B, distinct, n_ref, nfe, gain = 32, 2, 1, 10, 0.3
+    cfg, osde, eps64, lin64, ud, run, model = _cld_case(native_lib, cld_accr_dcifar10, 64, B, distinct, nfe, gain, seed=2)
+    xd, vd, n, runs = _chained_runs("CLD 64x64 NFE=10 B=32", run, B, distinct, n_ref, seed=2)
+    wx, wv, lx = _oracle(osde, eps64, lin64, ud[:n_ref], nfe)
+    ex, ev, moved = _report("CLD 64x64 NFE=10 B=32", xd[:n_ref], vd[:n_ref], wx, wv, lx)
     names = _profile_names(model, 6, 32)
     assert any("conv3x3_wino42_f32_kernel" in k for k in names), names
-    assert n == nfe and np.isfinite(x).all() and moved > 20 * ABS_TOL
+    assert n == nfe and moved > 20 * ABS_TOL
     assert ex <= ABS_TOL and ev <= ABS_TOL * max(1.0, float(np.abs(wv).max()))
 
 
 def test_cld_64x64_b512_full_size_absolute_parity(native_lib):
     """BASELINE config 5 AT ITS STATED SIZE: 64x64x3, B = 512, full accr U-Net, NFE = 10, hipGraph, through get_sampling_fn
     (cld_jax/sampling.py:204-239 at image_size = 64).  The 64x64-level activations are 512 * 4096 * 128 * 4 B = 1.07 GB per tensor
-    -- half of the int32 byte-offset range the kernels' buffer addressing lives in -- so besides the oracle comparison on image 0 the
-    LAST image of the batch is compared with the same noise run at B = 32 (an offset overflow would show at the far end).
+    -- half of the int32 byte-offset range the kernels' buffer addressing lives in.  2 distinct noises over the 512 positions in two
+    complementary layouts, noise 0 through the float64 oracle: every position (the far end included, where an offset overflow would
+    show) is bit-identical to the oracle-checked image in one of the two runs; and a B = 32 run (another captured graph, other tile
+    choices) of the same two noises agrees to round-off.
     (x is the quantity under the north-star bar; v is bounded by the bar scaled by max|v|, |v| <= 20 here.)"""
     from gddim_amd.configs import cld_accr_dcifar10
-    from gddim_amd.cld import sampling
-    from gddim_amd.datasets import get_data_inverse_scaler
-    from gddim_amd.models import utils as mutils
-    B, n_ref, nfe, gain = 512, 1, 10, 0.3
-    cfg, osde, eps64, lin64, u_ref, x, v, n, model = _cld_case(native_lib, cld_accr_dcifar10, 64, B, n_ref, nfe, gain, seed=2)
+    B, distinct, n_ref, nfe, gain = 512, 2, 1, 10, 0.3
+    cfg, osde, eps64, lin64, ud, run, model = _cld_case(native_lib, cld_accr_dcifar10, 64, B, distinct, nfe, gain, seed=2)
     ents = _profile_names(model, 6, B, entries=True)
     names = [p["name"] for p in ents]
     assert any("conv3x3_wino" in k for k in names) and any("igemm_f32_pers_kernel" in k for k in names), names
@@ -185,51 +250,41 @@ def test_cld_64x64_b512_full_size_absolute_parity(native_lib):
     total = sum(p["flops"] for p in ents)
     print("generic-kernel share of the flops at B=512 64x64: %.4f" % (generic / total))
     assert generic < 0.02 * total, [(p["name"], p["flops"]) for p in ents if p["name"].startswith("igemm_f32_kernel<")]
-    assert n == nfe and np.isfinite(x).all() and np.isfinite(v).all()
-    # the far end of the batch against a small-batch run on the same noise (same engine, batch 32: another captured graph)
-    params = _scaled_head(onet.random_params(cfg, 6, seed=2), gain)
-    rng = np.random.default_rng(2 + 100)
-    shape = (B, 64, 64, 3)
-    u = np.stack([rng.standard_normal(shape), rng.standard_normal(shape) / 2], axis=-1).astype(np.float32)
-    from gddim_amd.cld import sde_lib
-
-    class NearDenoiserCLD(sde_lib.CLD):
-        def mixed_u_matrix(self, t):
-            return _gauss_eps_matrix(self, t)
-
-    sde = sde_lib.from_config(cfg)
-    sde.__class__ = NearDenoiserCLD
-    sde.mixed_score = True
-    fn = sampling.get_sampling_fn(cfg, sde, model, None, get_data_inverse_scaler(cfg))
-    state = mutils.State(params_ema=params, model_state={})
-    xs32, vs32, _ = fn([0], state, 32, torch.as_tensor(u[None, B - 32:], device="cuda:0"))
-    x32, v32 = xs32[0].cpu().numpy(), vs32[0].cpu().numpy()
-    far_x = float(np.abs(x[B - 32:] - x32).max())
-    far_v = float(np.abs(v[B - 32:] - v32).max())
-    print("CLD 64x64 NFE=10 B=512: images 480..511 vs the same noise at B=32: max|dx| %.3e max|dv| %.3e" % (far_x, far_v))
+    xd, vd, n, runs = _chained_runs("CLD 64x64 NFE=10 B=512", run, B, distinct, n_ref, seed=2)
+    assert n == nfe
+    # the same noises at B = 32 (other kernels per level): round-off apart, not bits
+    x32, v32, _ = run(_layout(32, distinct, 7))
+    f32 = _assert_copies_identical("CLD 64x64 NFE=10 B=32", _layout(32, distinct, 7), x32, v32)
+    far_x, far_v = float(np.abs(x32[f32] - xd).max()), float(np.abs(v32[f32] - vd).max())
+    print("CLD 64x64 NFE=10 B=512 vs the same noises at B=32: max|dx| %.3e max|dv| %.3e" % (far_x, far_v))
     assert far_x <= 1e-4 and far_v <= 1e-3, (far_x, far_v)
-    # image 0 against the float64 oracle loop
-    wx, wv, _ = ocld.deis_sampler(osde, eps64, u_ref, nfe, 2, ts_order=2, denoising=True, inverse_scaler=ocld.inverse_scaler_centered)
-    lx, _, _ = ocld.deis_sampler(osde, lin64, u_ref, nfe, 2, ts_order=2, denoising=True, inverse_scaler=ocld.inverse_scaler_centered)
-    ex, ev, moved = _report("CLD 64x64 NFE=10 B=512", x, v, wx, wv, lx, n_ref)
+    wx, wv, lx = _oracle(osde, eps64, lin64, ud[:n_ref], nfe)
+    ex, ev, moved = _report("CLD 64x64 NFE=10 B=512 (512/512 positions chained, %d layouts)" % runs, xd[:n_ref], vd[:n_ref], wx, wv, lx)
     assert moved > 20 * ABS_TOL
     assert ex <= ABS_TOL and ev <= ABS_TOL * max(1.0, float(np.abs(wv).max()))
     model.close()  # 35 GB of arena
 
 
-# (GDDIM_PARITY_EXTRA_NFE="50,100" adds the configuration's longer schedules: minutes of float64 oracle each; profiles/r04_parity_config5_long.log)
-@pytest.mark.parametrize("nfe", [20] + [int(v) for v in os.environ.get("GDDIM_PARITY_EXTRA_NFE", "").split(",") if v])
-def test_cld_64x64_b512_nfe20_absolute_parity(native_lib, nfe):
-    """BASELINE config 5 at its stated size on a SECOND schedule: 64x64x3, B = 512, full accr U-Net, NFE = 20 (19 AB steps + denoising:
-    other step sizes, other DEIS rows, twice the error-growth horizon of the NFE 10 check above), hipGraph, through get_sampling_fn; image 0
-    against the float64 oracle loop.  (NFE 20 / 50 / 100 at this size existed as bench lines only.)"""
+@pytest.mark.parametrize("nfe", [20, 50, 100])
+def test_cld_64x64_b512_nfe_sweep_absolute_parity(native_lib, nfe):
+    """BASELINE config 5 at its stated size on its other schedules: 64x64x3, B = 512, full accr U-Net, NFE = 20 / 50 / 100 (other step
+    sizes, other DEIS rows, up to ten times the error-growth horizon of the NFE 10 check above), hipGraph, through get_sampling_fn.
+    2 distinct noises, noise 0 against the float64 oracle loop; NFE 20 covers all 512 positions with two complementary layouts, NFE 50
+    and 100 run one layout (256 positions hold the oracle-checked noise, the other 256 are bit-identical copies of noise 1; the
+    position coverage of this batch shape is held by NFE 10 and 20 -- the kernels do not depend on the schedule)."""
     from gddim_amd.configs import cld_accr_dcifar10
-    B, n_ref, gain = 512, 1, 0.3
-    cfg, osde, eps64, lin64, u_ref, x, v, n, model = _cld_case(native_lib, cld_accr_dcifar10, 64, B, n_ref, nfe, gain, seed=5)
-    assert n == nfe and np.isfinite(x).all() and np.isfinite(v).all()
-    wx, wv, _ = ocld.deis_sampler(osde, eps64, u_ref, nfe, 2, ts_order=2, denoising=True, inverse_scaler=ocld.inverse_scaler_centered)
-    lx, _, _ = ocld.deis_sampler(osde, lin64, u_ref, nfe, 2, ts_order=2, denoising=True, inverse_scaler=ocld.inverse_scaler_centered)
-    ex, ev, moved = _report("CLD 64x64 NFE=%d B=512" % nfe, x, v, wx, wv, lx, n_ref)
+    B, distinct, n_ref, gain = 512, 2, 1, 0.3
+    cfg, osde, eps64, lin64, ud, run, model = _cld_case(native_lib, cld_accr_dcifar10, 64, B, distinct, nfe, gain, seed=5)
+    if nfe <= 20:
+        xd, vd, n, runs = _chained_runs("CLD 64x64 NFE=%d B=512" % nfe, run, B, distinct, n_ref, seed=5)
+    else:
+        lay = _layout(B, distinct, 5)
+        x, v, n = run(lay)
+        first = _assert_copies_identical("CLD 64x64 NFE=%d B=512" % nfe, lay, x, v)
+        xd, vd, runs = x[first], v[first], 1
+    assert n == nfe and np.isfinite(xd).all() and np.isfinite(vd).all()
+    wx, wv, lx = _oracle(osde, eps64, lin64, ud[:n_ref], nfe)
+    ex, ev, moved = _report("CLD 64x64 NFE=%d B=512 (%d layouts)" % (nfe, runs), xd[:n_ref], vd[:n_ref], wx, wv, lx)
     assert moved > 20 * ABS_TOL
     assert ex <= ABS_TOL and ev <= ABS_TOL * max(1.0, float(np.abs(wv).max()))
     model.close()  # 35 GB of arena
@@ -301,7 +356,7 @@ def test_order0_is_em_matches_oracle(native_lib):
 
 def test_blur_nfe50_b256_absolute_parity(native_lib):
     """BASELINE config 3: blur gDDIM order0, NFE=50, 256 images, ddpm_deep U-Net on 3 channels, hipGraph; near-denoiser through
-    sde.model2eps: eps_y = DCT(NCSNpp(IDCT y, t)) + b(t) (.) y."""
+    sde.model2eps: eps_y = DCT(NCSNpp(IDCT y, t)) + b(t) (.) y.  Batch layout and position chaining as in the CLD tests."""
     from gddim_amd.blur import sampling, sde_lib
     from gddim_amd.configs import blur_ddpm_deep_cifar10
     from gddim_amd.datasets import get_data_inverse_scaler
@@ -325,11 +380,21 @@ def test_blur_nfe50_b256_absolute_parity(native_lib):
     osde = oblur.SDE(sigma_blur_max=cfg.model.sigma_blur_max, sampling_eps=cfg.sampling.t0)
     model = mutils.get_model(cfg.model.name)(config=cfg)
     state = mutils.State(params_ema=params, model_state={})
-    y = np.random.default_rng(7).standard_normal((B, 32, 32, 3)).astype(np.float32)
+    distinct = 8
+    yd = np.random.default_rng(7).standard_normal((distinct, 32, 32, 3)).astype(np.float32)
     cfg.sampling.nfe = nfe
     fn = sampling.get_sampling_fn(cfg, sde, model, None, get_data_inverse_scaler(cfg))
-    xs, n = fn([0], state, B, torch.as_tensor(y[None], device="cuda:0"))
-    x = xs[0].cpu().numpy()
+    yd_dev = torch.as_tensor(yd, device="cuda:0")
+
+    def run(layout):
+        yy = yd_dev[torch.as_tensor(np.asarray(layout), device="cuda:0", dtype=torch.long)]
+        xs, n_ = fn([0], state, len(layout), yy[None])
+        a = xs[0].cpu().numpy()
+        return a, a, n_
+
+    # 8 distinct noises over the 256 positions, 2 through the oracle, 4 complementary layouts: every position chained (module docstring)
+    xd, _, n, runs = _chained_runs("blur NFE=50 B=256", run, B, distinct, n_ref, seed=7)
+    x, y = xd, yd
     net64 = onet.blur_eps_fn(params, cfg, dtype=torch.float64)
 
     def lin64(xx, t):  # IDCT(b (.) DCT x): t is batch-uniform in the sampler
@@ -344,7 +409,7 @@ def test_blur_nfe50_b256_absolute_parity(native_lib):
     lx, _ = oblur.order0_sampler(osde, lin64, y[:n_ref].astype(np.float64), nfe, ts_order=cfg.sampling.ts_order, inverse_scaler=inv)
     err = float(np.abs(x[:n_ref] - wx).max())
     moved = float(np.abs(wx - lx).max())
-    print("blur NFE=50 B=256: max|dx| %.3e (abs, bar %.0e) | x in [%.3f, %.3f] std %.3f, network moved x by %.3f, max|y| along the trajectory %.2f"
+    print("blur NFE=50 B=256 (2 noises vs the oracle, 4 layouts, 256/256 positions chained): max|dx| %.3e (abs, bar %.0e) | x in [%.3f, %.3f] std %.3f, network moved x by %.3f, max|y| along the trajectory %.2f"
           % (err, ABS_TOL, wx.min(), wx.max(), wx.std(), moved, max(float(np.abs(a).max()) for a in trace)))
     assert n == wn == nfe and np.isfinite(x).all() and moved > 20 * ABS_TOL
     assert err <= ABS_TOL
