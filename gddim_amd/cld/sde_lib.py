@@ -44,7 +44,11 @@ def linspace_int(start, stop, num, ft=np.float64):
     R-table knots: 99 991 instead of 99 990), so the knot rows are the reference's only if the same arithmetic picks them."""
     ft = np.dtype(ft).type
     delta = (ft(stop) - ft(start)) / ft(num - 1)
-    return np.floor(ft(start) + np.arange(num).astype(ft) * delta).astype(np.int64)
+    out = np.floor(ft(start) + np.arange(num).astype(ft) * delta).astype(np.int64)
+    # the last knot is the exact stop, as numpy.linspace pins it (ADVICE r4): for every R_dt of the shipped configs floor((num-1) * delta)
+    # already lands there in both dtypes (tests/test_oracle_cld.py), so this changes nothing there and guards the table's last row elsewhere
+    out[-1] = int(stop)
+    return out
 
 
 _R_CACHE = {}

@@ -9,6 +9,7 @@
 namespace gd {
 
 void set_error(const char *fmt, ...);
+int device_cus();  // compute units of the current device (hipDeviceAttributeMultiprocessorCount, cached per device; 256 if no device answers)
 
 #define GD_HIP(expr)                                                                             \
     do {                                                                                         \

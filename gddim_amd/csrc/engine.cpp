@@ -46,6 +46,7 @@ struct PendingEvent {
 
 struct gd_engine {
     Plan plan;
+    const Options *opts = nullptr;  // the option snapshot this engine was created under; in force during every call on it (options.h)
     int device = -1;
     bool plan_only = true;
     bool params_uploaded = false;
@@ -588,7 +589,9 @@ int gd_device_count(void) {
 int gd_engine_create(const gd_model_desc *desc, int device, gd_engine **out) {
     GD_CHECK(desc && out, "null argument");
     gd_engine *e = new gd_engine();
-    options_reload();  // an engine is built under the environment of its creation (options.h)
+    options_reload();  // an engine is built under the environment of its creation and keeps that table for life (options.h)
+    e->opts = options_snapshot();
+    OptScope scope(e->opts);
     if (e->plan.build(*desc)) { delete e; return 1; }
     e->device = device;
     e->plan_only = device < 0;
@@ -643,6 +646,7 @@ int gd_engine_create(const gd_model_desc *desc, int device, gd_engine **out) {
 }
 
 int gd_engine_destroy(gd_engine *e) {
+    OptScope scope(e ? e->opts : nullptr);
     if (!e) return 0;
     if (!e->plan_only) {
         (void)hipSetDevice(e->device);
@@ -671,6 +675,7 @@ int gd_engine_destroy(gd_engine *e) {
 }
 
 int gd_engine_plan_json(gd_engine *e, char *buf, size_t cap, size_t *needed) {
+    OptScope scope(e ? e->opts : nullptr);
     GD_CHECK(e, "null engine");
     const std::string j = e->plan.json();
     if (needed) *needed = j.size() + 1;
@@ -697,6 +702,7 @@ int gd_engine_param_info(gd_engine *e, int index, char *name_buf, size_t name_ca
 }
 
 int gd_engine_load_param(gd_engine *e, const char *name, const float *host_data, const int64_t *shape, int ndim) {
+    OptScope scope(e ? e->opts : nullptr);
     GD_CHECK(e && name && host_data && shape, "null argument");
     e->params_uploaded = false;
     e->wsplit_valid = false;
@@ -761,7 +767,9 @@ static int build_wino_weights(gd_engine *e) {
         if ((op.N % 4 != 0 || op.N < 32) && (op.qstats.t >= 0 || op.egn_peer >= 0)) continue;
         const bool img4 = op.H == 4 && op.W == 4;  // the channel-split launch (conv3x3_wino2d_splitk_factor)
         if (!img4 && ((op.W != 8 && op.W != 16 && op.W != 32 && op.W != 64) || op.H % 2 != 0 || (op.H * op.W / 4) % 16 != 0)) continue;
-        if (!img4 && hybrid_takes(op)) continue;
+        // (Cin = 32 slots keep their F(2x2,3x3) copy: conv3x3_wino42_ok may still refuse such a launch at run time -- too few wide tiles --
+        // and it must then fall to this kernel, not to the direct one: ADVICE r4)
+        if (!img4 && hybrid_takes(op) && Cin != 32) continue;
         if (img4) need_ws = std::max(need_ws, 8LL * e->plan.desc.max_batch * 16 * op.N);
         if (img4) e->splitk_per_image = std::max(e->splitk_per_image, 8LL * 16 * op.N);
         e->wino2_off[op.w_slot] = total2;
@@ -773,7 +781,7 @@ static int build_wino_weights(gd_engine *e) {
         GD_HIP(hipMalloc((void **)&e->splitk_ws, (size_t)need_ws * sizeof(float)));
         e->splitk_ws_floats = need_ws;
     }
-    GD_CHECK(!e->wwino2 || total2 == e->wwino2_floats, "the option table changed between two parameter loads of one engine (GDDIM_NOWINO42)");
+    GD_CHECK(!e->wwino2 || total2 == e->wwino2_floats, "internal error: the F(2x2,3x3) weight layout of an engine changed between two parameter loads");
     if (total2 > 0) {
         if (!e->wwino2) GD_HIP(hipMalloc((void **)&e->wwino2, (size_t)total2 * sizeof(float)));
         e->wwino2_floats = total2;
@@ -796,7 +804,7 @@ static int build_wino_weights(gd_engine *e) {
         dims[op.w_slot] = {op.N, Cin};
         total42 += wino42_weight_floats(op.N, Cin);
     }
-    GD_CHECK(!e->wwino42 || total42 == e->wwino42_floats, "the option table changed between two parameter loads of one engine (GDDIM_NOWINO42)");
+    GD_CHECK(!e->wwino42 || total42 == e->wwino42_floats, "internal error: the hybrid Winograd weight layout of an engine changed between two parameter loads");
     if (total42 > 0) {
         if (!e->wwino42) GD_HIP(hipMalloc((void **)&e->wwino42, (size_t)total42 * sizeof(float)));
         e->wwino42_floats = total42;
@@ -809,6 +817,7 @@ static int build_wino_weights(gd_engine *e) {
 }
 
 int gd_engine_set_precision(gd_engine *e, int mode) {
+    OptScope scope(e ? e->opts : nullptr);
     GD_CHECK(e, "null engine");
     GD_CHECK(mode == 0 || mode == 1, "unknown precision mode %d (0 = fp32, 1 = bf16x3)", mode);
     if (!e->plan_only) {
@@ -824,6 +833,7 @@ int gd_engine_set_precision(gd_engine *e, int mode) {
 }
 
 int gd_engine_params_ready(gd_engine *e) {
+    OptScope scope(e ? e->opts : nullptr);
     GD_CHECK(e, "null engine");
     std::string missing;
     int nmiss = 0;
@@ -876,6 +886,7 @@ int gd_engine_packed_weight(gd_engine *e, const char *slot, float *host_out, siz
 
 // ---- score network ----
 int gd_unet_forward(gd_engine *e, const float *x_dev, const float *labels_dev, float *out_dev, int batch, void *stream) {
+    OptScope scope(e ? e->opts : nullptr);
     GD_TRY(check_compute(e, batch));
     GD_CHECK(x_dev && labels_dev && out_dev, "null device pointer");
     hipStream_t s = (hipStream_t)stream;
@@ -887,6 +898,7 @@ int gd_unet_forward(gd_engine *e, const float *x_dev, const float *labels_dev, f
 }
 
 int gd_cld_eps(gd_engine *e, const float *u_dev, const float *t_dev, float *eps_dev, int batch, void *stream) {
+    OptScope scope(e ? e->opts : nullptr);
     GD_TRY(check_compute(e, batch));
     GD_CHECK(u_dev && t_dev && eps_dev, "null device pointer");
     const gd_model_desc &d = e->plan.desc;
@@ -911,6 +923,7 @@ static int upload(float **dst, const float *src, size_t n) {
 
 int gd_engine_set_schedule_cld(gd_engine *e, int num_step, int n_slots, const float *ts_host, const float *coef_host,
                                int denoise, float t_denoise, const float *dn_F, const float *dn_GG, const float *dn_RinvT) {
+    OptScope scope(e ? e->opts : nullptr);
     GD_CHECK(e && !e->plan_only, "engine has no GPU");
     GD_CHECK(num_step >= 0 && n_slots >= 2 && ts_host && coef_host, "bad schedule");
     GD_CHECK(e->plan.desc.in_channels % 2 == 0, "CLD needs an even number of U-Net channels");
@@ -949,6 +962,7 @@ int gd_engine_set_schedule_cld(gd_engine *e, int num_step, int n_slots, const fl
 }
 
 int gd_engine_set_noise_cld(gd_engine *e, const float *pre_lin, const float *pre_noise, const float *post_noise) {
+    OptScope scope(e ? e->opts : nullptr);
     GD_CHECK(e && !e->plan_only, "engine has no GPU");
     GD_CHECK(e->sched_kind == 1, "install the CLD schedule first (gd_engine_set_schedule_cld)");
     GD_CHECK((pre_lin == nullptr) == (pre_noise == nullptr), "pre_lin and pre_noise come together");
@@ -995,6 +1009,7 @@ int gd_randn_pairs(float *out_dev, long long n_pairs, unsigned long long seed, u
 
 int gd_engine_set_transforms_cld(gd_engine *e, const float *pre, const float *eps_lin, const float *u_lin, const float *dn_u_lin,
                                  const float *post) {
+    OptScope scope(e ? e->opts : nullptr);
     GD_CHECK(e && !e->plan_only, "engine has no GPU");
     GD_CHECK(e->sched_kind == 1, "install the CLD schedule first (gd_engine_set_schedule_cld)");
     GD_HIP(hipSetDevice(e->device));
@@ -1050,6 +1065,7 @@ static int split_lanes(gd_engine *e, int batch, bool allow, int *start, int *siz
 
 int gd_sample_cld(gd_engine *e, int batch, const float *u_in_dev, float *x_out_dev, float *v_out_dev, int inverse_scale,
                   int use_graph, void *stream) {
+    OptScope scope(e ? e->opts : nullptr);
     GD_TRY(check_compute(e, batch));
     GD_CHECK(e->sched_kind == 1, "no CLD schedule installed (gd_engine_set_schedule_cld)");
     GD_CHECK(u_in_dev && x_out_dev && v_out_dev, "null device pointer");
@@ -1173,6 +1189,7 @@ int gd_sample_cld(gd_engine *e, int batch, const float *u_in_dev, float *x_out_d
 
 int gd_engine_set_schedule_blur(gd_engine *e, int nfe, const float *ts_host, const float *mean_coef_host,
                                 const float *std_coef_host) {
+    OptScope scope(e ? e->opts : nullptr);
     GD_CHECK(e && !e->plan_only, "engine has no GPU");
     GD_CHECK(nfe >= 1 && ts_host && mean_coef_host && std_coef_host, "bad schedule");
     GD_CHECK(e->plan.desc.image_size == 32, "the blur SDE is hard-wired to 32x32 (blur_jax/sde_lib.py:24)");
@@ -1188,6 +1205,7 @@ int gd_engine_set_schedule_blur(gd_engine *e, int nfe, const float *ts_host, con
 }
 
 int gd_engine_set_schedule_blur_deis(gd_engine *e, int nfe, int n_slots, const float *ts_host, const float *coef_host) {
+    OptScope scope(e ? e->opts : nullptr);
     GD_CHECK(e && !e->plan_only, "engine has no GPU");
     GD_CHECK(nfe >= 1 && n_slots >= 2 && ts_host && coef_host, "bad schedule");
     GD_CHECK(e->plan.desc.image_size == 32, "the blur SDE is hard-wired to 32x32 (blur_jax/sde_lib.py:24)");
@@ -1211,6 +1229,7 @@ int gd_engine_set_schedule_blur_deis(gd_engine *e, int nfe, int n_slots, const f
 }
 
 int gd_engine_set_model2eps_blur(gd_engine *e, const float *rows_host) {
+    OptScope scope(e ? e->opts : nullptr);
     GD_CHECK(e && !e->plan_only, "engine has no GPU");
     GD_CHECK(e->sched_kind == 2 || e->sched_kind == 3, "install a blur schedule first (gd_engine_set_schedule_blur[_deis])");
     GD_HIP(hipSetDevice(e->device));
@@ -1223,6 +1242,7 @@ int gd_engine_set_model2eps_blur(gd_engine *e, const float *rows_host) {
 
 int gd_sample_blur(gd_engine *e, int batch, const float *y_in_dev, float *x_out_dev, int inverse_scale, int use_graph,
                    void *stream) {
+    OptScope scope(e ? e->opts : nullptr);
     GD_TRY(check_compute(e, batch));
     GD_CHECK(e->sched_kind == 2 || e->sched_kind == 3, "no blur schedule installed (gd_engine_set_schedule_blur[_deis])");
     const bool multistep = e->sched_kind == 3;
@@ -1300,6 +1320,7 @@ int gd_sample_blur(gd_engine *e, int batch, const float *y_in_dev, float *x_out_
 
 // ---- profiling ----
 int gd_engine_profile(gd_engine *e, int enable) {
+    OptScope scope(e ? e->opts : nullptr);
     GD_CHECK(e, "null engine");
     e->prof = enable != 0;
     if (enable) {
@@ -1311,6 +1332,7 @@ int gd_engine_profile(gd_engine *e, int enable) {
 }
 
 int gd_engine_profile_read(gd_engine *e, gd_prof_entry *out, int cap, int *n) {
+    OptScope scope(e ? e->opts : nullptr);
     GD_CHECK(e && !e->plan_only, "engine has no GPU");
     GD_HIP(hipSetDevice(e->device));
     GD_HIP(hipDeviceSynchronize());

@@ -517,7 +517,7 @@ bool attn_fused_ok(int N, int C) {
 // workgroups to spread.  GDDIM_ATTN_Q=32 / 64 forces a form (A/B).  Bit-identical outputs.
 static int attn_qblock(int batch) {
     if (opts().attn_q == 32 || opts().attn_q == 64) return opts().attn_q;
-    return 4 * batch >= 256 ? 64 : 32;
+    return 4 * batch >= device_cus() ? 64 : 32;
 }
 const char *attn_fused_name(int batch) { return attn_qblock(batch) == 64 ? "attn256_f32_kernel" : "attn256_q32_f32_kernel"; }
 

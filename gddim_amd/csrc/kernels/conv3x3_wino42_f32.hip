@@ -1150,14 +1150,15 @@ bool conv3x3_wino42_shape_ok(const GemmParams &p) {
 // A persistent launch takes ceil(tiles / CUs) rounds; a 32-output tile costs W42_N32_COST of a 64-output one (measured:
 // profiles/r04_notes.md -- half the products, all of the pixel staging), so the narrow tile wins exactly where the wide one leaves CUs
 // idle: the 8x8 level below a batch of 256, the 16x16 level below 64, every level of a small batch.  GDDIM_WINO42_NW=1 / 2 forces a tile,
-// GDDIM_WINO42_MINBLOCKS is the least number of wide tiles a launch without a narrow alternative (Cin = 32) must have.
+// GDDIM_WINO42_MINBLOCKS is the least number of wide tiles a Cin = 32 launch (the two-chunk form: no narrow alternative) must have; it is not
+// consulted for any other shape.
 constexpr double W42_N32_COST = 0.6;
 static int wino42_nw(const GemmParams &p) {
     if (opts().no_wino42 || !conv3x3_wino42_shape_ok(p)) return 0;
     const long long mt = (p.M / 8 + 31) / 32, t64 = mt * ((p.N + 63) / 64), t32 = mt * ((p.N + 31) / 32);
     if (p.C0 + p.C1 == 32) return t64 >= opts().wino42_min_blocks ? 2 : 0;  // (the two-chunk form has the wide tile only)
     if (opts().wino42_nw == 1 || opts().wino42_nw == 2) return opts().wino42_nw;
-    const long long cus = 256;
+    const long long cus = device_cus();
     const double c64 = (double)((t64 + cus - 1) / cus), c32 = W42_N32_COST * (double)((t32 + cus - 1) / cus);
     return c32 < c64 ? 1 : 2;
 }
@@ -1188,13 +1189,7 @@ int launch_conv3x3_wino42(const GemmParams &p_in, hipStream_t s) {
     } else {
         // persistent: one workgroup per CU (a multiple of 8, so that a workgroup's tiles keep their XCD); GDDIM_WINO42_GRID overrides the
         // workgroup count (tests: a small grid makes every workgroup walk over several tiles)
-        static int cus = 0;
-        if (!cus) {
-            int dev = 0;
-            (void)hipGetDevice(&dev);
-            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-            cus = cus / 8 * 8 > 0 ? cus / 8 * 8 : 8;
-        }
+        const int cus = device_cus() / 8 * 8 > 0 ? device_cus() / 8 * 8 : 8;
         int grid = gx < cus ? gx : cus;
         if (const int g = opts().wino42_grid) {
             if (g > 0 && g < grid) grid = g;

@@ -1063,16 +1063,6 @@ static int pick_ksplit(const GemmParams &p, int batch_z, int bm, int bn) {
 // The persistent short-K kernel (igemm_f32_pers_kernel) takes a launch when it is eligible for the fast path with the 128x128
 // tile, K is short (<= GDDIM_IGEMM_PERS_MAXK, default 1024) and there are more tiles than resident workgroups (2 per CU).
 // GDDIM_IGEMM_NOPERSIST=1 routes everything back to one workgroup per tile (A/B).
-static int device_cus() {
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    }
-    return cus;
-}
-
 static bool pers_ok(const GemmParams &p, int batch_z, int bm, int bn) {
     const int off = opts().igemm_nopersist, maxk = opts().igemm_pers_maxk;
     if (off || bm != 128 || bn != 128 || big_variant() != 0 || !fast_ok(p) || p.b_kmajor || p.KH * p.KW > 32) return false;

@@ -1,12 +1,17 @@
 // The one place the native library reads its environment (options.h).
 #include "options.h"
 
+#include <atomic>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <mutex>
 #include <sstream>
+#include <strings.h>
 
 #include "../../include/gddim_amd.h"
+#include "common.h"
 
 namespace gd {
 namespace {
@@ -53,38 +58,71 @@ const Entry kEntries[] = {
     {"GDDIM_X3_VARIANT", &Options::x3_variant, nullptr},
 };
 
-Options g_opts;
-std::once_flag g_once;
+// every snapshot ever published stays alive (a few hundred bytes each): a reader that picked one up keeps a valid table whatever
+// other threads reload meanwhile
+std::deque<Options> g_history;
+std::mutex g_mutex;
+std::atomic<const Options *> g_current{nullptr};
+thread_local const Options *t_scope = nullptr;
 
-void parse() {
+bool is_boolean(const Entry &e) {  // switches (anything set = on) as opposed to numbers (must parse)
+    static const char *const numeric[] = {"GD_LANES", "GD_PROF_BY_LABEL", "GDDIM_ATTN_Q", "GDDIM_WINO2_KS", "GDDIM_WINO2_MINBLOCKS",
+                                          "GDDIM_WINO42_MINBLOCKS", "GDDIM_WINO42_GRID", "GDDIM_WINO42_NW", "GDDIM_IGEMM_VARIANT",
+                                          "GDDIM_IGEMM_BIGMIN", "GDDIM_IGEMM_MIDMIN", "GDDIM_IGEMM_KS", "GDDIM_IGEMM_PERS_MAXK",
+                                          "GDDIM_IGEMM_DIAG", "GDDIM_X3_FUSE_MAXN", "GDDIM_X3_VARIANT"};
+    for (const char *n : numeric)
+        if (strcmp(n, e.env) == 0) return false;
+    return true;
+}
+
+const Options *parse() {
     Options o;
     if (const char *pm = getenv("GDDIM_PRECISION")) o.precision = strcmp(pm, "bf16x3") == 0 ? 1 : 0;
     for (const Entry &e : kEntries) {
         const char *v = getenv(e.env);
         if (!v) continue;
-        // a variable set to nothing (or to a non-number) switches its entry on: `GDDIM_NO_EGN= cmd` and `GDDIM_NO_EGN=1 cmd` are the same
         char *end = nullptr;
         long long x = strtoll(v, &end, 10);
-        if (end == v) x = 1;
+        if (end == v) {
+            if (is_boolean(e)) {
+                // a switch set to nothing or to a word is on (`GDDIM_NO_EGN= cmd` = `GDDIM_NO_EGN=1 cmd`) -- except the words that say off
+                x = (strcasecmp(v, "off") == 0 || strcasecmp(v, "false") == 0 || strcasecmp(v, "no") == 0) ? 0 : 1;
+            } else {
+                fprintf(stderr, "gddim_amd: %s='%s' is not a number: ignored\n", e.env, v);
+                continue;
+            }
+        }
         if (e.i) o.*(e.i) = (int)x; else o.*(e.ll) = x;
     }
     if (o.lanes < 1) o.lanes = 1;
-    if (o.no_wino) o.no_wino2 = 1;     // the switches nest: no Winograd at all > no two-dimensional forms > no hybrid form
-    if (o.no_wino2) o.no_wino42 = 1;
+    // the switches nest: no Winograd at all > no two-dimensional forms > no hybrid form; a nested variable that is SET keeps its own value
+    if (o.no_wino && !getenv("GDDIM_NOWINO2")) o.no_wino2 = 1;
+    if (o.no_wino2 && !getenv("GDDIM_NOWINO42")) o.no_wino42 = 1;
     if (o.no_wino2 && !getenv("GDDIM_NOWINO2_SPLITK")) o.no_wino2_splitk = 1;
-    g_opts = o;
+    std::lock_guard<std::mutex> lock(g_mutex);
+    g_history.push_back(o);
+    const Options *p = &g_history.back();  // deque: growing never moves its elements
+    g_current.store(p, std::memory_order_release);
+    return p;
 }
 
 }  // namespace
 
-const Options &opts() {
-    std::call_once(g_once, parse);
-    return g_opts;
+const Options *options_snapshot() {
+    const Options *p = g_current.load(std::memory_order_acquire);
+    return p ? p : parse();
 }
 
-void options_reload() {
-    std::call_once(g_once, parse);
-    parse();
+const Options &opts() { return t_scope ? *t_scope : *options_snapshot(); }
+
+void options_reload() { parse(); }
+
+OptScope::OptScope(const Options *o) : prev_(t_scope), set_(o != nullptr) {
+    if (set_) t_scope = o;
+}
+
+OptScope::~OptScope() {
+    if (set_) t_scope = prev_;
 }
 
 std::string options_json() {
@@ -96,6 +134,19 @@ std::string options_json() {
     return s.str();
 }
 
+}  // namespace gd
+
+namespace gd {
+int device_cus() {
+    static std::atomic<int> cached[16] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
+    int c = cached[dev].load(std::memory_order_relaxed);
+    if (c > 0) return c;
+    if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) c = 256;
+    cached[dev].store(c, std::memory_order_relaxed);
+    return c;
+}
 }  // namespace gd
 
 extern "C" int gd_options_reload(void) {

@@ -1,8 +1,13 @@
 // Run-time switches of the native library: ONE table, parsed from the environment in one place.
 //
 // None is needed in normal use; they exist for in-box A/B measurements and for tests that force a kernel a small problem would not
-// select.  The table is parsed when the library first needs it, again at every gd_engine_create (so a process may build engines under
-// different settings) and on gd_options_reload(); gd_engine_plan_json prints the values an engine was built under ("options").
+// select.  The environment is parsed into an IMMUTABLE snapshot when the library first needs it, again at every gd_engine_create and on
+// gd_options_reload(); a new snapshot is published through an atomic pointer, old ones stay valid for whoever still reads them.  An
+// engine keeps the snapshot it was created under for its whole life (gd_engine::opts) and installs it on the calling thread for the
+// duration of each of its calls (OptScope), so every selector and launcher underneath -- they all read opts() -- sees the table the
+// engine's plan, weight copies, cached fusion decisions and captured graphs were made with: engines built under different settings
+// coexist in one process, and a reload never changes a live engine.  Stand-alone operator entry points (gd_conv2d, ...)
+// read the process-wide snapshot.  gd_engine_plan_json prints the engine's own table ("options").
 #pragma once
 #include <string>
 
@@ -27,7 +32,7 @@ struct Options {
     int no_wino2_splitk = 0;    // GDDIM_NOWINO2_SPLITK: 4x4 level back on the direct split-K tile
     int wino2_ks = 0;           // GDDIM_WINO2_KS: forced channel-split factor of the 4x4 level's launch (2, 4, 8)
     int wino2_min_blocks = 256; // GDDIM_WINO2_MINBLOCKS: workgroup tiles a launch must have for the F(2x2,3x3) kernel
-    int wino42_min_blocks = 256;  // GDDIM_WINO42_MINBLOCKS: ... for the hybrid kernel
+    int wino42_min_blocks = 256;  // GDDIM_WINO42_MINBLOCKS: wide tiles a Cin = 32 launch must have for the hybrid kernel's two-chunk form (other shapes: rounds x cost)
     int wino42_grid = 0;        // GDDIM_WINO42_GRID: persistent workgroups per launch (tests: several tiles per workgroup)
     int wino42_nw = 0;          // GDDIM_WINO42_NW: 0 the launcher's choice, 1 / 2 force the 32- / 64-output workgroup tile
     // ---- fp32 implicit GEMM ----
@@ -43,8 +48,21 @@ struct Options {
     int x3_nohalo = 0, x3_nofuse = 0, x3_fuse_maxn = 1 << 30, x3_nopersist = 0, x3_noattn = 0, x3_variant = 0;  // GDDIM_X3_*
 };
 
-const Options &opts();       // the current table
-void options_reload();       // parse the environment again
-std::string options_json();  // {"GDDIM_...": value, ...}: every entry, in the order above
+const Options &opts();               // the table in force on this thread: the running engine call's snapshot, else the process-wide one
+const Options *options_snapshot();   // the process-wide snapshot (immutable, never freed)
+void options_reload();               // parse the environment again and publish a new snapshot
+std::string options_json();          // {"GDDIM_...": value, ...}: every entry of opts(), in the order above
+
+// Installs an engine's snapshot as this thread's opts() for the lifetime of the object (nests; null = leave as is).
+struct OptScope {
+    explicit OptScope(const Options *o);
+    ~OptScope();
+    OptScope(const OptScope &) = delete;
+    OptScope &operator=(const OptScope &) = delete;
+
+private:
+    const Options *prev_;
+    bool set_;
+};
 
 }  // namespace gd

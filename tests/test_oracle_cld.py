@@ -217,6 +217,13 @@ def test_product_honours_x64_false_in_the_references_own_arithmetic(native_lib, 
     o32 = ocld.CLD(is_R_rk=cfg.model.is_R_rk, R_dt=cfg.model.R_dt, dtype=np.float32)
     idx = ocld.jnp_linspace_int(0, o32.R_table.shape[0] - 1, 100_000, dtype=np.float32)
     assert idx[9999] == 99991  # float32 picks a different knot row than exact arithmetic would (99 990)
+    # the product pins its last knot to the table's last row; the literal formula lands there by itself for both scan grids
+    # of the shipped configs (R_dt = 1e-6: 1 000 001 rows, R_dt = 1e-5: 100 000 rows) in both dtypes, so the pin is a no-op where tested
+    for rows in (1_000_001, 100_000):
+        for ft in (np.float32, np.float64):
+            lit = ocld.jnp_linspace_int(0, rows - 1, 100_000, dtype=ft)
+            assert lit[-1] == rows - 1 and np.array_equal(sde_lib.linspace_int(0, rows - 1, 100_000, ft=ft), lit)
+    assert sde_lib.linspace_int(0, 7, 4, ft=np.float32)[-1] == 7
     assert np.array_equal(sde._fp, o32.R_table[idx]) and np.array_equal(sde._xp, o32.R_table_ts[idx])  # the scan, bit for bit
     for t in (1e-3, 0.0123, 0.1, 0.5, 0.99999, 1.0):
         assert np.array_equal(sde.s_R(t), o32.s_R(np.float32(t)))

@@ -285,3 +285,29 @@ def test_written_forms_behind_the_lowering_switches_match_oracle(native_lib, gd_
     if switch == "GDDIM_NO_ATTN_FOLD":
         assert counts[False]["q_proj"] > 0 and counts[False]["proj"] == 0 and counts[True]["qk_proj"] == counts[False]["q_proj"] and counts[True]["proj"] > 0
     assert counts[True]["ops"] != counts[False]["ops"] or switch == "GDDIM_NO_UPSWAP"
+
+
+def test_engines_keep_the_option_table_they_were_created_under(native_lib, gd_env):
+    """the option table used to be one process-wide global that every gd_engine_create / gd_options_reload
+    overwrote, while selectors read it live -- an engine built under one setting ran under the next one's.  Now every engine keeps the
+    immutable snapshot of its creation and installs it for the duration of its calls; a reload (or another engine's creation) never
+    changes a live engine.  Also the parsing rules: a switch set to a word is on unless the word says off; a numeric entry that does not
+    parse is ignored; an explicitly set nested switch wins over its parent."""
+    from gddim_amd.engine import Engine
+    cfg = tiny_config("cld", nf=16, num_res_blocks=1, image_size=16, ch_mult=(1, 2), attn=(8,))
+    gd_env(GDDIM_NO_ATTN_FOLD=None, GDDIM_NO_EGN=None)
+    a = Engine(cfg, 6, max_batch=1, plan_only=True)
+    gd_env(GDDIM_NO_ATTN_FOLD="1", GDDIM_NO_EGN="yes", GDDIM_WINO42_GRID="3")
+    b = Engine(cfg, 6, max_batch=1, plan_only=True)
+    gd_env(GDDIM_NO_ATTN_FOLD=None, GDDIM_NO_EGN="off", GDDIM_WINO42_GRID="junk", GDDIM_IGEMM_BIGMIN="", GDDIM_NOWINO="1", GDDIM_NOWINO42="0")
+    c = Engine(cfg, 6, max_batch=1, plan_only=True)
+    oa, ob, oc = a.plan()["options"], b.plan()["options"], c.plan()["options"]  # read AFTER the later reloads
+    assert (oa["GDDIM_NO_ATTN_FOLD"], oa["GDDIM_NO_EGN"], oa["GDDIM_WINO42_GRID"]) == (0, 0, 0)
+    assert (ob["GDDIM_NO_ATTN_FOLD"], ob["GDDIM_NO_EGN"], ob["GDDIM_WINO42_GRID"]) == (1, 1, 3)
+    assert (oc["GDDIM_NO_ATTN_FOLD"], oc["GDDIM_NO_EGN"], oc["GDDIM_WINO42_GRID"], oc["GDDIM_IGEMM_BIGMIN"]) == (0, 0, 0, 384)
+    assert (oc["GDDIM_NOWINO"], oc["GDDIM_NOWINO2"], oc["GDDIM_NOWINO42"]) == (1, 1, 0)  # the nested variable that is set keeps its value
+    # and the plans differ the way their own tables say
+    la, lb = [op["label"] for op in a.plan()["ops"]], [op["label"] for op in b.plan()["ops"]]
+    assert any(l.endswith(".q_proj") for l in la) and not any(l.endswith(".q_proj") for l in lb)
+    for e in (a, b, c):
+        e.close()
