@@ -240,6 +240,8 @@ def test_cld_64x64_b512_full_size_absolute_parity(native_lib):
     from gddim_amd.configs import cld_accr_dcifar10
     B, distinct, n_ref, nfe, gain = 512, 2, 1, 10, 0.3
     cfg, osde, eps64, lin64, ud, run, model = _cld_case(native_lib, cld_accr_dcifar10, 64, B, distinct, nfe, gain, seed=2)
+    xd, vd, n, runs = _chained_runs("CLD 64x64 NFE=10 B=512", run, B, distinct, n_ref, seed=2)
+    assert n == nfe
     ents = _profile_names(model, 6, B, entries=True)
     names = [p["name"] for p in ents]
     assert any("conv3x3_wino" in k for k in names) and any("igemm_f32_pers_kernel" in k for k in names), names
@@ -250,8 +252,6 @@ def test_cld_64x64_b512_full_size_absolute_parity(native_lib):
     total = sum(p["flops"] for p in ents)
     print("generic-kernel share of the flops at B=512 64x64: %.4f" % (generic / total))
     assert generic < 0.02 * total, [(p["name"], p["flops"]) for p in ents if p["name"].startswith("igemm_f32_kernel<")]
-    xd, vd, n, runs = _chained_runs("CLD 64x64 NFE=10 B=512", run, B, distinct, n_ref, seed=2)
-    assert n == nfe
     # the same noises at B = 32 (other kernels per level): round-off apart, not bits
     x32, v32, _ = run(_layout(32, distinct, 7))
     f32 = _assert_copies_identical("CLD 64x64 NFE=10 B=32", _layout(32, distinct, 7), x32, v32)
