@@ -714,21 +714,22 @@ int conv3x3_wino2d_splitk_factor(const GemmParams &p) {
     const int Cin = p.C0 + p.C1;
     if (Cin % 32 != 0) return 0;
     const long long tiles = (long long)((p.M / 4 + 63) / 64) * ((p.N + 63) / 64);
-    if (tiles >= 256) return 0;  // (cannot happen on 4x4 images below B = 1024; the unsplit kernel does not take 4-wide images)
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    }
-    for (int ks = 8; ks >= 2; ks >>= 1) {
-        if (opts().wino2_ks ? ks != opts().wino2_ks : tiles * ks > cus) continue;  // at most one workgroup per CU (GDDIM_WINO2_KS forces a factor: A/B)
+    const int cus = device_cus();
+    // at most one workgroup per CU where the tiles allow it (GDDIM_WINO2_KS forces a factor: A/B); a launch with as many tiles as CUs or
+    // more (B >= 1024 on 256 CUs: the unsplit F(2x2,3x3) kernel does not take 4-wide images, and the direct kernel ran these layers at
+    // 124 TFLOP/s in round 5's batch sweep) still splits in two and walks its 2 x tiles workgroups in rounds
+    const auto eligible = [&](int ks) {
         GemmParams q = p;
         q.wk_split = ks;
         q.wk_partial = reinterpret_cast<float *>(16);  // (only tested for null)
         q.egn_out = nullptr; q.qstats = nullptr;        // (the main kernel emits neither)
-        if (conv3x3_wino2d_shape_ok(q)) return ks;
+        return conv3x3_wino2d_shape_ok(q);
+    };
+    for (int ks = 8; ks >= 2; ks >>= 1) {
+        if (opts().wino2_ks ? ks != opts().wino2_ks : tiles * ks > cus) continue;
+        if (eligible(ks)) return ks;
     }
+    if (!opts().wino2_ks && tiles * 2 > cus && tiles <= 4LL * cus && eligible(2)) return 2;
     return 0;
 }
 

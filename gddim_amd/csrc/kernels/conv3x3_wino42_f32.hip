@@ -102,6 +102,28 @@ __device__ __forceinline__ w4f32x2 pk_sub(w4f32x2 a, w4f32x2 b) {
         asm("v_pk_fma_f32 %0, %1, " KSTR ", %2 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(b));           \
         return r;                                                                                        \
     }
+#ifdef W42_XSCALAR  // A/B (profiles/r05_notes.md): the x transform on single floats (two VALU instructions where the packed form has one)
+#undef W4_PK_FMA
+__device__ __forceinline__ w4f32x2 pk_add_s(w4f32x2 a, w4f32x2 b) {
+    w4f32x2 r;
+    asm("v_add_f32 %0, %2, %4\n\tv_add_f32 %1, %3, %5" : "=&v"(r.x), "=&v"(r.y) : "v"(a.x), "v"(a.y), "v"(b.x), "v"(b.y));
+    return r;
+}
+__device__ __forceinline__ w4f32x2 pk_sub_s(w4f32x2 a, w4f32x2 b) {
+    w4f32x2 r;
+    asm("v_sub_f32 %0, %2, %4\n\tv_sub_f32 %1, %3, %5" : "=&v"(r.x), "=&v"(r.y) : "v"(a.x), "v"(a.y), "v"(b.x), "v"(b.y));
+    return r;
+}
+#define pk_add pk_add_s
+#define pk_sub pk_sub_s
+#define W4_PK_FMA(NAME, KSTR)                                                                            \
+    __device__ __forceinline__ w4f32x2 NAME(w4f32x2 a, w4f32x2 b) {                                      \
+        w4f32x2 r;                                                                                       \
+        asm("v_fma_f32 %0, %2, " KSTR ", %4\n\tv_fma_f32 %1, %3, " KSTR ", %5"                           \
+            : "=&v"(r.x), "=&v"(r.y) : "v"(a.x), "v"(a.y), "v"(b.x), "v"(b.y));                           \
+        return r;                                                                                        \
+    }
+#endif
 W4_PK_FMA(pk_fma_p2, "2.0")
 W4_PK_FMA(pk_fma_m2, "-2.0")
 W4_PK_FMA(pk_fma_p4, "4.0")

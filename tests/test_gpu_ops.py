@@ -158,6 +158,7 @@ WINO2D_CASES = [
     (64, 4, 4, 256, 256, True, True),     # 4x4 images: the channel range split over 8 workgroups per tile + the finishing pass
     (7, 4, 4, 64, 36, True, True),        # ... 28 quads (a ragged tile, a unit that is half past the batch), two splits of four chunks, ragged N
     (256, 4, 4, 128, 64, False, False),   # ... 16 tiles x 1 N tile, four splits of four chunks
+    (1024, 4, 4, 256, 256, True, True),   # ... B = 1024 (run_lib's eval.batch_size on one GPU): 256 tiles = one per CU already; two splits walked in rounds (round 5)
 ]
 
 
