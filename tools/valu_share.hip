@@ -70,6 +70,7 @@ __global__ __launch_bounds__(512, 2) void skeleton(float *out, unsigned long lon
             for (int k = 0; k < 4; ++k) { av[k] *= 0.5f; pv[k] *= 0.5f; }
         }
     }
+    __syncthreads();  // (the older wave of a SIMD wins the arbitration and would finish early: the stamp is taken when all eight are done)
     if (threadIdx.x == 0) {
         stamps[blockIdx.x * 2] = __builtin_readcyclecounter() - c0;
         stamps[blockIdx.x * 2 + 1] = wall_clock64() - w0;
