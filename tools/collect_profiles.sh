@@ -5,7 +5,7 @@
 # `python tools/update_profiles.py r0<N>` copies them to profiles/.
 set -u
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
-ROUND=${1:-4}
+ROUND=${1:-5}
 OUT=$REPO/gpurun_out/prof$ROUND
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
@@ -50,6 +50,6 @@ for g in none step loop; do
     $PY --batch 16 --nfe 10 --steps 20 --warmup 3 --graph $g --no-alt --no-cpu-baseline --no-profile 2>/dev/null | tail -1 > $OUT/small_b16_nfe10_graph_$g.json
 done
 # ---- the batch-size curve (per-level kernels) and the full-size parity checks with their printed errors
-python $REPO/tools/batch_sweep.py --out $OUT/batch_sweep.json > $OUT/batch_sweep.log 2>&1
+python $REPO/tools/batch_sweep.py --batches 16,32,64,128,192,256,320,512,1024 --out $OUT/batch_sweep.json > $OUT/batch_sweep.log 2>&1
 (cd $REPO && python -m pytest tests/test_gpu_parity_abs.py -m gpu -q -s 2>&1 | grep -a -E "max\|dx\||passed|failed|share of the flops" > $OUT/parity_abs_tests.log)
 find $OUT -type f -size +3M -delete 2>/dev/null; du -sh $OUT; ls $OUT
