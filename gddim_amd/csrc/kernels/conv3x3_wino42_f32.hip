@@ -80,6 +80,9 @@ __device__ __forceinline__ w4f32x4 w4_load16(__amdgpu_buffer_rsrc_t rsrc, int vo
 #ifndef W42_PX_AUX
 #define W42_PX_AUX 0  // ... of the pixel loads
 #endif
+#ifndef W42_OUT_AUX
+#define W42_OUT_AUX 0  // ... of the persistent form's output stores and residual loads (A/B, round 5: 2 = nt, streaming)
+#endif
 #ifndef W42_PRIO
 #define W42_PRIO 0    // 1: s_setprio 1 for the second-dispatched half of the workgroup (waves 4-7) before the main loop
 #endif
@@ -586,6 +589,22 @@ __device__ __forceinline__ void wino42_persistent(const GemmParams &p, float *sm
 
     // ---- virtual block id -> (mtile, ntile), XCD-aware as in the one-tile form (gridDim.x is a multiple of 8 or the whole tile count) ----
     const int nt = p.n_tiles;
+#ifdef W42_XCDMAP  // A/B (profiles/r05_notes.md): FOUR consecutive M tiles share an XCD (ids congruent mod 8) -- the M tiles of a 32x32 image, whose
+                   // neighbours read each other's halo rows (2 of the 10 pixel rows a tile reads) -- instead of one; groups of 32 M tiles
+    const int nvb = p.flat_tiles ? p.m_tiles * nt : ((p.m_tiles + 31) / 32) * 32 * nt;
+    auto decode = [&](int vb, int &mt, int &ntl) __attribute__((always_inline)) {
+        if (p.flat_tiles) {
+            mt = vb / nt;
+            ntl = vb - mt * nt;
+        } else {
+            const int grp = vb / (32 * nt);
+            const int rem = vb - grp * 32 * nt;
+            ntl = rem >> 5;
+            const int l = rem & 31;                      // id inside the group: XCD = l & 7
+            mt = grp * 32 + (l & 7) * 4 + (l >> 3);      // M tiles 4 x .. 4 x + 3 get ids x, x + 8, x + 16, x + 24
+        }
+    };
+#else
     const int nvb = p.flat_tiles ? p.m_tiles * nt : ((p.m_tiles + 7) / 8) * 8 * nt;
     auto decode = [&](int vb, int &mt, int &ntl) __attribute__((always_inline)) {
         if (p.flat_tiles) {
@@ -598,6 +617,7 @@ __device__ __forceinline__ void wino42_persistent(const GemmParams &p, float *sm
             mt = grp * 8 + (rem & 7);
         }
     };
+#endif
     // the first valid tile at or after vb (stride gridDim.x); vb >= nvb: none
     auto next_valid = [&](int vb, int &mt, int &ntl) __attribute__((always_inline)) {
         while (vb < nvb) {
@@ -818,7 +838,7 @@ __device__ __forceinline__ void wino42_persistent(const GemmParams &p, float *sm
     const bool has_res = p.res != nullptr;
     auto load_res = [&](int idx) __attribute__((always_inline)) {  // idx = (a * 4 + b) * 4 + vv
         const int a = idx >> 4, b = (idx >> 2) & 3, vv = idx & 3;
-        rs[a][b][vv] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_r, vo_r, pix_off(vv, a, b) * p.ldres * 4, 0));
+        rs[a][b][vv] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srd_r, vo_r, pix_off(vv, a, b) * p.ldres * 4, W42_OUT_AUX));
     };
 
     // ---- one 16-channel chunk: 48 MFMAs per wave between barriers, in 24 gaps of two.  Every chunk stages the chunk after it (registers
@@ -1008,7 +1028,7 @@ __device__ __forceinline__ void wino42_persistent(const GemmParams &p, float *sm
                         const float val = (p.alpha * y[a][b][vv] + add) * p.out_scale;
                         vals[a][b][vv] = val;
                         if (!p.egn_skip_raw)
-                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), srd_o, vo_o, pix_off(vv, a, b) * p.ldc * 4, 0);
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), srd_o, vo_o, pix_off(vv, a, b) * p.ldc * 4, W42_OUT_AUX);
                         ps[a] += val;
                         pq[a] += val * val;
                     }
@@ -1046,7 +1066,7 @@ __device__ __forceinline__ void wino42_persistent(const GemmParams &p, float *sm
                         for (int vv = 0; vv < 4; ++vv) {
                             float t = vals[a][b][vv] * sc + sh;
                             if (p.egn_act) t = swish_e(t);
-                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, t), srd_g, vo_o, pix_off(vv, a, b) * p.ldc * 4, 0);
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, t), srd_g, vo_o, pix_off(vv, a, b) * p.ldc * 4, W42_OUT_AUX);
                         }
             }
             if (p.qstats) {
@@ -1205,7 +1225,12 @@ int launch_conv3x3_wino42(const GemmParams &p_in, hipStream_t s) {
     p.m_tiles = (p.M / 8 + 31) / 32;
     p.n_tiles = (p.N + 32 * nw - 1) / (32 * nw);
     p.flat_tiles = p.m_tiles < 16;
+#ifdef W42_XCDMAP
+    const int gx = (p.flat_tiles || p.C0 + p.C1 == 32) ? (p.flat_tiles ? p.m_tiles * p.n_tiles : ((p.m_tiles + 7) / 8) * 8 * p.n_tiles)
+                                                        : ((p.m_tiles + 31) / 32) * 32 * p.n_tiles;
+#else
     const int gx = p.flat_tiles ? p.m_tiles * p.n_tiles : ((p.m_tiles + 7) / 8) * 8 * p.n_tiles;
+#endif
     if (p.C0 + p.C1 == 32) {
         hipLaunchKernelGGL(conv3x3_wino42_k32_f32_kernel, dim3(gx), dim3(512), 0, s, p);
     } else {

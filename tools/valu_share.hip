@@ -15,7 +15,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-enum Kind { NONE = 0, FMA = 1, ADD = 2, DPP = 3, PKFMA = 4, PKADD = 5, MOV = 6, LDSR = 7, LDSW = 8 };
+enum Kind { NONE = 0, FMA = 1, ADD = 2, DPP = 3, PKFMA = 4, PKADD = 5, MOV = 6, LDSR = 7, LDSW = 8, EXP = 9, RCP = 10, PKMUL = 11 };
 
 // (four independent destination registers in rotation: throughput, not the 4-cycle dependent latency or the DPP read-after-write hazard)
 template <int KIND>
@@ -26,6 +26,9 @@ __device__ __forceinline__ void valu(float &a, float &b, f32x2 &p, f32x2 &q, flo
     if (KIND == PKFMA) asm volatile("v_pk_fma_f32 %0, %0, 2.0, %1 op_sel_hi:[1,0,1]" : "+v"(p) : "v"(q));
     if (KIND == PKADD) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p) : "v"(q));
     if (KIND == MOV) asm volatile("v_mov_b32 %0, %1" : "+v"(a) : "v"(b));
+    if (KIND == EXP) asm volatile("v_exp_f32 %0, %1" : "+v"(a) : "v"(b));
+    if (KIND == RCP) asm volatile("v_rcp_f32 %0, %1" : "+v"(a) : "v"(b));
+    if (KIND == PKMUL) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p) : "v"(q));
     if (KIND == LDSR) {
         typedef float f32x4 __attribute__((ext_vector_type(4)));
         f32x4 v = *reinterpret_cast<volatile f32x4 *>(lds + lane * 4);
@@ -131,6 +134,10 @@ int main() {
     run<PKFMA, 2>("v_pk_fma_f32", out, stamps, g_base);
     run<PKADD, 1>("v_pk_add_f32", out, stamps, g_base);
     run<PKADD, 2>("v_pk_add_f32", out, stamps, g_base);
+    run<EXP, 1>("v_exp_f32", out, stamps, g_base);
+    run<EXP, 2>("v_exp_f32", out, stamps, g_base);
+    run<RCP, 2>("v_rcp_f32", out, stamps, g_base);
+    run<PKMUL, 2>("v_pk_mul_f32", out, stamps, g_base);
     run<LDSR, 1>("ds_read_b128", out, stamps, g_base);
     run<LDSW, 1>("ds_write_b64", out, stamps, g_base);
     return 0;
