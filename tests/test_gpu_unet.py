@@ -258,3 +258,34 @@ def test_3x3_levels_stay_on_the_hybrid_kernel_across_batch_sizes(native_lib, gd_
             assert max(got, key=got.get) == kern, (B, H, got)
         assert seen.get(4) == {"conv3x3_wino2d_splitk_f32_kernel": counts[4]}, (B, seen.get(4))
     eng.close()
+
+
+def test_groupnorm_side_output_matches_standalone_pass(native_lib, gd_env):
+    """The up-path blocks' first GroupNorm (+ swish) is written by the shortcut convolution's loader (`igemm_f32_pers_kernel<...>+gn`,
+    Op::side_peer) at batches where that launch is persistent.  Round 5 spread the side output over the N tiles of a launch (chunk k by
+    N tile k mod n_tiles) and moved its arithmetic to packed fp32: the same operations with the same roundings, so the network output
+    must equal -- to fp32 round-off of the whole network, in practice bit for bit -- the engine built with GDDIM_NO_SIDE_GN=1, where
+    `gn_apply_kernel` does it.  Two engines under two option snapshots in one process (csrc/options.h)."""
+    from gddim_amd.configs import cld_accr_dcifar10
+    from gddim_amd.engine import Engine
+    cfg = cld_accr_dcifar10.get_config()
+    params = onet.random_params(cfg, 6, seed=9)
+    rng = np.random.default_rng(10)
+    B = 128
+    x = torch.as_tensor(rng.standard_normal((B, 32, 32, 6)).astype(np.float32), device="cuda:0")
+    lab = torch.as_tensor((rng.uniform(1e-3, 1, B) * 999).astype(np.float32), device="cuda:0")
+    outs, names = {}, {}
+    for tag, off in (("side", None), ("standalone", "1")):
+        gd_env(GDDIM_NO_SIDE_GN=off)
+        eng = Engine(cfg, 6, max_batch=B, device=0)
+        eng.load_params(params)
+        eng.profile(True)
+        outs[tag] = eng.unet(x, lab).cpu().numpy()
+        names[tag] = [p["name"] for p in eng.profile_read()]
+        eng.profile(False)
+        eng.close()
+    assert any(n.endswith("+gn") for n in names["side"]) and not any(n.endswith("+gn") for n in names["standalone"]), names["side"]
+    scale = np.abs(outs["standalone"]).max()
+    err = np.abs(outs["side"] - outs["standalone"]).max() / scale
+    print("GroupNorm side output vs stand-alone pass: rel max|d| %.3e, bit-identical: %s" % (err, np.array_equal(outs["side"], outs["standalone"])))
+    assert np.isfinite(outs["side"]).all() and err < 2e-6, err
