@@ -45,29 +45,6 @@ constexpr int LDT = 36;  // LDS row stride (floats): 32 + 4 pad -> 144 B, odd mu
 
 __device__ __forceinline__ float swish_f(float x) { return swish_e(x); }
 
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-typedef float f32x4_t __attribute__((ext_vector_type(4)));
-// swish(x * sc + sh) on four channels in packed fp32: t = fma(x, sc, sh); m = t * -log2(e); e = 2^m; d = 1 + e; y = t * (1 / d)
-__device__ __forceinline__ f32x4_t gn_swish4_pk(f32x4_t x, f32x4_t sc, f32x4_t sh) {
-    f32x4_t y;
-    const f32x2_t nl2e = {-1.4426950408889634f, -1.4426950408889634f};  // (an aligned SGPR pair: packed operands are 64 bits wide)
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        f32x2_t xx = {x[2 * h], x[2 * h + 1]}, ss = {sc[2 * h], sc[2 * h + 1]}, hh = {sh[2 * h], sh[2 * h + 1]}, t, m, d, r;
-        asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(t) : "v"(xx), "v"(ss), "v"(hh));
-        asm("v_pk_mul_f32 %0, %1, %2" : "=v"(m) : "v"(t), "s"(nl2e));
-        m.x = __builtin_amdgcn_exp2f(m.x);
-        m.y = __builtin_amdgcn_exp2f(m.y);
-        asm("v_pk_add_f32 %0, %1, 1.0 op_sel_hi:[1,0]" : "=v"(d) : "v"(m));
-        r.x = __builtin_amdgcn_rcpf(d.x);
-        r.y = __builtin_amdgcn_rcpf(d.y);
-        asm("v_pk_mul_f32 %0, %1, %2" : "=v"(m) : "v"(t), "v"(r));
-        y[2 * h] = m.x;
-        y[2 * h + 1] = m.y;
-    }
-    return y;
-}
-
 // BM x BN block tile, WM x WN wave grid (64*WM*WN threads), DB: double-buffered LDS (one barrier per K chunk)
 // BM x BN block tile, WM x WN wave grid (64*WM*WN threads).
 //
@@ -868,11 +845,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_pers_kernel(const Gemm
     // when the chunk is staged) instead of being fetched at staging time, where the wave sat out its L2 round trip; a 128-row tile lies
     // inside one image when rows_per_image is a multiple of 128 (igemm_gn_side_ok), so one pair serves both of the thread's rows
     f32x4 tsc = {0.f, 0.f, 0.f, 0.f}, tsh = {0.f, 0.f, 0.f, 0.f};
-    // The N tiles of an M tile stage the same A elements; each CHUNK's side output is written by ONE of them: chunk k by N tile k mod
-    // n_tiles (round 5: with ntile == 0 writing all of them, and a workgroup's N tile fixed for the whole walk, half the workgroups of an
-    // N = 256 launch carried all of the normalisation's VALU work -- 54 cycles of the SIMD's pipe per 64 values -- and the rest waited).
-    const bool side_any = p.gn_side_out != nullptr;
-    auto side_mine = [&](int c0) __attribute__((always_inline)) { return nt == 1 || ((c0 / KC) % nt) == ntile; };
+    const bool side_any = p.gn_side_out != nullptr && ntile == 0;
     auto load_piece = [&](int pc) __attribute__((always_inline)) {
         if (pc < AJ) {
             const int j = pc;
@@ -884,7 +857,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_pers_kernel(const Gemm
                 const int soff = ((s_ty * p.W + s_tx) * p.lda1 + (s_c0 - p.C0)) * 4;
                 ra[j] = buf_load16(srd_a1, rb1[j] | (bad & OOB), soff);
             }
-            if (side_any && pc == AJ - 1 && ld_m0 >= 0 && side_mine(s_c0)) {
+            if (side_any && pc == AJ - 1 && ld_m0 >= 0) {
                 const unsigned img = fast_div((unsigned)ld_m0, (unsigned)p.rows_per_image, p.mg_rpi, p.sh_rpi);
                 const float *tb = p.gn_table + (size_t)img * 2 * Cin + s_c0 + kcol;
                 tsc = *reinterpret_cast<const f32x4 *>(tb);
@@ -895,18 +868,21 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_pers_kernel(const Gemm
             rb[j] = buf_load16(srd_b, bvo[j], (s_tap * Cin + s_c0) * 4);
         }
     };
-    const bool side = p.gn_side_out != nullptr;
+    const bool side = p.gn_side_out != nullptr && ntile == 0;  // (every N tile stages the same A elements: the first one writes them)
     auto store_piece = [&](int pc, float *st) __attribute__((always_inline)) {
         if (pc < AJ) {
             *reinterpret_cast<f32x4 *>(&st[(arow + RPP * pc) * LDT + kcol]) = ra[pc];
-            if (side && side_mine(st_c0)) {  // the GroupNorm (+ swish) of the raw element, as gn_apply_kernel computes it
+            if (side) {  // the GroupNorm (+ swish) of the raw element, as gn_apply_kernel computes it
                 const int m = st_m0 + arow + RPP * pc;
                 if (st_m0 >= 0 && m < p.M) {
                     const int c = st_c0 + kcol;
-                    // (packed fp32 where the hardware has it -- the affine map, the scale of the exponent, 1 + e, t * r: four instructions
-                    // per channel pair instead of eight; every VALU instruction here costs the matrix pipe 8 cycles, the two
-                    // transcendentals 12 each: profiles/r05_valu_share.log.  Same operations, same roundings as the scalar form.)
-                    const f32x4 y = p.gn_act ? gn_swish4_pk(ra[pc], tsc, tsh) : ra[pc] * tsc + tsh;
+                    const f32x4 sc = tsc, sh = tsh;
+                    f32x4 y;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float t = ra[pc][i] * sc[i] + sh[i];
+                        y[i] = p.gn_act ? swish_e(t) : t;
+                    }
                     *reinterpret_cast<f32x4 *>(p.gn_side_out + (size_t)m * Cin + c) = y;
                 }
             }

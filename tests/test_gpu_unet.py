@@ -262,10 +262,11 @@ def test_3x3_levels_stay_on_the_hybrid_kernel_across_batch_sizes(native_lib, gd_
 
 def test_groupnorm_side_output_matches_standalone_pass(native_lib, gd_env):
     """The up-path blocks' first GroupNorm (+ swish) is written by the shortcut convolution's loader (`igemm_f32_pers_kernel<...>+gn`,
-    Op::side_peer) at batches where that launch is persistent.  Round 5 spread the side output over the N tiles of a launch (chunk k by
-    N tile k mod n_tiles) and moved its arithmetic to packed fp32: the same operations with the same roundings, so the network output
-    must equal -- to fp32 round-off of the whole network, in practice bit for bit -- the engine built with GDDIM_NO_SIDE_GN=1, where
-    `gn_apply_kernel` does it.  Two engines under two option snapshots in one process (csrc/options.h)."""
+    Op::side_peer) at batches where that launch is persistent: the same operations with the same roundings as `gn_apply_kernel`, so the
+    network output must equal -- to fp32 round-off of the whole network, in practice bit for bit -- the engine built with
+    GDDIM_NO_SIDE_GN=1, where the stand-alone pass does it.  Two engines under two option snapshots in one process (csrc/options.h).
+    (Round 5 tried the side output spread over the N tiles and in packed fp32: no time gained, and a hand-written packed multiply right
+    behind a v_rcp read a stale register -- this test and the batch sweep above caught it at the first batch on this path.)"""
     from gddim_amd.configs import cld_accr_dcifar10
     from gddim_amd.engine import Engine
     cfg = cld_accr_dcifar10.get_config()
