@@ -19,6 +19,10 @@
 #include "../common.h"
 #include "../options.h"
 
+#ifndef AT_OUT_NT
+#define AT_OUT_NT 0  // nontemporal output stores (A/B, round 5)
+#endif
+
 namespace gd {
 
 typedef float af32x16 __attribute__((ext_vector_type(16)));
@@ -261,7 +265,8 @@ __global__ __launch_bounds__(512, 2) void attn256_f32_kernel(const AttnParams p)
             float val = acc[c][v] + bv;
             if (p.res) val += rv[c][v];
             val *= p.out_scale;
-            p.out[((size_t)img * AT_N + q0 + row) * p.ld_o + col] = val;
+            if (AT_OUT_NT) __builtin_nontemporal_store(val, &p.out[((size_t)img * AT_N + q0 + row) * p.ld_o + col]);
+            else p.out[((size_t)img * AT_N + q0 + row) * p.ld_o + col] = val;
             s += val;
             q += val * val;
         }
@@ -493,7 +498,8 @@ __global__ __launch_bounds__(256, 2) void attn256_q32_f32_kernel(const AttnParam
             float val = acc[c][v] + bv;
             if (p.res) val += rv[c][v];
             val *= p.out_scale;
-            p.out[((size_t)img * AT_N + q0 + row) * p.ld_o + col] = val;
+            if (AT_OUT_NT) __builtin_nontemporal_store(val, &p.out[((size_t)img * AT_N + q0 + row) * p.ld_o + col]);
+            else p.out[((size_t)img * AT_N + q0 + row) * p.ld_o + col] = val;
             s += val;
             q += val * val;
         }

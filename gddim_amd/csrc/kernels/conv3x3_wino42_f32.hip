@@ -81,7 +81,10 @@ __device__ __forceinline__ w4f32x4 w4_load16(__amdgpu_buffer_rsrc_t rsrc, int vo
 #define W42_PX_AUX 0  // ... of the pixel loads
 #endif
 #ifndef W42_OUT_AUX
-#define W42_OUT_AUX 0  // ... of the persistent form's output stores and residual loads (A/B, round 5: 2 = nt, streaming)
+#define W42_OUT_AUX 2  // ... of the persistent form's output stores and residual loads: nt (streaming).  Round 5, three alternating repetitions in
+                       // one box: 139.95 -> 140.46 images/s (+0.35 %), this kernel 228.4 -> 227.3 us per launch and the gn_apply passes that
+                       // read its output 94.7 -> 92.2 ms per step -- the 64 KB a tile writes and the residual it reads once no longer push
+                       // weight fragments and pixels out of the XCD's L2 (profiles/r05_notes.md).  0 = the default policy (A/B)
 #endif
 #ifndef W42_PRIO
 #define W42_PRIO 0    // 1: s_setprio 1 for the second-dispatched half of the workgroup (waves 4-7) before the main loop

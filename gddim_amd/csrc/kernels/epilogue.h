@@ -3,6 +3,9 @@
 // rows >= M fall outside the descriptor (dropped by the bounds check), columns >= N are pushed out of bounds once.  Adds bias, the
 // per-image bias row (rows_per_image is a multiple of 8), the residual, scales, stores, and emits the fused GroupNorm statistics.
 #pragma once
+#ifndef GD_EPI_AUX
+#define GD_EPI_AUX 0  // cache policy of the shared GEMM epilogue's output stores (A/B, round 5: 2 = nt)
+#endif
 #include "../common.h"
 #include "qstats.h"
 
@@ -80,7 +83,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmParams &p, const epi_f32
                 vals[v] = val;
                 if (no_store) { asm volatile("" ::"v"(val)); continue; }
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), srd_o, vo_o,
-                                                      (mrow + (v & 3) + 8 * (v >> 2)) * p.ldc * 4, 0);
+                                                      (mrow + (v & 3) + 8 * (v >> 2)) * p.ldc * 4, GD_EPI_AUX);
             }
             if (p.qstats) {
                 if (!nok || mrow + 32 > p.M) {

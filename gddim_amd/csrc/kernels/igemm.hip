@@ -44,6 +44,10 @@ constexpr int KC = 32;   // K chunk
 constexpr int LDT = 36;  // LDS row stride (floats): 32 + 4 pad -> 144 B, odd multiple of 16 B
 
 __device__ __forceinline__ float swish_f(float x) { return swish_e(x); }
+#ifndef IGEMM_OUT_AUX
+#define IGEMM_OUT_AUX 2  // cache policy of the persistent kernel's output / GroupNorm side-output stores: nt (streaming).  Round 5, three alternating
+                         // repetitions in one box: 138.11 -> 138.63 images/s (+0.4 %), the persistent launches 243.7 -> 241.8 ms per step (0 = default policy, A/B)
+#endif
 
 // BM x BN block tile, WM x WN wave grid (64*WM*WN threads), DB: double-buffered LDS (one barrier per K chunk)
 // BM x BN block tile, WM x WN wave grid (64*WM*WN threads).
@@ -883,7 +887,8 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_pers_kernel(const Gemm
                         const float t = ra[pc][i] * sc[i] + sh[i];
                         y[i] = p.gn_act ? swish_e(t) : t;
                     }
-                    *reinterpret_cast<f32x4 *>(p.gn_side_out + (size_t)m * Cin + c) = y;
+                    if (IGEMM_OUT_AUX & 2) __builtin_nontemporal_store(y, reinterpret_cast<f32x4 *>(p.gn_side_out + (size_t)m * Cin + c));
+                    else *reinterpret_cast<f32x4 *>(p.gn_side_out + (size_t)m * Cin + c) = y;
                 }
             }
         } else {
@@ -1005,7 +1010,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_pers_kernel(const Gemm
                         const float val = (p.alpha * acc[r][c][v] + addv[v]) * p.out_scale;
                         vals[v] = val;
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), srd_o, vo_o,
-                                                              (mrow + (v & 3) + 8 * (v >> 2)) * p.ldc * 4, 0);
+                                                              (mrow + (v & 3) + 8 * (v >> 2)) * p.ldc * 4, IGEMM_OUT_AUX);
                     }
                     if (p.qstats) {
                         if (!nok || mrow + 32 > p.M) {
