@@ -182,7 +182,7 @@ def main():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the secondary bf16x3 measurement")
     ap.add_argument("--cpu-batch", type=int, default=16)
-    ap.add_argument("--cpu-nfe", type=int, default=10)
+    ap.add_argument("--cpu-nfe", type=int, default=20, help="network evaluations per image of the CPU sample (batch 16 x 20 evaluations: 10-15 s on 16 threads)")
     ap.add_argument("--dry-run", action="store_true", help="CPU / gloo plumbing check of the N-rank harness (no sampler, no GPU)")
     args = ap.parse_args()
 
