@@ -85,6 +85,80 @@ __global__ __launch_bounds__(512, 2) void skeleton(float *out, unsigned long lon
     out[blockIdx.x * 512 + threadIdx.x] = s;
 }
 
+// The same skeleton on the bf16 matrix core (v_mfma_f32_32x32x16_bf16: 32 cycles per SIMD each, 96 x 32 = 3 072 per chunk): does a VALU
+// instruction cost matrix time THERE?  (What a Winograd-domain kernel on split bf16 operands would have to hide: profiles/r05_notes.md.)
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+template <int KIND, int PER_GAP>
+__global__ __launch_bounds__(512, 2) void skeleton_bf16(float *out, unsigned long long *stamps, int chunks) {
+    __shared__ float lds[16384];
+    f32x16 acc[6] = {};
+    const int lane = threadIdx.x & 63;
+    unsigned h = threadIdx.x * 2654435761u + blockIdx.x * 40503u + 12345u;
+    bf16x8 t[8];
+    float tf[8];
+    for (int i = 0; i < 8; ++i) {
+        for (int j = 0; j < 8; ++j) { h = h * 1664525u + 1013904223u; t[i][j] = (__bf16)(((int)(h >> 8) - (1 << 23)) * (1.0f / (1 << 23))); }
+        tf[i] = (float)t[i][0];
+    }
+    float av[4] = {tf[0], tf[1], tf[6], tf[7]}, b = tf[1] * 1e-3f;
+    f32x2 pv[4] = {{tf[2], tf[3]}, {tf[3], tf[4]}, {tf[4], tf[5]}, {tf[5], tf[6]}}, q = {tf[4] * 1e-3f, tf[5] * 1e-3f};
+    lds[threadIdx.x] = av[0];
+    __syncthreads();
+    unsigned long long c0 = 0, w0 = 0;
+    if (threadIdx.x == 0) { c0 = __builtin_readcyclecounter(); w0 = wall_clock64(); }
+    for (int c = 0; c < chunks; ++c) {
+#pragma unroll
+        for (int jp = 0; jp < 3; ++jp)
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                acc[2 * jp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t[g], t[(g + 1) & 7], acc[2 * jp], 0, 0, 0);
+                acc[2 * jp + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t[(g + 2) & 7], t[(g + 3) & 7], acc[2 * jp + 1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < PER_GAP; ++k) {
+                    const int r = (g * PER_GAP + k) & 3;
+                    valu<KIND>(av[r], b, pv[r], q, lds + (threadIdx.x >> 6) * 1024, lane);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        if ((c & 255) == 255) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) acc[k] *= 0.5f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { av[k] *= 0.5f; pv[k] *= 0.5f; }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        stamps[blockIdx.x * 2] = __builtin_readcyclecounter() - c0;
+        stamps[blockIdx.x * 2 + 1] = wall_clock64() - w0;
+    }
+    float s = 0.f;
+    for (int k = 0; k < 4; ++k) s += av[k] + pv[k].x + pv[k].y;
+    for (int k = 0; k < 6; ++k)
+        for (int v = 0; v < 16; ++v) s += acc[k][v];
+    out[blockIdx.x * 512 + threadIdx.x] = s;
+}
+
+template <int KIND, int PER_GAP>
+static double run_bf16(const char *name, float *out, unsigned long long *stamps, double base_cycles) {
+    const int blocks = 256, chunks = 40000;
+    hipLaunchKernelGGL((skeleton_bf16<KIND, PER_GAP>), dim3(blocks), dim3(512), 0, 0, out, stamps, 2000);
+    hipLaunchKernelGGL((skeleton_bf16<KIND, PER_GAP>), dim3(blocks), dim3(512), 0, 0, out, stamps, chunks);
+    hipDeviceSynchronize();
+    std::vector<unsigned long long> h(blocks * 2);
+    hipMemcpy(h.data(), stamps, blocks * 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    double cyc = 0, wall = 0;
+    for (int i = 0; i < blocks; ++i) { cyc += (double)h[2 * i]; wall += (double)h[2 * i + 1]; }
+    cyc /= blocks; wall /= blocks;
+    const double per_chunk = cyc / chunks;
+    const int nv = 24 * PER_GAP * 2;
+    printf("bf16 MFMA + %-22s %3d per gap: %8.0f cycles per chunk per SIMD (96 x 32 = 3072), %.3f GHz", name, PER_GAP, per_chunk, cyc / (wall * 10.0));
+    if (base_cycles > 0 && nv > 0) printf("   -> %.2f cycles per instruction", (per_chunk - base_cycles) / nv);
+    printf("\n");
+    return per_chunk;
+}
+
 template <int KIND, int PER_GAP>
 static void run(const char *name, float *out, unsigned long long *stamps, double base_cycles) {
     const int blocks = 256, chunks = 20000;
@@ -139,6 +213,14 @@ int main() {
     run<RCP, 2>("v_rcp_f32", out, stamps, g_base);
     run<PKMUL, 2>("v_pk_mul_f32", out, stamps, g_base);
     run<LDSR, 1>("ds_read_b128", out, stamps, g_base);
+    {
+        const double b16 = run_bf16<NONE, 0>("nothing", out, stamps, 0);
+        run_bf16<FMA, 2>("v_fma_f32", out, stamps, b16);
+        run_bf16<FMA, 4>("v_fma_f32", out, stamps, b16);
+        run_bf16<FMA, 8>("v_fma_f32", out, stamps, b16);
+        run_bf16<PKFMA, 4>("v_pk_fma_f32", out, stamps, b16);
+        run_bf16<EXP, 2>("v_exp_f32", out, stamps, b16);
+    }
     run<LDSW, 1>("ds_write_b64", out, stamps, g_base);
     return 0;
 }
