@@ -749,6 +749,11 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_pers_kernel(const Gemm
     while (id < total_ids && !tile_of(id, z_ld, mt_ld, ntile)) id += (int)gridDim.x;
     if (id >= total_ids) return;
     const int n0 = ntile * BN;  // the same for every tile of this workgroup
+#ifdef IGEMM_TRACE  // timing experiment (tools/pers_trace.py): thread 0 of every workgroup stamps the 100 MHz wall clock at entry and exit and
+                    // counts its tiles, into the LAST 3 * gridDim.x floats of the RESIDUAL tensor (never written by the kernel; the last rows' results are wrong by construction)
+    const unsigned long long tr_t0 = wall_clock64();
+    int tr_tiles = 0;
+#endif
 
     const int Cin = p.C0 + p.C1;
     const int taps = p.KH * p.KW;
@@ -913,7 +918,16 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_pers_kernel(const Gemm
     __syncthreads();
 
     int it = 0;  // chunks multiplied so far by this workgroup: LDS stage it & 1 holds the current one
+#ifndef IGEMM_PRIO
+#define IGEMM_PRIO 0  // A/B (profiles/r05_notes.md): 1 the second-dispatched half of the grid takes wave priority 1 on its odd tiles, 2 on all of them
+#endif
+    int tile_no = 0;
     for (;;) {
+        if (IGEMM_PRIO && blockIdx.x >= gridDim.x / 2) {
+            if (IGEMM_PRIO == 2 || (tile_no & 1)) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
+        ++tile_no;
 #pragma unroll
         for (int r = 0; r < RM; ++r)
 #pragma unroll
@@ -1023,10 +1037,22 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_f32_pers_kernel(const Gemm
                 }
             }
         }
+#ifdef IGEMM_TRACE
+        ++tr_tiles;
+#endif
         if (!more) break;
         z_ep = z_nx;
         m0_ep = m0_nx;
     }
+#ifdef IGEMM_TRACE
+    __syncthreads();
+    if (threadIdx.x == 0 && p.res) {
+        float *tr = const_cast<float *>(p.res) + (size_t)p.M * p.ldres - 3 * (size_t)gridDim.x;
+        tr[3 * blockIdx.x] = (float)(tr_t0 & 0xFFFFFFull);
+        tr[3 * blockIdx.x + 1] = (float)(wall_clock64() & 0xFFFFFFull);
+        tr[3 * blockIdx.x + 2] = (float)tr_tiles;
+    }
+#endif
 }
 
 // ---- variant selection ------------------------------------------------------------------------------------------
