@@ -176,8 +176,8 @@ def main():
     ap.add_argument("--precision", choices=["fp32", "bf16x3"], default="fp32",
                     help="fp32 = fp32 operands on the fp32 matrix core, 3x3 convolutions through the hybrid Winograd transform F(2,3)y x F(4,3)x (headline); bf16x3 = split-precision weight contractions on the bf16 matrix core")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--graph", choices=["step", "loop", "none"], default="step",
-                    help="step: one captured hipGraph per NFE step, replayed (default); loop: ONE graph for the whole sampler call; none: eager launches")
+    ap.add_argument("--graph", choices=["step", "loop", "none"], default="loop",
+                    help="loop: ONE hipGraph for the whole sampler call (default, the product's default); step: one captured graph per NFE step, replayed; none: eager launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the secondary bf16x3 measurement")

@@ -35,6 +35,12 @@ from ..models import utils as mutils
 from . import utils
 
 _LOCAL_DEVICE_COUNT = 1  # one process per GPU
+# How a sampler call reaches the GPU unless the caller says otherwise: 'loop' = ONE hipGraph for the whole call (pack, every step, the
+# denoising evaluation, finish: BASELINE north-star "the outer NFE loop captured as a hipGraph"), True = one graph per step replayed
+# num_step times, False = eager launches.  All three are bit-identical (tests/test_gpu_sampler.py); round 5 measured the two captured
+# forms equal in steady state (1 849.9 vs 1 851.9 ms per 256-image call), the whole-call graph costing 50 ms more on a batch size's first
+# call and 10.5 MB of device memory (tools/graph_first_call.py).
+DEFAULT_GRAPH = 'loop'
 _TOKENS = itertools.count(1)
 
 
@@ -141,7 +147,7 @@ def _make_sampler(sde, model, data_shape, nfe, inverse_scaler, rev_ts, coef, den
     ts32 = np.asarray(rev_ts[:num_step], dtype=np.float32)
     coef32 = np.ascontiguousarray(coef, dtype=np.float32)
 
-    def sampler(rng, state, batch_size, u=None, use_graph=True):
+    def sampler(rng, state, batch_size, u=None, use_graph=DEFAULT_GRAPH):
         import torch
         if u is None:
             u = sde.prior_sampling(_seed_of(rng), (batch_size,) + tuple(data_shape))
@@ -167,7 +173,7 @@ def _make_sampler(sde, model, data_shape, nfe, inverse_scaler, rev_ts, coef, den
             x = post_scale(x)
         return x, v, nfe
 
-    def psampler(prng, pstate, batch_size, u=None, use_graph=True):
+    def psampler(prng, pstate, batch_size, u=None, use_graph=DEFAULT_GRAPH):
         rng = _unreplicate_rng(prng)
         if u is None:
             u = sde.prior_sampling(_seed_of(rng), (_LOCAL_DEVICE_COUNT, batch_size,) + tuple(data_shape))

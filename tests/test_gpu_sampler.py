@@ -80,10 +80,11 @@ def test_deis_sampler_matches_oracle(cld_setup_ref, nfe, order, denoise):
     assert torch.equal(x, x2) and torch.equal(v, v2)
     x3, _, _ = fn(0, state, u.shape[0], torch.as_tensor(u, device="cuda:0"))
     assert torch.equal(x, x3)
-    # one hipGraph for the whole call (pack, every step, denoising evaluation, finish): same bits, and replayable
-    for _ in range(2):
-        x4, v4, _ = fn(0, state, u.shape[0], torch.as_tensor(u, device="cuda:0"), use_graph='loop')
-        assert torch.equal(x, x4) and torch.equal(v, v4)
+    # one hipGraph for the whole call (pack, every step, denoising evaluation, finish: the default since round 5) and one graph per step
+    # replayed num_step times: same bits, and replayable
+    for mode in ('loop', True, 'loop', True):
+        x4, v4, _ = fn(0, state, u.shape[0], torch.as_tensor(u, device="cuda:0"), use_graph=mode)
+        assert torch.equal(x, x4) and torch.equal(v, v4), mode
     x5, _, _ = fn(0, state, 2, torch.as_tensor(u[:2], device="cuda:0"), use_graph='loop')  # another batch size: its own graph
     assert torch.equal(x5, x[:2])
 
@@ -461,9 +462,10 @@ def test_production_batch_sampler_matches_oracle(native_lib):
     x2, v2, _ = fn(0, state, B, ut)
     x3, v3, _ = fn(0, state, B, ut, use_graph=False)
     x4, v4, _ = fn(0, state, B, ut, use_graph="loop")
-    assert torch.equal(x, x2) and torch.equal(v, v2) and torch.equal(x, x3) and torch.equal(v, v3)
+    x5, v5, _ = fn(0, state, B, ut, use_graph=True)
+    assert torch.equal(x, x2) and torch.equal(v, v2)
     if int(os.environ.get("GD_LANES", "1")) <= 1:  # (the whole-loop graph is one lane: with GD_LANES > 1 the other modes run other batch sizes)
-        assert torch.equal(x, x4) and torch.equal(v, v4)
+        assert torch.equal(x, x3) and torch.equal(v, v3) and torch.equal(x, x4) and torch.equal(v, v4) and torch.equal(x, x5) and torch.equal(v, v5)
     xr, vr, _ = fn(0, state, B, torch.flip(ut, dims=(0,)).contiguous())
     assert xr.shape[0] == B and torch.equal(torch.flip(xr, dims=(0,)), x) and torch.equal(torch.flip(vr, dims=(0,)), v)
 
