@@ -209,6 +209,9 @@ def main():
             torch.distributed.barrier()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # this process times ONE GPU (the contract: one process per GPU); without this the sampling function would drive every visible GPU
+    # from here, the way the reference's pmap does (gddim_amd/devices.py)
+    os.environ["GDDIM_LOCAL_DEVICES"] = str(local_rank)
 
     B = args.batch
     if args.workload == "cld":
@@ -242,15 +245,13 @@ def main():
         in_ch = cfg.data.num_channels
         desc = "blur gDDIM order0 NFE=%d (ts_order=2, t0=1e-5, sigma_blur_max=10)" % args.nfe
 
-        def sampling_fn(rng, st, bs, uu, use_graph=True):
+        def sampling_fn(rng, st, bs, uu, use_graph=None):
             xs, n = blur_fn(rng, st, bs, uu, use_graph=use_graph)
             return xs, None, n
 
     if args.no_graph:
         args.graph = "none"
     graph_mode = {"step": True, "loop": "loop", "none": False}[args.graph]
-    if args.workload == "blur" and graph_mode == "loop":
-        graph_mode = True  # the blur loop has the per-step graph only
 
     def step():
         xs, vs, nfe = sampling_fn([rank], state, B, u, use_graph=graph_mode)
@@ -365,7 +366,7 @@ def main():
     # ---- the two captured forms of the loop next to each other (north-star: "the outer NFE loop captured as a hipGraph"): per-step graph
     # replayed NFE - 1 times vs ONE graph for the whole sampler call; bit-identical outputs (tests/test_gpu_sampler.py), bounded sample ----
     side_steps = max(1, min(args.steps, 3))
-    if args.workload == "cld" and not args.no_alt and graph_mode is not False:
+    if not args.no_alt and graph_mode is not False:
         ms = {}
         for name, mode in (("step", True), ("loop", "loop")):
             ms[name] = 1e3 * timed(side_steps, mode) / side_steps

@@ -8,15 +8,20 @@
       `sampling.method = 'deis'` selects it, everything else raises RuntimeError as in the reference
 
 `sampling_fn(rng, state, batch_size, u=None) -> (x, nfe)` (2-tuple, unlike CLD).  The NFE loop
-[IDCT -> U-Net -> DCT -> per-frequency DDIM update] runs entirely in `gd_sample_blur`."""
+[IDCT -> U-Net -> DCT -> per-frequency DDIM update] runs entirely in `gd_sample_blur`, by default as ONE hipGraph per call.
+is_p=True keeps the reference's pmap contract (:82-87): u (n_dev, B, H, W, C) -> xs (n_dev, B, H, W, C), one engine per local GPU
+(gddim_amd.devices)."""
 import itertools
 
 import numpy as np
 
-from ..cld.sampling import _seed_of, _unreplicate_rng
+from .. import devices
+from ..cld.sampling import _seed_of
 from . import utils
 
-_LOCAL_DEVICE_COUNT = 1
+# 'loop' = one hipGraph for the whole sampler call (default), True = one graph per step replayed nfe times, False = eager launches;
+# bit-identical (tests/test_gpu_sampler.py).  Read at call time.
+DEFAULT_GRAPH = 'loop'
 _TOKENS = itertools.count(1)
 
 
@@ -62,28 +67,35 @@ def get_deis_sampler(sde, model, data_shape, ts_order, nfe, deis_order, inverse_
     token = ("blur_deis", next(_TOKENS))
     m2e = _model2eps_rows(sde, rev_ts, nfe)
 
-    def sampler(rng, state, batch_size, u=None, use_graph=True):
+    def install(eng):
+        eng.set_schedule_blur_deis(rev_ts[:nfe], coef, token=token)
+        eng.set_model2eps_blur(m2e)
+
+    return _make_sampler(sde, model, data_shape, nfe, fuse_scale, post_scale, token, install, is_p)
+
+
+def _make_sampler(sde, model, data_shape, nfe, fuse_scale, post_scale, token, install, is_p):
+    """The closure pair of blur_jax/sampling.py:55-89: `install(engine)` uploads this sampler's schedule."""
+
+    def sampler(rng, state, batch_size, u=None, use_graph=None, slot=0):
         import torch
+        if use_graph is None:
+            use_graph = DEFAULT_GRAPH
         if u is None:
             u = sde.prior_sampling(_seed_of(rng), (batch_size,) + tuple(data_shape))
         if not hasattr(u, 'is_cuda'):
             u = torch.as_tensor(np.asarray(u), dtype=torch.float32)
         if not u.is_cuda:
             u = u.to(torch.device('cuda', torch.cuda.current_device()))
-        eng = model.engine_for(state.params_ema, data_shape[-1], batch_size, u.device.index)
+        eng = model.engine_for(state.params_ema, data_shape[-1], batch_size, u.device.index, slot=slot)
         if eng._schedule_token != token:
-            eng.set_schedule_blur_deis(rev_ts[:nfe], coef, token=token)
-            eng.set_model2eps_blur(m2e)
+            install(eng)
         x = eng.sample_blur(u.to(torch.float32), inverse_scale=fuse_scale, use_graph=use_graph)
         return (post_scale(x) if post_scale is not None else x), nfe
 
-    def psampler(prng, pstate, batch_size, u=None, use_graph=True):
-        rng = _unreplicate_rng(prng)
-        if u is None:
-            u = sde.prior_sampling(_seed_of(rng), (_LOCAL_DEVICE_COUNT, batch_size,) + tuple(data_shape))
-        assert u.shape[0] == _LOCAL_DEVICE_COUNT, "one process drives one GPU: leading device axis must be 1"
-        x, n = sampler(rng, pstate, batch_size, u[0], use_graph)
-        return x[None], n
+    def psampler(prng, pstate, batch_size, u=None, use_graph=None):
+        # jax.pmap(sampler, static_broadcasted_argnums=2)(prng, pstate, batch_size, u) (blur_jax/sampling.py:86)
+        return devices.pmap_sampler(sampler, prng, pstate, batch_size, u, sde, tuple(data_shape), 1, use_graph=use_graph)
 
     return psampler if is_p else sampler
 
@@ -92,39 +104,15 @@ def get_order0_sampler(sde, model, data_shape, ts_order, nfe, inverse_scaler, is
     rev_ts = get_rev_ts(sde, ts_order=ts_order, num_step=nfe)
     mean_coef = sde.y_mean_coef(rev_ts)[..., 0]  # (nfe+1, 32, 32): identical for every image (t is batch-uniform)
     std_coef = sde.y_std_coef(rev_ts)
-    probe = np.array([-1.0, 0.0, 1.0])
-    scaled = np.asarray(inverse_scaler(probe), dtype=np.float64)
-    fuse_scale = bool(np.allclose(scaled, (probe + 1.0) / 2.0))
-    post_scale = None if fuse_scale or np.allclose(scaled, probe) else inverse_scaler
+    fuse_scale, post_scale = _scale_mode(inverse_scaler)
     token = ("blur_order0", next(_TOKENS))
     m2e = _model2eps_rows(sde, rev_ts, nfe)
 
-    def sampler(rng, state, batch_size, u=None, use_graph=True):
-        import torch
-        if u is None:
-            u = sde.prior_sampling(_seed_of(rng), (batch_size,) + tuple(data_shape))
-        if not hasattr(u, 'is_cuda'):
-            u = torch.as_tensor(np.asarray(u), dtype=torch.float32)
-        if not u.is_cuda:
-            u = u.to(torch.device('cuda', torch.cuda.current_device()))
-        eng = model.engine_for(state.params_ema, data_shape[-1], batch_size, u.device.index)
-        if eng._schedule_token != token:
-            eng.set_schedule_blur(rev_ts[:nfe], mean_coef, std_coef, token=token)
-            eng.set_model2eps_blur(m2e)
-        x = eng.sample_blur(u.to(torch.float32), inverse_scale=fuse_scale, use_graph=use_graph)
-        if post_scale is not None:
-            x = post_scale(x)
-        return x, nfe
+    def install(eng):
+        eng.set_schedule_blur(rev_ts[:nfe], mean_coef, std_coef, token=token)
+        eng.set_model2eps_blur(m2e)
 
-    def psampler(prng, pstate, batch_size, u=None, use_graph=True):
-        rng = _unreplicate_rng(prng)
-        if u is None:
-            u = sde.prior_sampling(_seed_of(rng), (_LOCAL_DEVICE_COUNT, batch_size,) + tuple(data_shape))
-        assert u.shape[0] == _LOCAL_DEVICE_COUNT, "one process drives one GPU: leading device axis must be 1"
-        x, n = sampler(rng, pstate, batch_size, u[0], use_graph)
-        return x[None], n
-
-    return psampler if is_p else sampler
+    return _make_sampler(sde, model, data_shape, nfe, fuse_scale, post_scale, token, install, is_p)
 
 
 def get_sampling_fn(config, sde, model, shape, inverse_scaler, is_p=True):

@@ -12,9 +12,12 @@ Same factory names, argument names and return tuples as the reference:
 
 The returned callable is `sampling_fn(rng, state, batch_size, u=None)`:
   is_p=False: u (B,H,W,C,2) -> (x (B,H,W,C), v (B,H,W,C), nfe)
-  is_p=True : the reference pmaps over jax.local_device_count(); here one process drives one GPU, so the
-              leading device axis has length 1: u (1,B,H,W,C,2) -> (xs (1,B,H,W,C), vs, nfe).  Multi-GPU runs
-              launch one process per GPU (gddim_amd.distributed).
+  is_p=True : the reference pmaps over jax.local_device_count() devices from ONE process (:232-237).  Same contract here:
+              prng is a stack of n_dev keys, u (n_dev,B,H,W,C,2) -> (xs (n_dev,B,H,W,C), vs, nfe) with n_dev =
+              gddim_amd.devices.local_device_count() native engines, one per local GPU, each call one asynchronous
+              hipGraphLaunch per engine issued back to back from the calling thread; xs / vs are ShardedDeviceArrays whose
+              shards stay on their GPUs until the caller's np.clip(xs * 255., 0, 255) concatenates them on the host
+              (cld_jax/run_lib.py:723).  Under a one-process-per-GPU launcher (WORLD_SIZE > 1, gddim_amd.distributed) n_dev is 1.
 `u` is the parity hook: with it the deterministic samplers never touch the RNG.
 
 Inside the callable nothing but the native engine runs: the whole NFE loop (U-Net forward + fused
@@ -30,16 +33,16 @@ import itertools
 
 import numpy as np
 
+from .. import devices
 from .._abi import GddimError
 from ..models import utils as mutils
 from . import utils
 
-_LOCAL_DEVICE_COUNT = 1  # one process per GPU
 # How a sampler call reaches the GPU unless the caller says otherwise: 'loop' = ONE hipGraph for the whole call (pack, every step, the
 # denoising evaluation, finish: BASELINE north-star "the outer NFE loop captured as a hipGraph"), True = one graph per step replayed
 # num_step times, False = eager launches.  All three are bit-identical (tests/test_gpu_sampler.py); round 5 measured the two captured
 # forms equal in steady state (1 849.9 vs 1 851.9 ms per 256-image call), the whole-call graph costing 50 ms more on a batch size's first
-# call and 10.5 MB of device memory (tools/graph_first_call.py).
+# call and 10.5 MB of device memory (tools/graph_first_call.py).  Read at call time (use_graph=None), so it can be changed on the module.
 DEFAULT_GRAPH = 'loop'
 _TOKENS = itertools.count(1)
 
@@ -147,8 +150,10 @@ def _make_sampler(sde, model, data_shape, nfe, inverse_scaler, rev_ts, coef, den
     ts32 = np.asarray(rev_ts[:num_step], dtype=np.float32)
     coef32 = np.ascontiguousarray(coef, dtype=np.float32)
 
-    def sampler(rng, state, batch_size, u=None, use_graph=DEFAULT_GRAPH):
+    def sampler(rng, state, batch_size, u=None, use_graph=None, slot=0):
         import torch
+        if use_graph is None:
+            use_graph = DEFAULT_GRAPH
         if u is None:
             u = sde.prior_sampling(_seed_of(rng), (batch_size,) + tuple(data_shape))
         if not hasattr(u, 'is_cuda'):
@@ -157,7 +162,7 @@ def _make_sampler(sde, model, data_shape, nfe, inverse_scaler, rev_ts, coef, den
             u = u.to(torch.device('cuda', torch.cuda.current_device()))
         u = u.to(torch.float32)
         assert tuple(u.shape) == (batch_size,) + tuple(data_shape) + (2,), "u must be (B, *data_shape, 2)"
-        eng = model.engine_for(state.params_ema, 2 * data_shape[-1], batch_size, u.device.index)
+        eng = model.engine_for(state.params_ema, 2 * data_shape[-1], batch_size, u.device.index, slot=slot)
         if init is not None:
             u = utils.sbmm(init, u)
         if eng._schedule_token != token:
@@ -173,13 +178,9 @@ def _make_sampler(sde, model, data_shape, nfe, inverse_scaler, rev_ts, coef, den
             x = post_scale(x)
         return x, v, nfe
 
-    def psampler(prng, pstate, batch_size, u=None, use_graph=DEFAULT_GRAPH):
-        rng = _unreplicate_rng(prng)
-        if u is None:
-            u = sde.prior_sampling(_seed_of(rng), (_LOCAL_DEVICE_COUNT, batch_size,) + tuple(data_shape))
-        assert u.shape[0] == _LOCAL_DEVICE_COUNT, "one process drives one GPU: leading device axis must be 1"
-        x, v, n = sampler(rng, pstate, batch_size, u[0], use_graph)
-        return x[None], v[None], n
+    def psampler(prng, pstate, batch_size, u=None, use_graph=None):
+        # jax.pmap(sampler, static_broadcasted_argnums=2)(prng, pstate, batch_size, u) (:236): one engine per local device
+        return devices.pmap_sampler(sampler, prng, pstate, batch_size, u, sde, tuple(data_shape), 2, use_graph=use_graph)
 
     return psampler if is_p else sampler
 
@@ -357,9 +358,9 @@ def get_ode_sampler(sde, model, data_shape, inverse_scaler, denoising=False, rto
     from scipy import integrate
     step_fn = get_denoising_step(sde, model, sde.sampling_eps, sde.sampling_eps) if denoising else (lambda _, u: u)
 
-    def _solve(state, u):
+    def _solve(state, u, slot=0):
         import torch
-        score_fn = mutils.get_score_fn(sde, model, state.params_ema, state.model_state, train=False, continuous=True)
+        score_fn = mutils.get_score_fn(sde, model, state.params_ema, state.model_state, train=False, continuous=True, slot=slot)
         d_shape = tuple(u.shape)
         ones = torch.ones(d_shape[0], device=u.device, dtype=torch.float32)
 
@@ -393,12 +394,20 @@ def get_ode_sampler(sde, model, data_shape, inverse_scaler, denoising=False, rto
         return inverse_scaler(x), v, nfe
 
     def psampler(prng, pstate, batch_size, u=None):
-        batch_size = batch_size // _LOCAL_DEVICE_COUNT
-        u = _prep(_unreplicate_rng(prng), u, (_LOCAL_DEVICE_COUNT, batch_size) + tuple(data_shape))
-        assert u.shape[0] == _LOCAL_DEVICE_COUNT, "one process drives one GPU: leading device axis must be 1"
-        out, nfe = _solve(pstate, u[0])
-        x, v = out[..., 0], out[..., 1]
-        return inverse_scaler(x)[None], v[None], nfe
+        # as in the reference (:480-493) the pmapped variant divides batch_size by the device count once more; the adaptive solve is
+        # driven by the host (scipy), so the devices take turns
+        devs = devices.local_devices()
+        batch_size = batch_size // len(devs)
+
+        def one(rng, state, bs, ud, slot=0):
+            out, nfe = _solve(state, ud, slot)
+            return inverse_scaler(out[..., 0]), out[..., 1], nfe
+
+        if u is None:
+            import torch
+            seeds = devices.device_seeds(prng, len(devs))
+            u = [_prep(seeds[d], None, (batch_size,) + tuple(data_shape)).to(torch.device('cuda', devs[d])) for d in range(len(devs))]
+        return devices.pmap_sampler(one, prng, pstate, batch_size, u, sde, tuple(data_shape) + (2,), 2)
 
     return psampler if is_p else sampler
 

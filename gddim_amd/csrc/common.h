@@ -222,6 +222,8 @@ int launch_cld_pre(const float *u8, float *xin, const float *tf, const int *step
 int launch_cld_finish(const float *u8, const float *eps, const float *dn, float dt, int denoise, int inverse_scale,
                       float *x_out, float *v_out, long long pixels, int C, int flags, hipStream_t s);
 int launch_advance_step(int *step, hipStream_t s);
+// step++ and row[0:width] = table[step + 1][0:width] (if step + 1 < rows): the hoisted time-embedding table (engine.cpp)
+int launch_advance_step_row(int *step, const float *table, float *row, int width, int rows, hipStream_t s);
 // blur fused-sampler kernels
 int launch_blur_idct_pad(const float *y, float *x8, int batch, int C, hipStream_t s);
 // m2e: optional per-step rows [a, b[32*32]] of sde.model2eps in linear form, eps_y = a DCT(net) + b (.) y (null: identity)

@@ -87,6 +87,14 @@ struct gd_engine {
     unsigned long long seed = 0;
     unsigned seed_words[2] = {0, 0};  // host staging of seed_dev (must outlive the async copy)
     int *step_dev = nullptr;  // GD_MAX_LANES counters (one per concurrent sub-batch)
+    // Hoisted time embedding (cld_jax/models/ncsnpp.py:71-91, layerspp.py:215-216): inside the fused samplers the label of a
+    // step is 999 ts[step] for every image, and ts is fixed when the schedule is installed -- so Fourier -> Dense_0 -> Dense_1 -> the
+    // concatenated per-block projection run ONCE per knot (ensure_temb_table, the same kernels on the same inputs: bit-identical rows) and the
+    // loop reads row `step` of the (knots, sum Cout) table: the step-advance launch copies the next row into the lane's temb_cur.
+    float *temb_tab = nullptr, *temb_cur = nullptr;  // [temb_rows][temb_w]; [MAX_LANES][temb_w]
+    int temb_rows = 0, temb_w = 0, temb_t = -1;      // temb_t: the plan tensor every per-image bias row is read from (-1: no hoist)
+    long long temb_cap = 0;
+    bool temb_valid = false;  // the table matches the installed schedule, weights and precision mode
     int sched_kind = 0;  // 1 cld, 2 blur order0, 3 blur multistep (per-frequency DEIS)
     int num_step = 0, n_slots = 0, denoise = 0;
     float t_denoise = 0;
@@ -127,6 +135,7 @@ struct Bind {
     float *eps_out;
     float *arena;         // activation arena of this sub-batch
     const int *step;      // device step counter of this sub-batch
+    const float *temb_row = nullptr;  // the current row of the hoisted time-embedding table (null: the embedding ops run in the loop)
 };
 
 static float *tptr(gd_engine *e, const Bind &b, const TRef &r, int batch) {
@@ -221,7 +230,8 @@ static int fill_gemm(gd_engine *e, const Op &op, const Bind &b, int batch, GemmP
     // the per-image bias rows are the time-embedding projections: inside the fused samplers every image of the batch carries the same
     // label (b.labels == nullptr: 999 t of the step), one row is computed (run_op) and every image reads it (row stride 0)
     const bool one_label = b.labels == nullptr && op.rowbias.t >= 0;
-    g.rowbias = one_label ? tptr(e, b, op.rowbias, batch) : tptr_at(e, b, op.rowbias, batch, i0);
+    g.rowbias = one_label ? (b.temb_row ? const_cast<float *>(b.temb_row) + op.rowbias.col : tptr(e, b, op.rowbias, batch))
+                          : tptr_at(e, b, op.rowbias, batch, i0);
     g.ld_rowbias = one_label ? 0 : op.ld_rowbias; g.rows_per_image = op.m_per_image;
     g.res = tptr_at(e, b, op.res, batch, i0); g.ldres = op.ldres; g.sR = op.sR; g.sQ = op.sQ;
     g.alpha = op.alpha; g.out_scale = op.out_scale; g.in_act = op.in_act;
@@ -483,6 +493,7 @@ static int run_gemm(gd_engine *e, int op_index, const Bind &b, int batch, int i0
 static int run_op(gd_engine *e, int op_index, const Bind &b, int batch, hipStream_t s) {
     const Op &op = e->plan.ops[op_index];
     const Plan &P = e->plan;
+    if (op.temb && b.temb_row) return 0;  // hoisted: the row of this step is already in place (ensure_temb_table)
     switch (op.kind) {
         case OP_FOURIER: {
             ProfScope ps(e, s, "fourier", 0, 0);
@@ -565,6 +576,69 @@ static int run_unet(gd_engine *e, const Bind &b, int batch, hipStream_t s) {
     return 0;
 }
 
+// Every entry point that touches an engine's GPU makes it the calling thread's current HIP device and puts the previous one back on
+// return: one host thread drives several engines on several GPUs (gddim_amd.devices: the reference's pmap), and the caller's own
+// runtime (PyTorch) must find the device it left.
+struct DeviceScope {
+    int prev = -1;
+    bool changed = false;
+    explicit DeviceScope(const gd_engine *e) {
+        if (!e || e->plan_only || e->device < 0) return;
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != e->device) changed = hipSetDevice(e->device) == hipSuccess;
+    }
+    ~DeviceScope() {
+        if (changed && prev >= 0) (void)hipSetDevice(prev);
+    }
+    DeviceScope(const DeviceScope &) = delete;
+    DeviceScope &operator=(const DeviceScope &) = delete;
+};
+
+// The hoisted time-embedding table of the installed schedule: one row per knot -- ts[0 .. num_step) and, for CLD, the denoising time --
+// computed by the plan's own time-embedding ops (Op::temb) on one row, exactly what the loop would compute at that step.
+static int run_op(gd_engine *e, int op_index, const Bind &b, int batch, hipStream_t s);
+static int ensure_temb_table(gd_engine *e) {
+    if (e->temb_valid) return 0;
+    e->temb_rows = 0;
+    const int rows = e->sched_kind == 1 ? e->num_step + 1 : e->num_step;
+    const int width = e->temb_t >= 0 ? e->plan.tensors[e->temb_t].C : 0;
+    if (opts().no_temb_hoist || e->temb_t < 0 || e->sched_kind == 0 || !e->ts_dev || rows < 1 || width % 4 != 0) {
+        e->temb_valid = true;  // (nothing to hoist: the loop computes the embedding itself)
+        return 0;
+    }
+    if ((long long)rows * width > e->temb_cap) {
+        if (e->temb_tab) (void)hipFree(e->temb_tab);
+        e->temb_tab = nullptr; e->temb_cap = 0;
+        GD_HIP(hipMalloc((void **)&e->temb_tab, (size_t)rows * width * sizeof(float)));
+        e->temb_cap = (long long)rows * width;
+    }
+    if (!e->temb_cur || e->temb_w != width) {
+        if (e->temb_cur) (void)hipFree(e->temb_cur);
+        e->temb_cur = nullptr;
+        GD_HIP(hipMalloc((void **)&e->temb_cur, (size_t)gd_engine::MAX_LANES * width * sizeof(float)));
+    }
+    e->temb_w = width;
+    hipStream_t s = e->stream[0];
+    const bool prof = e->prof;
+    e->prof = false;  // (set-up work, not part of a sampler call's profile)
+    int *counter = e->step_dev + gd_engine::MAX_LANES - 1;  // a lane counter no sampler call is using now (calls on an engine are serial)
+    Bind b{e->xin, nullptr, e->epsb, e->arena, counter};
+    const TRef row{e->temb_t, 0};
+    int r = 0;
+    for (int k = 0; k < rows && !r; ++k) {
+        if (hipMemcpyAsync(counter, &k, sizeof(int), hipMemcpyHostToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { r = 1; break; }
+        for (int i = 0; i < (int)e->plan.ops.size() && !r; ++i)
+            if (e->plan.ops[i].temb) r = run_op(e, i, b, 1, s);
+        if (!r && hipMemcpyAsync(e->temb_tab + (size_t)k * width, tptr(e, b, row, 1), (size_t)width * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) r = 1;
+    }
+    if (!r && hipStreamSynchronize(s) != hipSuccess) r = 1;
+    e->prof = prof;
+    GD_CHECK(!r, "building the time-embedding table failed: %s", g_err.c_str());
+    e->temb_rows = rows;
+    e->temb_valid = true;
+    return 0;
+}
+
 static int check_compute(gd_engine *e, int batch) {
     GD_CHECK(e != nullptr, "null engine");
     GD_CHECK(!e->plan_only, "engine was created in plan-only mode (device < 0): no GPU compute available");
@@ -589,8 +663,7 @@ int gd_device_count(void) {
 int gd_engine_create(const gd_model_desc *desc, int device, gd_engine **out) {
     GD_CHECK(desc && out, "null argument");
     gd_engine *e = new gd_engine();
-    options_reload();  // an engine is built under the environment of its creation and keeps that table for life (options.h)
-    e->opts = options_snapshot();
+    e->opts = options_reload();  // an engine is built under the environment of its creation and keeps THAT table for life (options.h)
     OptScope scope(e->opts);
     if (e->plan.build(*desc)) { delete e; return 1; }
     e->device = device;
@@ -602,7 +675,11 @@ int gd_engine_create(const gd_model_desc *desc, int device, gd_engine **out) {
         off += (e->plan.slots[i].rows * e->plan.slots[i].cols + 63) / 64 * 64;
     }
     e->wbuf_floats = off;
+    for (const Op &op : e->plan.ops)  // the tensor the per-image bias rows come from (one: the concatenated projection); else no hoist
+        if (op.rowbias.t >= 0) e->temb_t = (e->temb_t == -1 || e->temb_t == op.rowbias.t) ? op.rowbias.t : -2;
+    if (e->temb_t < 0) e->temb_t = -1;
     if (!e->plan_only) {
+        DeviceScope dscope(e);
         auto fail = [&](const char *what, hipError_t err) {
             set_error("%s: %s", what, hipGetErrorString(err));
             gd_engine_destroy(e);
@@ -649,6 +726,7 @@ int gd_engine_destroy(gd_engine *e) {
     OptScope scope(e ? e->opts : nullptr);
     if (!e) return 0;
     if (!e->plan_only) {
+        DeviceScope dscope(e);
         (void)hipSetDevice(e->device);
         (void)hipDeviceSynchronize();
         drop_graphs(e);
@@ -660,7 +738,7 @@ int gd_engine_destroy(gd_engine *e) {
         if (e->wsplit_lo) (void)hipFree(e->wsplit_lo);
         float *bufs[] = {e->arena, e->wbuf, e->xin, e->epsb, e->eps_planar, e->labels, e->u8, e->ring, e->ystate, e->uin_stage,
                          e->xout_stage, e->vout_stage,
-                         e->ts_dev, e->coef_dev, e->dn_dev, e->mean_dev, e->std_dev, e->tf_dev, e->nz_dev, e->m2e_dev, (float *)e->seed_dev,
+                         e->ts_dev, e->coef_dev, e->dn_dev, e->mean_dev, e->std_dev, e->tf_dev, e->nz_dev, e->m2e_dev, e->temb_tab, e->temb_cur, (float *)e->seed_dev,
                          (float *)e->step_dev};
         for (float *b : bufs)
             if (b) (void)hipFree(b);
@@ -820,6 +898,8 @@ int gd_engine_set_precision(gd_engine *e, int mode) {
     OptScope scope(e ? e->opts : nullptr);
     GD_CHECK(e, "null engine");
     GD_CHECK(mode == 0 || mode == 1, "unknown precision mode %d (0 = fp32, 1 = bf16x3)", mode);
+    DeviceScope dscope(e);
+    e->temb_valid = false;  // (the embedding GEMMs may run on other kernels)
     if (!e->plan_only) {
         GD_HIP(hipSetDevice(e->device));
         GD_HIP(hipDeviceSynchronize());
@@ -844,6 +924,8 @@ int gd_engine_params_ready(gd_engine *e) {
         }
     GD_CHECK(nmiss == 0, "%d parameters not loaded: %s%s", nmiss, missing.c_str(), nmiss > 8 ? ", ..." : "");
     e->plan.fold_params();  // derived weight slots (the folded attention projections)
+    DeviceScope dscope(e);
+    e->temb_valid = false;
     if (!e->plan_only) {
         GD_HIP(hipSetDevice(e->device));
         // the upload and the Winograd weight transforms below run on the null stream while the engine's lanes are non-blocking streams:
@@ -887,6 +969,7 @@ int gd_engine_packed_weight(gd_engine *e, const char *slot, float *host_out, siz
 // ---- score network ----
 int gd_unet_forward(gd_engine *e, const float *x_dev, const float *labels_dev, float *out_dev, int batch, void *stream) {
     OptScope scope(e ? e->opts : nullptr);
+    DeviceScope dscope(e);
     GD_TRY(check_compute(e, batch));
     GD_CHECK(x_dev && labels_dev && out_dev, "null device pointer");
     hipStream_t s = (hipStream_t)stream;
@@ -899,6 +982,7 @@ int gd_unet_forward(gd_engine *e, const float *x_dev, const float *labels_dev, f
 
 int gd_cld_eps(gd_engine *e, const float *u_dev, const float *t_dev, float *eps_dev, int batch, void *stream) {
     OptScope scope(e ? e->opts : nullptr);
+    DeviceScope dscope(e);
     GD_TRY(check_compute(e, batch));
     GD_CHECK(u_dev && t_dev && eps_dev, "null device pointer");
     const gd_model_desc &d = e->plan.desc;
@@ -927,6 +1011,8 @@ int gd_engine_set_schedule_cld(gd_engine *e, int num_step, int n_slots, const fl
     GD_CHECK(e && !e->plan_only, "engine has no GPU");
     GD_CHECK(num_step >= 0 && n_slots >= 2 && ts_host && coef_host, "bad schedule");
     GD_CHECK(e->plan.desc.in_channels % 2 == 0, "CLD needs an even number of U-Net channels");
+    DeviceScope dscope(e);
+    e->temb_valid = false;
     GD_HIP(hipSetDevice(e->device));
     GD_HIP(hipDeviceSynchronize());
     drop_graphs(e);
@@ -966,6 +1052,7 @@ int gd_engine_set_noise_cld(gd_engine *e, const float *pre_lin, const float *pre
     GD_CHECK(e && !e->plan_only, "engine has no GPU");
     GD_CHECK(e->sched_kind == 1, "install the CLD schedule first (gd_engine_set_schedule_cld)");
     GD_CHECK((pre_lin == nullptr) == (pre_noise == nullptr), "pre_lin and pre_noise come together");
+    DeviceScope dscope(e);
     GD_HIP(hipSetDevice(e->device));
     GD_HIP(hipDeviceSynchronize());
     drop_graphs(e);
@@ -1012,6 +1099,7 @@ int gd_engine_set_transforms_cld(gd_engine *e, const float *pre, const float *ep
     OptScope scope(e ? e->opts : nullptr);
     GD_CHECK(e && !e->plan_only, "engine has no GPU");
     GD_CHECK(e->sched_kind == 1, "install the CLD schedule first (gd_engine_set_schedule_cld)");
+    DeviceScope dscope(e);
     GD_HIP(hipSetDevice(e->device));
     GD_HIP(hipDeviceSynchronize());
     drop_graphs(e);
@@ -1035,6 +1123,29 @@ int gd_engine_set_transforms_cld(gd_engine *e, const float *pre, const float *ep
     if (post) { memcpy(tail + 4, post, 16); e->fin_flags |= 2; }
     GD_HIP(hipMemcpy(e->dn_dev + 12, tail, sizeof tail, hipMemcpyHostToDevice));
     return 0;
+}
+
+// step <- 0 and, with the hoisted time embedding, the first knot's row into the lane's current-row buffer
+static int reset_step(gd_engine *e, int *step, float *temb_row, hipStream_t s) {
+    GD_HIP(hipMemsetAsync(step, 0, sizeof(int), s));
+    if (temb_row) GD_HIP(hipMemcpyAsync(temb_row, e->temb_tab, (size_t)e->temb_w * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
+// step++ (and the next knot's row)
+static int advance_step(gd_engine *e, int *step, float *temb_row, hipStream_t s) {
+    if (temb_row) return launch_advance_step_row(step, e->temb_tab, temb_row, e->temb_w, e->temb_rows, s);
+    return launch_advance_step(step, s);
+}
+
+// GD_LANES > 1 splits a call over concurrent streams in the eager and per-step-graph forms; the whole-call graph is one lane.  Say so
+// once instead of ignoring the switch silently.
+static void warn_lanes_ignored(const gd_engine *e, bool whole) {
+    static bool said = false;
+    if (!whole || e->lanes <= 1 || said) return;
+    said = true;
+    fprintf(stderr, "gddim_amd: GD_LANES=%d applies to use_graph = 0 / 1; the whole-call hipGraph (use_graph = 2, the samplers' default) "
+                    "runs one lane\n", e->lanes);
 }
 
 static int capture_begin(hipStream_t s) {
@@ -1066,10 +1177,12 @@ static int split_lanes(gd_engine *e, int batch, bool allow, int *start, int *siz
 int gd_sample_cld(gd_engine *e, int batch, const float *u_in_dev, float *x_out_dev, float *v_out_dev, int inverse_scale,
                   int use_graph, void *stream) {
     OptScope scope(e ? e->opts : nullptr);
+    DeviceScope dscope(e);
     GD_TRY(check_compute(e, batch));
     GD_CHECK(e->sched_kind == 1, "no CLD schedule installed (gd_engine_set_schedule_cld)");
     GD_CHECK(u_in_dev && x_out_dev && v_out_dev, "null device pointer");
     GD_CHECK(!e->plan.desc.scale_by_sigma, "scale_by_sigma is not supported inside the fused sampler");
+    GD_TRY(ensure_temb_table(e));
     hipStream_t caller = (hipStream_t)stream;
     const gd_model_desc &d = e->plan.desc;
     const int C = d.in_channels / 2;
@@ -1077,6 +1190,7 @@ int gd_sample_cld(gd_engine *e, int batch, const float *u_in_dev, float *x_out_d
     const int ring_slots = e->n_slots - 2;
     const bool graph = use_graph && !e->prof;
     const bool whole = graph && use_graph == 2;  // one graph for the whole call (single lane)
+    warn_lanes_ignored(e, whole);
     int start[gd_engine::MAX_LANES], size[gd_engine::MAX_LANES];
     const int nl = split_lanes(e, batch, !e->prof && !whole, start, size);
     if (e->nz_dev) {  // the seed of this call, in device memory so that captured graphs read the current one
@@ -1091,7 +1205,7 @@ int gd_sample_cld(gd_engine *e, int batch, const float *u_in_dev, float *x_out_d
         int b;
         long long pix;
         unsigned long long elem0;
-        float *u8, *eps, *ring, *xin;
+        float *u8, *eps, *ring, *xin, *temb;
         int *step;
         Bind bind, bind_u;  // bind: U-Net reads the (possibly transformed) step input; bind_u: reads the state itself
         gd_engine::Graphs *g;
@@ -1108,7 +1222,8 @@ int gd_sample_cld(gd_engine *e, int batch, const float *u_in_dev, float *x_out_d
         l.eps = e->epsb + p0 * d.in_channels;
         l.ring = e->ring ? e->ring + p0 * d.in_channels * ring_slots : nullptr;
         l.step = e->step_dev + i;
-        l.bind_u = Bind{l.u8, nullptr, l.eps, e->arena + (size_t)e->plan.arena_per_image * start[i], l.step};
+        l.temb = e->temb_rows ? e->temb_cur + (size_t)i * e->temb_w : nullptr;
+        l.bind_u = Bind{l.u8, nullptr, l.eps, e->arena + (size_t)e->plan.arena_per_image * start[i], l.step, l.temb};
         l.bind = l.bind_u;
         if (e->tf_pre) l.bind.x_in = l.xin;
         l.g = graph ? &e->graphs[((long long)size[i] << 40) | ((long long)start[i] << 8) | i | (whole ? (1LL << 62) : 0) |
@@ -1116,7 +1231,7 @@ int gd_sample_cld(gd_engine *e, int batch, const float *u_in_dev, float *x_out_d
         GD_HIP(hipStreamWaitEvent(l.s, e->ev_in, 0));
         if (whole) continue;  // pack and the counter reset are nodes of the whole-loop graph
         GD_TRY(launch_cld_pack(u_in_dev + p0 * C * 2, l.u8, l.ring, ring_slots, l.pix, C, l.s));
-        GD_HIP(hipMemsetAsync(l.step, 0, sizeof(int), l.s));
+        GD_TRY(reset_step(e, l.step, l.temb, l.s));
     }
     auto step_body = [&](Lane &l) -> int {
         if (e->nz_pre) GD_TRY(launch_cld_noise_pre(l.u8, e->nz_dev, l.step, e->seed_dev, l.elem0, l.pix, C, l.s));
@@ -1124,7 +1239,7 @@ int gd_sample_cld(gd_engine *e, int batch, const float *u_in_dev, float *x_out_d
         GD_TRY(run_unet(e, l.bind, l.b, l.s));
         GD_TRY(launch_cld_ab_step(l.u8, l.eps, l.ring, ring_slots, e->coef_dev, e->n_slots, l.step, l.pix, C, e->tf_dev, e->nz_dev,
                                   e->seed_dev, l.elem0, l.s));
-        return launch_advance_step(l.step, l.s);
+        return advance_step(e, l.step, l.temb, l.s);
     };
     if (whole) {
         // ONE graph for the whole call: pack -> num_step x [U-Net, AB step, step++] -> denoising U-Net -> finish.  Every address is
@@ -1135,7 +1250,7 @@ int gd_sample_cld(gd_engine *e, int batch, const float *u_in_dev, float *x_out_d
         if (!l.g->loop) {
             GD_TRY(capture_begin(l.s));
             int r = launch_cld_pack(e->uin_stage, l.u8, l.ring, ring_slots, l.pix, C, l.s);
-            if (!r && hipMemsetAsync(l.step, 0, sizeof(int), l.s) != hipSuccess) r = 1;
+            if (!r) r = reset_step(e, l.step, l.temb, l.s);
             for (int k = 0; k < e->num_step && !r; ++k) r = step_body(l);
             if (!r && e->denoise) r = run_unet(e, l.bind_u, l.b, l.s);
             if (!r) r = launch_cld_finish(l.u8, l.eps, e->dn_dev, -e->t_denoise, e->denoise, inverse_scale, e->xout_stage, e->vout_stage,
@@ -1193,6 +1308,8 @@ int gd_engine_set_schedule_blur(gd_engine *e, int nfe, const float *ts_host, con
     GD_CHECK(e && !e->plan_only, "engine has no GPU");
     GD_CHECK(nfe >= 1 && ts_host && mean_coef_host && std_coef_host, "bad schedule");
     GD_CHECK(e->plan.desc.image_size == 32, "the blur SDE is hard-wired to 32x32 (blur_jax/sde_lib.py:24)");
+    DeviceScope dscope(e);
+    e->temb_valid = false;
     GD_HIP(hipSetDevice(e->device));
     GD_HIP(hipDeviceSynchronize());
     drop_graphs(e);
@@ -1209,6 +1326,8 @@ int gd_engine_set_schedule_blur_deis(gd_engine *e, int nfe, int n_slots, const f
     GD_CHECK(e && !e->plan_only, "engine has no GPU");
     GD_CHECK(nfe >= 1 && n_slots >= 2 && ts_host && coef_host, "bad schedule");
     GD_CHECK(e->plan.desc.image_size == 32, "the blur SDE is hard-wired to 32x32 (blur_jax/sde_lib.py:24)");
+    DeviceScope dscope(e);
+    e->temb_valid = false;
     GD_HIP(hipSetDevice(e->device));
     GD_HIP(hipDeviceSynchronize());
     drop_graphs(e);
@@ -1232,6 +1351,7 @@ int gd_engine_set_model2eps_blur(gd_engine *e, const float *rows_host) {
     OptScope scope(e ? e->opts : nullptr);
     GD_CHECK(e && !e->plan_only, "engine has no GPU");
     GD_CHECK(e->sched_kind == 2 || e->sched_kind == 3, "install a blur schedule first (gd_engine_set_schedule_blur[_deis])");
+    DeviceScope dscope(e);
     GD_HIP(hipSetDevice(e->device));
     GD_HIP(hipDeviceSynchronize());
     drop_graphs(e);  // captured launches bake the table pointer
@@ -1243,24 +1363,35 @@ int gd_engine_set_model2eps_blur(gd_engine *e, const float *rows_host) {
 int gd_sample_blur(gd_engine *e, int batch, const float *y_in_dev, float *x_out_dev, int inverse_scale, int use_graph,
                    void *stream) {
     OptScope scope(e ? e->opts : nullptr);
+    DeviceScope dscope(e);
     GD_TRY(check_compute(e, batch));
     GD_CHECK(e->sched_kind == 2 || e->sched_kind == 3, "no blur schedule installed (gd_engine_set_schedule_blur[_deis])");
+    GD_TRY(ensure_temb_table(e));
     const bool multistep = e->sched_kind == 3;
     const int ring_slots = multistep ? e->n_slots - 2 : 0;
     const long long slot_stride = (long long)e->plan.desc.max_batch * 1024 * e->plan.desc.in_channels;
+    // y <- the initial state; the reference's loops start their epsilon history from the state itself
+    auto load_state = [&](float *y, float *ring, const float *src, size_t n, hipStream_t s) -> int {
+        GD_HIP(hipMemcpyAsync(y, src, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+        for (int j = 0; j < ring_slots; ++j)
+            GD_HIP(hipMemcpyAsync(ring + (size_t)j * slot_stride, src, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+        return 0;
+    };
     GD_CHECK(y_in_dev && x_out_dev, "null device pointer");
     GD_CHECK(!e->plan.desc.scale_by_sigma, "scale_by_sigma is not supported inside the fused sampler");
     hipStream_t caller = (hipStream_t)stream;
     const gd_model_desc &d = e->plan.desc;
     const int C = d.in_channels;
     const bool graph = use_graph && !e->prof;
+    const bool whole = graph && use_graph == 2;  // one graph for the whole call (single lane), as in gd_sample_cld
+    warn_lanes_ignored(e, whole);
     int start[gd_engine::MAX_LANES], size[gd_engine::MAX_LANES];
-    const int nl = split_lanes(e, batch, !e->prof, start, size);
+    const int nl = split_lanes(e, batch, !e->prof && !whole, start, size);
     GD_HIP(hipEventRecord(e->ev_in, caller));
     struct Lane {
         hipStream_t s;
         int b;
-        float *y, *xin, *eps, *ring;
+        float *y, *xin, *eps, *ring, *temb;
         int *step;
         Bind bind;
         gd_engine::Graphs *g;
@@ -1274,15 +1405,15 @@ int gd_sample_blur(gd_engine *e, int batch, const float *y_in_dev, float *x_out_
         l.xin = e->xin + p0 * e->plan.CP;
         l.eps = e->epsb + p0 * C;
         l.step = e->step_dev + i;
-        l.bind = Bind{l.xin, nullptr, l.eps, e->arena + (size_t)e->plan.arena_per_image * start[i], l.step};
-        l.g = graph ? &e->graphs[((long long)size[i] << 40) | ((long long)start[i] << 8) | i] : nullptr;
-        GD_HIP(hipStreamWaitEvent(l.s, e->ev_in, 0));
-        GD_HIP(hipMemcpyAsync(l.y, y_in_dev + p0 * C, (size_t)l.b * 1024 * C * sizeof(float), hipMemcpyDeviceToDevice, l.s));
+        l.temb = e->temb_rows ? e->temb_cur + (size_t)i * e->temb_w : nullptr;
+        l.bind = Bind{l.xin, nullptr, l.eps, e->arena + (size_t)e->plan.arena_per_image * start[i], l.step, l.temb};
+        l.g = graph ? &e->graphs[((long long)size[i] << 40) | ((long long)start[i] << 8) | i | (whole ? (1LL << 62) : 0) |
+                                 (whole && inverse_scale ? (1LL << 61) : 0)] : nullptr;
         l.ring = (multistep && e->ring) ? e->ring + p0 * C : nullptr;
-        for (int j = 0; j < ring_slots; ++j)  // the reference's loops start their epsilon history from the state itself
-            GD_HIP(hipMemcpyAsync(l.ring + (size_t)j * slot_stride, y_in_dev + p0 * C, (size_t)l.b * 1024 * C * sizeof(float),
-                                  hipMemcpyDeviceToDevice, l.s));
-        GD_HIP(hipMemsetAsync(l.step, 0, sizeof(int), l.s));
+        GD_HIP(hipStreamWaitEvent(l.s, e->ev_in, 0));
+        if (whole) continue;  // the state / history copies and the counter reset are nodes of the whole-call graph
+        GD_TRY(load_state(l.y, l.ring, y_in_dev + p0 * C, (size_t)l.b * 1024 * C, l.s));
+        GD_TRY(reset_step(e, l.step, l.temb, l.s));
     }
     auto step_body = [&](Lane &l) -> int {
         GD_TRY(launch_blur_idct_pad(l.y, l.xin, l.b, C, l.s));
@@ -1291,8 +1422,29 @@ int gd_sample_blur(gd_engine *e, int batch, const float *y_in_dev, float *x_out_
             GD_TRY(launch_blur_ab_step(l.y, l.eps, l.ring, ring_slots, e->coef_dev, e->n_slots, l.step, l.b, C, slot_stride, e->m2e_dev, l.s));
         else
             GD_TRY(launch_blur_step(l.y, l.eps, e->mean_dev, e->std_dev, l.step, l.b, C, e->m2e_dev, l.s));
-        return launch_advance_step(l.step, l.s);
+        return advance_step(e, l.step, l.temb, l.s);
     };
+    if (whole) {
+        // ONE graph for the whole call (blur_jax/sampling.py:53-89: the fori_loop and the final y2x): state load -> nfe x [IDCT, U-Net,
+        // DCT + update, step++] -> finish.  Addresses are baked: the caller's buffers pass through the engine's staging copies.
+        Lane &l = L[0];
+        const size_t n = (size_t)l.b * 1024 * C;
+        GD_HIP(hipMemcpyAsync(e->uin_stage, y_in_dev, n * sizeof(float), hipMemcpyDeviceToDevice, l.s));
+        if (!l.g->loop) {
+            GD_TRY(capture_begin(l.s));
+            int r = load_state(l.y, l.ring, e->uin_stage, n, l.s);
+            if (!r) r = reset_step(e, l.step, l.temb, l.s);
+            for (int k = 0; k < e->num_step && !r; ++k) r = step_body(l);
+            if (!r) r = launch_blur_finish(l.y, e->xout_stage, l.b, C, inverse_scale, l.s);
+            int r2 = capture_end(l.s, &l.g->loop);
+            if (r || r2) return 1;
+        }
+        GD_HIP(hipGraphLaunch(l.g->loop, l.s));
+        GD_HIP(hipMemcpyAsync(x_out_dev, e->xout_stage, n * sizeof(float), hipMemcpyDeviceToDevice, l.s));
+        GD_HIP(hipEventRecord(e->ev_out[0], l.s));
+        GD_HIP(hipStreamWaitEvent(caller, e->ev_out[0], 0));
+        return 0;
+    }
     if (graph) {
         for (int i = 0; i < nl; ++i) {
             Lane &l = L[i];
@@ -1334,6 +1486,7 @@ int gd_engine_profile(gd_engine *e, int enable) {
 int gd_engine_profile_read(gd_engine *e, gd_prof_entry *out, int cap, int *n) {
     OptScope scope(e ? e->opts : nullptr);
     GD_CHECK(e && !e->plan_only, "engine has no GPU");
+    DeviceScope dscope(e);
     GD_HIP(hipSetDevice(e->device));
     GD_HIP(hipDeviceSynchronize());
     for (auto &p : e->pending) {

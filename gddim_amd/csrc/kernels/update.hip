@@ -329,6 +329,27 @@ int launch_advance_step(int *step, hipStream_t s) {
     return 0;
 }
 
+// step++ and, in the same launch, the NEXT step's row of the hoisted time-embedding table into the buffer the convolutions read their
+// per-image bias from (engine.cpp: build_temb_table): row[0:width] = table[step + 1][0:width] when that knot exists.  One workgroup:
+// every thread reads the counter before thread 0 rewrites it.
+__global__ void __launch_bounds__(1024) advance_step_row_kernel(int *step, const float4 *__restrict__ table, float4 *__restrict__ row,
+                                                                 int width4, int rows) {
+    const int next = *step + 1;
+    __syncthreads();
+    if (next < rows) {
+        const float4 *src = table + (size_t)next * width4;
+        for (int i = threadIdx.x; i < width4; i += 1024) row[i] = src[i];
+    }
+    if (threadIdx.x == 0) *step = next;
+}
+
+int launch_advance_step_row(int *step, const float *table, float *row, int width, int rows, hipStream_t s) {
+    GD_CHECK(width % 4 == 0, "advance_step_row: width %d is not a multiple of 4", width);
+    hipLaunchKernelGGL(advance_step_row_kernel, dim3(1), dim3(1024), 0, s, step, (const float4 *)table, (float4 *)row, width / 4, rows);
+    GD_HIP(hipGetLastError());
+    return 0;
+}
+
 // ---- 32x32 orthonormal DCT, LDS resident -------------------------------------------------------------
 // D[k][n] = s_k cos(pi (2n+1) k / 64), s_0 = 1/sqrt(32), s_k = sqrt(2/32).
 // forward  Y = D X D^T ; inverse X = D^T Y D.   One block of 256 threads per (b, c) plane.

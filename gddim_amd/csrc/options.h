@@ -21,6 +21,7 @@ struct Options {
     int no_egn = 0;             // GDDIM_NO_EGN: no GroupNorm in the producer's epilogue
     int no_side_gn = 0;         // GDDIM_NO_SIDE_GN: no GroupNorm as a side output of the shortcut convolution's loader
     int no_fused_attn = 0;      // GDDIM_NO_FUSED_ATTN: attention core as three launches
+    int no_temb_hoist = 0;      // GDDIM_NO_TEMB_HOIST: the time-embedding ops run inside every step instead of once per schedule knot
     int attn_q = 0;             // GDDIM_ATTN_Q: 0 the launcher's choice, 32 / 64 force the fused attention kernel's query block (A/B)
     // ---- lowering (Plan::build) ----
     int no_attn_fold = 0;       // GDDIM_NO_ATTN_FOLD: attention blocks keep their four projections
@@ -50,7 +51,7 @@ struct Options {
 
 const Options &opts();               // the table in force on this thread: the running engine call's snapshot, else the process-wide one
 const Options *options_snapshot();   // the process-wide snapshot (immutable, never freed)
-void options_reload();               // parse the environment again and publish a new snapshot
+const Options *options_reload();     // parse the environment again, publish a new snapshot and return THAT snapshot
 std::string options_json();          // {"GDDIM_...": value, ...}: every entry of opts(), in the order above
 
 // Installs an engine's snapshot as this thread's opts() for the lifetime of the object (nests; null = leave as is).

@@ -52,6 +52,19 @@ def to_uint8(x):
     return np.clip(np.asarray(x) * 255.0, 0, 255).astype(np.uint8)
 
 
+def any_rank_failed(failed):
+    """True on every rank as soon as one rank reports a failure: one 4-byte all-reduce, a no-op outside a process group.  run_lib asks
+    it at the top of every round so that a rank whose file writer died does not leave the others waiting in the round's gather."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+        return bool(failed)
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    flag = torch.tensor([1 if failed else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    return bool(int(flag.item()))
+
+
 def all_gather_samples(local, equal_shards=None, force=False):
     """Gather every rank's images (B_r, ...) into (sum B_r, ...) on every rank -- one collective per round, uint8 for the
     FID images (3 072 B per image), the only data-path exchange of the sampler.

@@ -262,10 +262,12 @@ class Engine(object):
         check(self._lib.gd_engine_set_model2eps_blur(self._h, p))
 
     def sample_blur(self, y, inverse_scale=True, use_graph=True):
+        """use_graph as in sample_cld: False eager, True one graph per step replayed nfe times, 'loop' one graph for the whole call."""
         import torch
+        use_graph = 2 if use_graph == 'loop' else int(bool(use_graph))
         y = y.contiguous()
         x = torch.empty_like(y)
-        check(self._lib.gd_sample_blur(self._h, y.shape[0], _ptr(y), _ptr(x), int(bool(inverse_scale)), int(bool(use_graph)),
+        check(self._lib.gd_sample_blur(self._h, y.shape[0], _ptr(y), _ptr(x), int(bool(inverse_scale)), use_graph,
                                        _stream(self.device)))
         return x
 

@@ -22,14 +22,15 @@ class NCSNpp(object):
         self.config = config
         self._engines = {}
 
-    # -- engine cache: at most ONE engine per (in_channels, device).  A different parameter tree (another checkpoint of the
+    # -- engine cache: at most ONE engine per (in_channels, device, slot); `slot` is the position in gddim_amd.devices.local_devices()
+    # of a psampler call (one engine per local GPU; the same GPU may appear in two slots).  A different parameter tree (another checkpoint of the
     # reference's evaluate() loop, a new EMA copy) or an in-place update of the same tree is detected by identity plus a cheap
     # content fingerprint and re-uploaded into the existing engine, so weights are never stale and GPU memory does not grow with
     # the number of parameter trees seen.  A larger batch replaces the engine (the arena is sized by max_batch).
-    def engine_for(self, params, in_channels, batch, device=None):
+    def engine_for(self, params, in_channels, batch, device=None, slot=0):
         import torch
         dev = torch.cuda.current_device() if device is None else device
-        key = (int(in_channels), dev)
+        key = (int(in_channels), dev, int(slot))
         ent = self._engines.get(key)
         fp = _fingerprint(params)
         if ent is None or ent['cap'] < batch:

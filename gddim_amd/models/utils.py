@@ -84,7 +84,7 @@ def init_model(rng, config, init_scale_override=None):
     return model, {}, params
 
 
-def get_model_fn(model, params, states, train=False, packed_pairs=True):
+def get_model_fn(model, params, states, train=False, packed_pairs=True, slot=0):
     """model_fn(x, labels, rng=None) -> (output, states).  packed_pairs: x is a CLD state (B,...,d,2)."""
 
     def model_fn(x, labels, rng=None):
@@ -92,7 +92,7 @@ def get_model_fn(model, params, states, train=False, packed_pairs=True):
             raise GddimError("training is out of scope of the gddim_amd sampling engine")
         variables = {'params': params, **states}
         if packed_pairs:
-            eng = model.engine_for(params, 2 * x.shape[-2], x.shape[0], x.device.index)
+            eng = model.engine_for(params, 2 * x.shape[-2], x.shape[0], x.device.index, slot=slot)
             # gd_cld_eps takes t and multiplies by 999 itself; labels come in as 999 t
             return eng.cld_eps(x, labels / 999.0), states
         return model.apply(variables, x, labels, train=False, mutable=False), states
@@ -100,14 +100,15 @@ def get_model_fn(model, params, states, train=False, packed_pairs=True):
     return model_fn
 
 
-def get_eps_fn(sde, model, params, states, train=False, continuous=False, return_state=False):
+def get_eps_fn(sde, model, params, states, train=False, continuous=False, return_state=False, slot=0):
+    """slot: which of this process's engines evaluates (gddim_amd.devices: one engine per local device of a psampler call)."""
     cld = hasattr(sde, 'mixed_score')
 
     def eps_fn(x, t, rng=None):
         if train:
             raise GddimError("training is out of scope of the gddim_amd sampling engine")
         if cld:
-            eng = model.engine_for(params, 2 * x.shape[-2], x.shape[0], x.device.index)
+            eng = model.engine_for(params, 2 * x.shape[-2], x.shape[0], x.device.index, slot=slot)
             out = eng.cld_eps(x, t)  # labels = t * 999 inside (models/utils.py:172)
             if sde.mixed_score:  # + bmm(v_invR(t), x.at[..., 0].set(0)) (models/utils.py:174-176)
                 from .. import ops
@@ -124,8 +125,8 @@ def get_eps_fn(sde, model, params, states, train=False, continuous=False, return
     return eps_fn
 
 
-def get_score_fn(sde, model, params, states, train=False, continuous=False, return_state=False):
-    eps_fn = get_eps_fn(sde, model, params, states, train, continuous, return_state)
+def get_score_fn(sde, model, params, states, train=False, continuous=False, return_state=False, slot=0):
+    eps_fn = get_eps_fn(sde, model, params, states, train, continuous, return_state, slot=slot)
 
     def score_fn(x, t, rng=None):
         out = eps_fn(x, t, rng)

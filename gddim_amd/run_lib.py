@@ -6,15 +6,19 @@
 
 Same files on disk: `samples_<r>.npz` with keys samples (uint8, clip(x*255, 0, 255) truncated), nfe_cnt, samples_v, samples_x;
 `statistics_<r>.npz` with pool_3, logits, nfe_cnt; `report.npz` with IS, fid, nfe.  The reference shards one round over
-`jax.local_device_count()` devices with pmap; here one process drives one GPU (launch with torchrun), every rank samples
-`eval.batch_size // world_size` images of the round and the shards meet in one all-gather (RCCL) before rank 0 writes the file --
-on writer threads behind pinned staging buffers, so that round r + 1 samples while round r is compressed (`_RoundWriter`).
-Training, logging and the rest of run_lib are out of scope."""
+`jax.local_device_count()` devices with pmap from ONE process (cld_jax/run_lib.py:711-725).  Two ways to the same files here:
+  * one process, no launcher (the reference's own form): the sampling function drives one engine per local GPU
+    (gddim_amd.devices), every device samples `eval.batch_size // n_dev` images, the shards go device -> pinned host memory;
+  * one process per GPU under torchrun (WORLD_SIZE > 1): every rank samples its share and the shards meet in one all-gather
+    (RCCL) before rank 0 writes the file.
+Either way the file is written on writer threads behind pinned staging buffers, so that round r + 1 samples while round r is
+compressed (`_RoundWriter`).  Training, logging and the rest of run_lib are out of scope."""
 import os
+import sys
 
 import numpy as np
 
-from . import checkpoints, datasets, distributed, evaluation
+from . import checkpoints, datasets, devices, distributed, evaluation
 from ._abi import GddimError
 
 
@@ -103,9 +107,9 @@ class _RoundWriter:
             job = self._jobs.get()
             if job is None:
                 return
-            r, f_sample, slot, event, views, extra = job
+            r, f_sample, slot, events, views, extra = job
             try:
-                if event is not None:
+                for event in events:
                     event.synchronize()
                 keys = {k: t.numpy().reshape(shape) for k, (t, shape) in views.items()}
                 keys.update(extra)
@@ -117,40 +121,48 @@ class _RoundWriter:
                 self._free.put(slot)
 
     def submit(self, r, f_sample, tensors, extra):
-        """tensors: {key: (tensor, shape on disk)}; extra: {key: small host value}.  Returns once the copies are QUEUED."""
+        """tensors: {key: (tensor or list of equally shaped shards -- one per device --, shape on disk)}; extra: {key: small host value}.
+        Returns once the copies are QUEUED (every shard on a side stream of its own device)."""
         import torch
         if self.error is not None:
             raise self.error
+        tensors = {k: (list(t) if isinstance(t, (list, tuple)) else [t], shape) for k, (t, shape) in tensors.items()}
         if self.writers <= 0:
-            keys = {k: t.cpu().numpy().reshape(shape) for k, (t, shape) in tensors.items()}
+            keys = {k: np.stack([p.cpu().numpy() for p in parts]).reshape(shape) for k, (parts, shape) in tensors.items()}
             keys.update(extra)
             self._save(f_sample, keys)
             self.written[r] = f_sample
             return
         slot = self._free.get()  # blocks while writers + 1 rounds are in flight
         stage = self._slots[slot]
-        on_gpu = any(t.is_cuda for t, _ in tensors.values())
-        event = None
+        gpus = sorted({p.device.index for parts, _ in tensors.values() for p in parts if p.is_cuda})
+        if self._stream is None:
+            self._stream = {}
+        for d in gpus:
+            if d not in self._stream:
+                self._stream[d] = torch.cuda.Stream(device=d)
+            self._stream[d].wait_stream(torch.cuda.current_stream(d))
         views = {}
-        if on_gpu:
-            if self._stream is None:
-                self._stream = torch.cuda.Stream()
-            self._stream.wait_stream(torch.cuda.current_stream())
-        for k, (t, shape) in tensors.items():
+        for k, (parts, shape) in tensors.items():
+            full = (len(parts),) + tuple(parts[0].shape)
             buf = stage.get(k)
-            if buf is None or buf.shape != t.shape or buf.dtype != t.dtype:
-                buf = stage[k] = torch.empty(t.shape, dtype=t.dtype, device="cpu", pin_memory=on_gpu)
-            if t.is_cuda:
-                with torch.cuda.stream(self._stream):
-                    buf.copy_(t, non_blocking=True)
-                t.record_stream(self._stream)  # the caching allocator must not hand this block out before the copy has run
-            else:
-                buf.copy_(t)
+            if buf is None or tuple(buf.shape) != full or buf.dtype != parts[0].dtype:
+                buf = stage[k] = torch.empty(full, dtype=parts[0].dtype, device="cpu", pin_memory=bool(gpus))
+            for i, t in enumerate(parts):
+                if t.is_cuda:
+                    side = self._stream[t.device.index]
+                    with torch.cuda.stream(side):
+                        buf[i].copy_(t, non_blocking=True)
+                    t.record_stream(side)  # the caching allocator must not hand this block out before the copy has run
+                else:
+                    buf[i].copy_(t)
             views[k] = (buf, shape)
-        if on_gpu:
-            event = torch.cuda.Event()
-            event.record(self._stream)
-        self._jobs.put((r, f_sample, slot, event, views, extra))
+        events = []
+        for d in gpus:
+            ev = torch.cuda.Event()
+            ev.record(self._stream[d])
+            events.append(ev)
+        self._jobs.put((r, f_sample, slot, events, views, extra))
 
     def close(self):
         if self.writers > 0:
@@ -171,42 +183,74 @@ def _writer_threads(config):
     return int(os.environ.get("GDDIM_WRITER_THREADS", "2"))
 
 
+def _shards(a):
+    """The per-device slices of one output of a psampler call: a ShardedDeviceArray, or any array with a leading device axis."""
+    if isinstance(a, devices.ShardedDeviceArray):
+        return list(a.shards)
+    return [a[d] for d in range(a.shape[0])]
+
+
 def _rounds(config, state, sampling_fn, result_folder, is_continue, rank, world, stats=None):
     import time
     import torch
     num_sampling_rounds = config.eval.num_samples // config.eval.batch_size + 1
-    # the reference gives every device eval.batch_size // n_dev images (cld_jax/run_lib.py:721) and silently drops the remainder;
-    # here the remainder goes to the first ranks so that a round always holds eval.batch_size images
-    _, per_rank = distributed.shard_batch(config.eval.batch_size, world, rank)
-    equal = config.eval.batch_size % world == 0
     if config.eval.batch_size < world:
         raise GddimError("eval.batch_size %d is smaller than the number of ranks %d" % (config.eval.batch_size, world))
+    if world > 1:
+        # one process per GPU.  The reference gives every device eval.batch_size // n_dev images and silently drops the remainder
+        # (cld_jax/run_lib.py:721); here the remainder goes to the first ranks so that a round always holds eval.batch_size images
+        n_dev = 1
+        _, per_call = distributed.shard_batch(config.eval.batch_size, world, rank)
+        equal = config.eval.batch_size % world == 0
+    else:
+        # the reference's own form: this process drives every local device, each takes eval.batch_size // n_dev images (:721)
+        n_dev = devices.local_device_count()
+        per_call = config.eval.batch_size // n_dev
+        equal = True
+        if per_call < 1:
+            raise GddimError("eval.batch_size %d is smaller than the number of local devices %d" % (config.eval.batch_size, n_dev))
     writer = _RoundWriter(_writer_threads(config) if rank == 0 else 0)
     gpu = torch.cuda.is_available()
     marks = []
+    img_shape = (config.data.image_size, config.data.image_size, config.data.num_channels)
     t_start = time.perf_counter()
     try:
         for r in range(num_sampling_rounds):
+            # a writer that failed stops the run at the next round on EVERY rank (the others would wait in the round's collective)
+            if distributed.any_rank_failed(writer.error is not None):
+                raise writer.error if writer.error is not None else GddimError("another rank's round writer failed")
             f_sample = os.path.join(result_folder, "samples_%d.npz" % r)
             if os.path.exists(f_sample) and is_continue:
                 continue
-            out = sampling_fn([distributed.rank_seed(config.seed + 1, r, rank)], state, per_rank)
-            samples_org_x, nfe_cnt = out[0], out[-1]
-            samples_v = out[1] if len(out) == 3 else None
-            x = samples_org_x.reshape((-1,) + tuple(samples_org_x.shape[2:]))
-            u8 = distributed.all_gather_samples(distributed.to_uint8(x), equal_shards=equal)
-            # the float copies the reference also stores (samples_x, samples_v): one more gather, x and v stacked
-            fl = x[..., None] if samples_v is None else torch.stack([x, samples_v.reshape(x.shape)], dim=-1)
-            fl = distributed.all_gather_samples(fl, equal_shards=equal)
-            # reference layout of the float arrays: (n_dev, B / n_dev, H, W, C); uneven shards (not possible there) are written as one row
-            lead = (world, config.eval.batch_size // world) if equal else (1, config.eval.batch_size)
-            if rank == 0:
-                xf = fl[..., 0].contiguous()
-                tensors = dict(samples=(u8, (-1, config.data.image_size, config.data.image_size, config.data.num_channels)),
-                               samples_x=(xf, lead + tuple(xf.shape[1:])))
-                if samples_v is not None:
-                    vf = fl[..., 1].contiguous()
-                    tensors['samples_v'] = (vf, lead + tuple(vf.shape[1:]))
+            # one key per device of this call (cld_jax/run_lib.py:715-720: jax.random.split(rng, n_dev + 1)[1:])
+            keys = [distributed.rank_seed(config.seed + 1, r, rank * n_dev + d) for d in range(n_dev)]
+            out = sampling_fn(keys, state, per_call)
+            nfe_cnt = out[-1]
+            xs = _shards(out[0])
+            vs = _shards(out[1]) if len(out) == 3 else None
+            if world > 1:
+                x = xs[0]
+                u8 = distributed.all_gather_samples(distributed.to_uint8(x), equal_shards=equal)
+                # the float copies the reference also stores (samples_x, samples_v): one more gather, x and v stacked
+                fl = x[..., None] if vs is None else torch.stack([x, vs[0].reshape(x.shape)], dim=-1)
+                fl = distributed.all_gather_samples(fl, equal_shards=equal)
+                # reference layout of the float arrays: (n_dev, B / n_dev, H, W, C); uneven shards (not possible there) are written as one row
+                lead = (world, config.eval.batch_size // world) if equal else (1, config.eval.batch_size)
+                if rank == 0:
+                    xf = fl[..., 0].contiguous()
+                    tensors = dict(samples=(u8, (-1,) + img_shape), samples_x=(xf, lead + tuple(xf.shape[1:])))
+                    if vs is not None:
+                        vf = fl[..., 1].contiguous()
+                        tensors['samples_v'] = (vf, lead + tuple(vf.shape[1:]))
+                    writer.submit(r, f_sample, tensors, dict(nfe_cnt=nfe_cnt))
+            else:
+                # no collective: every shard goes from its own device to the pinned staging buffer (the reference's host concatenation,
+                # cld_jax/run_lib.py:722-725); the uint8 conversion runs where the shard lives
+                lead = (n_dev, per_call)
+                tensors = dict(samples=([distributed.to_uint8(x) for x in xs], (-1,) + img_shape),
+                               samples_x=([x.contiguous() for x in xs], lead + tuple(xs[0].shape[1:])))
+                if vs is not None:
+                    tensors['samples_v'] = ([v.reshape(x.shape).contiguous() for v, x in zip(vs, xs)], lead + tuple(xs[0].shape[1:]))
                 writer.submit(r, f_sample, tensors, dict(nfe_cnt=nfe_cnt))
             if stats is not None:
                 if gpu:
@@ -215,18 +259,26 @@ def _rounds(config, state, sampling_fn, result_folder, is_continue, rank, world,
                     marks.append((r, ev, time.perf_counter()))
                 else:
                     marks.append((r, None, time.perf_counter()))
-    finally:
-        written = writer.close() if rank == 0 else []
+    except BaseException:
+        # the loop's own failure is what the caller must see; a writer error on top of it is reported, not raised over it
+        try:
+            writer.close()
+        except BaseException as werr:  # noqa: B902
+            sys.stderr.write("gddim_amd.run_lib: the round writer failed as well: %r\n" % (werr,))
+        raise
+    written = writer.close() if rank == 0 else []
     if stats is not None:
         if gpu:
-            torch.cuda.synchronize()
+            for d in devices.local_devices() if world == 1 else [torch.cuda.current_device()]:
+                torch.cuda.synchronize(d)
         stats["wall_s"] = time.perf_counter() - t_start
         stats["rounds"] = [m[0] for m in marks]
         stats["host_submit_s"] = [m[2] - t_start for m in marks]
         if gpu and len(marks) > 1:  # GPU time between the ends of consecutive rounds' device work
             stats["gpu_round_ms"] = [marks[i][1].elapsed_time(marks[i + 1][1]) for i in range(len(marks) - 1)]
-        stats["images"] = len(marks) * config.eval.batch_size
+        stats["images"] = len(marks) * n_dev * per_call if world == 1 else len(marks) * config.eval.batch_size
         stats["writer_threads"] = writer.writers
+        stats["local_devices"] = n_dev
     return written
 
 

@@ -197,7 +197,14 @@ int gd_randn_pairs(float *out_dev, long long n_pairs, unsigned long long seed, u
  * whole call (pack, every step, the denoising evaluation, finish; input / outputs pass through
  * engine-owned staging buffers because a graph bakes its addresses).
  * Replaces: sampler(rng, state, batch_size, u) (cld_jax/sampling.py:212-230 / :178-193):
- * fori_loop(body_fn) = eps_fn + multistep_ab_step, then step_fn, inverse_scaler. */
+ * fori_loop(body_fn) = eps_fn + multistep_ab_step, then step_fn, inverse_scaler.
+ * The call only QUEUES work (on the engine's stream, ordered after / before `stream` by events) and leaves the calling thread's
+ * current HIP device as it found it: one host thread can drive one engine per GPU back to back -- the reference's
+ * jax.pmap(sampler) over jax.local_device_count() devices (cld_jax/sampling.py:232-237; gddim_amd/devices.py).
+ * Inside the loop every image carries the step's label 999 ts[step] (cld_jax/sampling.py:217,221), and ts is fixed by
+ * gd_engine_set_schedule_*: the time embedding (ncsnpp.py:71-91) and the per-block Dense_0(act(temb)) rows (layerspp.py:215-216)
+ * are computed once per knot when the schedule, the parameters or the precision mode change, and the loop reads row `step` of
+ * that (knots, sum Cout) table (GDDIM_NO_TEMB_HOIST=1 at engine creation: computed inside every step; same bits). */
 int gd_sample_cld(gd_engine *e, int batch, const float *u_in_dev, float *x_out_dev, float *v_out_dev,
                   int inverse_scale, int use_graph, void *stream);
 
@@ -220,7 +227,8 @@ int gd_engine_set_schedule_blur_deis(gd_engine *e, int nfe, int n_slots, const f
  *   (a scalar b_i, i.e. a constant plane, is eps_x = a_i * model_output + b_i * x; identity = a 1, b 0: the reference's own SDE
  *   class).  Pass NULL to remove it.  Call after gd_engine_set_schedule_blur[_deis]. */
 int gd_engine_set_model2eps_blur(gd_engine *e, const float *rows_host);
-/* y_in_dev (B,32,32,C) -> x_out_dev (B,32,32,C) = inverse_scaler(IDCT(y_nfe)).
+/* y_in_dev (B,32,32,C) -> x_out_dev (B,32,32,C) = inverse_scaler(IDCT(y_nfe)).  use_graph as in gd_sample_cld:
+ * 0 eager, 1 one captured graph per step, 2 ONE hipGraph for the whole call (state load, nfe steps, finish).
  * Replaces: sampler(rng, state, batch_size, u) (blur_jax/sampling.py:55-80). */
 int gd_sample_blur(gd_engine *e, int batch, const float *y_in_dev, float *x_out_dev, int inverse_scale,
                    int use_graph, void *stream);

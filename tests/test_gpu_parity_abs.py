@@ -105,8 +105,13 @@ def _cld_case(native_lib, cfg_mod, image_size, B, distinct, nfe, gain, seed, met
     fn = sampling.get_sampling_fn(cfg, sde, model, None, get_data_inverse_scaler(cfg))  # the factory: is_p=True, hipGraph replay
     ud_dev = torch.as_tensor(ud, device="cuda:0")
 
-    def run(layout):
-        u = ud_dev[torch.as_tensor(np.asarray(layout), device="cuda:0", dtype=torch.long)]
+    def run(layout, fill=None):
+        """fill: optional (B, H, W, C, 2) noises for the positions whose layout entry is negative (all-distinct batches)."""
+        lay = np.asarray(layout)
+        u = ud_dev[torch.as_tensor(np.maximum(lay, 0), device="cuda:0", dtype=torch.long)]
+        if fill is not None:
+            mask = torch.as_tensor(lay < 0, device="cuda:0")
+            u = torch.where(mask[:, None, None, None, None], torch.as_tensor(fill, device="cuda:0"), u)
         xs, vs, n = fn([0], state, len(layout), u[None])
         return xs[0].cpu().numpy(), vs[0].cpu().numpy(), n
 
@@ -185,11 +190,30 @@ def test_cld_nfe50_b256_absolute_parity(native_lib, x64):
     assert moved > 20 * ABS_TOL, "the network must matter for the test to mean anything (moved x by %.3e)" % moved
     assert max(float(np.abs(a).max()) for a in trace) < 100.0
     assert ex <= ABS_TOL and ev <= ABS_TOL * max(1.0, float(np.abs(wv).max()))
+    if not x64:
+        # The copies above cannot see a defect that swaps data between two positions holding the SAME noise (1 pair in 8).
+        # So: a batch of 256 DISTINCT noises -- the 8 oracle-checked ones at seeded random positions, 248 fresh ones everywhere else --
+        # must reproduce each of the 8 images bit for bit where it sits (any exchange with a neighbour now changes the result), the 8
+        # must differ from one another, and no two of the 256 outputs may coincide.
+        rng = np.random.default_rng(77)
+        pos = rng.choice(B, size=distinct, replace=False)
+        lay = np.full(B, -1)
+        lay[pos] = np.arange(distinct)
+        shape = (B, 32, 32, 3)
+        fill = np.stack([rng.standard_normal(shape), rng.standard_normal(shape) / 2], axis=-1).astype(np.float32)
+        xa, va, _ = run(lay, fill)
+        for j, p_ in enumerate(pos):
+            assert np.array_equal(xa[p_], xd[j]) and np.array_equal(va[p_], vd[j]), \
+                "noise %d at position %d of an all-distinct batch gives other bits than among copies: max|d| %.3e" % (j, p_, float(np.abs(xa[p_] - xd[j]).max()))
+        assert all(not np.array_equal(xd[i], xd[j]) for i in range(distinct) for j in range(i))
+        flat = np.ascontiguousarray(xa.reshape(B, -1))
+        assert len({row.tobytes() for row in flat}) == B, "two positions of an all-distinct batch returned the same image"
+        print("all-distinct batch (8 oracle-checked noises among 248 fresh ones): the 8 images are bit-identical to their copies' result; 256 distinct outputs")
 
 
 def _profile_names(model, in_ch, B, entries=False):
     """Kernel names one U-Net evaluation at this batch size launches (engine profile of a single forward)."""
-    ent = model._engines[(in_ch, 0)]
+    ent = model._engines[(in_ch, 0, 0)]  # (input channels, device, slot)
     eng = ent['eng']
     eng.profile(True)
     xin = torch.zeros((B, eng.image_size, eng.image_size, in_ch), device="cuda:0")

@@ -292,7 +292,7 @@ def test_engines_keep_the_option_table_they_were_created_under(native_lib, gd_en
     overwrote, while selectors read it live -- an engine built under one setting ran under the next one's.  Now every engine keeps the
     immutable snapshot of its creation and installs it for the duration of its calls; a reload (or another engine's creation) never
     changes a live engine.  Also the parsing rules: a switch set to a word is on unless the word says off; a numeric entry that does not
-    parse is ignored; an explicitly set nested switch wins over its parent."""
+    parse is ignored; an outer switch forces the switches nested under it (GDDIM_NOWINO = no Winograd at all, whatever GDDIM_NOWINO42 says: ADVICE r5)."""
     from gddim_amd.engine import Engine
     cfg = tiny_config("cld", nf=16, num_res_blocks=1, image_size=16, ch_mult=(1, 2), attn=(8,))
     gd_env(GDDIM_NO_ATTN_FOLD=None, GDDIM_NO_EGN=None)
@@ -305,7 +305,7 @@ def test_engines_keep_the_option_table_they_were_created_under(native_lib, gd_en
     assert (oa["GDDIM_NO_ATTN_FOLD"], oa["GDDIM_NO_EGN"], oa["GDDIM_WINO42_GRID"]) == (0, 0, 0)
     assert (ob["GDDIM_NO_ATTN_FOLD"], ob["GDDIM_NO_EGN"], ob["GDDIM_WINO42_GRID"]) == (1, 1, 3)
     assert (oc["GDDIM_NO_ATTN_FOLD"], oc["GDDIM_NO_EGN"], oc["GDDIM_WINO42_GRID"], oc["GDDIM_IGEMM_BIGMIN"]) == (0, 0, 0, 384)
-    assert (oc["GDDIM_NOWINO"], oc["GDDIM_NOWINO2"], oc["GDDIM_NOWINO42"]) == (1, 1, 0)  # the nested variable that is set keeps its value
+    assert (oc["GDDIM_NOWINO"], oc["GDDIM_NOWINO2"], oc["GDDIM_NOWINO42"], oc["GDDIM_NOWINO2_SPLITK"]) == (1, 1, 1, 1)  # the outer switch wins
     # and the plans differ the way their own tables say
     la, lb = [op["label"] for op in a.plan()["ops"]], [op["label"] for op in b.plan()["ops"]]
     assert any(l.endswith(".q_proj") for l in la) and not any(l.endswith(".q_proj") for l in lb)
