@@ -71,32 +71,77 @@ def issued_ratio(name):
     return 1.0
 
 
-def cpu_baseline(cfg, params, nfe_full, cpu_batch, cpu_nfe):
-    """The reference JAX-CPU path cannot run here (no jax); timed instead: the torch-CPU fp32 ORACLE (a
-    restatement of the same algorithm, kind='port') on a bounded sample, all host cores."""
+def _cpu_worker(idx, threads, cpu_batch, cpu_nfe, image_size, barrier, out):
+    """One process of the CPU baseline: `cpu_batch` images of their own through the torch-CPU fp32 oracle on `threads` threads.  All
+    processes build the same network, warm up, meet at the barrier, then run at the same time; (start, end) on the shared clock go back."""
+    os.environ["OMP_NUM_THREADS"] = str(threads)
+    os.environ["MKL_NUM_THREADS"] = str(threads)
     import torch
+    torch.set_num_threads(threads)
+    from gddim_amd.configs import cld_accr_dcifar10
     from oracle import cld as ocld
     from oracle import ncsnpp as onet
-    # torch's CPU convolutions collapse when a 256-thread host pool is thrown at batch-4 problems (measured:
-    # 658 s for this sample with 256 threads), so the pool is capped; `cores` reports the threads actually used
-    cores = min(os.cpu_count() or 1, 16)
-    torch.set_num_threads(cores)
+    cfg = cld_accr_dcifar10.get_config()
+    cfg.data.image_size = image_size
+    params = onet.random_params(cfg, 2 * cfg.data.num_channels, seed=42)  # (timing only: any non-degenerate weights of the architecture)
     osde = ocld.CLD(is_R_rk=cfg.model.is_R_rk, R_dt=cfg.model.R_dt, dtype=np.float64)
-    rng = np.random.default_rng(0)
+    rng = np.random.default_rng(idx)
     H, C = cfg.data.image_size, cfg.data.num_channels
     u = np.stack([rng.standard_normal((cpu_batch, H, H, C)), rng.standard_normal((cpu_batch, H, H, C)) / 2], -1).astype(np.float32)
     eps_fn = onet.cld_eps_fn(params, cfg, dtype=torch.float32)
     rev_ts = ocld.get_rev_ts(osde, 2, cpu_nfe - 1)
     coef = osde.get_deis_coef(2, rev_ts)
     eps_fn(u[:1], np.full(1, 0.5, np.float32))  # warm the thread pool / allocator
-    t0 = time.perf_counter()
+    barrier.wait(timeout=900)
+    t0 = time.time()
     ocld.deis_sampler(osde, eps_fn, u, cpu_nfe, 2, ts_order=2, denoising=True, inverse_scaler=ocld.inverse_scaler_centered,
                       deis_coef=coef, rev_ts=rev_ts)
-    dt = time.perf_counter() - t0
-    per_img_eval = dt / (cpu_batch * cpu_nfe)
-    return {"value": 1.0 / (per_img_eval * nfe_full), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": "torch-CPU fp32 oracle, batch=%d x NFE=%d network evaluations of the same architecture in %.1f s, "
-                      "scaled linearly to NFE=%d" % (cpu_batch, cpu_nfe, dt, nfe_full)}
+    out.put((idx, t0, time.time()))
+
+
+def cpu_baseline(cfg, nfe_full, cpu_batch, cpu_nfe, threads_per_proc=16):
+    """The reference JAX-CPU path cannot run here (no jax); timed instead: the torch-CPU fp32 ORACLE (a restatement of the same
+    algorithm, kind='port') on a bounded sample, on the WHOLE box: images are independent, so P processes x T threads each take
+    `cpu_batch` images of their own (torch's CPU convolutions collapse when one 256-thread pool is thrown at a batch-16 problem --
+    measured 658 s for this sample in round 1 -- which is why the box is filled with processes, not with one pool).  Wall time =
+    last end - first start after a common barrier."""
+    import multiprocessing as mp
+    total = os.cpu_count() or 1
+    T = max(1, min(threads_per_proc, total))
+    P = max(1, total // T)
+    ctx = mp.get_context("spawn")
+    barrier, out = ctx.Barrier(P), ctx.Queue()
+    procs = [ctx.Process(target=_cpu_worker, args=(i, T, cpu_batch, cpu_nfe, cfg.data.image_size, barrier, out), daemon=True) for i in range(P)]
+    for p_ in procs:
+        p_.start()
+    import queue
+    marks, deadline, why = [], time.time() + 1500, None
+    while len(marks) < P and why is None:
+        try:
+            marks.append(out.get(timeout=2))
+        except queue.Empty:
+            dead = [p_.exitcode for p_ in procs if p_.exitcode not in (None, 0)]
+            if dead:
+                why = "a worker process exited with code %r" % dead[0]
+            elif time.time() > deadline:
+                why = "timed out"
+    if why is not None:  # a worker died or hung: report what there is instead of losing the bench line (exact processes, started here)
+        for p_ in procs:
+            if p_.is_alive():
+                p_.terminate()
+        return {"value": None, "unit": "images/s", "cores": 0, "cores_total": total, "kind": "port",
+                "sample": "CPU baseline failed: %d of %d worker processes reported (%s)" % (len(marks), P, why)}
+    for p_ in procs:
+        p_.join(timeout=60)
+    dt = max(m[2] for m in marks) - min(m[1] for m in marks)
+    per_proc = sorted(m[2] - m[1] for m in marks)
+    images, evals = P * cpu_batch, P * cpu_batch * cpu_nfe
+    return {"value": images / (dt * nfe_full / cpu_nfe), "unit": "images/s", "cores": P * T, "cores_used": P * T, "cores_total": total,
+            "processes": P, "threads_per_process": T, "kind": "port", "seconds": dt,
+            "per_process_seconds": {"min": per_proc[0], "median": per_proc[len(per_proc) // 2], "max": per_proc[-1]},
+            "sample": "torch-CPU fp32 oracle, %d processes x %d threads, each batch=%d x NFE=%d network evaluations of the same "
+                      "architecture (%d images, %d evaluations) in %.1f s wall, scaled linearly to NFE=%d"
+                      % (P, T, cpu_batch, cpu_nfe, images, evals, dt, nfe_full)}
 
 
 def self_launch(n, argv):
@@ -166,8 +211,8 @@ def dry_run(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)   # >= 3 warm-up calls, median of >= 5
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (weak scaling)")
     ap.add_argument("--nfe", type=int, default=50)
     ap.add_argument("--order", type=int, default=2)
@@ -183,6 +228,7 @@ def main():
     ap.add_argument("--no-alt", action="store_true", help="skip the secondary bf16x3 measurement")
     ap.add_argument("--cpu-batch", type=int, default=16)
     ap.add_argument("--cpu-nfe", type=int, default=20, help="network evaluations per image of the CPU sample (batch 16 x 20 evaluations: 10-15 s on 16 threads)")
+    ap.add_argument("--cpu-threads", type=int, default=16, help="threads per process of the CPU baseline; the box is filled with cpu_count // threads processes")
     ap.add_argument("--dry-run", action="store_true", help="CPU / gloo plumbing check of the N-rank harness (no sampler, no GPU)")
     args = ap.parse_args()
 
@@ -268,22 +314,31 @@ def main():
     for _ in range(args.warmup):
         out = step()
     fence()
+    # per-step device times from events on the stream the calls are ordered on (recorded, not waited for: the timed region below is
+    # exactly K back-to-back steps between two fences, as the contract says); BASELINE.md section 3 quotes the MEDIAN step
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for k in range(args.steps):
         out = step()
+        marks[k + 1].record()
     fence()
     dt = time.perf_counter() - t0
-    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    step_ms = [marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps)]
+    med_ms = float(np.median(step_ms)) if step_ms else 0.0
+    tt = torch.tensor([dt, med_ms], dtype=torch.float64, device=dev)
     if grouped:
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-    dt = float(tt.item())
+    dt, med_ms = float(tt[0].item()), float(tt[1].item())
     assert out.shape[0] == B * world and out.dtype == torch.uint8
 
     eng = model.engine_for(params, in_ch, B, local_rank)
     flops_img = eng.flops_per_image() * args.nfe
     result = {
-        "metric": METRIC if (args.workload == "cld" and args.nfe == 50 and args.image_size == 32) else "images/sec, " + desc, "value": world * B * args.steps / dt, "unit": "images/s", "n_gpus": world, "steps": args.steps,
+        "metric": METRIC if (args.workload == "cld" and args.nfe == 50 and args.image_size == 32) else "images/sec, " + desc, "value": world * B / (med_ms * 1e-3) if med_ms > 0 else 0.0, "unit": "images/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * dt / max(1, args.steps), "higher_is_better": True, "scaling": "weak",
+        "value_is": "whole-job images per MEDIAN step (BASELINE.md section 3: median of >= 5 after >= 3 warm-up calls; max over ranks of each rank's median)",
+        "value_mean": world * B * args.steps / dt, "ms_per_step_median": med_ms, "step_ms": [round(t, 3) for t in step_ms],
         "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16x3 (fp32 split into bf16 hi+lo, fp32 accumulate)", "data": "synthetic",
         "config": {"workload": "%s, batch=%d per GPU, %dx%dx3 synthetic noise, random-init NCSN++ "
                                "(nf=128, ch_mult=(1,2,2,2), 8 res blocks, attn@16)" % (desc, B, cfg.data.image_size, cfg.data.image_size),
@@ -398,7 +453,7 @@ def main():
         result["bf16x3"] = alt
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "cld":
-        result["cpu_baseline"] = cpu_baseline(cfg, params, args.nfe, args.cpu_batch, args.cpu_nfe)
+        result["cpu_baseline"] = cpu_baseline(cfg, args.nfe, args.cpu_batch, args.cpu_nfe, args.cpu_threads)
     if rank == 0:
         print(json.dumps(result))
     if grouped:
