@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 BUILD = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libgddim_amd.so")
-SOURCES = ["engine.cpp", "plan.cpp", "options.cpp", "host_math.cpp", "kernels/igemm.hip", "kernels/igemm_bf16x3.hip", "kernels/conv3x3_halo_bf16x3.hip", "kernels/conv3x3_wino2d_f32.hip", "kernels/conv3x3_wino42_f32.hip", "kernels/attn_fused_f32.hip", "kernels/norm_act.hip", "kernels/update.hip"]
+SOURCES = ["engine.cpp", "plan.cpp", "options.cpp", "host_math.cpp", "kernels/igemm.hip", "kernels/igemm_bf16x3.hip", "kernels/conv3x3_halo_bf16x3.hip", "kernels/conv3x3_wino2d_f32.hip", "kernels/conv3x3_wino42_f32.hip", "kernels/conv3x3_wino2d_split6.hip", "kernels/attn_fused_f32.hip", "kernels/norm_act.hip", "kernels/update.hip"]
 HEADERS = ["common.h", "plan.h", "options.h", "kernels/qstats.h", "kernels/epilogue.h", "kernels/rng.h", "kernels/act.h", "../../include/gddim_amd.h"]
 ARCH = "gfx950"
 

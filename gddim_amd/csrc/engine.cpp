@@ -1601,6 +1601,21 @@ int gd_conv3x3_winograd42(const float *x_dev, const float *w_dev, float *u_scrat
     return launch_conv3x3_wino42(g, (hipStream_t)stream);
 }
 
+long long gd_conv3x3_winograd2d_split6_weight_bytes(int Cin, int Cout) { return conv3x3_wino2d_split6_weight_bytes(Cin, Cout); }
+
+int gd_conv3x3_winograd2d_split6_weights(const float *w_dev, void *u_dev, int Cin, int Cout, void *stream) {
+    GD_CHECK(w_dev && u_dev, "null pointer");
+    GD_CHECK(Cin % 16 == 0 && Cout % 64 == 0, "conv3x3_winograd2d_split6_weights: Cin %% 16 and Cout %% 64 must be 0 (Cin=%d Cout=%d)", Cin, Cout);
+    return launch_wino2d_split6_weights(w_dev, (unsigned short *)u_dev, Cout, Cin, (hipStream_t)stream);
+}
+
+int gd_conv3x3_winograd2d_split6(const float *x_dev, const void *u_dev, const float *bias_dev, const float *res_dev, float *out_dev, int batch,
+                                 int H, int W, int Cin, int Cout, float out_scale, void *stream) {
+    GD_CHECK(x_dev && u_dev && out_dev, "null pointer");
+    return launch_conv3x3_wino2d_split6(x_dev, (const unsigned short *)u_dev, bias_dev, res_dev, out_dev, batch, H, W, Cin, Cout, out_scale,
+                                        (hipStream_t)stream);
+}
+
 int gd_conv3x3_winograd42_gn(const float *x_dev, const float *w_dev, float *u_scratch_dev, const float *bias_dev, const float *res_dev,
                              float *out_dev, const float *gamma_dev, const float *beta_dev, float *gn_out_dev, int groups, int act,
                              int batch, int H, int W, int Cin, int Cout, float alpha, float out_scale, void *stream) {

@@ -138,6 +138,32 @@ def conv3x3_winograd42(x, w_packed, bias=None, res=None, alpha=1.0, out_scale=1.
     return out
 
 
+def conv3x3_winograd2d_split6_weights(w_packed):
+    """Pre-split Winograd-domain weight fragments of conv3x3_winograd2d_split6 (a uint8 device tensor; once per parameter load)."""
+    import torch
+    _need_gpu(w_packed)
+    w_packed = _f32c(w_packed)
+    Cout, Cin = w_packed.shape[0], w_packed.shape[1] // 9
+    u = torch.empty(_abi.lib().gd_conv3x3_winograd2d_split6_weight_bytes(Cin, Cout), dtype=torch.uint8, device=w_packed.device)
+    check(_abi.lib().gd_conv3x3_winograd2d_split6_weights(_ptr(w_packed), _ptr(u), Cin, Cout, _stream(w_packed)))
+    return u
+
+
+def conv3x3_winograd2d_split6(x, u_split, cout, bias=None, res=None, out_scale=1.0):
+    """3x3 / stride 1 / pad 1 NHWC conv through F(2x2,3x3) in the exact three-piece bf16 split on the bf16 matrix core (prototype operator:
+    gd_conv3x3_winograd2d_split6); u_split from conv3x3_winograd2d_split6_weights."""
+    import torch
+    _need_gpu(x)
+    x = _f32c(x)
+    B, H, W, Cin = x.shape
+    out = torch.empty((B, H, W, cout), dtype=torch.float32, device=x.device)
+    bias = _f32c(bias) if bias is not None else None
+    res = _f32c(res) if res is not None else None
+    check(_abi.lib().gd_conv3x3_winograd2d_split6(_ptr(x), _ptr(u_split), _ptr(bias), _ptr(res), _ptr(out), B, H, W, Cin, int(cout),
+                                                  float(out_scale), _stream(x)))
+    return out
+
+
 def conv3x3_winograd42_gn(x, w_packed, gamma, beta, groups, act=True, bias=None, res=None, out_scale=1.0, keep_raw=True):
     """conv3x3_winograd42 followed by GroupNorm (+ swish) in the kernel's epilogue (gd_conv3x3_winograd42_gn): returns (raw, normalised),
     raw = None with keep_raw=False (the engine's sole-reader case: the convolution output itself is never stored)."""

@@ -289,6 +289,16 @@ int gd_conv3x3_winograd2d(const float *x_dev, const float *w_dev, float *u_scrat
 int gd_conv3x3_winograd42(const float *x_dev, const float *w_dev, float *u_scratch_dev, const float *bias_dev,
                           const float *res_dev, float *out_dev, int batch, int H, int W, int Cin, int Cout, float alpha,
                           float out_scale, void *stream);
+/* PROTOTYPE (round 6; not planned into the engine): the same convolution -- nn.Conv(features, (3, 3), padding 1),
+ * cld_jax/models/layers.py:95-107 -- through F(2x2,3x3) with every component GEMM in the exact three-piece bf16 split on
+ * v_mfma_f32_32x32x16_bf16 (six products per fp32 product, fp32 accumulation; kernels/conv3x3_wino2d_split6.hip).
+ *   gd_conv3x3_winograd2d_split6_weights: w_dev [Cout][9 Cin] (gd_conv2d's packing) -> u_dev, ..._weight_bytes(Cin, Cout) bytes of
+ *     pre-split fragments (done once per parameter load);
+ *   gd_conv3x3_winograd2d_split6: out = (conv(x, w) + bias + res) * out_scale.  H % 16 == 0, W % 16 == 0, Cin % 16 == 0, Cout % 64 == 0. */
+long long gd_conv3x3_winograd2d_split6_weight_bytes(int Cin, int Cout);
+int gd_conv3x3_winograd2d_split6_weights(const float *w_dev, void *u_dev, int Cin, int Cout, void *stream);
+int gd_conv3x3_winograd2d_split6(const float *x_dev, const void *u_dev, const float *bias_dev, const float *res_dev, float *out_dev, int batch,
+                                 int H, int W, int Cin, int Cout, float out_scale, void *stream);
 /* ... with the GroupNorm (+ swish) that follows the convolution computed in its epilogue (the engine's Op::egn_peer path): gn_out_dev
  * (B,H,W,Cout) = act(GroupNorm_groups(conv output)) with flax's epsilon 1e-6; out_dev receives the convolution output itself, or is
  * null when nothing else reads it.  Images of 8x8, 16x16 (one workgroup tile) and 32x32 pixels (four tiles walked by one persistent

@@ -1,0 +1,68 @@
+"""The gate of VERDICT r5 item 2: gd_conv3x3_winograd2d_split6 against the production hybrid kernel on 16x16 256->256 and 32x32 128->128 at
+B = 256 -- time per launch (hipEvents around `reps` back-to-back launches, weights pre-transformed for both) and rms error against float64
+on 4 images.  python tools/bench_split6.py [reps]   (under rocprofv3 --kernel-trace --stats the per-kernel averages are the cross-check)"""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from gddim_amd import _abi, ops  # noqa: E402
+from gddim_amd.ops import _ptr, _stream  # noqa: E402
+
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+dev = torch.device("cuda", 0)
+lib = _abi.lib()
+out = {}
+for H, C in ((16, 256), (32, 128)):
+    B, N = 256, C
+    g = torch.Generator(device=dev).manual_seed(H)
+    x = torch.randn((B, H, H, C), generator=g, device=dev)
+    x = x * torch.sigmoid(x)
+    w = torch.randn((N, 9 * C), generator=g, device=dev) * (2.0 / (9 * C)) ** 0.5
+    b = torch.randn((N,), generator=g, device=dev) * 0.1
+    u6 = ops.conv3x3_winograd2d_split6_weights(w)
+    y6 = torch.empty((B, H, H, N), device=dev)
+    yh = torch.empty_like(y6)
+
+    def run6():
+        _abi.check(lib.gd_conv3x3_winograd2d_split6(_ptr(x), _ptr(u6), _ptr(b), None, _ptr(y6), B, H, H, C, N, 1.0, _stream(x)))
+
+    # the hybrid kernel through its stand-alone operator re-transforms the weights on every call: time that launch alone and take it off
+    uh = torch.empty(24 * N * C, device=dev)
+
+    def runh():
+        _abi.check(lib.gd_conv3x3_winograd42(_ptr(x), _ptr(w), _ptr(uh), _ptr(b), None, _ptr(yh), B, H, H, C, N, 1.0, 1.0, _stream(x)))
+
+    def timed(fn, n):
+        fn()
+        torch.cuda.synchronize()
+        a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(n):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(e) * 1e3 / n  # us
+
+    t6 = timed(run6, reps)
+    th_all = timed(runh, reps)
+    # weight transform of the hybrid operator alone: a 1-image problem has the same weight launch and a negligible convolution
+    x1 = x[:1].contiguous()
+    y1 = torch.empty((1, H, H, N), device=dev)
+    tw = timed(lambda: _abi.check(lib.gd_conv3x3_winograd42(_ptr(x1), _ptr(w), _ptr(uh), _ptr(b), None, _ptr(y1), 1, H, H, C, N, 1.0, 1.0, _stream(x))), reps)
+    # error on 4 images
+    xs, want = x[:4].cpu(), None
+    wd = w.cpu().double().reshape(N, 3, 3, C).permute(0, 3, 1, 2)
+    want = torch.nn.functional.conv2d(xs.double().permute(0, 3, 1, 2), wd, bias=b.cpu().double(), padding=1).permute(0, 2, 3, 1)
+    run6()
+    runh()
+    torch.cuda.synchronize()
+    rms = lambda a: float(((a[:4].cpu().double() - want) ** 2).mean().sqrt() / (want ** 2).mean().sqrt())  # noqa: E731
+    flops = 2.0 * B * H * H * C * N * 9
+    key = "%dx%d_%d" % (H, H, C)
+    out[key] = {"split6_us": t6, "hybrid_op_us": th_all, "hybrid_weight_launch_us_est": tw, "split6_algorithmic_tflops": flops / t6 / 1e6,
+                "rms_rel_error_split6": rms(y6), "rms_rel_error_hybrid": rms(yh), "max_abs_diff_split6_vs_hybrid": float((y6 - yh).abs().max())}
+    print(key, json.dumps(out[key]), flush=True)
+print(json.dumps(out))
