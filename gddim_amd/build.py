@@ -14,6 +14,8 @@ LIB = os.path.join(HERE, "libgddim_amd.so")
 SOURCES = ["engine.cpp", "plan.cpp", "options.cpp", "host_math.cpp", "kernels/igemm.hip", "kernels/igemm_bf16x3.hip", "kernels/conv3x3_halo_bf16x3.hip", "kernels/conv3x3_wino2d_f32.hip", "kernels/conv3x3_wino42_f32.hip", "kernels/conv3x3_wino2d_split6.hip", "kernels/attn_fused_f32.hip", "kernels/norm_act.hip", "kernels/update.hip"]
 HEADERS = ["common.h", "plan.h", "options.h", "kernels/qstats.h", "kernels/epilogue.h", "kernels/rng.h", "kernels/act.h", "../../include/gddim_amd.h"]
 ARCH = "gfx950"
+# per-file flags: the split6 kernel wants its fp32 adds scalar (v_pk_add_f32 costs issue time beside bf16 MFMAs)
+EXTRA_FLAGS = {"kernels/conv3x3_wino2d_split6.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc():
@@ -34,7 +36,7 @@ def build(force=False, verbose=False):
         obj = os.path.join(BUILD, src.replace("/", "_") + ".o")
         objs.append(obj)
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(sp), hdr_mtime):
-            cmd = [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-c", sp, "-o", obj]
+            cmd = [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC"] + EXTRA_FLAGS.get(src, []) + ["-c", sp, "-o", obj]
             if src.endswith(".cpp"):
                 cmd[1:1] = ["-x", "hip"]
             if verbose:

@@ -22,12 +22,19 @@
 //   U     straight from global / L2 into the B registers, fragment order [n tile][chunk][h][wave][i & 1][n block][piece][lane][8 bf16]
 //         (split6_weights_kernel): a wave's 12 fragments of a phase are 12 contiguous KB; a ring of four 3-fragment slots, refilled as soon
 //         as a slot's 12 MFMAs are issued (three groups = 1.1k cycles ahead).
-//   d     thread (tile, quad) loads the three patch rows its component-row half needs (12 x 16 B, zero padding by the buffer bounds check),
-//         one phase ahead; B^T rows in registers, then per component: column combination (4 adds), split (8 and / 8 sub / 6 perm), 3 stores.
+//   d     the tile's 18 x 18-pixel input region, 16 channels at a time, ONCE per chunk: 1 296 16-byte pieces, six coalesced loads per thread
+//         (zero padding by the buffer bounds check) two chunks ahead, parked in registers for a phase, then stored into a two-stage raw
+//         ring in LDS laid out [row][column parity][column / 2][channel quad] so that the (tile, quad) threads' ds_read_b128 of one patch
+//         position are conflict-free.  (First form: every thread loaded its own 3 x 4 patch pixels from global memory, 12 loads of 16 B
+//         per phase touching 32 cache lines each -- 196 KB per phase through a 64 B/clk L1 for 48 KB of payload: the loop ran at 4 030
+//         cycles per phase, 2 070 without those loads; profiles/r06_notes.md.)  Thread (tile, quad) then reads the three patch rows its
+//         component-row half needs, forms the B^T rows in registers, and per component: column combination (4 adds), split (8 and /
+//         8 sub / 6 perm), 3 stores.
 //   loop  the last 12-MFMA group of a phase runs AFTER the barrier, under the first fragment reads of the next phase (its operands are
 //         registers): the matrix pipe never waits for LDS.
 // Epilogue: the row transform A^T . is in-lane (a wave holds all four i of its column), the column transform . A crosses the four waves
-// through LDS (128 KB, the idle stages); wave (tile block, n block) finishes 32 tiles x 32 outputs: bias, residual, scale, store.
+// through LDS (128 KB over the idle stages, [tile][n] so that a reader holds four consecutive outputs); thread (tile, n quad) finishes
+// 2 x 2 pixels x 4 outputs: bias, residual, scale, 16-byte stores.
 // Shapes: H % 16 == 0, W % 16 == 0, Cin % 16 == 0, N % 64 == 0.
 #include <cstdio>
 #include <cstdlib>
@@ -48,7 +55,8 @@ typedef __bf16 s6bf16x8 __attribute__((ext_vector_type(8)));
 #endif
 
 constexpr int S6_STAGE = 8 * 3 * 2 * 64 * 16;  // bytes of one V stage (8 components x 3 pieces x 2 k halves x 64 tiles x 16 B)
-constexpr int S6_SMEM = 131072;                // two stages (96 KB) during the K loop, the 128 KB exchange area in the epilogue
+constexpr int S6_RAW = 6 * 256 * 16;           // bytes of one raw stage: 18 x 18 pixels x 64 B = 1 296 pieces, padded to 6 per thread
+constexpr int S6_SMEM = 2 * S6_STAGE + 2 * S6_RAW;  // 147 456 B during the K loop; the epilogue's exchange area (128 KB) lies over it
 constexpr int S6_OOB = (int)0x80000000u;
 
 struct Split6Params {
@@ -61,20 +69,13 @@ struct Split6Params {
     float out_scale;
 };
 
-// scalar fp32 VALU on purpose: beside bf16 MFMAs a v_pk_add_f32 costs issue time, v_add_f32 does not (MI355X_MICROARCH.md), and the
-// compiler SLP-packs adjacent fp32 adds by itself
-__device__ __forceinline__ float s6_add(float a, float b) {
-    float r;
-    asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ float s6_sub(float a, float b) {
-    float r;
-    asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ s6f32x4 s6_add4(s6f32x4 a, s6f32x4 b) { return s6f32x4{s6_add(a[0], b[0]), s6_add(a[1], b[1]), s6_add(a[2], b[2]), s6_add(a[3], b[3])}; }
-__device__ __forceinline__ s6f32x4 s6_sub4(s6f32x4 a, s6f32x4 b) { return s6f32x4{s6_sub(a[0], b[0]), s6_sub(a[1], b[1]), s6_sub(a[2], b[2]), s6_sub(a[3], b[3])}; }
+// Scalar fp32 VALU on purpose: beside bf16 MFMAs a v_pk_add_f32 costs issue time, v_add_f32 does not (MI355X_MICROARCH.md).  The
+// compiler packs adjacent fp32 adds by itself (SLP vectoriser): this file is built with -fno-slp-vectorize (build.py) and keeps its
+// arithmetic on scalars, so that the instruction scheduler still sees plain VALU instructions it can place between the MFMAs
+// (inline assembly would be opaque to the sched_group_barrier pipeline below).
+struct s6v4 { float e[4]; };
+__device__ __forceinline__ s6v4 s6_add4(s6v4 a, s6v4 b) { return s6v4{{a.e[0] + b.e[0], a.e[1] + b.e[1], a.e[2] + b.e[2], a.e[3] + b.e[3]}}; }
+__device__ __forceinline__ s6v4 s6_sub4(s6v4 a, s6v4 b) { return s6v4{{a.e[0] - b.e[0], a.e[1] - b.e[1], a.e[2] - b.e[2], a.e[3] - b.e[3]}}; }
 
 // (x0, x1) -> one dword holding the top halves: bf16(x0) in bits 15:0, bf16(x1) in 31:16 (truncation)
 __device__ __forceinline__ unsigned s6_pack_hi(float x0, float x1) {
@@ -83,19 +84,21 @@ __device__ __forceinline__ unsigned s6_pack_hi(float x0, float x1) {
 __device__ __forceinline__ float s6_trunc(float x) { return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x) & 0xFFFF0000u); }
 
 // the three bf16 pieces of four channels: out[piece] = 8 bytes in channel order
-__device__ __forceinline__ void s6_split4(s6f32x4 v, s6u32x2 out[3]) {
+__device__ __forceinline__ void s6_split4(s6v4 vv, s6u32x2 out[3]) {
+    const float *v = vv.e;
     float r1[4], r2[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) r1[e] = s6_sub(v[e], s6_trunc(v[e]));
+    for (int e = 0; e < 4; ++e) r1[e] = v[e] - s6_trunc(v[e]);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) r2[e] = s6_sub(r1[e], s6_trunc(r1[e]));
+    for (int e = 0; e < 4; ++e) r2[e] = r1[e] - s6_trunc(r1[e]);
     out[0] = s6u32x2{s6_pack_hi(v[0], v[1]), s6_pack_hi(v[2], v[3])};
     out[1] = s6u32x2{s6_pack_hi(r1[0], r1[1]), s6_pack_hi(r1[2], r1[3])};
     out[2] = s6u32x2{s6_pack_hi(r2[0], r2[1]), s6_pack_hi(r2[2], r2[3])};
 }
 
-__device__ __forceinline__ s6f32x4 s6_load16(__amdgpu_buffer_rsrc_t rsrc, int voffset, int soffset) {
-    return __builtin_bit_cast(s6f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voffset, soffset, 0));
+__device__ __forceinline__ s6v4 s6_load16(__amdgpu_buffer_rsrc_t rsrc, int voffset, int soffset) {
+    const s6f32x4 t = __builtin_bit_cast(s6f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voffset, soffset, 0));
+    return s6v4{{t[0], t[1], t[2], t[3]}};
 }
 
 __global__ void __launch_bounds__(256) conv3x3_wino2d_split6_kernel(const Split6Params p) {
@@ -118,6 +121,22 @@ __global__ void __launch_bounds__(256) conv3x3_wino2d_split6_kernel(const Split6
         ntile = blockIdx.x - mtile * p.n_tiles;
     }
     if (mtile >= p.m_tiles) return;
+#ifdef S6_TRACE  // in-kernel timeline (tools/split6_trace.py): lane 0 of waves 0 and 3 of two workgroups stamps the 100 MHz wall clock and the
+                 // shader clock into the tail of the residual tensor: slot = 80 stamps x (wall, cycles)
+    const int trslot = blockIdx.x == 0 ? 0 : blockIdx.x == 601 ? 1 : -1;
+    float *trbuf = const_cast<float *>(p.res) + (size_t)p.B * p.H * p.W * p.N - 1024 + ((trslot < 0 ? 0 : trslot) * 2 + (wave == 3 ? 1 : 0)) * 160;
+    const bool trw = trslot >= 0 && lane == 0 && (wave == 0 || wave == 3) && p.res;
+    auto trace = [&](int idx) __attribute__((always_inline)) {
+        if (trw && idx < 80) {
+            trbuf[idx] = (float)(wall_clock64() & 0xFFFFFFull);
+            trbuf[80 + idx] = (float)(__builtin_readcyclecounter() & 0xFFFFFFull);
+        }
+    };
+    trace(0);
+#define S6_TR(i) trace(i)
+#else
+#define S6_TR(i)
+#endif
     const int img = mtile / p.tiles_per_image;
     const int brem = mtile - img * p.tiles_per_image;
     const int by = brem / p.bx_tiles, bx = brem - by * p.bx_tiles;
@@ -129,15 +148,19 @@ __global__ void __launch_bounds__(256) conv3x3_wino2d_split6_kernel(const Split6
     const int tile = (wave << 4) | (((lane >> 5) & 1) << 3) | ((lane >> 1) & 7);
     const int q = (lane & 1) | (((lane >> 4) & 1) << 1);
     const int ty = tile >> 3, tx = tile & 7;
-    int voff[4][4];
+    // raw ring: piece L = ((row * 2 + column parity) * 9 + column / 2) * 4 + quad of the 18 x 18 region; thread t moves pieces t + 256 i
+    int rvo[6];
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int y = Y0 + 2 * ty + r - 1, x = X0 + 2 * tx + s - 1;
-            const bool ok = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
-            voff[r][s] = ok ? (((img * H + y) * W + x) * C + q * 4) * 4 : S6_OOB;
-        }
+    for (int i = 0; i < 6; ++i) {
+        const int L = i * 256 + tid;
+        const int row = L / 72, rem = L - row * 72, par = rem / 36, r2 = rem - par * 36;
+        const int y = Y0 - 1 + row, x = X0 - 1 + 2 * (r2 >> 2) + par;
+        const bool ok = L < 1296 && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+        rvo[i] = ok ? (((img * H + y) * W + x) * C + (r2 & 3) * 4) * 4 : S6_OOB;
+    }
+    const int raw_wr = tid * 16;  // + i * 4096 + stage
+    // the thread's patch position (r, s): region row 2 ty + r, column 2 tx + s -> parity s & 1, column / 2 = tx + (s >> 1)
+    const int raw_rd = ((2 * ty * 2) * 9 + tx) * 64 + q * 16;  // + (r * 2 + (s & 1)) * 576 + (s >> 1) * 64
     const __amdgpu_buffer_rsrc_t srd_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(reinterpret_cast<const char *>(p.x)), 0,
                                                                           p.B * H * W * C * 4, 0x00020000);
     // the wave's weight fragments: [n tile][phase][wave][12 fragments of 1 KB]
@@ -163,18 +186,33 @@ __global__ void __launch_bounds__(256) conv3x3_wino2d_split6_kernel(const Split6
                 for (int v = 0; v < 16; ++v) acc[i][a][b][v] = 0.f;
 
     const int NP = 2 * p.nk;  // phases
-    s6f32x4 pr[3][4];         // the three patch rows of the half to produce next
-    s6f32x4 rc[2][4];         // B^T rows (2 component rows x 4 patch columns)
+    s6v4 pr[3][4];            // the three patch rows of the half to produce next
+    s6f32x4 rawreg[6];        // the region pieces of the chunk after next, between their loads and their LDS stores
+    s6v4 rc[2][4];            // B^T rows (2 component rows x 4 patch columns)
     s6bf16x8 Areg[2][2][3];   // [i & 1][tile block][piece]
     s6bf16x8 Ureg[4][3];      // ring: slot = (i & 1) * 2 + n block
 
-    // patch rows of half hp of chunk kc -> pr
-    auto load_patch = [&](int kc, int hp) __attribute__((always_inline)) {
+    unsigned char *raw0 = smem + 2 * S6_STAGE, *raw1 = raw0 + S6_RAW;
+    // region pieces of chunk kc -> registers (a chunk past the last one reads whatever follows: its stage is never read)
+    auto load_raw = [&](int kc) __attribute__((always_inline)) {
+        if ((S6_ABL & 1) && kc >= 2) return;
         const int so = __builtin_amdgcn_readfirstlane(kc * 64);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) rawreg[i] = __builtin_bit_cast(s6f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_x, rvo[i], so, 0));
+    };
+    auto store_raw = [&](unsigned char *st) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) *reinterpret_cast<s6f32x4 *>(st + i * 4096 + raw_wr) = rawreg[i];
+    };
+    // patch rows of half hp out of raw stage st -> pr (hp = 0: rows 0, 1, 2; hp = 1: rows 1, 2, 3)
+    auto read_patch = [&](const unsigned char *st, int hp) __attribute__((always_inline)) {
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
-            for (int s = 0; s < 4; ++s) pr[r][s] = hp == 0 ? s6_load16(srd_x, voff[r][s], so) : s6_load16(srd_x, voff[r + 1][s], so);
+            for (int sx = 0; sx < 4; ++sx) {
+                const s6f32x4 t = *reinterpret_cast<const s6f32x4 *>(st + raw_rd + ((r + hp) * 2 + (sx & 1)) * 576 + (sx >> 1) * 64);
+                pr[r][sx] = s6v4{{t[0], t[1], t[2], t[3]}};
+            }
     };
     // B^T rows of half hp: hp = 0: d0 - d2, d1 + d2 (pr = rows 0, 1, 2); hp = 1: d2 - d1, d1 - d3 (pr = rows 1, 2, 3)
     auto row_combine = [&](int hp) __attribute__((always_inline)) {
@@ -191,14 +229,14 @@ __global__ void __launch_bounds__(256) conv3x3_wino2d_split6_kernel(const Split6
     };
     // component (i2, j) of the half in rc -> three 8-byte stores into stage `st`
     auto produce = [&](int i2, int j, unsigned char *st) __attribute__((always_inline)) {
-        s6f32x4 v;
+        s6v4 v;
         if (S6_ABL & 16) v = rc[i2][j];
         else if (j == 0) v = s6_sub4(rc[i2][0], rc[i2][2]);
         else if (j == 1) v = s6_add4(rc[i2][1], rc[i2][2]);
         else if (j == 2) v = s6_sub4(rc[i2][2], rc[i2][1]);
         else v = s6_sub4(rc[i2][1], rc[i2][3]);
         s6u32x2 pc[3];
-        if (S6_ABL & 16) { pc[0] = s6u32x2{__builtin_bit_cast(unsigned, v[0]), __builtin_bit_cast(unsigned, v[1])}; pc[1] = pc[0]; pc[2] = pc[0]; }
+        if (S6_ABL & 16) { pc[0] = s6u32x2{__builtin_bit_cast(unsigned, v.e[0]), __builtin_bit_cast(unsigned, v.e[1])}; pc[1] = pc[0]; pc[2] = pc[0]; }
         else s6_split4(v, pc);
         if (S6_ABL & 2) { asm volatile("" ::"v"(pc[0]), "v"(pc[1]), "v"(pc[2])); return; }
 #pragma unroll
@@ -221,129 +259,189 @@ __global__ void __launch_bounds__(256) conv3x3_wino2d_split6_kernel(const Split6
             Ureg[slot][pi] = __builtin_bit_cast(s6bf16x8, __builtin_amdgcn_raw_buffer_load_b128(srd_u, u_vo, so + pi * 1024, 0));
     };
 
-    // six products per (tile block): a1 u1, a2 u0, a0 u2, a1 u0, a0 u1, a0 u0 -- the small ones first; the two tile blocks alternate so that
-    // consecutive MFMAs never share an accumulator
-    constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};
-#define S6_MFMA(I, I2, NB, T, TB)                                                                                                      \
-    if (!(S6_ABL & 64)) acc[I][TB][NB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Areg[I2][TB][PA[T]], Ureg[(I2) * 2 + (NB)][PB[T]], acc[I][TB][NB], 0, 0, 0)
-#define S6_HALF_GROUP(I, I2, NB, T0)                                                                    \
-    S6_MFMA(I, I2, NB, T0, 0); S6_MFMA(I, I2, NB, T0, 1); S6_MFMA(I, I2, NB, T0 + 1, 0); S6_MFMA(I, I2, NB, T0 + 1, 1); \
-    S6_MFMA(I, I2, NB, T0 + 2, 0); S6_MFMA(I, I2, NB, T0 + 2, 1)
+    // The 48 MFMAs of a phase as ONE sequence k = 0..47: 0..11 the group the previous phase left over (its component row 2 (1 - HH) + 1,
+    // n block 1), then (row 2 HH, n block 0), (row 2 HH, n block 1), (row 2 HH + 1, n block 0); the group (row 2 HH + 1, n block 1) is left
+    // to the next phase.  Inside a group six products per tile block -- a1 u1, a2 u0, a0 u2, a1 u0, a0 u1, a0 u0, the small ones first --
+    // with the two tile blocks alternating, so that consecutive MFMAs never share an accumulator.
+    auto mfma_k = [&](int hh, bool first, int k) __attribute__((always_inline)) {
+        constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};
+        if (S6_ABL & 64) return;
+        const int g = k / 12, r = k % 12, t = r >> 1, tb = r & 1;
+        if (g == 0 && first) return;
+        const int i = g == 0 ? 2 * (1 - hh) + 1 : g == 3 ? 2 * hh + 1 : 2 * hh;
+        const int i2 = (g == 0 || g == 3) ? 1 : 0;
+        const int nb = (g == 0 || g == 2) ? 1 : 0;
+        acc[i][tb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Areg[i2][tb][PA[t]], Ureg[i2 * 2 + nb][PB[t]], acc[i][tb][nb], 0, 0, 0);
+    };
 
     unsigned char *stage0 = smem, *stage1 = smem + S6_STAGE;
 
     // ---- prologue: V of phase 0 -> stage 0; the patch rows phase 0 will turn into phase 1's V; the weight slots 0..2 of phase 0 ----
-    load_patch(0, 0);
+    load_raw(0);
+    store_raw(raw0);
+    load_raw(1);
     load_u(0, 0);
     load_u(0, 1);
     load_u(0, 2);
+    store_raw(raw1);
+    __syncthreads();
+    read_patch(raw0, 0);
     row_combine(0);
 #pragma unroll
     for (int i2 = 0; i2 < 2; ++i2)
 #pragma unroll
         for (int j = 0; j < 4; ++j) produce(i2, j, stage0);
-    load_patch(0, 1);
     __syncthreads();
+    S6_TR(1);
 
-    // One phase.  HH: component-row half being multiplied (stage HH is read, stage 1 - HH is written with the next phase's V).
-#define S6_PHASE(HH, PHASE_INDEX, FIRST)                                                                                               \
+    // One phase.  HH: component-row half being multiplied (stage HH is read, stage 1 - HH is written with the next phase's V).  Nine
+    // scheduling regions: 8 MFMAs beside the B^T rows (32 VALU), then eight times 5 MFMAs beside one component's column combination, split
+    // and stores (26 VALU, 3 LDS stores) and the region's share of the loads; inside a region the sched_group_barrier pipeline asks for
+    // MFMA / VALU / LDS / global-load groups in turn, so that the matrix pipe and the vector lanes run side by side.
+#define S6_PIPE(NM, NV, ND, NG)                                                                   \
+    _Pragma("unroll") for (int s_ = 0; s_ < (NM); ++s_) {                                         \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                        \
+        __builtin_amdgcn_sched_group_barrier(0x002, (NV), 0);                                     \
+        if ((ND) > 0) __builtin_amdgcn_sched_group_barrier(0x080, (ND), 0);                       \
+        if ((NG) > 0) __builtin_amdgcn_sched_group_barrier(0x020, (NG), 0);                       \
+    }                                                                                             \
+    __builtin_amdgcn_sched_barrier(0)
+#define S6_UNIT(HH, FIRST, MORE1, K0, I2, J)                                                      \
+    _Pragma("unroll") for (int k_ = (K0); k_ < (K0) + 5; ++k_) mfma_k((HH), (FIRST), k_);         \
+    if (MORE1) produce((I2), (J), wr)
+#define S6_PHASE(HH, PHASE_INDEX, FIRST, MORE1, MORE2)                                                                                 \
     {                                                                                                                                  \
         const int ph = (PHASE_INDEX);                                                                                                  \
         unsigned char *rd = (HH) ? stage1 : stage0, *wr = (HH) ? stage0 : stage1;                                                      \
-        const bool more1 = ph + 1 < NP, more2 = ph + 2 < NP;                                                                           \
+        constexpr bool more1 = (MORE1), more2 = (MORE2); /* a phase after this one / two phases after: compile time, no branches */    \
+        /* region 0: the next phase is (chunk kc_ + HH, half 1 - HH): its patch rows out of that chunk's raw stage */                  \
+        const int kc_ = ph >> 1;                                                                                                       \
         read_a(0, rd);                                                                                                                 \
-        if (!(FIRST)) { S6_HALF_GROUP(2 * (1 - (HH)) + 1, 1, 1, 0); S6_HALF_GROUP(2 * (1 - (HH)) + 1, 1, 1, 3); }                      \
-        __builtin_amdgcn_sched_barrier(0);                                                                                             \
-        load_u(ph, 3);                                                                                                                 \
+        if (more1) read_patch((((kc_ + (HH)) & 1) ? raw1 : raw0), 1 - (HH));                                                           \
+        _Pragma("unroll") for (int k_ = 0; k_ < 8; ++k_) mfma_k((HH), (FIRST), k_);                                                    \
         if (more1) row_combine(1 - (HH));                                                                                              \
-        if (more2 && !((S6_ABL & 1) && ph >= 2)) load_patch((ph + 2) >> 1, (HH));                                                      \
-        __builtin_amdgcn_sched_barrier(0);                                                                                             \
-        S6_HALF_GROUP(2 * (HH), 0, 0, 0);                                                                                              \
-        if (more1) { produce(0, 0, wr); }                                                                                              \
-        __builtin_amdgcn_sched_barrier(0);                                                                                             \
-        S6_HALF_GROUP(2 * (HH), 0, 0, 3);                                                                                              \
-        if (more1) { produce(0, 1, wr); }                                                                                              \
-        if (more1) load_u(ph + 1, 0);                                                                                                  \
+        S6_PIPE(8, 4, 3, 0);                                                                                                           \
+        if (ph == 6 || ph == 7) S6_TR(48 + (ph - 6) * 10 + 0);                                                                         \
+        /* regions 1..8 */                                                                                                             \
+        S6_UNIT(HH, FIRST, more1, 8, 0, 0);                                                                                            \
+        /* the region of chunk kc_ + 2: loaded in this chunk's first phase, stored (its stage was last read in that phase) in the second */ \
+        if (more2 && (HH) == 0) load_raw(kc_ + 2);                                                                                     \
+        if (more2 && (HH) == 1) store_raw((kc_ & 1) ? raw1 : raw0);                                                                    \
+        S6_PIPE(5, 6, 2, 2);                                                                                                           \
+        if (ph == 6 || ph == 7) S6_TR(48 + (ph - 6) * 10 + 1);                                        \
+        S6_UNIT(HH, FIRST, more1, 13, 0, 1);                                                                                           \
+        load_u(ph, 3);                                                                                                                 \
+        S6_PIPE(5, 6, 1, 1);                                                                                                           \
+        if (ph == 6 || ph == 7) S6_TR(48 + (ph - 6) * 10 + 2);                                        \
+        S6_UNIT(HH, FIRST, more1, 18, 0, 2);                                                                                           \
         read_a(1, rd);                                                                                                                 \
-        __builtin_amdgcn_sched_barrier(0);                                                                                             \
-        S6_HALF_GROUP(2 * (HH), 0, 1, 0);                                                                                              \
-        if (more1) { produce(0, 2, wr); produce(0, 3, wr); }                                                                           \
-        __builtin_amdgcn_sched_barrier(0);                                                                                             \
-        S6_HALF_GROUP(2 * (HH), 0, 1, 3);                                                                                              \
-        if (more1) { produce(1, 0, wr); }                                                                                              \
+        S6_PIPE(5, 6, 2, 0);                                                                                                           \
+        if (ph == 6 || ph == 7) S6_TR(48 + (ph - 6) * 10 + 3);                                        \
+        S6_UNIT(HH, FIRST, more1, 23, 0, 3);                                                                                           \
+        S6_PIPE(5, 6, 1, 0);                                                                                                           \
+        if (ph == 6 || ph == 7) S6_TR(48 + (ph - 6) * 10 + 4);                                        \
+        S6_UNIT(HH, FIRST, more1, 28, 1, 0);                                                                                           \
+        if (more1) load_u(ph + 1, 0);                                                                                                  \
+        S6_PIPE(5, 6, 1, 1);                                                                                                           \
+        if (ph == 6 || ph == 7) S6_TR(48 + (ph - 6) * 10 + 5);                                        \
+        S6_UNIT(HH, FIRST, more1, 33, 1, 1);                                                                                           \
+        S6_PIPE(5, 6, 1, 0);                                                                                                           \
+        if (ph == 6 || ph == 7) S6_TR(48 + (ph - 6) * 10 + 6);                                        \
+        S6_UNIT(HH, FIRST, more1, 38, 1, 2);                                                                                           \
         if (more1) load_u(ph + 1, 1);                                                                                                  \
-        __builtin_amdgcn_sched_barrier(0);                                                                                             \
-        S6_HALF_GROUP(2 * (HH) + 1, 1, 0, 0);                                                                                          \
-        if (more1) { produce(1, 1, wr); produce(1, 2, wr); }                                                                           \
-        __builtin_amdgcn_sched_barrier(0);                                                                                             \
-        S6_HALF_GROUP(2 * (HH) + 1, 1, 0, 3);                                                                                          \
-        if (more1) { produce(1, 3, wr); }                                                                                              \
+        S6_PIPE(5, 6, 1, 1);                                                                                                           \
+        if (ph == 6 || ph == 7) S6_TR(48 + (ph - 6) * 10 + 7);                                        \
+        S6_UNIT(HH, FIRST, more1, 43, 1, 3);                                                                                           \
+        S6_PIPE(5, 6, 1, 0);                                                                                                           \
+        if (ph == 6 || ph == 7) S6_TR(48 + (ph - 6) * 10 + 8);                                        \
         if (more1) load_u(ph + 1, 2);                                                                                                  \
-        __builtin_amdgcn_sched_barrier(0);                                                                                             \
         if (!(S6_ABL & 8)) __syncthreads();                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                                             \
+        S6_TR(2 + ph);                                                                                                                 \
     }
 
-    S6_PHASE(0, 0, true);
-    S6_PHASE(1, 1, false);
-    for (int kc = 1; kc < p.nk; ++kc) {
-        S6_PHASE(0, 2 * kc, false);
-        S6_PHASE(1, 2 * kc + 1, false);
+    (void)NP;
+    if (p.nk == 1) {
+        S6_PHASE(0, 0, true, true, false);
+        S6_PHASE(1, 1, false, false, false);
+    } else {
+        S6_PHASE(0, 0, true, true, true);
+        S6_PHASE(1, 1, false, true, true);
+        for (int kc = 1; kc < p.nk - 1; ++kc) {
+            S6_PHASE(0, 2 * kc, false, true, true);
+            S6_PHASE(1, 2 * kc + 1, false, true, true);
+        }
+        S6_PHASE(0, 2 * p.nk - 2, false, true, false);
+        S6_PHASE(1, 2 * p.nk - 1, false, false, false);
     }
-    // the deferred group of the last phase (component row 3, n block 1)
-    S6_HALF_GROUP(3, 1, 1, 0);
-    S6_HALF_GROUP(3, 1, 1, 3);
+    // the group the last phase left over (component row 3, n block 1)
+#pragma unroll
+    for (int k = 0; k < 12; ++k) mfma_k(0, false, k);
+    S6_TR(39);
 #undef S6_PHASE
-#undef S6_HALF_GROUP
-#undef S6_MFMA
+#undef S6_UNIT
+#undef S6_PIPE
 
-    // ---- epilogue.  In-lane: z_a = sum_i A^T[a][i] M_i (a = 0: m0 + m1 + m2, a = 1: m1 - m2 - m3).  Exchange through LDS:
-    // zx[wave j][a][tile block][n block][register quad][lane][4] (lane-contiguous 16-byte slots: conflict-free both ways) ----
+    // ---- epilogue.  In-lane: z_a = sum_i A^T[a][i] M_i (a = 0: m0 + m1 + m2, a = 1: m1 - m2 - m3).  Exchange through LDS as
+    // zx[wave j][a][tile][n] (floats, n contiguous): the MFMA layout has a lane = one output n, so the writers store single floats (lanes
+    // = consecutive n: conflict-free) and the readers get FOUR consecutive n per lane -- a store instruction costs the CU's store path
+    // about the same whatever its width, and 64 dword stores per lane made the first form's epilogue 9-11 us of an 80 us tile ----
     float *zx = reinterpret_cast<float *>(smem);
 #pragma unroll
     for (int tb = 0; tb < 2; ++tb)
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-                s6f32x4 z0, z1;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int v = rq * 4 + e;
-                    z0[e] = (acc[0][tb][nb][v] + acc[1][tb][nb][v]) + acc[2][tb][nb][v];
-                    z1[e] = (acc[1][tb][nb][v] - acc[2][tb][nb][v]) - acc[3][tb][nb][v];
-                }
-                *reinterpret_cast<s6f32x4 *>(zx + ((((wave * 2 + 0) * 2 + tb) * 2 + nb) * 4 + rq) * 256 + lane * 4) = z0;
-                *reinterpret_cast<s6f32x4 *>(zx + ((((wave * 2 + 1) * 2 + tb) * 2 + nb) * 4 + rq) * 256 + lane * 4) = z1;
+            for (int v = 0; v < 16; ++v) {
+                const float z0 = (acc[0][tb][nb][v] + acc[1][tb][nb][v]) + acc[2][tb][nb][v];
+                const float z1 = (acc[1][tb][nb][v] - acc[2][tb][nb][v]) - acc[3][tb][nb][v];
+                const int t = tb * 32 + (v & 3) + 8 * (v >> 2);  // + 4 (lane >> 5): tile of accumulator register v (MFMA C / D layout)
+                const int o = (t + 4 * (lane >> 5)) * 64 + nb * 32 + (lane & 31);
+                zx[(wave * 2 + 0) * 4096 + o] = z0;
+                zx[(wave * 2 + 1) * 4096 + o] = z1;
             }
+    S6_TR(40);
     __syncthreads();
-    // wave (tb, nb) finishes 32 tiles x 32 outputs: y_a0 = z_a[0] + z_a[1] + z_a[2], y_a1 = z_a[1] - z_a[2] - z_a[3]
+    S6_TR(41);
+    // thread (tile, n quad): y_ab = sum_j z_a[j] A^T[b][j] (b = 0: z0 + z1 + z2, b = 1: z1 - z2 - z3) for four consecutive outputs, 16-byte stores.
+    // lane bits 0..3 = n quad (a wave-level store covers whole 256-byte rows of four pixels); tile = 4 (wave * 4 + k) + (lane >> 4), k = 0..3
     {
-        const int tb = wave >> 1, nb = wave & 1;
-        const int n = ntile * 64 + nb * 32 + (lane & 31);
-        const float bias = p.bias ? p.bias[n] : 0.f;
+        const int nq = lane & 15;
+        const int n = ntile * 64 + nq * 4;
+        s6f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) bias = *reinterpret_cast<const s6f32x4 *>(p.bias + n);
+        const __amdgpu_buffer_rsrc_t srd_o = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(p.out), 0, p.B * H * W * p.N * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t srd_r = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char *>(reinterpret_cast<const char *>(p.res ? p.res : p.out)), 0, p.B * H * W * p.N * 4, 0x00020000);
+        const bool has_res = p.res != nullptr;
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int k = 0; k < 4; ++k) {
+            const int t = 4 * (wave * 4 + k) + (lane >> 4);
+            const int oy = Y0 + 2 * (t >> 3), ox = X0 + 2 * (t & 7);
+            const int vo = (((img * H + oy) * W + ox) * p.N + n) * 4;
 #pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
+            for (int a = 0; a < 2; ++a) {
                 s6f32x4 zj[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    zj[j] = *reinterpret_cast<const s6f32x4 *>(zx + ((((j * 2 + a) * 2 + tb) * 2 + nb) * 4 + rq) * 256 + lane * 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int v = rq * 4 + e;
-                    const int t = tb * 32 + (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5);  // tile of accumulator register v (MFMA C/D layout)
-                    const int oy = Y0 + 2 * (t >> 3) + a, ox = X0 + 2 * (t & 7);
-                    const float y0 = (zj[0][e] + zj[1][e]) + zj[2][e];
-                    const float y1 = (zj[1][e] - zj[2][e]) - zj[3][e];
-                    const size_t o = ((size_t)(img * H + oy) * W + ox) * p.N + n;
-                    float r0 = y0 + bias, r1 = y1 + bias;
-                    if (p.res) { r0 += p.res[o]; r1 += p.res[o + p.N]; }
-                    __builtin_nontemporal_store(r0 * p.out_scale, p.out + o);
-                    __builtin_nontemporal_store(r1 * p.out_scale, p.out + o + p.N);
+                for (int j = 0; j < 4; ++j) zj[j] = *reinterpret_cast<const s6f32x4 *>(zx + (j * 2 + a) * 4096 + t * 64 + nq * 4);
+                s6f32x4 r0 = (zj[0] + zj[1]) + zj[2] + bias;
+                s6f32x4 r1 = (zj[1] - zj[2]) - zj[3] + bias;
+                const int so = __builtin_amdgcn_readfirstlane(a * W * p.N * 4);
+                if (has_res) {
+                    r0 += __builtin_bit_cast(s6f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_r, vo, so, 0));
+                    r1 += __builtin_bit_cast(s6f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_r, vo, so + p.N * 4, 0));
                 }
+                const s6u32x4 d0 = __builtin_bit_cast(s6u32x4, r0 * p.out_scale), d1 = __builtin_bit_cast(s6u32x4, r1 * p.out_scale);
+                __builtin_amdgcn_raw_buffer_store_b128(d0, srd_o, vo, so, 2);  // (aux 2: nt)
+                __builtin_amdgcn_raw_buffer_store_b128(d1, srd_o, vo, so + p.N * 4, 2);
+                // A 16-byte store reads its last data register for the last lanes many cycles after issue: with the registers rewritten two
+                // instructions later, element 3 of lanes 12..15 (mod 16) of the FIRST store came out as the second store's (measured, every
+                // shape, deterministic).  The hazard recogniser does not cover it; keep the data registers alone for a while.
+                asm volatile("s_nop 15\n\ts_nop 15" ::"v"(d0), "v"(d1));
             }
+        }
     }
+    S6_TR(42);
 }
 
 // U = G g G^T in double, rounded once to fp32, then three round-to-nearest bf16 pieces, in the fragment order of the kernel above.
