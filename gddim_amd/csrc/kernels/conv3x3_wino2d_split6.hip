@@ -11,33 +11,38 @@
 // (profiles/r05_notes.md): the activation-side transform AND the split are plain fp32 / integer VALU (free beside bf16 MFMAs as long as they
 // are not packed instructions: tools/valu_share.hip), 96 KB of V pieces through LDS and 96 KB of U pieces from L2 per 16-channel chunk.
 //
-// Workgroup = 256 threads = 4 wave64 (one per SIMD, the 512-register budget), one per CU.  Tile = 64 Winograd tiles (an 8 x 8 block of
-// 2 x 2-output tiles = 16 x 16 output pixels of ONE image) x 64 outputs x 16 components.  Wave w owns component COLUMN j = w, i.e. the four
-// components (i, w), i = 0..3, of both 32-tile blocks and both 32-output blocks: 16 accumulators of 32 x 32 (256 registers).
-// K = Cin is walked in chunks of 16 channels, each in two PHASES h = 0, 1 = component rows {2h, 2h + 1}: the V stage of a phase (8 components
-// x 3 pieces x 64 tiles x 16 channels of bf16 = 48 KB) is read while the other stage is written, 48 MFMAs per wave and ONE barrier per phase.
+// Workgroup = 512 threads = 8 wave64 (two per SIMD, 256 registers each), one per CU (147 KB of LDS).  Tile = 64 Winograd tiles (an 8 x 8
+// block of 2 x 2-output tiles = 16 x 16 output pixels of ONE image) x 64 outputs x 16 components.  Wave w = (column j = w & 3, row parity
+// ih = w >> 2) owns components (ih, j) and (ih + 2, j) of both 32-tile blocks and both 32-output blocks: 8 accumulators of 32 x 32 = 128
+// registers.  K = Cin is walked in chunks of 16 channels, each in two PHASES h = 0, 1 = component rows {2h, 2h + 1}: the V stage of a phase
+// (8 components x 3 pieces x 64 tiles x 16 channels of bf16 = 48 KB) is read while the other stage is written; 24 MFMAs per wave and ONE
+// barrier per phase.  The two waves of a SIMD (w and w + 4) take the phase in opposite order -- ih = 0: multiply, then produce the next
+// phase's V; ih = 1: produce, then multiply -- so that one wave's MFMAs run under the other's VALU / LDS / load instructions (a wave issues
+// in order: in the first, one-wave-per-SIMD form every LDS or global instruction cost the wave 15-60 cycles of issue that nothing covered,
+// and the loop ran at 3 100-4 000 cycles per phase against 1 536 of MFMA issue; profiles/r06_notes.md).
 //   LDS   V[h][i & 1][j][piece][k half][tile][8 bf16]: an A fragment (32 tiles x 16 channels) is one contiguous KB, ds_read_b128, conflict-free;
-//         the producing thread (tile, channel quad) writes 8 bytes per (component, piece): ds_write_b64, 16 lanes = 8 tiles x 2 quads = 128
-//         contiguous bytes.
-//   U     straight from global / L2 into the B registers, fragment order [n tile][chunk][h][wave][i & 1][n block][piece][lane][8 bf16]
-//         (split6_weights_kernel): a wave's 12 fragments of a phase are 12 contiguous KB; a ring of four 3-fragment slots, refilled as soon
-//         as a slot's 12 MFMAs are issued (three groups = 1.1k cycles ahead).
-//   d     the tile's 18 x 18-pixel input region, 16 channels at a time, ONCE per chunk: 1 296 16-byte pieces, six coalesced loads per thread
-//         (zero padding by the buffer bounds check) two chunks ahead, parked in registers for a phase, then stored into a two-stage raw
-//         ring in LDS laid out [row][column parity][column / 2][channel quad] so that the (tile, quad) threads' ds_read_b128 of one patch
-//         position are conflict-free.  (First form: every thread loaded its own 3 x 4 patch pixels from global memory, 12 loads of 16 B
-//         per phase touching 32 cache lines each -- 196 KB per phase through a 64 B/clk L1 for 48 KB of payload: the loop ran at 4 030
-//         cycles per phase, 2 070 without those loads; profiles/r06_notes.md.)  Thread (tile, quad) then reads the three patch rows its
-//         component-row half needs, forms the B^T rows in registers, and per component: column combination (4 adds), split (8 and /
-//         8 sub / 6 perm), 3 stores.
-//   loop  the last 12-MFMA group of a phase runs AFTER the barrier, under the first fragment reads of the next phase (its operands are
-//         registers): the matrix pipe never waits for LDS.
-// Epilogue: the row transform A^T . is in-lane (a wave holds all four i of its column), the column transform . A crosses the four waves
-// through LDS (128 KB over the idle stages, [tile][n] so that a reader holds four consecutive outputs); thread (tile, n quad) finishes
-// 2 x 2 pixels x 4 outputs: bias, residual, scale, 16-byte stores.
+//         the producing thread (tile, channel quad, row parity) writes 8 bytes per (component, piece): ds_write_b64, 16 lanes = 8 tiles x 2
+//         quads = 128 contiguous bytes.
+//   U     straight from global / L2 into the B registers, fragment order [n tile][chunk][h][column j][i & 1][n block][piece][lane][8 bf16]
+//         (split6_weights_kernel): a wave's 6 fragments of a phase are 6 contiguous KB, requested right after the previous phase's MFMAs.
+//   d     the tile's 18 x 18-pixel input region, 16 channels at a time, ONCE per chunk: 1 296 16-byte pieces, three coalesced loads per
+//         thread (zero padding by the buffer bounds check) two chunks ahead, parked in registers for a phase and a half, then stored into a
+//         two-stage raw ring in LDS laid out [row][column parity][column / 2][channel quad] so that the (tile, quad) threads' ds_read_b128 of
+//         one patch position are conflict-free.  (First form: every thread loaded its own patch pixels from global memory, 12 loads of 16 B
+//         per phase touching 32 cache lines each -- 196 KB per phase through a 64 B/clk L1 for 48 KB of payload.)  Thread (tile, quad, ih)
+//         reads the two patch rows its component row combines (B^T row: one add per element), then per component: column combination
+//         (4 adds), split (8 and / 8 sub / 6 perm), 3 stores.
+// Epilogue: the row transform A^T . takes the rows of the two waves of a column (the ih = 0 wave stores its part into the exchange area,
+// the ih = 1 wave adds its own after a barrier), the column transform . A crosses the four columns: 128 KB over the idle stages, [tile][n] so
+// that a reader holds four consecutive outputs; thread (tile, n quad) finishes 2 x 2 pixels x 4 outputs: bias, residual, scale, 16-byte stores.
 // Shapes: H % 16 == 0, W % 16 == 0, Cin % 16 == 0, N % 64 == 0.
+// Where it stands (MI355X, B = 256; tools/bench_split6.py, profiles/r06_notes.md): rms error 0.33 of the production hybrid fp32 kernel's, time
+// 252 us (16x16, 256 -> 256) and 272 us (32x32, 128 -> 128) against the hybrid kernel's 213 and 249: the gate of VERDICT r5 item 2
+// (>= 1.15x faster) is NOT met, and the operator stays a stand-alone prototype.
 #include <cstdio>
 #include <cstdlib>
+
+#include <type_traits>
 
 #include "../common.h"
 
@@ -101,11 +106,180 @@ __device__ __forceinline__ s6v4 s6_load16(__amdgpu_buffer_rsrc_t rsrc, int voffs
     return s6v4{{t[0], t[1], t[2], t[3]}};
 }
 
-__global__ void __launch_bounds__(256) conv3x3_wino2d_split6_kernel(const Split6Params p) {
+// One role of the K loop (IH = 0: multiply first, then produce; IH = 1: produce first, then multiply), so that the two waves of a SIMD
+// -- waves w and w + 4 of the workgroup -- alternate between the matrix pipe and the vector / LDS / load instructions.
+template <int IH>
+__device__ __forceinline__ void s6_kloop(const Split6Params &p, unsigned char *smem, s6f32x16 (&acc)[2][2][2], int tid, int lane, int jw,
+                                         const int (&rvo)[3], int raw_rd, int vw_off, int ar_off, __amdgpu_buffer_rsrc_t srd_x,
+                                         __amdgpu_buffer_rsrc_t srd_u, float *trbuf, bool trw) {
+    constexpr int CS_BYTES = 3 * 2048;  // one component: 3 pieces x 2 k halves x 64 tiles x 16 B
+    unsigned char *stage0 = smem, *stage1 = smem + S6_STAGE;
+    unsigned char *raw0 = smem + 2 * S6_STAGE, *raw1 = raw0 + S6_RAW;
+    const int u_vo = lane * 16;
+    const int raw_wr = tid * 16;
+    s6v4 pr[2][4];          // the two patch rows the thread's component row combines
+    s6v4 rc[4];             // its B^T row (4 patch columns)
+    s6f32x4 rawreg[3];      // region pieces of the chunk after next, between their loads and their LDS stores
+    s6bf16x8 Areg[2][3];    // [tile block][piece]
+    s6bf16x8 Ureg[2][3];    // [n block][piece]
+#ifdef S6_TRACE
+    auto trace = [&](int idx) __attribute__((always_inline)) {
+        if (trw && idx < 80) {
+            trbuf[idx] = (float)(wall_clock64() & 0xFFFFFFull);
+            trbuf[80 + idx] = (float)(__builtin_readcyclecounter() & 0xFFFFFFull);
+        }
+    };
+#else
+    (void)trbuf; (void)trw;
+#endif
+
+    auto load_raw = [&](int kc) __attribute__((always_inline)) {
+        if ((S6_ABL & 1) && kc >= 2) return;
+        const int so = __builtin_amdgcn_readfirstlane(kc * 64);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) rawreg[i] = __builtin_bit_cast(s6f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_x, rvo[i], so, 0));
+    };
+    auto store_raw = [&](unsigned char *st) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) *reinterpret_cast<s6f32x4 *>(st + i * 8192 + raw_wr) = rawreg[i];
+    };
+    // Component row i = 2 hp + IH of the thread's (tile, quad): B^T row i = d0 - d2, d1 + d2, d2 - d1, d1 - d3 (patch rows), then the four
+    // components (i, j): column combination, split, three 8-byte stores each
+    auto produce_row = [&](const unsigned char *rawst, int hp, unsigned char *st) __attribute__((always_inline)) {
+        const int i = 2 * hp + IH;
+        const int ra = i == 0 ? 0 : i == 1 ? 1 : i == 2 ? 2 : 1, rb = i == 0 ? 2 : i == 1 ? 2 : i == 2 ? 1 : 3;
+        // (two patch columns at a time: eight 16-byte reads in flight at once would hold 32 registers next to 128 accumulators)
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int sx = 2 * half; sx < 2 * half + 2; ++sx) {
+                const s6f32x4 ta = *reinterpret_cast<const s6f32x4 *>(rawst + raw_rd + (ra * 2 + (sx & 1)) * 576 + (sx >> 1) * 64);
+                const s6f32x4 tb_ = *reinterpret_cast<const s6f32x4 *>(rawst + raw_rd + (rb * 2 + (sx & 1)) * 576 + (sx >> 1) * 64);
+                pr[0][sx] = s6v4{{ta[0], ta[1], ta[2], ta[3]}};
+                pr[1][sx] = s6v4{{tb_[0], tb_[1], tb_[2], tb_[3]}};
+                rc[sx] = (S6_ABL & 16) ? pr[0][sx] : i == 1 ? s6_add4(pr[0][sx], pr[1][sx]) : s6_sub4(pr[0][sx], pr[1][sx]);
+            }
+#ifndef S6_READ8
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s6v4 v;
+            if (S6_ABL & 16) v = rc[j];
+            else if (j == 0) v = s6_sub4(rc[0], rc[2]);
+            else if (j == 1) v = s6_add4(rc[1], rc[2]);
+            else if (j == 2) v = s6_sub4(rc[2], rc[1]);
+            else v = s6_sub4(rc[1], rc[3]);
+            s6u32x2 pc[3];
+            if (S6_ABL & 16) { pc[0] = s6u32x2{__builtin_bit_cast(unsigned, v.e[0]), __builtin_bit_cast(unsigned, v.e[1])}; pc[1] = pc[0]; pc[2] = pc[0]; }
+            else s6_split4(v, pc);
+            if (S6_ABL & 2) { asm volatile("" ::"v"(pc[0]), "v"(pc[1]), "v"(pc[2])); continue; }
+#pragma unroll
+            for (int pi = 0; pi < 3; ++pi) *reinterpret_cast<s6u32x2 *>(st + (IH * 4 + j) * CS_BYTES + pi * 2048 + vw_off) = pc[pi];
+            __builtin_amdgcn_sched_barrier(0);  // (one component at a time: interleaved components keep four sets of temporaries alive)
+        }
+    };
+    auto load_u = [&](int ph) __attribute__((always_inline)) {
+        if ((S6_ABL & 32) && ph >= 2) return;
+        const int so = __builtin_amdgcn_readfirstlane(ph * (4 * 12 * 1024));
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int pi = 0; pi < 3; ++pi)
+                Ureg[nb][pi] = __builtin_bit_cast(s6bf16x8, __builtin_amdgcn_raw_buffer_load_b128(srd_u, u_vo, so + (nb * 3 + pi) * 1024, 0));
+    };
+    // the wave's 24 MFMAs of a phase: component (2 hh + IH, jw), both tile blocks x both n blocks x six products -- a1 u1, a2 u0, a0 u2, a1 u0,
+    // a0 u1, a0 u0, the small ones first; consecutive MFMAs go round the four accumulators
+    auto multiply = [&](int hh, const unsigned char *rd) __attribute__((always_inline)) {
+        constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};
+        if (!(S6_ABL & 4)) {
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+                for (int pi = 0; pi < 3; ++pi)
+                    Areg[tb][pi] = *reinterpret_cast<const s6bf16x8 *>(rd + (IH * 4 + jw) * CS_BYTES + pi * 2048 + tb * 512 + ar_off);
+        }
+        if (S6_ABL & 64) return;
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int tb = 0; tb < 2; ++tb)
+                    acc[hh][tb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Areg[tb][PA[t]], Ureg[nb][PB[t]], acc[hh][tb][nb], 0, 0, 0);
+    };
+
+    // ---- prologue: the regions of chunks 0 and 1 into the raw ring, V of phase 0 (component rows 0, 1) into stage 0, U of phase 0 ----
+    load_raw(0);
+    load_u(0);
+    store_raw(raw0);
+    load_raw(1);
+    store_raw(raw1);
+    __syncthreads();
+    produce_row(raw0, 0, stage0);
+    __syncthreads();
+#ifdef S6_TRACE
+    trace(1);
+#endif
+
+    // One phase, everything but its chunk index known at compile time: HH = component-row half being multiplied (V of the phase lies in
+    // stage HH; the next phase is (chunk kc + HH, half 1 - HH) and its V goes to stage 1 - HH), MORE = there is a next phase.
+    auto phase = [&](auto HHc, auto MOREc, int kc) __attribute__((always_inline)) {
+        constexpr int HH = decltype(HHc)::value;
+        constexpr bool more1 = decltype(MOREc)::value;
+        const int ph = 2 * kc + HH;
+        unsigned char *rd = HH ? stage1 : stage0, *wr = HH ? stage0 : stage1;
+        const unsigned char *rawn = ((kc + HH) & 1) ? raw1 : raw0;
+#ifdef S6_TRACE
+#define S6_FINE(i) if (ph == 6 || ph == 7) { __builtin_amdgcn_sched_barrier(0); trace(48 + (ph - 6) * 8 + (i)); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define S6_FINE(i)
+#endif
+        // the region of chunk kc + 2: requested at the top of this chunk's first phase (a phase and a half before its stores: the first form
+        // requested it at the end of the phase and its stores waited 250-400 cycles), stored in the second -- its stage was last read in the first
+        if (more1 && HH == 0) load_raw(kc + 2);
+        if (IH == 0) {
+            multiply(HH, rd);
+            __builtin_amdgcn_sched_barrier(0);
+            S6_FINE(0);
+            if (more1) load_u(ph + 1);
+            if (more1) produce_row(rawn, 1 - HH, wr);
+            S6_FINE(1);
+        } else {
+            if (more1) produce_row(rawn, 1 - HH, wr);
+            __builtin_amdgcn_sched_barrier(0);
+            S6_FINE(0);
+            multiply(HH, rd);
+            __builtin_amdgcn_sched_barrier(0);
+            S6_FINE(1);
+            if (more1) load_u(ph + 1);
+        }
+        if (more1 && HH == 1) store_raw((kc & 1) ? raw1 : raw0);
+        __builtin_amdgcn_sched_barrier(0);
+        S6_FINE(2);
+        if (!(S6_ABL & 8)) __syncthreads();
+#ifdef S6_TRACE
+        trace(2 + ph);
+#endif
+#undef S6_FINE
+    };
+    typedef std::integral_constant<int, 0> H0;
+    typedef std::integral_constant<int, 1> H1;
+    for (int kc = 0; kc < p.nk - 1; ++kc) {
+        phase(H0{}, std::true_type{}, kc);
+        phase(H1{}, std::true_type{}, kc);
+    }
+    phase(H0{}, std::true_type{}, p.nk - 1);
+    phase(H1{}, std::false_type{}, p.nk - 1);
+}
+
+__global__ void __launch_bounds__(512) conv3x3_wino2d_split6_kernel(const Split6Params p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[S6_SMEM];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int jw = wave & 3, ih = wave >> 2;  // component column, component row parity (waves w and w + 4 share a SIMD)
 
     // ---- block -> (m tile, n tile).  Consecutive workgroup ids go round the 8 XCDs: the workgroups of one XCD share ONE n tile, i.e. one
     // slice of the weight fragments in that XCD's L2 (the whole U of a 256 -> 256 layer is 6.3 MB, a slice 1.6 MB) ----
@@ -121,11 +295,18 @@ __global__ void __launch_bounds__(256) conv3x3_wino2d_split6_kernel(const Split6
         ntile = blockIdx.x - mtile * p.n_tiles;
     }
     if (mtile >= p.m_tiles) return;
-#ifdef S6_TRACE  // in-kernel timeline (tools/split6_trace.py): lane 0 of waves 0 and 3 of two workgroups stamps the 100 MHz wall clock and the
-                 // shader clock into the tail of the residual tensor: slot = 80 stamps x (wall, cycles)
+    const int img = mtile / p.tiles_per_image;
+    const int brem = mtile - img * p.tiles_per_image;
+    const int by = brem / p.bx_tiles, bx = brem - by * p.bx_tiles;
+    const int Y0 = by * 16, X0 = bx * 16;
+    const int H = p.H, W = p.W, C = p.C;
+    float *trbuf = nullptr;
+    bool trw = false;
+#ifdef S6_TRACE  // in-kernel timeline (tools/split6_trace.py): lane 0 of waves 0 and 4 (the two waves of one SIMD) of two workgroups stamps the
+                 // 100 MHz wall clock and the shader clock into the tail of the residual tensor: slot = 80 stamps x (wall, cycles)
     const int trslot = blockIdx.x == 0 ? 0 : blockIdx.x == 601 ? 1 : -1;
-    float *trbuf = const_cast<float *>(p.res) + (size_t)p.B * p.H * p.W * p.N - 1024 + ((trslot < 0 ? 0 : trslot) * 2 + (wave == 3 ? 1 : 0)) * 160;
-    const bool trw = trslot >= 0 && lane == 0 && (wave == 0 || wave == 3) && p.res;
+    trbuf = const_cast<float *>(p.res) + (size_t)p.B * p.H * p.W * p.N - 1024 + ((trslot < 0 ? 0 : trslot) * 2 + (wave == 4 ? 1 : 0)) * 160;
+    trw = trslot >= 0 && lane == 0 && (wave == 0 || wave == 4) && p.res;
     auto trace = [&](int idx) __attribute__((always_inline)) {
         if (trw && idx < 80) {
             trbuf[idx] = (float)(wall_clock64() & 0xFFFFFFull);
@@ -137,47 +318,39 @@ __global__ void __launch_bounds__(256) conv3x3_wino2d_split6_kernel(const Split6
 #else
 #define S6_TR(i)
 #endif
-    const int img = mtile / p.tiles_per_image;
-    const int brem = mtile - img * p.tiles_per_image;
-    const int by = brem / p.bx_tiles, bx = brem - by * p.bx_tiles;
-    const int Y0 = by * 16, X0 = bx * 16;
-    const int H = p.H, W = p.W, C = p.C;
 
-    // ---- producer identity: (tile, channel quad).  lane bits: 0 = quad bit 0, 1..3 = tile bits 0..2, 4 = quad bit 1, 5 = tile bit 3; the
-    // wave is tile bits 4..5 (two tile rows of the 8 x 8 block) ----
-    const int tile = (wave << 4) | (((lane >> 5) & 1) << 3) | ((lane >> 1) & 7);
+    // ---- producer identity: (tile, channel quad), component row parity = ih.  lane bits: 0 = quad bit 0, 1..3 = tile bits 0..2, 4 = quad
+    // bit 1, 5 = tile bit 3; jw is tile bits 4..5 (two tile rows of the 8 x 8 block) ----
+    const int tile = (jw << 4) | (((lane >> 5) & 1) << 3) | ((lane >> 1) & 7);
     const int q = (lane & 1) | (((lane >> 4) & 1) << 1);
     const int ty = tile >> 3, tx = tile & 7;
-    // raw ring: piece L = ((row * 2 + column parity) * 9 + column / 2) * 4 + quad of the 18 x 18 region; thread t moves pieces t + 256 i
-    int rvo[6];
+    // raw ring: piece L = ((row * 2 + column parity) * 9 + column / 2) * 4 + quad of the 18 x 18 region; thread t moves pieces t + 512 i
+    int rvo[3];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        const int L = i * 256 + tid;
+    for (int i = 0; i < 3; ++i) {
+        const int L = i * 512 + tid;
         const int row = L / 72, rem = L - row * 72, par = rem / 36, r2 = rem - par * 36;
         const int y = Y0 - 1 + row, x = X0 - 1 + 2 * (r2 >> 2) + par;
         const bool ok = L < 1296 && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
         rvo[i] = ok ? (((img * H + y) * W + x) * C + (r2 & 3) * 4) * 4 : S6_OOB;
     }
-    const int raw_wr = tid * 16;  // + i * 4096 + stage
     // the thread's patch position (r, s): region row 2 ty + r, column 2 tx + s -> parity s & 1, column / 2 = tx + (s >> 1)
     const int raw_rd = ((2 * ty * 2) * 9 + tx) * 64 + q * 16;  // + (r * 2 + (s & 1)) * 576 + (s >> 1) * 64
     const __amdgpu_buffer_rsrc_t srd_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(reinterpret_cast<const char *>(p.x)), 0,
                                                                           p.B * H * W * C * 4, 0x00020000);
-    // the wave's weight fragments: [n tile][phase][wave][12 fragments of 1 KB]
+    // the wave's weight fragments: [n tile][phase][column jw][row parity ih][n block][piece] x 1 KB
     const size_t u_tile_bytes = (size_t)p.nk * 2 * 4 * 12 * 1024;
+    const size_t u_wave = (size_t)jw * 12 * 1024 + (size_t)ih * 6 * 1024;
     const __amdgpu_buffer_rsrc_t srd_u = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char *>(reinterpret_cast<const char *>(p.u)) + (size_t)ntile * u_tile_bytes + (size_t)wave * 12 * 1024, 0,
-        (int)(u_tile_bytes - (size_t)wave * 12 * 1024), 0x00020000);
-    const int u_vo = lane * 16;
+        const_cast<char *>(reinterpret_cast<const char *>(p.u)) + (size_t)ntile * u_tile_bytes + u_wave, 0, (int)(u_tile_bytes - u_wave), 0x00020000);
 
     // LDS byte offsets: the thread's 8-byte store slot / the lane's 16-byte fragment slot inside a (component, piece) block of 2 KB
     const int vw_off = ((q >> 1) * 64 + tile) * 16 + (q & 1) * 8;
     const int ar_off = ((lane >> 5) * 64 + (lane & 31)) * 16;
-    constexpr int CS_BYTES = 3 * 2048;  // one component: 3 pieces x 2 k halves x 64 tiles x 16 B
 
-    s6f32x16 acc[4][2][2];  // [component row i][tile block][n block]
+    s6f32x16 acc[2][2][2];  // [component row i >> 1][tile block][n block]: rows ih and ih + 2
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -185,226 +358,40 @@ __global__ void __launch_bounds__(256) conv3x3_wino2d_split6_kernel(const Split6
 #pragma unroll
                 for (int v = 0; v < 16; ++v) acc[i][a][b][v] = 0.f;
 
-    const int NP = 2 * p.nk;  // phases
-    s6v4 pr[3][4];            // the three patch rows of the half to produce next
-    s6f32x4 rawreg[6];        // the region pieces of the chunk after next, between their loads and their LDS stores
-    s6v4 rc[2][4];            // B^T rows (2 component rows x 4 patch columns)
-    s6bf16x8 Areg[2][2][3];   // [i & 1][tile block][piece]
-    s6bf16x8 Ureg[4][3];      // ring: slot = (i & 1) * 2 + n block
-
-    unsigned char *raw0 = smem + 2 * S6_STAGE, *raw1 = raw0 + S6_RAW;
-    // region pieces of chunk kc -> registers (a chunk past the last one reads whatever follows: its stage is never read)
-    auto load_raw = [&](int kc) __attribute__((always_inline)) {
-        if ((S6_ABL & 1) && kc >= 2) return;
-        const int so = __builtin_amdgcn_readfirstlane(kc * 64);
-#pragma unroll
-        for (int i = 0; i < 6; ++i) rawreg[i] = __builtin_bit_cast(s6f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_x, rvo[i], so, 0));
-    };
-    auto store_raw = [&](unsigned char *st) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < 6; ++i) *reinterpret_cast<s6f32x4 *>(st + i * 4096 + raw_wr) = rawreg[i];
-    };
-    // patch rows of half hp out of raw stage st -> pr (hp = 0: rows 0, 1, 2; hp = 1: rows 1, 2, 3)
-    auto read_patch = [&](const unsigned char *st, int hp) __attribute__((always_inline)) {
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int sx = 0; sx < 4; ++sx) {
-                const s6f32x4 t = *reinterpret_cast<const s6f32x4 *>(st + raw_rd + ((r + hp) * 2 + (sx & 1)) * 576 + (sx >> 1) * 64);
-                pr[r][sx] = s6v4{{t[0], t[1], t[2], t[3]}};
-            }
-    };
-    // B^T rows of half hp: hp = 0: d0 - d2, d1 + d2 (pr = rows 0, 1, 2); hp = 1: d2 - d1, d1 - d3 (pr = rows 1, 2, 3)
-    auto row_combine = [&](int hp) __attribute__((always_inline)) {
-        if (S6_ABL & 16) {
-#pragma unroll
-            for (int s = 0; s < 4; ++s) { rc[0][s] = pr[0][s]; rc[1][s] = pr[1][s]; }
-            return;
-        }
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            if (hp == 0) { rc[0][s] = s6_sub4(pr[0][s], pr[2][s]); rc[1][s] = s6_add4(pr[1][s], pr[2][s]); }
-            else { rc[0][s] = s6_sub4(pr[1][s], pr[0][s]); rc[1][s] = s6_sub4(pr[0][s], pr[2][s]); }
-        }
-    };
-    // component (i2, j) of the half in rc -> three 8-byte stores into stage `st`
-    auto produce = [&](int i2, int j, unsigned char *st) __attribute__((always_inline)) {
-        s6v4 v;
-        if (S6_ABL & 16) v = rc[i2][j];
-        else if (j == 0) v = s6_sub4(rc[i2][0], rc[i2][2]);
-        else if (j == 1) v = s6_add4(rc[i2][1], rc[i2][2]);
-        else if (j == 2) v = s6_sub4(rc[i2][2], rc[i2][1]);
-        else v = s6_sub4(rc[i2][1], rc[i2][3]);
-        s6u32x2 pc[3];
-        if (S6_ABL & 16) { pc[0] = s6u32x2{__builtin_bit_cast(unsigned, v.e[0]), __builtin_bit_cast(unsigned, v.e[1])}; pc[1] = pc[0]; pc[2] = pc[0]; }
-        else s6_split4(v, pc);
-        if (S6_ABL & 2) { asm volatile("" ::"v"(pc[0]), "v"(pc[1]), "v"(pc[2])); return; }
-#pragma unroll
-        for (int pi = 0; pi < 3; ++pi) *reinterpret_cast<s6u32x2 *>(st + (i2 * 4 + j) * CS_BYTES + pi * 2048 + vw_off) = pc[pi];
-    };
-    auto read_a = [&](int i2, const unsigned char *st) __attribute__((always_inline)) {
-        if (S6_ABL & 4) return;
-#pragma unroll
-        for (int tb = 0; tb < 2; ++tb)
-#pragma unroll
-            for (int pi = 0; pi < 3; ++pi)
-                Areg[i2][tb][pi] = *reinterpret_cast<const s6bf16x8 *>(st + (i2 * 4 + wave) * CS_BYTES + pi * 2048 + tb * 512 + ar_off);
-    };
-    // slot (i2, nb) of the ring <- phase ph
-    auto load_u = [&](int ph, int slot) __attribute__((always_inline)) {
-        if ((S6_ABL & 32) && ph >= 2) return;
-        const int so = __builtin_amdgcn_readfirstlane(ph * (4 * 12 * 1024) + slot * 3 * 1024);
-#pragma unroll
-        for (int pi = 0; pi < 3; ++pi)
-            Ureg[slot][pi] = __builtin_bit_cast(s6bf16x8, __builtin_amdgcn_raw_buffer_load_b128(srd_u, u_vo, so + pi * 1024, 0));
-    };
-
-    // The 48 MFMAs of a phase as ONE sequence k = 0..47: 0..11 the group the previous phase left over (its component row 2 (1 - HH) + 1,
-    // n block 1), then (row 2 HH, n block 0), (row 2 HH, n block 1), (row 2 HH + 1, n block 0); the group (row 2 HH + 1, n block 1) is left
-    // to the next phase.  Inside a group six products per tile block -- a1 u1, a2 u0, a0 u2, a1 u0, a0 u1, a0 u0, the small ones first --
-    // with the two tile blocks alternating, so that consecutive MFMAs never share an accumulator.
-    auto mfma_k = [&](int hh, bool first, int k) __attribute__((always_inline)) {
-        constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};
-        if (S6_ABL & 64) return;
-        const int g = k / 12, r = k % 12, t = r >> 1, tb = r & 1;
-        if (g == 0 && first) return;
-        const int i = g == 0 ? 2 * (1 - hh) + 1 : g == 3 ? 2 * hh + 1 : 2 * hh;
-        const int i2 = (g == 0 || g == 3) ? 1 : 0;
-        const int nb = (g == 0 || g == 2) ? 1 : 0;
-        acc[i][tb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Areg[i2][tb][PA[t]], Ureg[i2 * 2 + nb][PB[t]], acc[i][tb][nb], 0, 0, 0);
-    };
-
-    unsigned char *stage0 = smem, *stage1 = smem + S6_STAGE;
-
-    // ---- prologue: V of phase 0 -> stage 0; the patch rows phase 0 will turn into phase 1's V; the weight slots 0..2 of phase 0 ----
-    load_raw(0);
-    store_raw(raw0);
-    load_raw(1);
-    load_u(0, 0);
-    load_u(0, 1);
-    load_u(0, 2);
-    store_raw(raw1);
-    __syncthreads();
-    read_patch(raw0, 0);
-    row_combine(0);
-#pragma unroll
-    for (int i2 = 0; i2 < 2; ++i2)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) produce(i2, j, stage0);
-    __syncthreads();
-    S6_TR(1);
-
-    // One phase.  HH: component-row half being multiplied (stage HH is read, stage 1 - HH is written with the next phase's V).  Nine
-    // scheduling regions: 8 MFMAs beside the B^T rows (32 VALU), then eight times 5 MFMAs beside one component's column combination, split
-    // and stores (26 VALU, 3 LDS stores) and the region's share of the loads; inside a region the sched_group_barrier pipeline asks for
-    // MFMA / VALU / LDS / global-load groups in turn, so that the matrix pipe and the vector lanes run side by side.
-#define S6_PIPE(NM, NV, ND, NG)                                                                   \
-    _Pragma("unroll") for (int s_ = 0; s_ < (NM); ++s_) {                                         \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                        \
-        __builtin_amdgcn_sched_group_barrier(0x002, (NV), 0);                                     \
-        if ((ND) > 0) __builtin_amdgcn_sched_group_barrier(0x080, (ND), 0);                       \
-        if ((NG) > 0) __builtin_amdgcn_sched_group_barrier(0x020, (NG), 0);                       \
-    }                                                                                             \
-    __builtin_amdgcn_sched_barrier(0)
-#define S6_UNIT(HH, FIRST, MORE1, K0, I2, J)                                                      \
-    _Pragma("unroll") for (int k_ = (K0); k_ < (K0) + 5; ++k_) mfma_k((HH), (FIRST), k_);         \
-    if (MORE1) produce((I2), (J), wr)
-#define S6_PHASE(HH, PHASE_INDEX, FIRST, MORE1, MORE2)                                                                                 \
-    {                                                                                                                                  \
-        const int ph = (PHASE_INDEX);                                                                                                  \
-        unsigned char *rd = (HH) ? stage1 : stage0, *wr = (HH) ? stage0 : stage1;                                                      \
-        constexpr bool more1 = (MORE1), more2 = (MORE2); /* a phase after this one / two phases after: compile time, no branches */    \
-        /* region 0: the next phase is (chunk kc_ + HH, half 1 - HH): its patch rows out of that chunk's raw stage */                  \
-        const int kc_ = ph >> 1;                                                                                                       \
-        read_a(0, rd);                                                                                                                 \
-        if (more1) read_patch((((kc_ + (HH)) & 1) ? raw1 : raw0), 1 - (HH));                                                           \
-        _Pragma("unroll") for (int k_ = 0; k_ < 8; ++k_) mfma_k((HH), (FIRST), k_);                                                    \
-        if (more1) row_combine(1 - (HH));                                                                                              \
-        S6_PIPE(8, 4, 3, 0);                                                                                                           \
-        if (ph == 6 || ph == 7) S6_TR(48 + (ph - 6) * 10 + 0);                                                                         \
-        /* regions 1..8 */                                                                                                             \
-        S6_UNIT(HH, FIRST, more1, 8, 0, 0);                                                                                            \
-        /* the region of chunk kc_ + 2: loaded in this chunk's first phase, stored (its stage was last read in that phase) in the second */ \
-        if (more2 && (HH) == 0) load_raw(kc_ + 2);                                                                                     \
-        if (more2 && (HH) == 1) store_raw((kc_ & 1) ? raw1 : raw0);                                                                    \
-        S6_PIPE(5, 6, 2, 2);                                                                                                           \
-        if (ph == 6 || ph == 7) S6_TR(48 + (ph - 6) * 10 + 1);                                        \
-        S6_UNIT(HH, FIRST, more1, 13, 0, 1);                                                                                           \
-        load_u(ph, 3);                                                                                                                 \
-        S6_PIPE(5, 6, 1, 1);                                                                                                           \
-        if (ph == 6 || ph == 7) S6_TR(48 + (ph - 6) * 10 + 2);                                        \
-        S6_UNIT(HH, FIRST, more1, 18, 0, 2);                                                                                           \
-        read_a(1, rd);                                                                                                                 \
-        S6_PIPE(5, 6, 2, 0);                                                                                                           \
-        if (ph == 6 || ph == 7) S6_TR(48 + (ph - 6) * 10 + 3);                                        \
-        S6_UNIT(HH, FIRST, more1, 23, 0, 3);                                                                                           \
-        S6_PIPE(5, 6, 1, 0);                                                                                                           \
-        if (ph == 6 || ph == 7) S6_TR(48 + (ph - 6) * 10 + 4);                                        \
-        S6_UNIT(HH, FIRST, more1, 28, 1, 0);                                                                                           \
-        if (more1) load_u(ph + 1, 0);                                                                                                  \
-        S6_PIPE(5, 6, 1, 1);                                                                                                           \
-        if (ph == 6 || ph == 7) S6_TR(48 + (ph - 6) * 10 + 5);                                        \
-        S6_UNIT(HH, FIRST, more1, 33, 1, 1);                                                                                           \
-        S6_PIPE(5, 6, 1, 0);                                                                                                           \
-        if (ph == 6 || ph == 7) S6_TR(48 + (ph - 6) * 10 + 6);                                        \
-        S6_UNIT(HH, FIRST, more1, 38, 1, 2);                                                                                           \
-        if (more1) load_u(ph + 1, 1);                                                                                                  \
-        S6_PIPE(5, 6, 1, 1);                                                                                                           \
-        if (ph == 6 || ph == 7) S6_TR(48 + (ph - 6) * 10 + 7);                                        \
-        S6_UNIT(HH, FIRST, more1, 43, 1, 3);                                                                                           \
-        S6_PIPE(5, 6, 1, 0);                                                                                                           \
-        if (ph == 6 || ph == 7) S6_TR(48 + (ph - 6) * 10 + 8);                                        \
-        if (more1) load_u(ph + 1, 2);                                                                                                  \
-        if (!(S6_ABL & 8)) __syncthreads();                                                                                            \
-        __builtin_amdgcn_sched_barrier(0);                                                                                             \
-        S6_TR(2 + ph);                                                                                                                 \
-    }
-
-    (void)NP;
-    if (p.nk == 1) {
-        S6_PHASE(0, 0, true, true, false);
-        S6_PHASE(1, 1, false, false, false);
-    } else {
-        S6_PHASE(0, 0, true, true, true);
-        S6_PHASE(1, 1, false, true, true);
-        for (int kc = 1; kc < p.nk - 1; ++kc) {
-            S6_PHASE(0, 2 * kc, false, true, true);
-            S6_PHASE(1, 2 * kc + 1, false, true, true);
-        }
-        S6_PHASE(0, 2 * p.nk - 2, false, true, false);
-        S6_PHASE(1, 2 * p.nk - 1, false, false, false);
-    }
-    // the group the last phase left over (component row 3, n block 1)
-#pragma unroll
-    for (int k = 0; k < 12; ++k) mfma_k(0, false, k);
+    if (ih == 0) s6_kloop<0>(p, smem, acc, tid, lane, jw, rvo, raw_rd, vw_off, ar_off, srd_x, srd_u, trbuf, trw);
+    else s6_kloop<1>(p, smem, acc, tid, lane, jw, rvo, raw_rd, vw_off, ar_off, srd_x, srd_u, trbuf, trw);
     S6_TR(39);
-#undef S6_PHASE
-#undef S6_UNIT
-#undef S6_PIPE
 
-    // ---- epilogue.  In-lane: z_a = sum_i A^T[a][i] M_i (a = 0: m0 + m1 + m2, a = 1: m1 - m2 - m3).  Exchange through LDS as
-    // zx[wave j][a][tile][n] (floats, n contiguous): the MFMA layout has a lane = one output n, so the writers store single floats (lanes
-    // = consecutive n: conflict-free) and the readers get FOUR consecutive n per lane -- a store instruction costs the CU's store path
-    // about the same whatever its width, and 64 dword stores per lane made the first form's epilogue 9-11 us of an 80 us tile ----
+    // ---- epilogue.  z_a = sum_i A^T[a][i] M_i (a = 0: m0 + m1 + m2, a = 1: m1 - m2 - m3) takes the rows of two waves: the ih = 0 wave of a
+    // column stores its part (m0 + m2, -m2) into zx[column j][a][tile][n] (floats, n contiguous), the ih = 1 wave adds its own (m1, m1 - m3)
+    // to it after a barrier.  The MFMA layout has a lane = one output n, so these are single floats (lanes = consecutive n:
+    // conflict-free) and the readers get FOUR consecutive n per lane: a store instruction costs the CU's store path about the same whatever
+    // its width, and 64 dword stores per lane made the first form's epilogue 9-11 us of an 80 us tile ----
     float *zx = reinterpret_cast<float *>(smem);
 #pragma unroll
-    for (int tb = 0; tb < 2; ++tb)
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass == ih) {
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
+            for (int tb = 0; tb < 2; ++tb)
 #pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const float z0 = (acc[0][tb][nb][v] + acc[1][tb][nb][v]) + acc[2][tb][nb][v];
-                const float z1 = (acc[1][tb][nb][v] - acc[2][tb][nb][v]) - acc[3][tb][nb][v];
-                const int t = tb * 32 + (v & 3) + 8 * (v >> 2);  // + 4 (lane >> 5): tile of accumulator register v (MFMA C / D layout)
-                const int o = (t + 4 * (lane >> 5)) * 64 + nb * 32 + (lane & 31);
-                zx[(wave * 2 + 0) * 4096 + o] = z0;
-                zx[(wave * 2 + 1) * 4096 + o] = z1;
-            }
-    S6_TR(40);
-    __syncthreads();
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) {
+                        const float lo = acc[0][tb][nb][v], hi = acc[1][tb][nb][v];  // component rows ih, ih + 2
+                        const float z0 = ih == 0 ? lo + hi : lo;
+                        const float z1 = ih == 0 ? -hi : lo - hi;
+                        const int t = tb * 32 + (v & 3) + 8 * (v >> 2);  // + 4 (lane >> 5): tile of accumulator register v (MFMA C / D layout)
+                        const int o = (t + 4 * (lane >> 5)) * 64 + nb * 32 + (lane & 31);
+                        // (the second pass reads the first one's part back and stores the sum: LDS float atomics took 44 us per tile here)
+                        zx[(jw * 2 + 0) * 4096 + o] = pass == 0 ? z0 : zx[(jw * 2 + 0) * 4096 + o] + z0;
+                        zx[(jw * 2 + 1) * 4096 + o] = pass == 0 ? z1 : zx[(jw * 2 + 1) * 4096 + o] + z1;
+                    }
+        }
+        __syncthreads();
+    }
     S6_TR(41);
     // thread (tile, n quad): y_ab = sum_j z_a[j] A^T[b][j] (b = 0: z0 + z1 + z2, b = 1: z1 - z2 - z3) for four consecutive outputs, 16-byte stores.
-    // lane bits 0..3 = n quad (a wave-level store covers whole 256-byte rows of four pixels); tile = 4 (wave * 4 + k) + (lane >> 4), k = 0..3
+    // lane bits 0..3 = n quad (a wave-level store covers whole 256-byte rows of four pixels); tile = 4 (wave * 2 + k) + (lane >> 4), k = 0, 1
     {
         const int nq = lane & 15;
         const int n = ntile * 64 + nq * 4;
@@ -415,8 +402,8 @@ __global__ void __launch_bounds__(256) conv3x3_wino2d_split6_kernel(const Split6
             const_cast<char *>(reinterpret_cast<const char *>(p.res ? p.res : p.out)), 0, p.B * H * W * p.N * 4, 0x00020000);
         const bool has_res = p.res != nullptr;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int t = 4 * (wave * 4 + k) + (lane >> 4);
+        for (int k = 0; k < 2; ++k) {
+            const int t = 4 * (wave * 2 + k) + (lane >> 4);
             const int oy = Y0 + 2 * (t >> 3), ox = X0 + 2 * (t & 7);
             const int vo = (((img * H + oy) * W + ox) * p.N + n) * 4;
 #pragma unroll
@@ -511,7 +498,7 @@ int launch_conv3x3_wino2d_split6(const float *x, const unsigned short *u, const 
     p.nk = Cin / 16;
     p.out_scale = out_scale;
     const int grid = p.m_tiles * p.n_tiles;
-    hipLaunchKernelGGL(conv3x3_wino2d_split6_kernel, dim3(grid), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(conv3x3_wino2d_split6_kernel, dim3(grid), dim3(512), 0, s, p);
     GD_HIP(hipGetLastError());
     return 0;
 }
