@@ -228,6 +228,8 @@ int launch_wino2d_split6_weights(const float *w, unsigned short *u, int Cout, in
 int launch_conv3x3_wino2d_split6(const float *x, const unsigned short *u, const float *bias, const float *res, float *out, int batch, int H,
                                  int W, int Cin, int Cout, float out_scale, hipStream_t s);
 int launch_advance_step(int *step, hipStream_t s);
+int launch_reset_step_row(int *step, const float *table, float *row, int width, hipStream_t s);  // *step = 0; row = table[0] (row may be null)
+int launch_copy_floats(const float *src, float *dst, long long n, hipStream_t s);  // dst[0:n] = src[0:n], a kernel (not the runtime's copy engine)
 // step++ and row[0:width] = table[step + 1][0:width] (if step + 1 < rows): the hoisted time-embedding table (engine.cpp)
 int launch_advance_step_row(int *step, const float *table, float *row, int width, int rows, hipStream_t s);
 // blur fused-sampler kernels

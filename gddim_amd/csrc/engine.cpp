@@ -1125,11 +1125,10 @@ int gd_engine_set_transforms_cld(gd_engine *e, const float *pre, const float *ep
     return 0;
 }
 
-// step <- 0 and, with the hoisted time embedding, the first knot's row into the lane's current-row buffer
+// step <- 0 and, with the hoisted time embedding, the first knot's row into the lane's current-row buffer.  One kernel: no memset / memcpy
+// node ever goes into a captured graph (launch_reset_step_row: a replayed hipMemsetAsync node wrote other bytes than it was captured with).
 static int reset_step(gd_engine *e, int *step, float *temb_row, hipStream_t s) {
-    GD_HIP(hipMemsetAsync(step, 0, sizeof(int), s));
-    if (temb_row) GD_HIP(hipMemcpyAsync(temb_row, e->temb_tab, (size_t)e->temb_w * sizeof(float), hipMemcpyDeviceToDevice, s));
-    return 0;
+    return launch_reset_step_row(step, e->temb_tab, temb_row, temb_row ? e->temb_w : 0, s);
 }
 
 // step++ (and the next knot's row)
@@ -1246,7 +1245,7 @@ int gd_sample_cld(gd_engine *e, int batch, const float *u_in_dev, float *x_out_d
         // baked, so the caller's buffers are copied to / from engine-owned staging buffers around the single hipGraphLaunch.
         Lane &l = L[0];
         const size_t n_in = (size_t)l.pix * C * 2, n_out = (size_t)l.pix * C;
-        GD_HIP(hipMemcpyAsync(e->uin_stage, u_in_dev, n_in * sizeof(float), hipMemcpyDeviceToDevice, l.s));
+        GD_TRY(launch_copy_floats(u_in_dev, e->uin_stage, (long long)n_in, l.s));  // (kernels only around and inside the graph: launch_copy_floats)
         if (!l.g->loop) {
             GD_TRY(capture_begin(l.s));
             int r = launch_cld_pack(e->uin_stage, l.u8, l.ring, ring_slots, l.pix, C, l.s);
@@ -1259,8 +1258,8 @@ int gd_sample_cld(gd_engine *e, int batch, const float *u_in_dev, float *x_out_d
             if (r || r2) return 1;
         }
         GD_HIP(hipGraphLaunch(l.g->loop, l.s));
-        GD_HIP(hipMemcpyAsync(x_out_dev, e->xout_stage, n_out * sizeof(float), hipMemcpyDeviceToDevice, l.s));
-        GD_HIP(hipMemcpyAsync(v_out_dev, e->vout_stage, n_out * sizeof(float), hipMemcpyDeviceToDevice, l.s));
+        GD_TRY(launch_copy_floats(e->xout_stage, x_out_dev, (long long)n_out, l.s));
+        GD_TRY(launch_copy_floats(e->vout_stage, v_out_dev, (long long)n_out, l.s));
         GD_HIP(hipEventRecord(e->ev_out[0], l.s));
         GD_HIP(hipStreamWaitEvent(caller, e->ev_out[0], 0));
         return 0;
@@ -1371,10 +1370,10 @@ int gd_sample_blur(gd_engine *e, int batch, const float *y_in_dev, float *x_out_
     const int ring_slots = multistep ? e->n_slots - 2 : 0;
     const long long slot_stride = (long long)e->plan.desc.max_batch * 1024 * e->plan.desc.in_channels;
     // y <- the initial state; the reference's loops start their epsilon history from the state itself
+    // (copy kernels, not hipMemcpyAsync: this runs inside the captured graphs too -- see reset_step)
     auto load_state = [&](float *y, float *ring, const float *src, size_t n, hipStream_t s) -> int {
-        GD_HIP(hipMemcpyAsync(y, src, n * sizeof(float), hipMemcpyDeviceToDevice, s));
-        for (int j = 0; j < ring_slots; ++j)
-            GD_HIP(hipMemcpyAsync(ring + (size_t)j * slot_stride, src, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+        GD_TRY(launch_copy_floats(src, y, (long long)n, s));
+        for (int j = 0; j < ring_slots; ++j) GD_TRY(launch_copy_floats(src, ring + (size_t)j * slot_stride, (long long)n, s));
         return 0;
     };
     GD_CHECK(y_in_dev && x_out_dev, "null device pointer");
@@ -1429,7 +1428,7 @@ int gd_sample_blur(gd_engine *e, int batch, const float *y_in_dev, float *x_out_
         // DCT + update, step++] -> finish.  Addresses are baked: the caller's buffers pass through the engine's staging copies.
         Lane &l = L[0];
         const size_t n = (size_t)l.b * 1024 * C;
-        GD_HIP(hipMemcpyAsync(e->uin_stage, y_in_dev, n * sizeof(float), hipMemcpyDeviceToDevice, l.s));
+        GD_TRY(launch_copy_floats(y_in_dev, e->uin_stage, (long long)n, l.s));
         if (!l.g->loop) {
             GD_TRY(capture_begin(l.s));
             int r = load_state(l.y, l.ring, e->uin_stage, n, l.s);
@@ -1440,7 +1439,7 @@ int gd_sample_blur(gd_engine *e, int batch, const float *y_in_dev, float *x_out_
             if (r || r2) return 1;
         }
         GD_HIP(hipGraphLaunch(l.g->loop, l.s));
-        GD_HIP(hipMemcpyAsync(x_out_dev, e->xout_stage, n * sizeof(float), hipMemcpyDeviceToDevice, l.s));
+        GD_TRY(launch_copy_floats(e->xout_stage, x_out_dev, (long long)n, l.s));
         GD_HIP(hipEventRecord(e->ev_out[0], l.s));
         GD_HIP(hipStreamWaitEvent(caller, e->ev_out[0], 0));
         return 0;

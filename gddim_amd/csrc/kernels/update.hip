@@ -14,6 +14,8 @@
 // which IS the U-Net input, so no pack/unpack runs inside the NFE loop.  The epsilon history is a
 // ring of n_hist slots in the U-Net output layout (pixels, 2C); the ring head and the coefficient
 // row are derived from a device-side step counter so one captured hipGraph serves every step.
+#include <cstdint>
+
 #include "../common.h"
 #include "rng.h"
 
@@ -329,6 +331,28 @@ int launch_advance_step(int *step, hipStream_t s) {
     return 0;
 }
 
+// dst[0:n] = src[0:n] as a kernel (n floats; 16-byte pieces when both pointers allow it).  Used wherever a sampler call moves data
+// between the caller's buffers, the engine's staging copies and the sampler state: since round 6 a sampler call consists of kernel
+// launches (and graphs of kernel nodes) only -- see launch_reset_step_row for what a runtime fill node did inside a replayed graph.
+__global__ void copy_floats_kernel(const float *__restrict__ src, float *__restrict__ dst, long long n, int vec) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (vec) {
+        if (i * 4 + 3 < n) reinterpret_cast<float4 *>(dst)[i] = reinterpret_cast<const float4 *>(src)[i];
+        else for (long long k = i * 4; k < n; ++k) dst[k] = src[k];
+    } else if (i < n) {
+        dst[i] = src[i];
+    }
+}
+
+int launch_copy_floats(const float *src, float *dst, long long n, hipStream_t s) {
+    if (n <= 0) return 0;
+    const int vec = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0 ? 1 : 0;
+    const long long items = vec ? (n + 3) / 4 : n;
+    hipLaunchKernelGGL(copy_floats_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, src, dst, n, vec);
+    GD_HIP(hipGetLastError());
+    return 0;
+}
+
 // step++ and, in the same launch, the NEXT step's row of the hoisted time-embedding table into the buffer the convolutions read their
 // per-image bias from (engine.cpp: build_temb_table): row[0:width] = table[step + 1][0:width] when that knot exists.  One workgroup:
 // every thread reads the counter before thread 0 rewrites it.
@@ -341,6 +365,22 @@ __global__ void __launch_bounds__(1024) advance_step_row_kernel(int *step, const
         for (int i = threadIdx.x; i < width4; i += 1024) row[i] = src[i];
     }
     if (threadIdx.x == 0) *step = next;
+}
+
+// *step = 0 (and the first knot's row of the hoisted table into `row` when there is one), as a KERNEL: inside a captured whole-call graph a
+// hipMemsetAsync node replayed with other bytes than it was captured with -- the counter read 0x05050505 after an unrelated framework
+// launch with large kernel arguments (a 5-d broadcast torch.where) had run between two replays, and the AB step indexed its tables with it
+// (round 6: rocgdb on tests/test_gpu_parity_abs.py).  Kernel nodes keep their arguments in the graph; nothing else goes into a capture now.
+__global__ void __launch_bounds__(1024) reset_step_row_kernel(int *step, const float4 *__restrict__ table, float4 *__restrict__ row, int width4) {
+    for (int i = threadIdx.x; i < width4; i += 1024) row[i] = table[i];
+    if (threadIdx.x == 0) *step = 0;
+}
+
+int launch_reset_step_row(int *step, const float *table, float *row, int width, hipStream_t s) {
+    GD_CHECK(width % 4 == 0, "reset_step_row: width %d is not a multiple of 4", width);
+    hipLaunchKernelGGL(reset_step_row_kernel, dim3(1), dim3(1024), 0, s, step, (const float4 *)table, (float4 *)row, row ? width / 4 : 0);
+    GD_HIP(hipGetLastError());
+    return 0;
 }
 
 int launch_advance_step_row(int *step, const float *table, float *row, int width, int rows, hipStream_t s) {
