@@ -66,6 +66,8 @@ def issued_ratio(name):
         return 1.0 / 3.0   # F(2,3)y x F(4,3)x: 24 products per 8 outputs instead of 72
     if "wino2d" in name:
         return 4.0 / 9.0   # F(2x2,3x3): 16 per 4 outputs instead of 36
+    if "split6" in name:
+        return 24.0 / 9.0  # F(2x2,3x3): 16 components per 2x2 outputs, six bf16 products each, instead of 36
     if "bf16x3" in name:
         return 3.0
     return 1.0
@@ -218,7 +220,7 @@ def main():
     ap.add_argument("--order", type=int, default=2)
     ap.add_argument("--image-size", type=int, default=32)
     ap.add_argument("--workload", choices=["cld", "blur"], default="cld", help="cld = BASELINE configs 2/4/5, blur = config 3")
-    ap.add_argument("--precision", choices=["fp32", "bf16x3"], default="fp32",
+    ap.add_argument("--precision", choices=["fp32", "bf16x3", "split6"], default="fp32",
                     help="fp32 = fp32 operands on the fp32 matrix core, 3x3 convolutions through the hybrid Winograd transform F(2,3)y x F(4,3)x (headline); bf16x3 = split-precision weight contractions on the bf16 matrix core")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--graph", choices=["step", "loop", "none"], default="loop",
@@ -339,7 +341,7 @@ def main():
         "warmup": args.warmup, "ms_per_step": 1e3 * dt / max(1, args.steps), "higher_is_better": True, "scaling": "weak",
         "value_is": "whole-job images per MEDIAN step (BASELINE.md section 3: median of >= 5 after >= 3 warm-up calls; max over ranks of each rank's median)",
         "value_mean": world * B * args.steps / dt, "ms_per_step_median": med_ms, "step_ms": [round(t, 3) for t in step_ms],
-        "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "bf16x3 (fp32 split into bf16 hi+lo, fp32 accumulate)", "data": "synthetic",
+        "vs_baseline": None, "dtype": {"fp32": "f32", "bf16x3": "bf16x3 (fp32 split into bf16 hi+lo, fp32 accumulate)", "split6": "f32 (3x3 convolutions: exact three-piece bf16 split, fp32 accumulate)"}[args.precision], "data": "synthetic",
         "config": {"workload": "%s, batch=%d per GPU, %dx%dx3 synthetic noise, random-init NCSN++ "
                                "(nf=128, ch_mult=(1,2,2,2), 8 res blocks, attn@16)" % (desc, B, cfg.data.image_size, cfg.data.image_size),
                    "global_batch": B * world, "parallelism": "dp%d (one process per GPU, uint8 all-gather per round%s)" % (world, ", RCCL" if grouped else ""),
@@ -451,6 +453,34 @@ def main():
                                "avg_launch_ms": dom["ms"] / max(1, dom["launches"])}
         eng.set_precision("fp32")
         result["bf16x3"] = alt
+        # ---- second secondary measurement (round 6): split6 mode -- fp32 mode with the 3x3 convolutions of the 32x32 / 16x16 levels through
+        # F(2x2,3x3) in the exact three-piece bf16 split on the bf16 matrix core (fp32-class error: tests/test_gpu_split6*.py); never the
+        # headline `value` this round ----
+        eng.set_precision("split6")
+        dts = timed(side_steps, graph_mode)
+        alt6 = {"dtype": "f32 operands; 3x3 convolutions of the 16x16-tileable levels as F(2x2,3x3) in the exact three-piece bf16 split (six bf16 MFMAs per "
+                         "product, fp32 accumulate), everything else fp32 MFMA",
+                "value": world * B * side_steps / dts, "unit": "images/s", "ms_per_step": 1e3 * dts / side_steps, "steps": side_steps,
+                "e2e_algorithmic_tflops_per_gpu": B * side_steps * flops_img / dts / 1e12,
+                "parity": "same oracles and bars as fp32 (tests/test_gpu_split6_mode.py); per-layer rms error 0.33 of the fp32 hybrid Winograd kernel's (tests/test_gpu_split6.py)"}
+        if not args.no_profile:
+            eng.profile(True)
+            sampling_fn([rank], state, B, u, use_graph=False)
+            torch.cuda.synchronize()
+            prof = eng.profile_read()
+            eng.profile(False)
+            k6 = [p_ for p_ in prof if "split6" in p_["name"]]
+            if k6:
+                k6 = k6[0]
+                ach = k6["flops"] / (k6["ms"] * 1e-3) / 1e12 if k6["ms"] > 0 else 0.0
+                alt6["roofline"] = {"kernel": k6["name"], "bound": "mfma", "achieved": ach, "peak": BF16_MFMA_PEAK_TFLOPS,
+                                    "unit": "TFLOP/s (algorithmic; the kernel issues 24/9 of this in bf16 MFMAs)",
+                                    "frac": ach * 24.0 / 9.0 / BF16_MFMA_PEAK_TFLOPS, "algorithmic_frac": ach / BF16_MFMA_PEAK_TFLOPS,
+                                    "launches": k6["launches"], "avg_launch_ms": k6["ms"] / max(1, k6["launches"]),
+                                    "share_of_gpu_time": k6["ms"] / max(1e-9, sum(p_["ms"] for p_ in prof))}
+            alt6["kernel_breakdown"] = [{"name": p_["name"], "ms": round(p_["ms"], 3), "launches": p_["launches"]} for p_ in sorted(prof, key=lambda q: -q["ms"])[:8]]
+        eng.set_precision("fp32")
+        result["split6"] = alt6
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "cld":
         result["cpu_baseline"] = cpu_baseline(cfg, args.nfe, args.cpu_batch, args.cpu_nfe, args.cpu_threads)

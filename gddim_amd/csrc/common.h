@@ -225,6 +225,8 @@ int launch_cld_finish(const float *u8, const float *eps, const float *dn, float 
 bool conv3x3_wino2d_split6_shape_ok(int batch, int H, int W, int Cin, int Cout);
 long long conv3x3_wino2d_split6_weight_bytes(int Cin, int Cout);
 int launch_wino2d_split6_weights(const float *w, unsigned short *u, int Cout, int Cin, hipStream_t s);
+bool conv3x3_wino2d_split6_gemm_ok(const GemmParams &g);  // a GEMM op the kernel takes (bias, per-image bias row, residual, scale, statistics)
+int launch_conv3x3_wino2d_split6_gemm(const GemmParams &g, const unsigned short *u, hipStream_t s);
 int launch_conv3x3_wino2d_split6(const float *x, const unsigned short *u, const float *bias, const float *res, float *out, int batch, int H,
                                  int W, int Cin, int Cout, float out_scale, hipStream_t s);
 int launch_advance_step(int *step, hipStream_t s);

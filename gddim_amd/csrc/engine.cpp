@@ -53,8 +53,13 @@ struct gd_engine {
     // device memory
     float *arena = nullptr;
     float *wbuf = nullptr;
-    // precision mode: 0 = exact fp32 MFMA (default), 1 = bf16x3 split precision for the weight GEMMs
+    // precision mode: 0 = exact fp32 MFMA (default), 1 = bf16x3 split precision for the weight GEMMs, 2 = split6: the 3x3 convolutions of
+    // the levels whose images are multiples of 16 x 16 through F(2x2,3x3) in the exact three-piece bf16 split (everything else as mode 0)
     int precision = 0;
+    unsigned short *wsplit6 = nullptr;      // pre-split Winograd-domain fragments of those slots (kernels/conv3x3_wino2d_split6.hip)
+    std::vector<long long> split6_off;      // byte offsets into wsplit6, -1 = the slot has none
+    long long wsplit6_bytes = 0;
+    bool wsplit6_valid = false;
     unsigned short *wsplit_hi = nullptr, *wsplit_lo = nullptr;  // bf16 hi / lo of wbuf, same element offsets
     bool wsplit_valid = false;
     // ... and their two-dimensional F(2x2, 3x3) copies (kernels/conv3x3_wino2d_f32.hip), 16 N Cin floats per eligible slot
@@ -201,7 +206,7 @@ static float *tptr_at(gd_engine *e, const Bind &b, const TRef &r, int batch, int
 // 256-channel tensors of the 64x64 level at batch 512 are exactly 2 GiB -- runs as several launches over image sub-ranges instead of
 // falling back to the 64-bit-addressed generic kernel (images are independent rows of the GEMM).  Returns the number of launches.
 static int gemm_parts(const gd_engine *e, const Op &op, int batch) {
-    if (e->precision != 0 || op.kind != OP_GEMM || op.z_per_image || op.w_slot < 0 || op.a_slot >= 0 || batch < 2) return 1;
+    if (e->precision == 1 || op.kind != OP_GEMM || op.z_per_image || op.w_slot < 0 || op.a_slot >= 0 || batch < 2) return 1;
     long long per = (long long)op.H * op.W * std::max(op.lda0, op.C1 > 0 ? op.lda1 : 0) * 4;
     per = std::max(per, (long long)op.m_per_image * op.ldc * 4);
     if (op.res.t >= 0) per = std::max(per, (long long)op.m_per_image * op.ldres * 4);
@@ -312,8 +317,14 @@ static void fill_egn(gd_engine *e, const Op &op, const Bind &b, int batch, GemmP
     g.egn_skip_raw = op.egn_sole;
 }
 
+// split6 mode: the convolution goes to the split6 kernel (no epilogue GroupNorm there: the stand-alone pass runs)
+static bool split6_takes(const gd_engine *e, const Op &op, const GemmParams &g, int z) {
+    return e->precision == 2 && e->wsplit6_valid && z == 1 && op.w_slot >= 0 && op.w_slot < (int)e->split6_off.size() &&
+           e->split6_off[op.w_slot] >= 0 && conv3x3_wino2d_split6_gemm_ok(g);
+}
+
 static bool egn_fused(gd_engine *e, const Bind &b, int batch, int gemm_index) {
-    if (opts().no_egn || e->precision != 0 || gemm_index < 0) return false;
+    if (opts().no_egn || e->precision == 1 || gemm_index < 0) return false;
     auto it = e->egn_ok.find(batch);
     if (it == e->egn_ok.end()) {
         std::vector<char> ok(e->plan.ops.size(), 0);
@@ -322,6 +333,7 @@ static bool egn_fused(gd_engine *e, const Bind &b, int batch, int gemm_index) {
             if (op.kind != OP_GEMM || op.egn_peer < 0) continue;
             GemmParams g{};
             const int z = fill_gemm_first(e, op, b, batch, g);
+            if (split6_takes(e, op, g, z)) continue;
             fill_egn(e, op, b, batch, g);
             const bool wino2 = z == 1 && op.w_slot >= 0 && e->wwino2 && e->wino2_off[op.w_slot] >= 0;
             const bool wino42 = z == 1 && op.w_slot >= 0 && e->wwino42 && e->wino42_off[op.w_slot] >= 0;
@@ -346,7 +358,7 @@ static void fill_side(gd_engine *e, const Op &op, const Bind &b, int batch, Gemm
 }
 
 static bool side_fused(gd_engine *e, const Bind &b, int batch, int gemm_index) {
-    if (opts().no_side_gn || e->precision != 0 || gemm_index < 0) return false;
+    if (opts().no_side_gn || e->precision == 1 || gemm_index < 0) return false;
     auto it = e->side_ok.find(batch);
     if (it == e->side_ok.end()) {
         std::vector<char> ok(e->plan.ops.size(), 0);
@@ -380,7 +392,7 @@ static int launch_apply_op(gd_engine *e, const Op &op, const Bind &b, int batch,
 // output and by the product of that output with a k-contiguous V^T (whose epilogue may carry the block's residual, scale and statistics).
 static bool attn_core_at(const gd_engine *e, int i) {
     const std::vector<Op> &ops = e->plan.ops;
-    if (e->precision != 0 || i < 0 || i + 2 >= (int)ops.size()) return false;
+    if (e->precision == 1 || i < 0 || i + 2 >= (int)ops.size()) return false;
     const Op &qk = ops[i], &sm = ops[i + 1], &av = ops[i + 2];
     if (qk.kind != OP_GEMM || sm.kind != OP_SOFTMAX || av.kind != OP_GEMM) return false;
     if (!qk.z_per_image || qk.w_slot >= 0 || qk.a_slot >= 0 || qk.bten.t < 0 || qk.b_kmajor ||
@@ -461,17 +473,21 @@ static int run_gemm(gd_engine *e, int op_index, const Bind &b, int batch, int i0
         ProfScope ps(e, s, pkey(e, op, std::string("igemm_bf16x3_kernel<256,128,4,2,act>")), op.flops_per_image * nb, gemm_alg_bytes(g, z));
         return launch_igemm_bf16x3_act(g, z, s);
     }
-    if (e->precision == 0 && z == 1 && op.w_slot >= 0 && e->wwino42 && e->wino42_off[op.w_slot] >= 0 && conv3x3_wino42_ok(g)) {
+    if (split6_takes(e, op, g, z)) {
+        ProfScope ps(e, s, pkey(e, op, std::string("conv3x3_wino2d_split6_kernel")), op.flops_per_image * nb, gemm_alg_bytes(g, z));
+        return launch_conv3x3_wino2d_split6_gemm(g, reinterpret_cast<const unsigned short *>(reinterpret_cast<const char *>(e->wsplit6) + e->split6_off[op.w_slot]), s);
+    }
+    if (e->precision != 1 && z == 1 && op.w_slot >= 0 && e->wwino42 && e->wino42_off[op.w_slot] >= 0 && conv3x3_wino42_ok(g)) {
         g.b_wino = e->wwino42 + e->wino42_off[op.w_slot];
         ProfScope ps(e, s, pkey(e, op, std::string(conv3x3_wino42_name_for(g))), op.flops_per_image * nb, gemm_alg_bytes(g, z));
         return launch_conv3x3_wino42(g, s);
     }
-    if (e->precision == 0 && z == 1 && op.w_slot >= 0 && e->wwino2 && e->wino2_off[op.w_slot] >= 0 && conv3x3_wino2d_ok(g)) {
+    if (e->precision != 1 && z == 1 && op.w_slot >= 0 && e->wwino2 && e->wino2_off[op.w_slot] >= 0 && conv3x3_wino2d_ok(g)) {
         g.b_wino = e->wwino2 + e->wino2_off[op.w_slot];
         ProfScope ps(e, s, pkey(e, op, std::string(conv3x3_wino2d_name())), op.flops_per_image * nb, gemm_alg_bytes(g, z));
         return launch_conv3x3_wino2d(g, s);
     }
-    if (e->precision == 0 && z == 1 && op.w_slot >= 0 && e->wwino2 && e->wino2_off[op.w_slot] >= 0 && e->splitk_ws &&
+    if (e->precision != 1 && z == 1 && op.w_slot >= 0 && e->wwino2 && e->wino2_off[op.w_slot] >= 0 && e->splitk_ws &&
         conv3x3_wino2d_splitk_factor(g) > 1) {  // 4x4 images: the channel range split over workgroups + a finishing pass
         g.b_wino = e->wwino2 + e->wino2_off[op.w_slot];
         const long long img0 = (long long)(b.arena - e->arena) / e->plan.arena_per_image + i0;  // first image of this sub-batch (lanes)
@@ -736,6 +752,7 @@ int gd_engine_destroy(gd_engine *e) {
         if (e->splitk_ws) (void)hipFree(e->splitk_ws);
         if (e->wsplit_hi) (void)hipFree(e->wsplit_hi);
         if (e->wsplit_lo) (void)hipFree(e->wsplit_lo);
+        if (e->wsplit6) (void)hipFree(e->wsplit6);
         float *bufs[] = {e->arena, e->wbuf, e->xin, e->epsb, e->eps_planar, e->labels, e->u8, e->ring, e->ystate, e->uin_stage,
                          e->xout_stage, e->vout_stage,
                          e->ts_dev, e->coef_dev, e->dn_dev, e->mean_dev, e->std_dev, e->tf_dev, e->nz_dev, e->m2e_dev, e->temb_tab, e->temb_cur, (float *)e->seed_dev,
@@ -784,6 +801,7 @@ int gd_engine_load_param(gd_engine *e, const char *name, const float *host_data,
     GD_CHECK(e && name && host_data && shape, "null argument");
     e->params_uploaded = false;
     e->wsplit_valid = false;
+    e->wsplit6_valid = false;
     return e->plan.load_param(name, host_data, shape, ndim);
 }
 
@@ -894,10 +912,40 @@ static int build_wino_weights(gd_engine *e) {
     return 0;
 }
 
+// split6 mode: pre-split Winograd-domain fragments of every 3x3 / stride 1 slot whose images are multiples of 16 x 16 (allocated once; the
+// plan fixes the layout), built on the device from wbuf
+static int build_split6_weights(gd_engine *e) {
+    const Plan &P = e->plan;
+    std::vector<std::pair<int, int>> dims(P.slots.size(), {0, 0});
+    e->split6_off.assign(P.slots.size(), -1);
+    long long total = 0;
+    for (const Op &op : P.ops) {
+        if (op.kind != OP_GEMM || op.w_slot < 0 || op.a_slot >= 0 || op.z_per_image || e->split6_off[op.w_slot] >= 0) continue;
+        if (op.KH != 3 || op.KW != 3 || op.stride != 1 || op.pad != 1 || op.C1 != 0 || op.K != 9 * op.C0 || op.ldb != op.K) continue;
+        if (P.slots[op.w_slot].rows != op.N || P.slots[op.w_slot].cols != op.K) continue;
+        if (op.H % 16 != 0 || op.W % 16 != 0 || op.C0 % 16 != 0 || op.N % 64 != 0) continue;
+        e->split6_off[op.w_slot] = total;
+        dims[op.w_slot] = {op.N, op.C0};
+        total += conv3x3_wino2d_split6_weight_bytes(op.C0, op.N);
+    }
+    GD_CHECK(!e->wsplit6 || total == e->wsplit6_bytes, "internal error: the split6 weight layout of an engine changed between two parameter loads");
+    if (total > 0) {
+        if (!e->wsplit6) GD_HIP(hipMalloc((void **)&e->wsplit6, (size_t)total));
+        e->wsplit6_bytes = total;
+        for (size_t i = 0; i < P.slots.size(); ++i)
+            if (e->split6_off[i] >= 0)
+                GD_TRY(launch_wino2d_split6_weights(e->wbuf + e->slot_off[i], reinterpret_cast<unsigned short *>(reinterpret_cast<char *>(e->wsplit6) + e->split6_off[i]),
+                                                    dims[i].first, dims[i].second, nullptr));
+    }
+    GD_HIP(hipDeviceSynchronize());
+    e->wsplit6_valid = true;
+    return 0;
+}
+
 int gd_engine_set_precision(gd_engine *e, int mode) {
     OptScope scope(e ? e->opts : nullptr);
     GD_CHECK(e, "null engine");
-    GD_CHECK(mode == 0 || mode == 1, "unknown precision mode %d (0 = fp32, 1 = bf16x3)", mode);
+    GD_CHECK(mode == 0 || mode == 1 || mode == 2, "unknown precision mode %d (0 = fp32, 1 = bf16x3, 2 = split6)", mode);
     DeviceScope dscope(e);
     e->temb_valid = false;  // (the embedding GEMMs may run on other kernels)
     if (!e->plan_only) {
@@ -907,6 +955,7 @@ int gd_engine_set_precision(gd_engine *e, int mode) {
         e->egn_ok.clear();
         e->side_ok.clear();
         if (mode == 1 && e->params_uploaded && !e->wsplit_valid) GD_TRY(upload_split_weights(e));
+        if (mode == 2 && e->params_uploaded && !e->wsplit6_valid) GD_TRY(build_split6_weights(e));
     }
     e->precision = mode;
     return 0;
@@ -937,8 +986,10 @@ int gd_engine_params_ready(gd_engine *e) {
         }
         e->params_uploaded = true;
         e->wsplit_valid = false;
+        e->wsplit6_valid = false;
         GD_TRY(build_wino_weights(e));
         if (e->precision == 1) GD_TRY(upload_split_weights(e));
+        if (e->precision == 2) GD_TRY(build_split6_weights(e));
     }
     return 0;
 }
@@ -948,7 +999,7 @@ int gd_engine_weight_bytes(gd_engine *e, long long out4[4]) {
     out4[0] = e->wbuf_floats * 4;
     out4[1] = e->wwino2_floats * 4;
     out4[2] = e->wwino42_floats * 4;
-    out4[3] = e->wsplit_hi ? e->wbuf_floats * 4 : 0;  // bf16 hi + lo
+    out4[3] = (e->wsplit_hi ? e->wbuf_floats * 4 : 0) + (e->wsplit6 ? e->wsplit6_bytes : 0);  // bf16 hi + lo (mode 1), split6 fragments (mode 2)
     return 0;
 }
 
@@ -1613,6 +1664,27 @@ int gd_conv3x3_winograd2d_split6(const float *x_dev, const void *u_dev, const fl
     GD_CHECK(x_dev && u_dev && out_dev, "null pointer");
     return launch_conv3x3_wino2d_split6(x_dev, (const unsigned short *)u_dev, bias_dev, res_dev, out_dev, batch, H, W, Cin, Cout, out_scale,
                                         (hipStream_t)stream);
+}
+
+int gd_conv3x3_winograd42_weights(const float *w_dev, float *u_dev, int Cin, int Cout, void *stream) {
+    GD_CHECK(w_dev && u_dev, "null pointer");
+    return launch_wino42_weights(w_dev, u_dev, Cout, Cin, (hipStream_t)stream);
+}
+
+int gd_conv3x3_winograd42_pretransformed(const float *x_dev, const float *u_dev, const float *bias_dev, const float *res_dev, float *out_dev,
+                                         int batch, int H, int W, int Cin, int Cout, float alpha, float out_scale, void *stream) {
+    GD_CHECK(x_dev && u_dev && out_dev, "null pointer");
+    GemmParams g{};
+    g.a0 = x_dev; g.C0 = Cin; g.lda0 = Cin; g.lda1 = 4;
+    g.H = H; g.W = W; g.KH = 3; g.KW = 3; g.stride = 1; g.pad = 1; g.OH = H; g.OW = W;
+    g.M = batch * H * W; g.N = Cout; g.K = 9 * Cin;
+    g.b = u_dev; g.ldb = g.K;  // (only the Winograd-domain copy is read)
+    g.out = out_dev; g.ldc = Cout; g.bias = bias_dev; g.res = res_dev; g.ldres = Cout;
+    g.rows_per_image = H * W;
+    g.alpha = alpha; g.out_scale = out_scale;
+    GD_CHECK(conv3x3_wino42_shape_ok(g), "conv3x3_winograd42_pretransformed: shape not eligible (B=%d H=%d W=%d Cin=%d Cout=%d)", batch, H, W, Cin, Cout);
+    g.b_wino = u_dev;
+    return launch_conv3x3_wino42(g, (hipStream_t)stream);
 }
 
 int gd_conv3x3_winograd42_gn(const float *x_dev, const float *w_dev, float *u_scratch_dev, const float *bias_dev, const float *res_dev,

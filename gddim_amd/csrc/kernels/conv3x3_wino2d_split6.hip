@@ -68,6 +68,9 @@ struct Split6Params {
     const float *x;
     const unsigned short *u;  // split6_weights_kernel's fragments
     const float *bias, *res;
+    const float *rowbias;  // per-image bias row (the time-embedding projection), rowbias[img * ld_rowbias + n]; null: none
+    float *qstats;         // fused GroupNorm statistics of the output, float2 [img][slice][n / 4] = (sum, sum of squares); null: none
+    int ld_rowbias, qs_slices;
     float *out;
     int B, H, W, C, N;
     int bx_tiles, tiles_per_image, m_tiles, n_tiles, nk;  // 16x16-pixel blocks per row / per image, in the batch; 64-output tiles; chunks
@@ -106,42 +109,107 @@ __device__ __forceinline__ s6v4 s6_load16(__amdgpu_buffer_rsrc_t rsrc, int voffs
     return s6v4{{t[0], t[1], t[2], t[3]}};
 }
 
-// One role of the K loop (IH = 0: multiply first, then produce; IH = 1: produce first, then multiply), so that the two waves of a SIMD
-// -- waves w and w + 4 of the workgroup -- alternate between the matrix pipe and the vector / LDS / load instructions.
+// The workgroup's program for one role (IH = 0: multiply first, then produce; IH = 1: produce first, then multiply), so that the two waves
+// of a SIMD -- waves w and w + 4 of the workgroup -- alternate between the matrix pipe and the vector / LDS / load instructions.
+// PERSISTENT: one workgroup per CU walks its tiles; the first loads of the next tile (two region chunks, the first U fragments) are
+// requested before the epilogue of the current one, and nothing is dispatched between tiles (the one-tile-per-workgroup form lost 34-50 us
+// per launch between workgroups: profiles/r06_notes.md).
 template <int IH>
-__device__ __forceinline__ void s6_kloop(const Split6Params &p, unsigned char *smem, s6f32x16 (&acc)[2][2][2], int tid, int lane, int jw,
-                                         const int (&rvo)[3], int raw_rd, int vw_off, int ar_off, __amdgpu_buffer_rsrc_t srd_x,
-                                         __amdgpu_buffer_rsrc_t srd_u, float *trbuf, bool trw) {
+__device__ __forceinline__ void s6_body(const Split6Params &p, unsigned char *smem, int tid, int lane, int wave) {
     constexpr int CS_BYTES = 3 * 2048;  // one component: 3 pieces x 2 k halves x 64 tiles x 16 B
+    const int jw = wave & 3;            // component column
     unsigned char *stage0 = smem, *stage1 = smem + S6_STAGE;
     unsigned char *raw0 = smem + 2 * S6_STAGE, *raw1 = raw0 + S6_RAW;
+    const int H = p.H, W = p.W, C = p.C;
     const int u_vo = lane * 16;
     const int raw_wr = tid * 16;
+    // ---- producer identity: (tile, channel quad), component row parity = IH.  lane bits: 0 = quad bit 0, 1..3 = tile bits 0..2, 4 = quad
+    // bit 1, 5 = tile bit 3; jw is tile bits 4..5 (two tile rows of the 8 x 8 block) ----
+    const int tile = (jw << 4) | (((lane >> 5) & 1) << 3) | ((lane >> 1) & 7);
+    const int q = (lane & 1) | (((lane >> 4) & 1) << 1);
+    const int ty = tile >> 3, tx = tile & 7;
+    // the thread's patch position (r, s): region row 2 ty + r, column 2 tx + s -> parity s & 1, column / 2 = tx + (s >> 1)
+    const int raw_rd = ((2 * ty * 2) * 9 + tx) * 64 + q * 16;  // + (r * 2 + (s & 1)) * 576 + (s >> 1) * 64
+    // LDS byte offsets: the thread's 8-byte store slot / the lane's 16-byte fragment slot inside a (component, piece) block of 2 KB
+    const int vw_off = ((q >> 1) * 64 + tile) * 16 + (q & 1) * 8;
+    const int ar_off = ((lane >> 5) * 64 + (lane & 31)) * 16;
+    const __amdgpu_buffer_rsrc_t srd_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(reinterpret_cast<const char *>(p.x)), 0,
+                                                                          p.B * H * W * C * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srd_o = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(p.out), 0, p.B * H * W * p.N * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srd_r = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(reinterpret_cast<const char *>(p.res ? p.res : p.out)), 0, p.B * H * W * p.N * 4, 0x00020000);
+    const size_t u_tile_bytes = (size_t)p.nk * 2 * 4 * 12 * 1024;
+    const size_t u_wave = (size_t)jw * 12 * 1024 + (size_t)IH * 6 * 1024;  // [n tile][phase][column jw][row parity][n block][piece] x 1 KB
+
     s6v4 pr[2][4];          // the two patch rows the thread's component row combines
     s6v4 rc[4];             // its B^T row (4 patch columns)
-    s6f32x4 rawreg[3];      // region pieces of the chunk after next, between their loads and their LDS stores
+    s6f32x4 rawreg[2][3];   // region pieces between their loads and their LDS stores ([1]: the second chunk of a tile's first two)
     s6bf16x8 Areg[2][3];    // [tile block][piece]
     s6bf16x8 Ureg[2][3];    // [n block][piece]
-#ifdef S6_TRACE
+    s6f32x16 acc[2][2][2];  // [component row i >> 1][tile block][n block]: rows IH and IH + 2
+    int rvo[3];             // the thread's three region pieces of the current tile (byte offsets into x; out of the image: out of bounds)
+
+#ifdef S6_TRACE  // in-kernel timeline (tools/split6_trace.py): lane 0 of waves 0 and 4 (the two waves of one SIMD) of two workgroups stamps the
+                 // 100 MHz wall clock and the shader clock into the tail of the residual tensor: slot = 80 stamps x (wall, cycles)
+    const int trslot = blockIdx.x == 0 ? 0 : blockIdx.x == 201 ? 1 : -1;
+    float *trbuf = const_cast<float *>(p.res) + (size_t)p.B * p.H * p.W * p.N - 1024 + ((trslot < 0 ? 0 : trslot) * 2 + (wave == 4 ? 1 : 0)) * 160;
+    const bool trw = trslot >= 0 && lane == 0 && (wave == 0 || wave == 4) && p.res;
+    bool tr_first = true;
     auto trace = [&](int idx) __attribute__((always_inline)) {
-        if (trw && idx < 80) {
+        if (trw && tr_first && idx < 80) {
             trbuf[idx] = (float)(wall_clock64() & 0xFFFFFFull);
             trbuf[80 + idx] = (float)(__builtin_readcyclecounter() & 0xFFFFFFull);
         }
     };
+#define S6_TR(i) trace(i)
 #else
-    (void)trbuf; (void)trw;
+#define S6_TR(i)
 #endif
 
-    auto load_raw = [&](int kc) __attribute__((always_inline)) {
+    // ---- the workgroup's tiles.  Consecutive workgroup ids go round the 8 XCDs: the workgroups of one XCD share ONE n tile, i.e. one slice
+    // of the weight fragments in that XCD's L2 (the whole U of a 256 -> 256 layer is 6.3 MB, a slice 1.6 MB), and walk its m tiles ----
+    const int total = p.m_tiles * p.n_tiles;
+    const bool xcd_map = (8 % p.n_tiles) == 0 && (int)gridDim.x % 8 == 0;
+    const int per = xcd_map ? 8 / p.n_tiles : 1;
+    const int xcd = blockIdx.x & 7;
+    const int m_step = xcd_map ? (int)gridDim.x / p.n_tiles : 0;       // m tiles between two of this workgroup's
+    int mtile = xcd_map ? (blockIdx.x >> 3) * per + xcd / p.n_tiles : 0, ntile = xcd_map ? xcd % p.n_tiles : 0;
+    int flat = blockIdx.x;                                             // (the plain walk when the n tiles do not divide the XCDs)
+    if (!xcd_map) { mtile = flat / p.n_tiles; ntile = flat - mtile * p.n_tiles; }
+    auto have_tile = [&]() { return xcd_map ? mtile < p.m_tiles : flat < total; };
+    auto next_tile = [&]() {
+        if (xcd_map) mtile += m_step;
+        else { flat += gridDim.x; mtile = flat / p.n_tiles; ntile = flat - mtile * p.n_tiles; }
+    };
+    int img = 0, Y0 = 0, X0 = 0;
+    __amdgpu_buffer_rsrc_t srd_u = srd_x;
+    auto enter_tile = [&]() __attribute__((always_inline)) {  // coordinates, region offsets and weight slice of (mtile, ntile)
+        img = mtile / p.tiles_per_image;
+        const int brem = mtile - img * p.tiles_per_image;
+        const int by = brem / p.bx_tiles, bx = brem - by * p.bx_tiles;
+        Y0 = by * 16; X0 = bx * 16;
+        // raw ring: piece L = ((row * 2 + column parity) * 9 + column / 2) * 4 + quad of the 18 x 18 region; thread t moves pieces t + 512 i
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int L = i * 512 + tid;
+            const int row = L / 72, rem = L - row * 72, par = rem / 36, r2 = rem - par * 36;
+            const int y = Y0 - 1 + row, x = X0 - 1 + 2 * (r2 >> 2) + par;
+            const bool ok = L < 1296 && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+            rvo[i] = ok ? (((img * H + y) * W + x) * C + (r2 & 3) * 4) * 4 : S6_OOB;
+        }
+        srd_u = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(reinterpret_cast<const char *>(p.u)) + (size_t)ntile * u_tile_bytes + u_wave, 0,
+                                                  (int)(u_tile_bytes - u_wave), 0x00020000);
+    };
+
+    auto load_raw = [&](int kc, int set) __attribute__((always_inline)) {
         if ((S6_ABL & 1) && kc >= 2) return;
         const int so = __builtin_amdgcn_readfirstlane(kc * 64);
 #pragma unroll
-        for (int i = 0; i < 3; ++i) rawreg[i] = __builtin_bit_cast(s6f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_x, rvo[i], so, 0));
+        for (int i = 0; i < 3; ++i) rawreg[set][i] = __builtin_bit_cast(s6f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_x, rvo[i], so, 0));
     };
-    auto store_raw = [&](unsigned char *st) __attribute__((always_inline)) {
+    auto store_raw = [&](unsigned char *st, int set) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) *reinterpret_cast<s6f32x4 *>(st + i * 8192 + raw_wr) = rawreg[i];
+        for (int i = 0; i < 3; ++i) *reinterpret_cast<s6f32x4 *>(st + i * 8192 + raw_wr) = rawreg[set][i];
     };
     // Component row i = 2 hp + IH of the thread's (tile, quad): B^T row i = d0 - d2, d1 + d2, d2 - d1, d1 - d3 (patch rows), then the four
     // components (i, j): column combination, split, three 8-byte stores each
@@ -159,9 +227,7 @@ __device__ __forceinline__ void s6_kloop(const Split6Params &p, unsigned char *s
                 pr[1][sx] = s6v4{{tb_[0], tb_[1], tb_[2], tb_[3]}};
                 rc[sx] = (S6_ABL & 16) ? pr[0][sx] : i == 1 ? s6_add4(pr[0][sx], pr[1][sx]) : s6_sub4(pr[0][sx], pr[1][sx]);
             }
-#ifndef S6_READ8
             __builtin_amdgcn_sched_barrier(0);
-#endif
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -209,20 +275,6 @@ __device__ __forceinline__ void s6_kloop(const Split6Params &p, unsigned char *s
                 for (int tb = 0; tb < 2; ++tb)
                     acc[hh][tb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Areg[tb][PA[t]], Ureg[nb][PB[t]], acc[hh][tb][nb], 0, 0, 0);
     };
-
-    // ---- prologue: the regions of chunks 0 and 1 into the raw ring, V of phase 0 (component rows 0, 1) into stage 0, U of phase 0 ----
-    load_raw(0);
-    load_u(0);
-    store_raw(raw0);
-    load_raw(1);
-    store_raw(raw1);
-    __syncthreads();
-    produce_row(raw0, 0, stage0);
-    __syncthreads();
-#ifdef S6_TRACE
-    trace(1);
-#endif
-
     // One phase, everything but its chunk index known at compile time: HH = component-row half being multiplied (V of the phase lies in
     // stage HH; the next phase is (chunk kc + HH, half 1 - HH) and its V goes to stage 1 - HH), MORE = there is a next phase.
     auto phase = [&](auto HHc, auto MOREc, int kc) __attribute__((always_inline)) {
@@ -231,47 +283,155 @@ __device__ __forceinline__ void s6_kloop(const Split6Params &p, unsigned char *s
         const int ph = 2 * kc + HH;
         unsigned char *rd = HH ? stage1 : stage0, *wr = HH ? stage0 : stage1;
         const unsigned char *rawn = ((kc + HH) & 1) ? raw1 : raw0;
-#ifdef S6_TRACE
-#define S6_FINE(i) if (ph == 6 || ph == 7) { __builtin_amdgcn_sched_barrier(0); trace(48 + (ph - 6) * 8 + (i)); __builtin_amdgcn_sched_barrier(0); }
-#else
-#define S6_FINE(i)
-#endif
         // the region of chunk kc + 2: requested at the top of this chunk's first phase (a phase and a half before its stores: the first form
         // requested it at the end of the phase and its stores waited 250-400 cycles), stored in the second -- its stage was last read in the first
-        if (more1 && HH == 0) load_raw(kc + 2);
+        if (more1 && HH == 0) load_raw(kc + 2, 0);
         if (IH == 0) {
             multiply(HH, rd);
             __builtin_amdgcn_sched_barrier(0);
-            S6_FINE(0);
             if (more1) load_u(ph + 1);
             if (more1) produce_row(rawn, 1 - HH, wr);
-            S6_FINE(1);
         } else {
             if (more1) produce_row(rawn, 1 - HH, wr);
             __builtin_amdgcn_sched_barrier(0);
-            S6_FINE(0);
             multiply(HH, rd);
             __builtin_amdgcn_sched_barrier(0);
-            S6_FINE(1);
             if (more1) load_u(ph + 1);
         }
-        if (more1 && HH == 1) store_raw((kc & 1) ? raw1 : raw0);
+        if (more1 && HH == 1) store_raw((kc & 1) ? raw1 : raw0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        S6_FINE(2);
         if (!(S6_ABL & 8)) __syncthreads();
-#ifdef S6_TRACE
-        trace(2 + ph);
-#endif
-#undef S6_FINE
+        S6_TR(2 + ph);
     };
     typedef std::integral_constant<int, 0> H0;
     typedef std::integral_constant<int, 1> H1;
-    for (int kc = 0; kc < p.nk - 1; ++kc) {
-        phase(H0{}, std::true_type{}, kc);
-        phase(H1{}, std::true_type{}, kc);
+
+    if (!have_tile()) return;
+    enter_tile();
+    S6_TR(0);
+    load_raw(0, 0);
+    load_raw(1, 1);
+    load_u(0);
+    while (true) {
+        // ---- prologue of the tile: its first two region chunks (already requested) into the raw ring, V of phase 0 into stage 0 ----
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) acc[i][a][b][v] = 0.f;
+        store_raw(raw0, 0);
+        store_raw(raw1, 1);
+        __syncthreads();
+        produce_row(raw0, 0, stage0);
+        __syncthreads();
+        S6_TR(1);
+        for (int kc = 0; kc < p.nk - 1; ++kc) {
+            phase(H0{}, std::true_type{}, kc);
+            phase(H1{}, std::true_type{}, kc);
+        }
+        phase(H0{}, std::true_type{}, p.nk - 1);
+        phase(H1{}, std::false_type{}, p.nk - 1);
+        S6_TR(39);
+
+        // ---- the next tile's first loads go out before this tile's epilogue (their registers are idle until the next prologue) ----
+        const int e_img = img, e_Y0 = Y0, e_X0 = X0, e_ntile = ntile, e_mtile = mtile;
+        next_tile();
+        const bool more_tiles = have_tile();
+        if (more_tiles) {
+            enter_tile();
+            load_raw(0, 0);
+            load_raw(1, 1);
+            load_u(0);
+        }
+
+        // ---- epilogue, one output row parity a at a time.  z_a = sum_i A^T[a][i] M_i (a = 0: m0 + m1 + m2, a = 1: m1 - m2 - m3) takes the
+        // rows of the two waves of a column: EVERY wave stores its part (IH = 0: m0 + m2 | -m2, IH = 1: m1 | m1 - m3) into
+        // zx[column j][IH][tile][n] (floats, n contiguous: 8 planes of 16 KB = the 128 KB over the idle stages) and the readers add the two
+        // parts.  (First 8-wave form: both parities at once, the IH = 1 waves adding to the IH = 0 waves' planes in a second pass while those
+        // idled: 3.2 us of exchange per tile.)  The MFMA layout has a lane = one output n, so the stores are single floats (lanes =
+        // consecutive n: conflict-free) and the readers get FOUR consecutive n per lane: a store instruction costs the CU's store path about
+        // the same whatever its width, and 64 dword stores per lane made the first form's epilogue 9-11 us of an 80 us tile.
+        // Reader = thread (tile, n quad): y_ab = sum_j z_a[j] A^T[b][j] (b = 0: z0 + z1 + z2, b = 1: z1 - z2 - z3), 16-byte stores; lane bits
+        // 0..3 = n quad (a wave-level store covers whole 256-byte rows of four pixels); tile = 4 (wave * 2 + k) + (lane >> 4) ----
+        float *zx = reinterpret_cast<float *>(smem);
+        const int nq = lane & 15;
+        const int n = e_ntile * 64 + nq * 4;
+        s6f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) bias = *reinterpret_cast<const s6f32x4 *>(p.bias + n);
+        if (p.rowbias) bias += *reinterpret_cast<const s6f32x4 *>(p.rowbias + (size_t)e_img * p.ld_rowbias + n);  // (a tile is one image)
+        const bool has_res = p.res != nullptr;
+        float qs_s = 0.f, qs_q = 0.f;  // the lane's share of the statistics entry (tile row = wave, channel quad nq)
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) {
+                        const float lo = acc[0][tb][nb][v], hi = acc[1][tb][nb][v];  // component rows IH, IH + 2
+                        const float z = a == 0 ? (IH == 0 ? lo + hi : lo) : (IH == 0 ? -hi : lo - hi);
+                        const int t = tb * 32 + (v & 3) + 8 * (v >> 2);  // + 4 (lane >> 5): tile of accumulator register v (MFMA C / D layout)
+                        zx[(jw * 2 + IH) * 4096 + (t + 4 * (lane >> 5)) * 64 + nb * 32 + (lane & 31)] = z;
+                    }
+            __syncthreads();
+            if (a == 0) S6_TR(41);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int t = 4 * (wave * 2 + k) + (lane >> 4);
+                const int oy = e_Y0 + 2 * (t >> 3) + a, ox = e_X0 + 2 * (t & 7);
+                const int vo = (((e_img * H + oy) * W + ox) * p.N + n) * 4;
+                s6f32x4 zj[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    zj[j] = *reinterpret_cast<const s6f32x4 *>(zx + (j * 2 + 0) * 4096 + t * 64 + nq * 4) +
+                            *reinterpret_cast<const s6f32x4 *>(zx + (j * 2 + 1) * 4096 + t * 64 + nq * 4);
+                s6f32x4 r0 = (zj[0] + zj[1]) + zj[2] + bias;
+                s6f32x4 r1 = (zj[1] - zj[2]) - zj[3] + bias;
+                if (has_res) {
+                    r0 += __builtin_bit_cast(s6f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_r, vo, 0, 0));
+                    r1 += __builtin_bit_cast(s6f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_r, vo, p.N * 4, 0));
+                }
+                r0 *= p.out_scale;
+                r1 *= p.out_scale;
+#pragma unroll
+                for (int e4 = 0; e4 < 4; ++e4) {
+                    qs_s += r0[e4] + r1[e4];
+                    qs_q += r0[e4] * r0[e4] + r1[e4] * r1[e4];
+                }
+                const s6u32x4 d0 = __builtin_bit_cast(s6u32x4, r0), d1 = __builtin_bit_cast(s6u32x4, r1);
+                __builtin_amdgcn_raw_buffer_store_b128(d0, srd_o, vo, 0, 2);  // (aux 2: nt)
+                __builtin_amdgcn_raw_buffer_store_b128(d1, srd_o, vo, p.N * 4, 2);
+                // A 16-byte store reads its last data register for the last lanes many cycles after issue: with the registers rewritten two
+                // instructions later, element 3 of lanes 12..15 (mod 16) of the FIRST store came out as the second store's (measured, every
+                // shape, deterministic).  The hazard recogniser does not cover it; keep the data registers alone for a while.
+                asm volatile("s_nop 15\n\ts_nop 15" ::"v"(d0), "v"(d1));
+            }
+            if (a == 0) __syncthreads();  // (the planes are rewritten with the other parity)
+        }
+        // Fused GroupNorm statistics (kernels/qstats.h: one writer per entry, no atomics): wave w finished tile row w of the block = 32
+        // output pixels = one "slice"; its lanes hold 2 x 2 tiles x 2 x 2 pixels x 4 channels each, the four 16-lane groups the four
+        // tiles of a k.  Entry (image, slice = block-in-image * 8 + w, channel quad) = (sum, sum of squares) over those 32 pixels x 4 channels.
+        if (p.qstats) {
+            qs_s += __shfl_xor(qs_s, 16); qs_q += __shfl_xor(qs_q, 16);
+            qs_s += __shfl_xor(qs_s, 32); qs_q += __shfl_xor(qs_q, 32);
+            if (lane < 16) {
+                const int brem_e = e_mtile - e_img * p.tiles_per_image;
+                float2 *o = reinterpret_cast<float2 *>(p.qstats) + ((size_t)e_img * p.qs_slices + brem_e * 8 + wave) * (p.N >> 2) + (n >> 2);
+                *o = make_float2(qs_s, qs_q);
+            }
+        }
+        S6_TR(42);
+#ifdef S6_TRACE
+        tr_first = false;
+#endif
+        if (!more_tiles) break;
+        __syncthreads();  // (the exchange area lies over the stages and the raw ring the next prologue writes)
     }
-    phase(H0{}, std::true_type{}, p.nk - 1);
-    phase(H1{}, std::false_type{}, p.nk - 1);
+#undef S6_TR
 }
 
 __global__ void __launch_bounds__(512) conv3x3_wino2d_split6_kernel(const Split6Params p) {
@@ -279,156 +439,9 @@ __global__ void __launch_bounds__(512) conv3x3_wino2d_split6_kernel(const Split6
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int jw = wave & 3, ih = wave >> 2;  // component column, component row parity (waves w and w + 4 share a SIMD)
-
-    // ---- block -> (m tile, n tile).  Consecutive workgroup ids go round the 8 XCDs: the workgroups of one XCD share ONE n tile, i.e. one
-    // slice of the weight fragments in that XCD's L2 (the whole U of a 256 -> 256 layer is 6.3 MB, a slice 1.6 MB) ----
-    int mtile, ntile;
-    const int total = p.m_tiles * p.n_tiles;
-    if ((8 % p.n_tiles) == 0 && total % 8 == 0) {
-        const int per = 8 / p.n_tiles;  // XCDs per n tile
-        const int xcd = blockIdx.x & 7, grp = blockIdx.x >> 3;
-        ntile = xcd % p.n_tiles;
-        mtile = grp * per + xcd / p.n_tiles;
-    } else {
-        mtile = blockIdx.x / p.n_tiles;
-        ntile = blockIdx.x - mtile * p.n_tiles;
-    }
-    if (mtile >= p.m_tiles) return;
-    const int img = mtile / p.tiles_per_image;
-    const int brem = mtile - img * p.tiles_per_image;
-    const int by = brem / p.bx_tiles, bx = brem - by * p.bx_tiles;
-    const int Y0 = by * 16, X0 = bx * 16;
-    const int H = p.H, W = p.W, C = p.C;
-    float *trbuf = nullptr;
-    bool trw = false;
-#ifdef S6_TRACE  // in-kernel timeline (tools/split6_trace.py): lane 0 of waves 0 and 4 (the two waves of one SIMD) of two workgroups stamps the
-                 // 100 MHz wall clock and the shader clock into the tail of the residual tensor: slot = 80 stamps x (wall, cycles)
-    const int trslot = blockIdx.x == 0 ? 0 : blockIdx.x == 601 ? 1 : -1;
-    trbuf = const_cast<float *>(p.res) + (size_t)p.B * p.H * p.W * p.N - 1024 + ((trslot < 0 ? 0 : trslot) * 2 + (wave == 4 ? 1 : 0)) * 160;
-    trw = trslot >= 0 && lane == 0 && (wave == 0 || wave == 4) && p.res;
-    auto trace = [&](int idx) __attribute__((always_inline)) {
-        if (trw && idx < 80) {
-            trbuf[idx] = (float)(wall_clock64() & 0xFFFFFFull);
-            trbuf[80 + idx] = (float)(__builtin_readcyclecounter() & 0xFFFFFFull);
-        }
-    };
-    trace(0);
-#define S6_TR(i) trace(i)
-#else
-#define S6_TR(i)
-#endif
-
-    // ---- producer identity: (tile, channel quad), component row parity = ih.  lane bits: 0 = quad bit 0, 1..3 = tile bits 0..2, 4 = quad
-    // bit 1, 5 = tile bit 3; jw is tile bits 4..5 (two tile rows of the 8 x 8 block) ----
-    const int tile = (jw << 4) | (((lane >> 5) & 1) << 3) | ((lane >> 1) & 7);
-    const int q = (lane & 1) | (((lane >> 4) & 1) << 1);
-    const int ty = tile >> 3, tx = tile & 7;
-    // raw ring: piece L = ((row * 2 + column parity) * 9 + column / 2) * 4 + quad of the 18 x 18 region; thread t moves pieces t + 512 i
-    int rvo[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int L = i * 512 + tid;
-        const int row = L / 72, rem = L - row * 72, par = rem / 36, r2 = rem - par * 36;
-        const int y = Y0 - 1 + row, x = X0 - 1 + 2 * (r2 >> 2) + par;
-        const bool ok = L < 1296 && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
-        rvo[i] = ok ? (((img * H + y) * W + x) * C + (r2 & 3) * 4) * 4 : S6_OOB;
-    }
-    // the thread's patch position (r, s): region row 2 ty + r, column 2 tx + s -> parity s & 1, column / 2 = tx + (s >> 1)
-    const int raw_rd = ((2 * ty * 2) * 9 + tx) * 64 + q * 16;  // + (r * 2 + (s & 1)) * 576 + (s >> 1) * 64
-    const __amdgpu_buffer_rsrc_t srd_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(reinterpret_cast<const char *>(p.x)), 0,
-                                                                          p.B * H * W * C * 4, 0x00020000);
-    // the wave's weight fragments: [n tile][phase][column jw][row parity ih][n block][piece] x 1 KB
-    const size_t u_tile_bytes = (size_t)p.nk * 2 * 4 * 12 * 1024;
-    const size_t u_wave = (size_t)jw * 12 * 1024 + (size_t)ih * 6 * 1024;
-    const __amdgpu_buffer_rsrc_t srd_u = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char *>(reinterpret_cast<const char *>(p.u)) + (size_t)ntile * u_tile_bytes + u_wave, 0, (int)(u_tile_bytes - u_wave), 0x00020000);
-
-    // LDS byte offsets: the thread's 8-byte store slot / the lane's 16-byte fragment slot inside a (component, piece) block of 2 KB
-    const int vw_off = ((q >> 1) * 64 + tile) * 16 + (q & 1) * 8;
-    const int ar_off = ((lane >> 5) * 64 + (lane & 31)) * 16;
-
-    s6f32x16 acc[2][2][2];  // [component row i >> 1][tile block][n block]: rows ih and ih + 2
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int v = 0; v < 16; ++v) acc[i][a][b][v] = 0.f;
-
-    if (ih == 0) s6_kloop<0>(p, smem, acc, tid, lane, jw, rvo, raw_rd, vw_off, ar_off, srd_x, srd_u, trbuf, trw);
-    else s6_kloop<1>(p, smem, acc, tid, lane, jw, rvo, raw_rd, vw_off, ar_off, srd_x, srd_u, trbuf, trw);
-    S6_TR(39);
-
-    // ---- epilogue.  z_a = sum_i A^T[a][i] M_i (a = 0: m0 + m1 + m2, a = 1: m1 - m2 - m3) takes the rows of two waves: the ih = 0 wave of a
-    // column stores its part (m0 + m2, -m2) into zx[column j][a][tile][n] (floats, n contiguous), the ih = 1 wave adds its own (m1, m1 - m3)
-    // to it after a barrier.  The MFMA layout has a lane = one output n, so these are single floats (lanes = consecutive n:
-    // conflict-free) and the readers get FOUR consecutive n per lane: a store instruction costs the CU's store path about the same whatever
-    // its width, and 64 dword stores per lane made the first form's epilogue 9-11 us of an 80 us tile ----
-    float *zx = reinterpret_cast<float *>(smem);
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-        if (pass == ih) {
-#pragma unroll
-            for (int tb = 0; tb < 2; ++tb)
-#pragma unroll
-                for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-                    for (int v = 0; v < 16; ++v) {
-                        const float lo = acc[0][tb][nb][v], hi = acc[1][tb][nb][v];  // component rows ih, ih + 2
-                        const float z0 = ih == 0 ? lo + hi : lo;
-                        const float z1 = ih == 0 ? -hi : lo - hi;
-                        const int t = tb * 32 + (v & 3) + 8 * (v >> 2);  // + 4 (lane >> 5): tile of accumulator register v (MFMA C / D layout)
-                        const int o = (t + 4 * (lane >> 5)) * 64 + nb * 32 + (lane & 31);
-                        // (the second pass reads the first one's part back and stores the sum: LDS float atomics took 44 us per tile here)
-                        zx[(jw * 2 + 0) * 4096 + o] = pass == 0 ? z0 : zx[(jw * 2 + 0) * 4096 + o] + z0;
-                        zx[(jw * 2 + 1) * 4096 + o] = pass == 0 ? z1 : zx[(jw * 2 + 1) * 4096 + o] + z1;
-                    }
-        }
-        __syncthreads();
-    }
-    S6_TR(41);
-    // thread (tile, n quad): y_ab = sum_j z_a[j] A^T[b][j] (b = 0: z0 + z1 + z2, b = 1: z1 - z2 - z3) for four consecutive outputs, 16-byte stores.
-    // lane bits 0..3 = n quad (a wave-level store covers whole 256-byte rows of four pixels); tile = 4 (wave * 2 + k) + (lane >> 4), k = 0, 1
-    {
-        const int nq = lane & 15;
-        const int n = ntile * 64 + nq * 4;
-        s6f32x4 bias = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias) bias = *reinterpret_cast<const s6f32x4 *>(p.bias + n);
-        const __amdgpu_buffer_rsrc_t srd_o = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(p.out), 0, p.B * H * W * p.N * 4, 0x00020000);
-        const __amdgpu_buffer_rsrc_t srd_r = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<char *>(reinterpret_cast<const char *>(p.res ? p.res : p.out)), 0, p.B * H * W * p.N * 4, 0x00020000);
-        const bool has_res = p.res != nullptr;
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int t = 4 * (wave * 2 + k) + (lane >> 4);
-            const int oy = Y0 + 2 * (t >> 3), ox = X0 + 2 * (t & 7);
-            const int vo = (((img * H + oy) * W + ox) * p.N + n) * 4;
-#pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                s6f32x4 zj[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) zj[j] = *reinterpret_cast<const s6f32x4 *>(zx + (j * 2 + a) * 4096 + t * 64 + nq * 4);
-                s6f32x4 r0 = (zj[0] + zj[1]) + zj[2] + bias;
-                s6f32x4 r1 = (zj[1] - zj[2]) - zj[3] + bias;
-                const int so = __builtin_amdgcn_readfirstlane(a * W * p.N * 4);
-                if (has_res) {
-                    r0 += __builtin_bit_cast(s6f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_r, vo, so, 0));
-                    r1 += __builtin_bit_cast(s6f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_r, vo, so + p.N * 4, 0));
-                }
-                const s6u32x4 d0 = __builtin_bit_cast(s6u32x4, r0 * p.out_scale), d1 = __builtin_bit_cast(s6u32x4, r1 * p.out_scale);
-                __builtin_amdgcn_raw_buffer_store_b128(d0, srd_o, vo, so, 2);  // (aux 2: nt)
-                __builtin_amdgcn_raw_buffer_store_b128(d1, srd_o, vo, so + p.N * 4, 2);
-                // A 16-byte store reads its last data register for the last lanes many cycles after issue: with the registers rewritten two
-                // instructions later, element 3 of lanes 12..15 (mod 16) of the FIRST store came out as the second store's (measured, every
-                // shape, deterministic).  The hazard recogniser does not cover it; keep the data registers alone for a while.
-                asm volatile("s_nop 15\n\ts_nop 15" ::"v"(d0), "v"(d1));
-            }
-        }
-    }
-    S6_TR(42);
+    // component row parity ih = wave >> 2: waves w and w + 4 share a SIMD and take a phase in opposite order
+    if ((wave >> 2) == 0) s6_body<0>(p, smem, tid, lane, wave);
+    else s6_body<1>(p, smem, tid, lane, wave);
 }
 
 // U = G g G^T in double, rounded once to fp32, then three round-to-nearest bf16 pieces, in the fragment order of the kernel above.
@@ -484,6 +497,30 @@ int launch_wino2d_split6_weights(const float *w, unsigned short *u, int Cout, in
     return 0;
 }
 
+// The engine's GEMM op on this kernel (precision mode 2): a single-source 3x3 / stride 1 / pad 1 convolution with dense rows, optional bias,
+// per-image bias row, residual, output scale and fused GroupNorm statistics (one slice per 32 output pixels); no epilogue GroupNorm.
+bool conv3x3_wino2d_split6_gemm_ok(const GemmParams &g) {
+    if (g.KH != 3 || g.KW != 3 || g.stride != 1 || g.pad != 1 || g.C1 != 0 || g.lda0 != g.C0 || g.ldc != g.N || g.K != 9 * g.C0) return false;
+    if (g.alpha != 1.f || g.in_act || g.b_kmajor || g.egn_out || g.gn_side_out || g.a_presplit || g.wk_partial) return false;
+    if (g.res && g.ldres != g.N) return false;
+    const int HW = g.H * g.W;
+    if (HW <= 0 || g.M % HW != 0 || g.OH != g.H || g.OW != g.W) return false;
+    if (g.qstats && g.qs_slices != HW / 32) return false;
+    return conv3x3_wino2d_split6_shape_ok(g.M / HW, g.H, g.W, g.C0, g.N);
+}
+
+static int launch_split6_params(Split6Params &p, hipStream_t s);
+
+int launch_conv3x3_wino2d_split6_gemm(const GemmParams &g, const unsigned short *u, hipStream_t s) {
+    GD_CHECK(conv3x3_wino2d_split6_gemm_ok(g), "conv3x3_wino2d_split6: launch not eligible (M=%d H=%d W=%d Cin=%d N=%d)", g.M, g.H, g.W, g.C0, g.N);
+    Split6Params p{};
+    p.x = g.a0; p.u = u; p.bias = g.bias; p.res = g.res; p.out = g.out;
+    p.rowbias = g.rowbias; p.ld_rowbias = g.ld_rowbias; p.qstats = g.qstats; p.qs_slices = g.qs_slices;
+    p.B = g.M / (g.H * g.W); p.H = g.H; p.W = g.W; p.C = g.C0; p.N = g.N;
+    p.out_scale = g.out_scale;
+    return launch_split6_params(p, s);
+}
+
 int launch_conv3x3_wino2d_split6(const float *x, const unsigned short *u, const float *bias, const float *res, float *out, int batch, int H,
                                  int W, int Cin, int Cout, float out_scale, hipStream_t s) {
     GD_CHECK(conv3x3_wino2d_split6_shape_ok(batch, H, W, Cin, Cout), "conv3x3_winograd2d_split6: shape not eligible (B=%d H=%d W=%d Cin=%d Cout=%d)",
@@ -491,13 +528,20 @@ int launch_conv3x3_wino2d_split6(const float *x, const unsigned short *u, const 
     Split6Params p{};
     p.x = x; p.u = u; p.bias = bias; p.res = res; p.out = out;
     p.B = batch; p.H = H; p.W = W; p.C = Cin; p.N = Cout;
-    p.bx_tiles = W / 16;
-    p.tiles_per_image = (H / 16) * (W / 16);
-    p.m_tiles = batch * p.tiles_per_image;
-    p.n_tiles = Cout / 64;
-    p.nk = Cin / 16;
     p.out_scale = out_scale;
-    const int grid = p.m_tiles * p.n_tiles;
+    return launch_split6_params(p, s);
+}
+
+static int launch_split6_params(Split6Params &p, hipStream_t s) {
+    p.bx_tiles = p.W / 16;
+    p.tiles_per_image = (p.H / 16) * (p.W / 16);
+    p.m_tiles = p.B * p.tiles_per_image;
+    p.n_tiles = p.N / 64;
+    p.nk = p.C / 16;
+    // persistent: one workgroup per CU walks the tiles (a multiple of 8 workgroups so that a workgroup's XCD fixes its n tile)
+    const int total = p.m_tiles * p.n_tiles;
+    const int cus = device_cus() / 8 * 8;
+    const int grid = total < cus ? total : cus;
     hipLaunchKernelGGL(conv3x3_wino2d_split6_kernel, dim3(grid), dim3(512), 0, s, p);
     GD_HIP(hipGetLastError());
     return 0;

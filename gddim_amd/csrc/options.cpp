@@ -69,7 +69,7 @@ thread_local const Options *t_scope = nullptr;
 
 const Options *parse() {
     Options o;
-    if (const char *pm = getenv("GDDIM_PRECISION")) o.precision = strcmp(pm, "bf16x3") == 0 ? 1 : 0;
+    if (const char *pm = getenv("GDDIM_PRECISION")) o.precision = strcmp(pm, "bf16x3") == 0 ? 1 : strcmp(pm, "split6") == 0 ? 2 : 0;
     for (const Entry &e : kEntries) {
         const char *v = getenv(e.env);
         if (!v) continue;
@@ -120,7 +120,7 @@ OptScope::~OptScope() {
 std::string options_json() {
     const Options &o = opts();
     std::ostringstream s;
-    s << "{\"GDDIM_PRECISION\":\"" << (o.precision ? "bf16x3" : "fp32") << "\"";
+    s << "{\"GDDIM_PRECISION\":\"" << (o.precision == 1 ? "bf16x3" : o.precision == 2 ? "split6" : "fp32") << "\"";
     for (const Entry &e : kEntries) s << ",\"" << e.env << "\":" << (e.i ? (long long)(o.*(e.i)) : o.*(e.ll));
     s << "}";
     return s.str();

@@ -15,7 +15,7 @@ namespace gd {
 
 struct Options {
     // ---- engine ----
-    int precision = 0;          // GDDIM_PRECISION=bf16x3 -> 1: engines start in split-precision mode
+    int precision = 0;          // GDDIM_PRECISION=bf16x3 -> 1: engines start in split-precision mode; =split6 -> 2 (gd_engine_set_precision)
     int lanes = 1;              // GD_LANES: concurrent streams a sampler call is split over
     int prof_key = 0;           // GD_PROF_BY_LABEL: profile entries keyed by 0 kernel name, 1 plan-label class, 2 "label class|kernel"
     int no_egn = 0;             // GDDIM_NO_EGN: no GroupNorm in the producer's epilogue

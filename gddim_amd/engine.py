@@ -161,8 +161,10 @@ class Engine(object):
         return self
 
     def set_precision(self, mode):
-        """'fp32' (fp32 MFMA, 3x3 convolutions through the hybrid Winograd transform F(2,3)y x F(4,3)x; default) or 'bf16x3' (split-precision weight contractions on the bf16 matrix core)."""
-        code = {"fp32": 0, "f32": 0, 0: 0, "bf16x3": 1, 1: 1}[mode]
+        """'fp32' (fp32 MFMA, 3x3 convolutions through the hybrid Winograd transform F(2,3)y x F(4,3)x; default), 'bf16x3' (split-precision
+        weight contractions on the bf16 matrix core) or 'split6' (fp32 mode with the 3x3 convolutions of the 16x16-tileable levels through
+        F(2x2,3x3) in the exact three-piece bf16 split: fp32-class error, round 6)."""
+        code = {"fp32": 0, "f32": 0, 0: 0, "bf16x3": 1, 1: 1, "split6": 2, 2: 2}[mode]
         check(self._lib.gd_engine_set_precision(self._h, code))
         self._schedule_token = None
         return self

@@ -140,7 +140,13 @@ int gd_engine_weight_bytes(gd_engine *e, long long out4[4]);
  *      transform along x (additions in fp32, weights transformed in double; GDDIM_NOWINO=1 keeps the direct sum);
  *   1  "bf16x3": fp32 operands split into bf16 hi + lo, a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on the bf16 matrix
  *      core with fp32 accumulation (per-product error ~2^-16, measured as close to float64 as mode 0 on this network).
- * Also selectable with GDDIM_PRECISION=bf16x3 at engine creation.  The reference has one arithmetic only (XLA fp32);
+ *   2  "split6" (round 6): mode 0 with the 3x3 stride-1 convolutions of the levels whose images are multiples of 16 x 16 pixels through
+ *      the two-dimensional Winograd transform F(2x2,3x3) whose component GEMMs run in the EXACT three-piece bf16 split (six bf16 MFMAs per
+ *      fp32 product, every dropped term <= 2^-24 of the product, fp32 accumulation): rms error 0.33 of mode 0's hybrid Winograd kernel
+ *      against float64, 1.18-1.23x its speed on the benchmarked layers (profiles/r06_notes.md).  Bias, per-image bias row, residual,
+ *      scale and the fused GroupNorm statistics in its epilogue; the GroupNorm that mode 0 fuses into the producer's epilogue on 16x16
+ *      images runs as its own pass.
+ * Also selectable with GDDIM_PRECISION=bf16x3 / split6 at engine creation.  The reference has one arithmetic only (XLA fp32);
  * this switch has no counterpart there. */
 int gd_engine_set_precision(gd_engine *e, int mode);
 
@@ -289,6 +295,11 @@ int gd_conv3x3_winograd2d(const float *x_dev, const float *w_dev, float *u_scrat
 int gd_conv3x3_winograd42(const float *x_dev, const float *w_dev, float *u_scratch_dev, const float *bias_dev,
                           const float *res_dev, float *out_dev, int batch, int H, int W, int Cin, int Cout, float alpha,
                           float out_scale, void *stream);
+/* gd_conv3x3_winograd42 in two steps, as the engine runs it: the Winograd-domain weight copy once (u_dev: the scratch size of
+ * gd_conv3x3_winograd42), then the convolution alone (what tools/bench_split6.py times against the prototype below). */
+int gd_conv3x3_winograd42_weights(const float *w_dev, float *u_dev, int Cin, int Cout, void *stream);
+int gd_conv3x3_winograd42_pretransformed(const float *x_dev, const float *u_dev, const float *bias_dev, const float *res_dev, float *out_dev,
+                                         int batch, int H, int W, int Cin, int Cout, float alpha, float out_scale, void *stream);
 /* PROTOTYPE (round 6; not planned into the engine): the same convolution -- nn.Conv(features, (3, 3), padding 1),
  * cld_jax/models/layers.py:95-107 -- through F(2x2,3x3) with every component GEMM in the exact three-piece bf16 split on
  * v_mfma_f32_32x32x16_bf16 (six products per fp32 product, fp32 accumulation; kernels/conv3x3_wino2d_split6.hip).

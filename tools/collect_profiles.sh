@@ -1,5 +1,5 @@
 #!/bin/bash
-# Per-round evidence, run on the GPU box (via gpurun) from the repo root:  bash tools/collect_profiles.sh 4   (-> gpurun_out/prof4).  rocprofv3 kernel-trace statistics of the default bench
+# Per-round evidence, run on the GPU box (via gpurun) from the repo root:  bash tools/collect_profiles.sh 6   (-> gpurun_out/prof6).  rocprofv3 kernel-trace statistics of the default bench
 # command, separate PMC passes (never combined with trace domains other than --kernel-trace), and warmed bench lines (+ rocprofv3
 # statistics) of BASELINE configs 3 and 5, the batch-size curve and the full-size parity log.  Summaries land under gpurun_out/prof<N>;
 # `python tools/update_profiles.py r0<N>` copies them to profiles/.
@@ -49,6 +49,12 @@ stats config5_nfe10 --image-size 64 --batch 512 --nfe 10 --steps 1 --warmup 1 --
 for g in none step loop; do
     $PY --batch 16 --nfe 10 --steps 20 --warmup 3 --graph $g --no-alt --no-cpu-baseline --no-profile 2>/dev/null | tail -1 > $OUT/small_b16_nfe10_graph_$g.json
 done
+# ---- the driver's own flags, and the split6 prototype against the hybrid kernel: hipEvent times, then rocprofv3's per-kernel averages
+$PY --steps 20 --warmup 5 > $OUT/bench_line_driver_flags.json 2>/dev/null
+python $REPO/tools/bench_split6.py 20 2>/dev/null | tail -1 > $OUT/split6_bench.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_split6 -o s6 -- python $REPO/tools/bench_split6.py 20 > $OUT/trace_split6.log 2>&1
+find $OUT/trace_split6 -name "*kernel_stats.csv" -exec cp {} $OUT/split6_kernel_stats.csv \;
+rm -rf $OUT/trace_split6
 # ---- the batch-size curve (per-level kernels) and the full-size parity checks with their printed errors
 python $REPO/tools/batch_sweep.py --batches 16,32,64,128,192,256,320,512,1024 --out $OUT/batch_sweep.json > $OUT/batch_sweep.log 2>&1
 (cd $REPO && python -m pytest tests/test_gpu_parity_abs.py -m gpu -q -s 2>&1 | grep -a -E "max\|dx\||passed|failed|share of the flops" > $OUT/parity_abs_tests.log)

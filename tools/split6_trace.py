@@ -17,7 +17,7 @@ for (H, C) in [(16, 256), (32, 128)]:
     torch.cuda.synchronize()
     t = r.flatten()[-1024:].cpu().numpy().astype(np.float64)
     NP = 2 * (C // 16)
-    for slot, name in enumerate(("wg0 wave0", "wg0 wave4", "wg601 wave0", "wg601 wave4")):
+    for slot, name in enumerate(("wg0 wave0", "wg0 wave4", "wg201 wave0", "wg201 wave4")):
         wall = t[slot * 160: slot * 160 + 80] / 100.0
         cyc = t[slot * 160 + 80: slot * 160 + 160]
         d = lambda a, i, j: (a[j] - a[i]) % (1 << 24 if a is cyc else (1 << 24) / 100.0)  # noqa: E731
@@ -30,7 +30,3 @@ for (H, C) in [(16, 256), (32, 128)]:
               % (H, C, name, tot_us, d(wall, 0, 1), d(wall, 1, 2 + NP - 1), np.mean(phases), np.median(phases), clock, d(wall, 2 + NP - 1, 39),
                  d(wall, 39, 41), d(wall, 41, 42)))
         print("      phases (cycles): " + " ".join("%.0f" % v for v in phases))
-        for ph in (6, 7):
-            base = 48 + (ph - 6) * 8
-            seg = [d(cyc, 2 + ph - 1, base), d(cyc, base, base + 1), d(cyc, base + 1, base + 2), d(cyc, base + 2, 2 + ph)]
-            print("      phase %d (cycles): first segment %.0f, second segment %.0f, raw load / store %.0f, barrier wait %.0f   (wave0: multiply | produce; wave4: produce | multiply)" % ((ph,) + tuple(seg)))
