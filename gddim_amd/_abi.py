@@ -98,6 +98,7 @@ SIGNATURES = {
     "gd_conv3x3_winograd2d_split6_weight_bytes": (_LL, [_I, _I]),
     "gd_conv3x3_winograd2d_split6_weights": (_I, [_P, _P, _I, _I, _P]),
     "gd_conv3x3_winograd2d_split6": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
+    "gd_conv3x3_winograd2d_split6_gn": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P]),
     "gd_conv3x3_winograd42_gn": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _F, _P]),
     "gd_group_norm": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "gd_fir_resample": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),

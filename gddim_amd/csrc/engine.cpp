@@ -317,7 +317,7 @@ static void fill_egn(gd_engine *e, const Op &op, const Bind &b, int batch, GemmP
     g.egn_skip_raw = op.egn_sole;
 }
 
-// split6 mode: the convolution goes to the split6 kernel (no epilogue GroupNorm there: the stand-alone pass runs)
+// split6 mode: the convolution goes to the split6 kernel (g without the egn_* fields: egn_fused decides those for the kernel that runs)
 static bool split6_takes(const gd_engine *e, const Op &op, const GemmParams &g, int z) {
     return e->precision == 2 && e->wsplit6_valid && z == 1 && op.w_slot >= 0 && op.w_slot < (int)e->split6_off.size() &&
            e->split6_off[op.w_slot] >= 0 && conv3x3_wino2d_split6_gemm_ok(g);
@@ -333,7 +333,11 @@ static bool egn_fused(gd_engine *e, const Bind &b, int batch, int gemm_index) {
             if (op.kind != OP_GEMM || op.egn_peer < 0) continue;
             GemmParams g{};
             const int z = fill_gemm_first(e, op, b, batch, g);
-            if (split6_takes(e, op, g, z)) continue;
+            if (split6_takes(e, op, g, z)) {  // split6 mode: its kernel normalises whole 16 x 16 images; elsewhere the stand-alone pass runs
+                fill_egn(e, op, b, batch, g);
+                ok[i] = conv3x3_wino2d_split6_gemm_ok(g) ? 1 : 0;
+                continue;
+            }
             fill_egn(e, op, b, batch, g);
             const bool wino2 = z == 1 && op.w_slot >= 0 && e->wwino2 && e->wino2_off[op.w_slot] >= 0;
             const bool wino42 = z == 1 && op.w_slot >= 0 && e->wwino42 && e->wino42_off[op.w_slot] >= 0;
@@ -474,7 +478,7 @@ static int run_gemm(gd_engine *e, int op_index, const Bind &b, int batch, int i0
         return launch_igemm_bf16x3_act(g, z, s);
     }
     if (split6_takes(e, op, g, z)) {
-        ProfScope ps(e, s, pkey(e, op, std::string("conv3x3_wino2d_split6_kernel")), op.flops_per_image * nb, gemm_alg_bytes(g, z));
+        ProfScope ps(e, s, pkey(e, op, std::string(g.egn_out ? "conv3x3_wino2d_split6_kernel+gn" : "conv3x3_wino2d_split6_kernel")), op.flops_per_image * nb, gemm_alg_bytes(g, z));
         return launch_conv3x3_wino2d_split6_gemm(g, reinterpret_cast<const unsigned short *>(reinterpret_cast<const char *>(e->wsplit6) + e->split6_off[op.w_slot]), s);
     }
     if (e->precision != 1 && z == 1 && op.w_slot >= 0 && e->wwino42 && e->wino42_off[op.w_slot] >= 0 && conv3x3_wino42_ok(g)) {
@@ -1664,6 +1668,26 @@ int gd_conv3x3_winograd2d_split6(const float *x_dev, const void *u_dev, const fl
     GD_CHECK(x_dev && u_dev && out_dev, "null pointer");
     return launch_conv3x3_wino2d_split6(x_dev, (const unsigned short *)u_dev, bias_dev, res_dev, out_dev, batch, H, W, Cin, Cout, out_scale,
                                         (hipStream_t)stream);
+}
+
+int gd_conv3x3_winograd2d_split6_gn(const float *x_dev, const void *u_dev, const float *bias_dev, const float *res_dev, float *out_dev,
+                                    const float *gamma_dev, const float *beta_dev, float *gn_out_dev, int groups, int act, int batch, int H, int W,
+                                    int Cin, int Cout, float out_scale, void *stream) {
+    GD_CHECK(x_dev && u_dev && gamma_dev && beta_dev && gn_out_dev, "null pointer");
+    GD_CHECK(groups >= 1 && Cout % groups == 0, "conv3x3_winograd2d_split6_gn: %d channels do not split into %d groups", Cout, groups);
+    GemmParams g{};
+    g.a0 = x_dev; g.C0 = Cin; g.lda0 = Cin; g.lda1 = 4;
+    g.H = H; g.W = W; g.KH = 3; g.KW = 3; g.stride = 1; g.pad = 1; g.OH = H; g.OW = W;
+    g.M = batch * H * W; g.N = Cout; g.K = 9 * Cin;
+    g.ldb = g.K;
+    g.out = out_dev ? out_dev : gn_out_dev; g.ldc = Cout; g.bias = bias_dev; g.res = res_dev; g.ldres = Cout;
+    g.rows_per_image = H * W;
+    g.alpha = 1.f; g.out_scale = out_scale;
+    g.egn_out = gn_out_dev; g.egn_gamma = gamma_dev; g.egn_beta = beta_dev; g.egn_cpg = Cout / groups; g.egn_act = act;
+    g.egn_skip_raw = out_dev ? 0 : 1;
+    GD_CHECK(conv3x3_wino2d_split6_gemm_ok(g), "conv3x3_winograd2d_split6_gn: shape not eligible (B=%d H=%d W=%d Cin=%d Cout=%d groups=%d; 16x16 images, 4 / 8 / 16 channels per group)",
+             batch, H, W, Cin, Cout, groups);
+    return launch_conv3x3_wino2d_split6_gemm(g, (const unsigned short *)u_dev, (hipStream_t)stream);
 }
 
 int gd_conv3x3_winograd42_weights(const float *w_dev, float *u_dev, int Cin, int Cout, void *stream) {

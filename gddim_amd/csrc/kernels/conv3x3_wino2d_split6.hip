@@ -45,6 +45,7 @@
 #include <type_traits>
 
 #include "../common.h"
+#include "act.h"
 
 namespace gd {
 
@@ -71,6 +72,11 @@ struct Split6Params {
     const float *rowbias;  // per-image bias row (the time-embedding projection), rowbias[img * ld_rowbias + n]; null: none
     float *qstats;         // fused GroupNorm statistics of the output, float2 [img][slice][n / 4] = (sum, sum of squares); null: none
     int ld_rowbias, qs_slices;
+    // GroupNorm (+ swish) of the OUTPUT in the epilogue (common.h: GemmParams::egn_out; 16 x 16 images only: a tile is a whole image x 64
+    // outputs = whole groups of egn_cpg = 4 / 8 / 16 channels); egn_skip_raw: the raw output has no other reader and is not stored
+    float *egn_out;
+    const float *egn_gamma, *egn_beta;
+    int egn_cpg, egn_act, egn_skip_raw;
     float *out;
     int B, H, W, C, N;
     int bx_tiles, tiles_per_image, m_tiles, n_tiles, nk;  // 16x16-pixel blocks per row / per image, in the batch; 64-output tiles; chunks
@@ -114,7 +120,7 @@ __device__ __forceinline__ s6v4 s6_load16(__amdgpu_buffer_rsrc_t rsrc, int voffs
 // PERSISTENT: one workgroup per CU walks its tiles; the first loads of the next tile (two region chunks, the first U fragments) are
 // requested before the epilogue of the current one, and nothing is dispatched between tiles (the one-tile-per-workgroup form lost 34-50 us
 // per launch between workgroups: profiles/r06_notes.md).
-template <int IH>
+template <int IH, bool EGN>
 __device__ __forceinline__ void s6_body(const Split6Params &p, unsigned char *smem, int tid, int lane, int wave) {
     constexpr int CS_BYTES = 3 * 2048;  // one component: 3 pieces x 2 k halves x 64 tiles x 16 B
     const int jw = wave & 3;            // component column
@@ -337,15 +343,20 @@ __device__ __forceinline__ void s6_body(const Split6Params &p, unsigned char *sm
         S6_TR(39);
 
         // ---- the next tile's first loads go out before this tile's epilogue (their registers are idle until the next prologue) ----
+        // (EGN variant: after the accumulators' last use -- its epilogue keeps the tile's 32 outputs per lane in registers until the
+        // group statistics are complete)
         const int e_img = img, e_Y0 = Y0, e_X0 = X0, e_ntile = ntile, e_mtile = mtile;
         next_tile();
         const bool more_tiles = have_tile();
-        if (more_tiles) {
-            enter_tile();
-            load_raw(0, 0);
-            load_raw(1, 1);
-            load_u(0);
-        }
+        auto prefetch_next = [&]() __attribute__((always_inline)) {
+            if (more_tiles) {
+                enter_tile();
+                load_raw(0, 0);
+                load_raw(1, 1);
+                load_u(0);
+            }
+        };
+        if (!EGN) prefetch_next();
 
         // ---- epilogue, one output row parity a at a time.  z_a = sum_i A^T[a][i] M_i (a = 0: m0 + m1 + m2, a = 1: m1 - m2 - m3) takes the
         // rows of the two waves of a column: EVERY wave stores its part (IH = 0: m0 + m2 | -m2, IH = 1: m1 | m1 - m3) into
@@ -364,6 +375,7 @@ __device__ __forceinline__ void s6_body(const Split6Params &p, unsigned char *sm
         if (p.rowbias) bias += *reinterpret_cast<const s6f32x4 *>(p.rowbias + (size_t)e_img * p.ld_rowbias + n);  // (a tile is one image)
         const bool has_res = p.res != nullptr;
         float qs_s = 0.f, qs_q = 0.f;  // the lane's share of the statistics entry (tile row = wave, channel quad nq)
+        s6f32x4 keep[2][2][2];         // EGN: the lane's outputs [a][k][pixel column]
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
 #pragma unroll
@@ -377,6 +389,7 @@ __device__ __forceinline__ void s6_body(const Split6Params &p, unsigned char *sm
                         const int t = tb * 32 + (v & 3) + 8 * (v >> 2);  // + 4 (lane >> 5): tile of accumulator register v (MFMA C / D layout)
                         zx[(jw * 2 + IH) * 4096 + (t + 4 * (lane >> 5)) * 64 + nb * 32 + (lane & 31)] = z;
                     }
+            if (EGN && a == 1) prefetch_next();
             __syncthreads();
             if (a == 0) S6_TR(41);
 #pragma unroll
@@ -391,7 +404,8 @@ __device__ __forceinline__ void s6_body(const Split6Params &p, unsigned char *sm
                             *reinterpret_cast<const s6f32x4 *>(zx + (j * 2 + 1) * 4096 + t * 64 + nq * 4);
                 s6f32x4 r0 = (zj[0] + zj[1]) + zj[2] + bias;
                 s6f32x4 r1 = (zj[1] - zj[2]) - zj[3] + bias;
-                if (has_res) {
+                if (has_res) {  // (requested where it is consumed: a prefetch of 8 or 16 registers per lane spills next to the accumulators and the
+                                // next tile's loads in flight, and measured no faster in the U-Net)
                     r0 += __builtin_bit_cast(s6f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_r, vo, 0, 0));
                     r1 += __builtin_bit_cast(s6f32x4, __builtin_amdgcn_raw_buffer_load_b128(srd_r, vo, p.N * 4, 0));
                 }
@@ -402,6 +416,8 @@ __device__ __forceinline__ void s6_body(const Split6Params &p, unsigned char *sm
                     qs_s += r0[e4] + r1[e4];
                     qs_q += r0[e4] * r0[e4] + r1[e4] * r1[e4];
                 }
+                if (EGN) { keep[a][k][0] = r0; keep[a][k][1] = r1; }
+                if (EGN && p.egn_skip_raw) continue;
                 const s6u32x4 d0 = __builtin_bit_cast(s6u32x4, r0), d1 = __builtin_bit_cast(s6u32x4, r1);
                 __builtin_amdgcn_raw_buffer_store_b128(d0, srd_o, vo, 0, 2);  // (aux 2: nt)
                 __builtin_amdgcn_raw_buffer_store_b128(d1, srd_o, vo, p.N * 4, 2);
@@ -411,6 +427,48 @@ __device__ __forceinline__ void s6_body(const Split6Params &p, unsigned char *sm
                 asm volatile("s_nop 15\n\ts_nop 15" ::"v"(d0), "v"(d1));
             }
             if (a == 0) __syncthreads();  // (the planes are rewritten with the other parity)
+        }
+        if (EGN) {
+            // GroupNorm (+ swish) of the output (plan.h: Op::egn_peer), as the fp32 Winograd kernels do it on 16 x 16 images: the tile is
+            // the whole image for 64 channels.  Lane sums (32 values: 8 pixels x 4 channels, already in qs_s / qs_q) -> the lanes of the
+            // group's other channel quads (egn_cpg / 4 neighbours in n) and the wave's four tile columns -> the eight waves through the
+            // 1 KB behind the exchange area (free until the next prologue) -> (mean, rstd) as flax: var = E[y^2] - E[y]^2, eps 1e-6.
+            float gsum = qs_s, gsq = qs_q;
+            for (int o = 4; o < p.egn_cpg; o <<= 1) { gsum += __shfl_xor(gsum, o >> 2); gsq += __shfl_xor(gsq, o >> 2); }
+            gsum += __shfl_xor(gsum, 16); gsq += __shfl_xor(gsq, 16);
+            gsum += __shfl_xor(gsum, 32); gsq += __shfl_xor(gsq, 32);
+            float2 *red = reinterpret_cast<float2 *>(smem + 131072);  // [wave][n quad]
+            if (lane < 16) red[wave * 16 + lane] = make_float2(gsum, gsq);
+            __syncthreads();
+            gsum = 0.f; gsq = 0.f;
+#pragma unroll
+            for (int w8 = 0; w8 < 8; ++w8) {
+                const float2 v = red[w8 * 16 + nq];
+                gsum += v.x; gsq += v.y;
+            }
+            const float inv_n = 1.0f / (256.0f * (float)p.egn_cpg);
+            const float mean = gsum * inv_n;
+            const float rstd = rsqrtf(gsq * inv_n - mean * mean + 1e-6f);
+            const s6f32x4 ga = *reinterpret_cast<const s6f32x4 *>(p.egn_gamma + n), be = *reinterpret_cast<const s6f32x4 *>(p.egn_beta + n);
+            const s6f32x4 sc = rstd * ga, sh = be - mean * rstd * ga;
+            const __amdgpu_buffer_rsrc_t srd_g = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char *>(p.egn_out), 0, p.B * H * W * p.N * 4, 0x00020000);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int t = 4 * (wave * 2 + k) + (lane >> 4);
+                    const int oy = e_Y0 + 2 * (t >> 3) + a, ox = e_X0 + 2 * (t & 7);
+                    const int vo = (((e_img * H + oy) * W + ox) * p.N + n) * 4;
+                    s6f32x4 t0 = keep[a][k][0] * sc + sh, t1 = keep[a][k][1] * sc + sh;
+                    if (p.egn_act) {
+#pragma unroll
+                        for (int e4 = 0; e4 < 4; ++e4) { t0[e4] = swish_e(t0[e4]); t1[e4] = swish_e(t1[e4]); }
+                    }
+                    const s6u32x4 d0 = __builtin_bit_cast(s6u32x4, t0), d1 = __builtin_bit_cast(s6u32x4, t1);
+                    __builtin_amdgcn_raw_buffer_store_b128(d0, srd_g, vo, 0, 2);
+                    __builtin_amdgcn_raw_buffer_store_b128(d1, srd_g, vo, p.N * 4, 2);
+                    asm volatile("s_nop 15\n\ts_nop 15" ::"v"(d0), "v"(d1));  // (the store-data hazard above)
+                }
         }
         // Fused GroupNorm statistics (kernels/qstats.h: one writer per entry, no atomics): wave w finished tile row w of the block = 32
         // output pixels = one "slice"; its lanes hold 2 x 2 tiles x 2 x 2 pixels x 4 channels each, the four 16-lane groups the four
@@ -434,14 +492,15 @@ __device__ __forceinline__ void s6_body(const Split6Params &p, unsigned char *sm
 #undef S6_TR
 }
 
+template <bool EGN>
 __global__ void __launch_bounds__(512) conv3x3_wino2d_split6_kernel(const Split6Params p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[S6_SMEM];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // component row parity ih = wave >> 2: waves w and w + 4 share a SIMD and take a phase in opposite order
-    if ((wave >> 2) == 0) s6_body<0>(p, smem, tid, lane, wave);
-    else s6_body<1>(p, smem, tid, lane, wave);
+    if ((wave >> 2) == 0) s6_body<0, EGN>(p, smem, tid, lane, wave);
+    else s6_body<1, EGN>(p, smem, tid, lane, wave);
 }
 
 // U = G g G^T in double, rounded once to fp32, then three round-to-nearest bf16 pieces, in the fragment order of the kernel above.
@@ -501,7 +560,9 @@ int launch_wino2d_split6_weights(const float *w, unsigned short *u, int Cout, in
 // per-image bias row, residual, output scale and fused GroupNorm statistics (one slice per 32 output pixels); no epilogue GroupNorm.
 bool conv3x3_wino2d_split6_gemm_ok(const GemmParams &g) {
     if (g.KH != 3 || g.KW != 3 || g.stride != 1 || g.pad != 1 || g.C1 != 0 || g.lda0 != g.C0 || g.ldc != g.N || g.K != 9 * g.C0) return false;
-    if (g.alpha != 1.f || g.in_act || g.b_kmajor || g.egn_out || g.gn_side_out || g.a_presplit || g.wk_partial) return false;
+    if (g.alpha != 1.f || g.in_act || g.b_kmajor || g.gn_side_out || g.a_presplit || g.wk_partial) return false;
+    // epilogue GroupNorm: whole images per tile (16 x 16) and whole groups per lane neighbourhood
+    if (g.egn_out && (g.H != 16 || g.W != 16 || (g.egn_cpg != 4 && g.egn_cpg != 8 && g.egn_cpg != 16) || !g.egn_gamma || !g.egn_beta)) return false;
     if (g.res && g.ldres != g.N) return false;
     const int HW = g.H * g.W;
     if (HW <= 0 || g.M % HW != 0 || g.OH != g.H || g.OW != g.W) return false;
@@ -516,6 +577,8 @@ int launch_conv3x3_wino2d_split6_gemm(const GemmParams &g, const unsigned short 
     Split6Params p{};
     p.x = g.a0; p.u = u; p.bias = g.bias; p.res = g.res; p.out = g.out;
     p.rowbias = g.rowbias; p.ld_rowbias = g.ld_rowbias; p.qstats = g.qstats; p.qs_slices = g.qs_slices;
+    p.egn_out = g.egn_out; p.egn_gamma = g.egn_gamma; p.egn_beta = g.egn_beta; p.egn_cpg = g.egn_cpg; p.egn_act = g.egn_act;
+    p.egn_skip_raw = g.egn_skip_raw;
     p.B = g.M / (g.H * g.W); p.H = g.H; p.W = g.W; p.C = g.C0; p.N = g.N;
     p.out_scale = g.out_scale;
     return launch_split6_params(p, s);
@@ -542,7 +605,8 @@ static int launch_split6_params(Split6Params &p, hipStream_t s) {
     const int total = p.m_tiles * p.n_tiles;
     const int cus = device_cus() / 8 * 8;
     const int grid = total < cus ? total : cus;
-    hipLaunchKernelGGL(conv3x3_wino2d_split6_kernel, dim3(grid), dim3(512), 0, s, p);
+    if (p.egn_out) hipLaunchKernelGGL(conv3x3_wino2d_split6_kernel<true>, dim3(grid), dim3(512), 0, s, p);
+    else hipLaunchKernelGGL(conv3x3_wino2d_split6_kernel<false>, dim3(grid), dim3(512), 0, s, p);
     GD_HIP(hipGetLastError());
     return 0;
 }

@@ -164,6 +164,22 @@ def conv3x3_winograd2d_split6(x, u_split, cout, bias=None, res=None, out_scale=1
     return out
 
 
+def conv3x3_winograd2d_split6_gn(x, u_split, cout, gamma, beta, groups, act=True, bias=None, res=None, out_scale=1.0, keep_raw=True):
+    """conv3x3_winograd2d_split6 followed by GroupNorm (+ swish) in the kernel's epilogue (gd_conv3x3_winograd2d_split6_gn; 16x16 images):
+    returns (raw, normalised), raw = None with keep_raw=False."""
+    import torch
+    _need_gpu(x)
+    x, gamma, beta = _f32c(x), _f32c(gamma), _f32c(beta)
+    B, H, W, Cin = x.shape
+    raw = torch.empty((B, H, W, cout), dtype=torch.float32, device=x.device) if keep_raw else None
+    gn = torch.empty((B, H, W, cout), dtype=torch.float32, device=x.device)
+    bias = _f32c(bias) if bias is not None else None
+    res = _f32c(res) if res is not None else None
+    check(_abi.lib().gd_conv3x3_winograd2d_split6_gn(_ptr(x), _ptr(u_split), _ptr(bias), _ptr(res), _ptr(raw), _ptr(gamma), _ptr(beta), _ptr(gn),
+                                                     int(groups), int(bool(act)), B, H, W, Cin, int(cout), float(out_scale), _stream(x)))
+    return raw, gn
+
+
 def conv3x3_winograd42_gn(x, w_packed, gamma, beta, groups, act=True, bias=None, res=None, out_scale=1.0, keep_raw=True):
     """conv3x3_winograd42 followed by GroupNorm (+ swish) in the kernel's epilogue (gd_conv3x3_winograd42_gn): returns (raw, normalised),
     raw = None with keep_raw=False (the engine's sole-reader case: the convolution output itself is never stored)."""

@@ -310,7 +310,13 @@ long long gd_conv3x3_winograd2d_split6_weight_bytes(int Cin, int Cout);
 int gd_conv3x3_winograd2d_split6_weights(const float *w_dev, void *u_dev, int Cin, int Cout, void *stream);
 int gd_conv3x3_winograd2d_split6(const float *x_dev, const void *u_dev, const float *bias_dev, const float *res_dev, float *out_dev, int batch,
                                  int H, int W, int Cin, int Cout, float out_scale, void *stream);
-/* ... with the GroupNorm (+ swish) that follows the convolution computed in its epilogue (the engine's Op::egn_peer path): gn_out_dev
+/* ... and with the GroupNorm (+ swish) that follows the convolution in its epilogue, as gd_conv3x3_winograd42_gn below (split6 mode's
+ * Op::egn_peer path): 16x16 images only (a workgroup tile is a whole image x 64 outputs), Cout / groups = 4, 8 or 16; out_dev null =
+ * the convolution output itself is not stored.  Replaces: nn.GroupNorm + swish after conv3x3 (cld_jax/models/layerspp.py:196-220). */
+int gd_conv3x3_winograd2d_split6_gn(const float *x_dev, const void *u_dev, const float *bias_dev, const float *res_dev, float *out_dev,
+                                    const float *gamma_dev, const float *beta_dev, float *gn_out_dev, int groups, int act, int batch, int H, int W,
+                                    int Cin, int Cout, float out_scale, void *stream);
+/* gd_conv3x3_winograd42 with the GroupNorm (+ swish) that follows the convolution computed in its epilogue (the engine's Op::egn_peer path): gn_out_dev
  * (B,H,W,Cout) = act(GroupNorm_groups(conv output)) with flax's epsilon 1e-6; out_dev receives the convolution output itself, or is
  * null when nothing else reads it.  Images of 8x8, 16x16 (one workgroup tile) and 32x32 pixels (four tiles walked by one persistent
  * workgroup, Cin >= 64).  Replaces: nn.GroupNorm + swish after conv3x3 (cld_jax/models/layerspp.py:196-220). */

@@ -74,3 +74,36 @@ def test_split6_refuses_other_shapes(native_lib):
     u = ops.conv3x3_winograd2d_split6_weights(w.cuda())
     with pytest.raises(GddimError, match="not eligible"):
         ops.conv3x3_winograd2d_split6(x.cuda(), u, 64)
+
+
+@pytest.mark.parametrize("B,C,N,groups,keep_raw", [(3, 64, 128, 32, True), (2, 128, 256, 32, True), (5, 32, 64, 4, False), (2, 256, 256, 32, False)])
+def test_split6_epilogue_groupnorm(native_lib, B, C, N, groups, keep_raw):
+    """gd_conv3x3_winograd2d_split6_gn: the GroupNorm (+ swish) that follows the convolution, in the split6 kernel's epilogue on 16x16 images
+    (split6 mode's Op::egn_peer path; 4, 8 and 16 channels per group), against float64 -- bias, residual and scale in front of it."""
+    from gddim_amd import ops
+    x, w, b, r = _case(B, 16, 16, C, N, seed=B * 100 + N + groups)
+    g = torch.Generator().manual_seed(groups)
+    gamma = 1 + 0.3 * torch.randn(N, generator=g)
+    beta = 0.3 * torch.randn(N, generator=g)
+    u = ops.conv3x3_winograd2d_split6_weights(w.cuda())
+    raw, gn = ops.conv3x3_winograd2d_split6_gn(x.cuda(), u, N, gamma.cuda(), beta.cuda(), groups, act=True, bias=b.cuda(), res=r.cuda(), out_scale=0.7,
+                                               keep_raw=keep_raw)
+    y = _conv64(x, w, b, r, 0.7)
+    yg = y.reshape(B, 256, groups, N // groups)
+    mean = yg.mean(dim=(1, 3), keepdim=True)
+    var = (yg * yg).mean(dim=(1, 3), keepdim=True) - mean * mean
+    t = ((yg - mean) * torch.rsqrt(var + 1e-6)).reshape(B, 16, 16, N) * gamma.double() + beta.double()
+    want = t * torch.sigmoid(t)
+    err = float((gn.cpu().double() - want).abs().max())
+    eraw = float((raw.cpu().double() - y).abs().max()) if keep_raw else 0.0
+    print("split6 + GroupNorm B=%d %d->%d groups %d: max|d| %.2e (raw %.2e)" % (B, C, N, groups, err, eraw))
+    assert (raw is None) == (not keep_raw)
+    assert err < 2e-5 and eraw < 2e-5
+    # no activation, no residual
+    raw2, gn2 = ops.conv3x3_winograd2d_split6_gn(x.cuda(), u, N, gamma.cuda(), beta.cuda(), groups, act=False, bias=b.cuda())
+    y2 = _conv64(x, w, b, None, 1.0)
+    yg = y2.reshape(B, 256, groups, N // groups)
+    mean = yg.mean(dim=(1, 3), keepdim=True)
+    var = (yg * yg).mean(dim=(1, 3), keepdim=True) - mean * mean
+    t2 = ((yg - mean) * torch.rsqrt(var + 1e-6)).reshape(B, 16, 16, N) * gamma.double() + beta.double()
+    assert float((gn2.cpu().double() - t2).abs().max()) < 2e-5 and float((raw2.cpu().double() - y2).abs().max()) < 2e-5

@@ -50,11 +50,13 @@ def test_split6_mode_full_architecture_forward(native_lib, B):
     scale = max(1.0, np.abs(want64).max())
     e6, e32, ef = (np.abs(a[:n] - want64).max() / scale for a in (got, got32, want32))
     print("full arch B=%d: |split6-f64| %.3e  |hip fp32-f64| %.3e  |f32 oracle-f64| %.3e; split6 launches %d, hybrid %d (fp32 mode: %d)"
-          % (B, e6, e32, ef, names.get("conv3x3_wino2d_split6_kernel", 0), sum(v for k, v in names.items() if "wino42" in k),
+          % (B, e6, e32, ef, sum(v for k, v in names.items() if "split6" in k), sum(v for k, v in names.items() if "wino42" in k),
              sum(v for k, v in names32.items() if "wino42" in k)))
     assert np.isfinite(got).all() and np.array_equal(got32, again32) and not np.array_equal(got, got32)
     assert e6 < max(4 * ef, 2e-5), (e6, ef)
-    assert names.get("conv3x3_wino2d_split6_kernel", 0) == 74 and "conv3x3_wino2d_split6_kernel" not in names32
+    assert sum(v for k, v in names.items() if "split6" in k) == 74 and not any("split6" in k for k in names32)
+    # the GroupNorm of the 16x16 level in the split6 kernel's epilogue where fp32 mode has it in the hybrid kernel's (production batch sizes)
+    assert names.get("conv3x3_wino2d_split6_kernel+gn", 0) >= 9 and names.get("gn_apply", 0) <= names32.get("gn_apply", 0) + 2, (names, names32)
     assert any("wino42" in k for k in names)  # the 8x8 level
 
 
