@@ -73,9 +73,37 @@ def issued_ratio(name):
     return 1.0
 
 
-def _cpu_worker(idx, threads, cpu_batch, cpu_nfe, image_size, barrier, out):
+def effective_cpus():
+    """CPUs this process may really use: the affinity mask and the cgroup CPU quota (v2 cpu.max, v1 cfs_quota / cfs_period) -- a box
+    can show 256 logical CPUs to os.cpu_count() and grant far fewer; filling the visible count with threads then only adds throttling."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and per > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(quota)))
+    return n
+
+
+def _cpu_worker(idx, threads, cpu_batch, cpu_nfe, image_size, budget_s, barrier, out):
     """One process of the CPU baseline: `cpu_batch` images of their own through the torch-CPU fp32 oracle on `threads` threads.  All
-    processes build the same network, warm up, meet at the barrier, then run at the same time; (start, end) on the shared clock go back."""
+    processes build the same network, warm up, meet at the barrier, then run at the same time.  BOUNDED: the first full-batch network
+    evaluation after the barrier is timed and the sampler then runs with as many evaluations as fit `budget_s` (between 2 and `cpu_nfe`),
+    so that the leg takes tens of seconds on any box.  (start, end, evaluations) on the shared clock go back."""
     os.environ["OMP_NUM_THREADS"] = str(threads)
     os.environ["MKL_NUM_THREADS"] = str(threads)
     import torch
@@ -91,33 +119,39 @@ def _cpu_worker(idx, threads, cpu_batch, cpu_nfe, image_size, barrier, out):
     H, C = cfg.data.image_size, cfg.data.num_channels
     u = np.stack([rng.standard_normal((cpu_batch, H, H, C)), rng.standard_normal((cpu_batch, H, H, C)) / 2], -1).astype(np.float32)
     eps_fn = onet.cld_eps_fn(params, cfg, dtype=torch.float32)
-    rev_ts = ocld.get_rev_ts(osde, 2, cpu_nfe - 1)
-    coef = osde.get_deis_coef(2, rev_ts)
     eps_fn(u[:1], np.full(1, 0.5, np.float32))  # warm the thread pool / allocator
     barrier.wait(timeout=900)
     t0 = time.time()
-    ocld.deis_sampler(osde, eps_fn, u, cpu_nfe, 2, ts_order=2, denoising=True, inverse_scaler=ocld.inverse_scaler_centered,
+    eps_fn(u, np.full(cpu_batch, 0.5, np.float32))  # evaluation 1: also the calibration
+    t1 = time.time() - t0
+    n = int(max(2, min(cpu_nfe, round((budget_s - t1) / max(t1, 1e-3)))))
+    rev_ts = ocld.get_rev_ts(osde, 2, n - 1)
+    coef = osde.get_deis_coef(2, rev_ts)
+    ocld.deis_sampler(osde, eps_fn, u, n, 2, ts_order=2, denoising=True, inverse_scaler=ocld.inverse_scaler_centered,
                       deis_coef=coef, rev_ts=rev_ts)
-    out.put((idx, t0, time.time()))
+    out.put((idx, t0, time.time(), n + 1))
 
 
-def cpu_baseline(cfg, nfe_full, cpu_batch, cpu_nfe, threads_per_proc=16):
+def cpu_baseline(cfg, nfe_full, cpu_batch, cpu_nfe, threads_per_proc=16, budget_s=20.0, procs=0):
     """The reference JAX-CPU path cannot run here (no jax); timed instead: the torch-CPU fp32 ORACLE (a restatement of the same
-    algorithm, kind='port') on a bounded sample, on the WHOLE box: images are independent, so P processes x T threads each take
-    `cpu_batch` images of their own (torch's CPU convolutions collapse when one 256-thread pool is thrown at a batch-16 problem --
-    measured 658 s for this sample in round 1 -- which is why the box is filled with processes, not with one pool).  Wall time =
-    last end - first start after a common barrier."""
+    algorithm, kind='port') on a BOUNDED sample, on the cores the box really grants (effective_cpus: affinity and cgroup quota --
+    the GPU boxes show 256 logical CPUs; filling those with 16 x 16 threads took 414-520 s for this sample in round 6 where ONE
+    16-thread process takes 14 s): images are independent, so P processes x T threads each take `cpu_batch` images of their own
+    (torch's CPU convolutions collapse when one large pool is thrown at a batch-16 problem, which is why the cores are filled with
+    processes, not with one pool).  Every process sizes its own sample to `budget_s` seconds from its first timed evaluation.
+    Wall time = last end - first start after a common barrier; value = (images x evaluations done / NFE) / wall."""
     import multiprocessing as mp
     total = os.cpu_count() or 1
-    T = max(1, min(threads_per_proc, total))
-    P = max(1, total // T)
+    usable = effective_cpus()
+    T = max(1, min(threads_per_proc, usable))
+    P = max(1, usable // T) if procs <= 0 else procs
     ctx = mp.get_context("spawn")
     barrier, out = ctx.Barrier(P), ctx.Queue()
-    procs = [ctx.Process(target=_cpu_worker, args=(i, T, cpu_batch, cpu_nfe, cfg.data.image_size, barrier, out), daemon=True) for i in range(P)]
+    procs = [ctx.Process(target=_cpu_worker, args=(i, T, cpu_batch, cpu_nfe, cfg.data.image_size, budget_s, barrier, out), daemon=True) for i in range(P)]
     for p_ in procs:
         p_.start()
     import queue
-    marks, deadline, why = [], time.time() + 1500, None
+    marks, deadline, why = [], time.time() + 300, None
     while len(marks) < P and why is None:
         try:
             marks.append(out.get(timeout=2))
@@ -137,13 +171,16 @@ def cpu_baseline(cfg, nfe_full, cpu_batch, cpu_nfe, threads_per_proc=16):
         p_.join(timeout=60)
     dt = max(m[2] for m in marks) - min(m[1] for m in marks)
     per_proc = sorted(m[2] - m[1] for m in marks)
-    images, evals = P * cpu_batch, P * cpu_batch * cpu_nfe
-    return {"value": images / (dt * nfe_full / cpu_nfe), "unit": "images/s", "cores": P * T, "cores_used": P * T, "cores_total": total,
+    evals_pp = sorted(m[3] for m in marks)
+    images, evals = P * cpu_batch, cpu_batch * sum(evals_pp)
+    return {"value": evals / nfe_full / dt, "unit": "images/s", "cores": P * T, "cores_used": P * T, "cores_total": total, "cores_granted": usable,
             "processes": P, "threads_per_process": T, "kind": "port", "seconds": dt,
             "per_process_seconds": {"min": per_proc[0], "median": per_proc[len(per_proc) // 2], "max": per_proc[-1]},
-            "sample": "torch-CPU fp32 oracle, %d processes x %d threads, each batch=%d x NFE=%d network evaluations of the same "
-                      "architecture (%d images, %d evaluations) in %.1f s wall, scaled linearly to NFE=%d"
-                      % (P, T, cpu_batch, cpu_nfe, images, evals, dt, nfe_full)}
+            "evaluations_per_process": {"min": evals_pp[0], "max": evals_pp[-1]},
+            "sample": "torch-CPU fp32 oracle, %d processes x %d threads (%d of the %d logical CPUs are granted to this process), each batch=%d "
+                      "through %d..%d network evaluations of the same architecture sized to a %.0f s budget (%d images, %d image-evaluations) "
+                      "in %.1f s wall, scaled linearly to NFE=%d"
+                      % (P, T, usable, total, cpu_batch, evals_pp[0], evals_pp[-1], budget_s, images, evals, dt, nfe_full)}
 
 
 def self_launch(n, argv):
@@ -231,6 +268,8 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=16)
     ap.add_argument("--cpu-nfe", type=int, default=20, help="network evaluations per image of the CPU sample (batch 16 x 20 evaluations: 10-15 s on 16 threads)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="threads per process of the CPU baseline; the box is filled with cpu_count // threads processes")
+    ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds each CPU-baseline process sizes its sample to")
+    ap.add_argument("--cpu-procs", type=int, default=0, help="processes of the CPU baseline (0: granted CPUs // threads)")
     ap.add_argument("--dry-run", action="store_true", help="CPU / gloo plumbing check of the N-rank harness (no sampler, no GPU)")
     args = ap.parse_args()
 
@@ -484,7 +523,7 @@ def main():
         result["split6"] = alt6
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "cld":
-        result["cpu_baseline"] = cpu_baseline(cfg, args.nfe, args.cpu_batch, args.cpu_nfe, args.cpu_threads)
+        result["cpu_baseline"] = cpu_baseline(cfg, args.nfe, args.cpu_batch, args.cpu_nfe, args.cpu_threads, args.cpu_budget, args.cpu_procs)
     if rank == 0:
         print(json.dumps(result))
     if grouped:
