@@ -73,7 +73,7 @@ def issued_ratio(name):
     return 1.0
 
 
-def effective_cpus():
+def effective_cpus(cgroup_root="/sys/fs/cgroup"):
     """CPUs this process may really use: the affinity mask and the cgroup CPU quota (v2 cpu.max, v1 cfs_quota / cfs_period) -- a box
     can show 256 logical CPUs to os.cpu_count() and grant far fewer; filling the visible count with threads then only adds throttling."""
     n = os.cpu_count() or 1
@@ -83,13 +83,13 @@ def effective_cpus():
         pass
     quota = None
     try:
-        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        q, per = open(os.path.join(cgroup_root, "cpu.max")).read().split()[:2]
         if q != "max":
             quota = float(q) / float(per)
     except (OSError, ValueError):
         try:
-            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
-            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            q = float(open(os.path.join(cgroup_root, "cpu", "cpu.cfs_quota_us")).read())
+            per = float(open(os.path.join(cgroup_root, "cpu", "cpu.cfs_period_us")).read())
             if q > 0 and per > 0:
                 quota = q / per
         except (OSError, ValueError):

@@ -143,9 +143,9 @@ int gd_engine_weight_bytes(gd_engine *e, long long out4[4]);
  *   2  "split6" (round 6): mode 0 with the 3x3 stride-1 convolutions of the levels whose images are multiples of 16 x 16 pixels through
  *      the two-dimensional Winograd transform F(2x2,3x3) whose component GEMMs run in the EXACT three-piece bf16 split (six bf16 MFMAs per
  *      fp32 product, every dropped term <= 2^-24 of the product, fp32 accumulation): rms error 0.33 of mode 0's hybrid Winograd kernel
- *      against float64, 1.18-1.23x its speed on the benchmarked layers (profiles/r06_notes.md).  Bias, per-image bias row, residual,
- *      scale and the fused GroupNorm statistics in its epilogue; the GroupNorm that mode 0 fuses into the producer's epilogue on 16x16
- *      images runs as its own pass.
+ *      against float64; per launch 1.08-1.23x its speed stand-alone, end to end the speed of mode 0 (the mode runs the socket at its
+ *      power cap at a lower shader clock: profiles/r06_notes.md).  Bias, per-image bias row, residual, scale, the fused GroupNorm
+ *      statistics and -- on 16x16 images -- the GroupNorm (+ swish) itself in its epilogue.
  * Also selectable with GDDIM_PRECISION=bf16x3 / split6 at engine creation.  The reference has one arithmetic only (XLA fp32);
  * this switch has no counterpart there. */
 int gd_engine_set_precision(gd_engine *e, int mode);
@@ -300,7 +300,7 @@ int gd_conv3x3_winograd42(const float *x_dev, const float *w_dev, float *u_scrat
 int gd_conv3x3_winograd42_weights(const float *w_dev, float *u_dev, int Cin, int Cout, void *stream);
 int gd_conv3x3_winograd42_pretransformed(const float *x_dev, const float *u_dev, const float *bias_dev, const float *res_dev, float *out_dev,
                                          int batch, int H, int W, int Cin, int Cout, float alpha, float out_scale, void *stream);
-/* PROTOTYPE (round 6; not planned into the engine): the same convolution -- nn.Conv(features, (3, 3), padding 1),
+/* The operator behind precision mode 2 (round 6): the same convolution -- nn.Conv(features, (3, 3), padding 1),
  * cld_jax/models/layers.py:95-107 -- through F(2x2,3x3) with every component GEMM in the exact three-piece bf16 split on
  * v_mfma_f32_32x32x16_bf16 (six products per fp32 product, fp32 accumulation; kernels/conv3x3_wino2d_split6.hip).
  *   gd_conv3x3_winograd2d_split6_weights: w_dev [Cout][9 Cin] (gd_conv2d's packing) -> u_dev, ..._weight_bytes(Cin, Cout) bytes of

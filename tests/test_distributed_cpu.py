@@ -216,3 +216,25 @@ def test_round_writer_error_reaches_the_caller(tmp_path, monkeypatch):
     with pytest.raises(OSError, match="disk full"):
         run_lib.sample_data(cfg, "unused", str(tmp_path / "e"), state=State(params_ema={}))
     assert not os.path.exists(os.path.join(str(tmp_path / "e"), "samples_1.npz"))
+
+
+def test_bench_cpu_baseline_counts_the_granted_cpus(tmp_path):
+    """bench.effective_cpus: the CPU baseline fills the CPUs the box GRANTS, not the ones it shows (round 6: the GPU boxes show 256 logical
+    CPUs under a cgroup quota of 16; 16 x 16 threads took 414-520 s for a 14 s sample) -- cgroup v2 `cpu.max`, v1 quota / period, no quota."""
+    sys.path.insert(0, ROOT)
+    import bench
+    n = os.cpu_count()
+    v2 = tmp_path / "v2"
+    v2.mkdir()
+    (v2 / "cpu.max").write_text("300000 100000\n")
+    assert bench.effective_cpus(str(v2)) == min(3, n)
+    (v2 / "cpu.max").write_text("max 100000\n")
+    assert bench.effective_cpus(str(v2)) == min(n, len(os.sched_getaffinity(0)))
+    v1 = tmp_path / "v1"
+    (v1 / "cpu").mkdir(parents=True)
+    (v1 / "cpu" / "cpu.cfs_quota_us").write_text("250000\n")
+    (v1 / "cpu" / "cpu.cfs_period_us").write_text("100000\n")
+    assert bench.effective_cpus(str(v1)) == min(2, n)
+    (v1 / "cpu" / "cpu.cfs_quota_us").write_text("-1\n")
+    assert bench.effective_cpus(str(v1)) == min(n, len(os.sched_getaffinity(0)))
+    assert 1 <= bench.effective_cpus(str(tmp_path / "absent")) <= n
