@@ -1,3 +1,4 @@
+"""The persistent short-K implicit-GEMM kernel alone on the 1x1 / NIN shapes of the U-Net at B = 256 (bias, with / without residual), same box: profiles/r04_notes.md."""
 import os, sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
 import torch

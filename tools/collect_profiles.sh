@@ -52,6 +52,10 @@ done
 # ---- the driver's own flags, and the split6 prototype against the hybrid kernel: hipEvent times, then rocprofv3's per-kernel averages
 $PY --steps 20 --warmup 5 > $OUT/bench_line_driver_flags.json 2>/dev/null
 python $REPO/tools/bench_split6.py 20 2>/dev/null | tail -1 > $OUT/split6_bench.json
+python $REPO/tools/bench_split6.py 100 2>/dev/null | tail -1 > $OUT/split6_bench_100_launches.json
+python $REPO/tools/bench_split6.py 20 res 2>/dev/null | tail -1 > $OUT/split6_bench_residual.json
+(cd $REPO && python tools/split6_layers.py 2>/dev/null | grep -v amdgpu.ids > $OUT/split6_layers.log)
+(cd $REPO && bash tools/power_modes.sh $OUT/power > /dev/null 2>&1; cp $OUT/power/power_modes.json $OUT/power_modes.json)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_split6 -o s6 -- python $REPO/tools/bench_split6.py 20 > $OUT/trace_split6.log 2>&1
 find $OUT/trace_split6 -name "*kernel_stats.csv" -exec cp {} $OUT/split6_kernel_stats.csv \;
 rm -rf $OUT/trace_split6

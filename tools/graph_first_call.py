@@ -1,3 +1,4 @@
+"""First-call cost of the sampler's launch forms at one batch size (eager / per-step hipGraph / one graph per call): capture time and graph memory; profiles/r05_notes.md."""
 import os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
 import torch

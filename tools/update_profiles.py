@@ -16,7 +16,7 @@ if tag != "r01":
     import glob
     for f in sorted(glob.glob(os.path.join(SRC, "*"))):
         base = os.path.basename(f)
-        if os.path.isfile(f) and (base.endswith(".json") or base.endswith(".csv") or base in ("parity_abs_tests.log",)) and os.path.getsize(f) > 0:
+        if os.path.isfile(f) and (base.endswith(".json") or base.endswith(".csv") or base in ("parity_abs_tests.log", "split6_layers.log")) and os.path.getsize(f) > 0:
             shutil.copy(f, os.path.join(DST, "%s_%s" % (tag, base)))
     os.replace(os.path.join(DST, "%s_pmc_FETCH_SIZE_summary.json" % tag), os.path.join(DST, "%s_pmc_fetch_summary.json" % tag))
     os.replace(os.path.join(DST, "%s_pmc_WRITE_SIZE_summary.json" % tag), os.path.join(DST, "%s_pmc_write_summary.json" % tag))

@@ -1,3 +1,4 @@
+"""What the residual read costs the hybrid Winograd kernel: the production launches with and without a residual tensor, same box; profiles/r05_notes.md."""
 import os, sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
 import torch
