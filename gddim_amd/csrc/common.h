@@ -221,7 +221,7 @@ int launch_cld_pre(const float *u8, float *xin, const float *tf, const int *step
 // dn: 20 floats F, GG, RinvT, X (mixed score, flags & 1), POST (final frame change, flags & 2)
 int launch_cld_finish(const float *u8, const float *eps, const float *dn, float dt, int denoise, int inverse_scale,
                       float *x_out, float *v_out, long long pixels, int C, int flags, hipStream_t s);
-// F(2x2,3x3) with the component GEMMs in the exact three-piece bf16 split (kernels/conv3x3_wino2d_split6.hip; prototype, stand-alone operator)
+// F(2x2,3x3) with the component GEMMs in the exact three-piece bf16 split (kernels/conv3x3_wino2d_split6.hip; precision mode 2 and the stand-alone operator)
 bool conv3x3_wino2d_split6_shape_ok(int batch, int H, int W, int Cin, int Cout);
 long long conv3x3_wino2d_split6_weight_bytes(int Cin, int Cout);
 int launch_wino2d_split6_weights(const float *w, unsigned short *u, int Cout, int Cin, hipStream_t s);

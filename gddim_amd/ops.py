@@ -150,7 +150,7 @@ def conv3x3_winograd2d_split6_weights(w_packed):
 
 
 def conv3x3_winograd2d_split6(x, u_split, cout, bias=None, res=None, out_scale=1.0):
-    """3x3 / stride 1 / pad 1 NHWC conv through F(2x2,3x3) in the exact three-piece bf16 split on the bf16 matrix core (prototype operator:
+    """3x3 / stride 1 / pad 1 NHWC conv through F(2x2,3x3) in the exact three-piece bf16 split on the bf16 matrix core (the operator of precision mode 2:
     gd_conv3x3_winograd2d_split6); u_split from conv3x3_winograd2d_split6_weights."""
     import torch
     _need_gpu(x)

@@ -296,7 +296,7 @@ int gd_conv3x3_winograd42(const float *x_dev, const float *w_dev, float *u_scrat
                           const float *res_dev, float *out_dev, int batch, int H, int W, int Cin, int Cout, float alpha,
                           float out_scale, void *stream);
 /* gd_conv3x3_winograd42 in two steps, as the engine runs it: the Winograd-domain weight copy once (u_dev: the scratch size of
- * gd_conv3x3_winograd42), then the convolution alone (what tools/bench_split6.py times against the prototype below). */
+ * gd_conv3x3_winograd42), then the convolution alone (what tools/bench_split6.py times against the split6 operator below). */
 int gd_conv3x3_winograd42_weights(const float *w_dev, float *u_dev, int Cin, int Cout, void *stream);
 int gd_conv3x3_winograd42_pretransformed(const float *x_dev, const float *u_dev, const float *bias_dev, const float *res_dev, float *out_dev,
                                          int batch, int H, int W, int Cin, int Cout, float alpha, float out_scale, void *stream);

@@ -1,4 +1,4 @@
-"""gd_conv3x3_winograd2d_split6 (prototype): F(2x2,3x3) with the component GEMMs in the exact three-piece bf16 split on
+"""gd_conv3x3_winograd2d_split6 (the operator of precision mode 2): F(2x2,3x3) with the component GEMMs in the exact three-piece bf16 split on
 the bf16 matrix core, every output against a float64 convolution, next to the production fp32 kernels on the same inputs."""
 import numpy as np
 import pytest

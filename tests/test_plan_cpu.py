@@ -311,3 +311,24 @@ def test_engines_keep_the_option_table_they_were_created_under(native_lib, gd_en
     assert any(l.endswith(".q_proj") for l in la) and not any(l.endswith(".q_proj") for l in lb)
     for e in (a, b, c):
         e.close()
+
+
+def test_precision_modes_are_selectable_without_a_gpu(native_lib, gd_env):
+    """The three arithmetics of the engine (0 fp32, 1 bf16x3, 2 split6: round 6) by name, by number and through GDDIM_PRECISION at engine
+    creation; an unknown mode is an error with a message, not a silent fp32."""
+    from gddim_amd._abi import GddimError
+    from gddim_amd.engine import Engine
+    cfg = tiny_config("cld", nf=16, num_res_blocks=1, image_size=16, ch_mult=(1, 2), attn=(8,))
+    for name in ("fp32", "bf16x3", "split6"):
+        gd_env(GDDIM_PRECISION=name)
+        e = Engine(cfg, 6, max_batch=1, plan_only=True)
+        assert e.plan()["options"]["GDDIM_PRECISION"] == name
+        for mode in ("fp32", "bf16x3", "split6", 0, 1, 2):
+            e.set_precision(mode)
+        with pytest.raises(KeyError):
+            e.set_precision("fp16")
+        with pytest.raises(GddimError, match="unknown precision mode"):
+            from gddim_amd._abi import check
+            check(e._lib.gd_engine_set_precision(e._h, 3))
+        e.close()
+    gd_env(GDDIM_PRECISION=None)

@@ -21,7 +21,7 @@ done
 for p in "${pids[@]}"; do wait "$p" || exit 1; done
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC -fsanitize=address,undefined -shared-libsan -o "$B/libgddim_amd_asan.so" \
    "$B"/asan/{engine,plan,options,host_math}.o \
-   "$B"/kernels_{igemm,igemm_bf16x3,conv3x3_halo_bf16x3,conv3x3_wino2d_f32,conv3x3_wino42_f32,attn_fused_f32,norm_act,update}.hip.o || exit 1
+   "$B"/kernels_{igemm,igemm_bf16x3,conv3x3_halo_bf16x3,conv3x3_wino2d_f32,conv3x3_wino42_f32,conv3x3_wino2d_split6,attn_fused_f32,norm_act,update}.hip.o || exit 1
 {
   echo "# $(date -u +%FT%TZ)  host ASan + UBSan build of gddim_amd (engine.cpp plan.cpp options.cpp host_math.cpp), runtime $RT"
   echo "# GDDIM_LIB=$B/libgddim_amd_asan.so LD_PRELOAD=<asan rt> pytest tests/test_abi_cpu.py tests/test_plan_cpu.py tests/test_oracle_cld.py tests/test_golden.py tests/test_checkpoints_cpu.py"
