@@ -80,16 +80,18 @@ def test_split6_mode_cld_nfe50_b256_absolute_parity(native_lib, gd_env):
     model.close()
 
 
-def test_split6_mode_64x64_nfe10_absolute_parity(native_lib, gd_env):
-    """BASELINE config 5's shape (64x64x3; B = 32, NFE = 10) in split6 mode: the 64x64 level is tiled by 16 blocks per image."""
+@pytest.mark.parametrize("B", [32, 512])
+def test_split6_mode_64x64_nfe10_absolute_parity(native_lib, gd_env, B):
+    """BASELINE config 5 (64x64x3, NFE = 10) in split6 mode, at B = 32 and at its full size B = 512 (the 256-channel tensors of the 64x64
+    level are 2 GiB there: the engine runs those launches over image sub-ranges): the 64x64 level is tiled by 16 blocks per image."""
     from gddim_amd.configs import cld_accr_dcifar10
     gd_env(GDDIM_PRECISION="split6")
-    B, distinct, n_ref, nfe = 32, 2, 1, 10
+    distinct, n_ref, nfe = 2, 1, 10
     cfg, osde, eps64, lin64, ud, run, model = T._cld_case(native_lib, cld_accr_dcifar10, 64, B, distinct, nfe, 0.3, seed=2)
-    xd, vd, n, runs = T._chained_runs("split6 CLD 64x64 NFE=10 B=32", run, B, distinct, n_ref, seed=2)
+    xd, vd, n, runs = T._chained_runs("split6 CLD 64x64 NFE=10 B=%d" % B, run, B, distinct, n_ref, seed=2)
     wx, wv, lx = T._oracle(osde, eps64, lin64, ud[:n_ref], nfe)
-    ex, ev, moved = T._report("split6 mode, CLD 64x64 NFE=10 B=32", xd[:n_ref], vd[:n_ref], wx, wv, lx)
-    names = T._profile_names(model, 6, 32)
+    ex, ev, moved = T._report("split6 mode, CLD 64x64 NFE=10 B=%d" % B, xd[:n_ref], vd[:n_ref], wx, wv, lx)
+    names = T._profile_names(model, 6, B)
     assert any("conv3x3_wino2d_split6_kernel" in k for k in names), names
     assert n == nfe and moved > 20 * T.ABS_TOL
     assert ex <= T.ABS_TOL and ev <= T.ABS_TOL * max(1.0, float(np.abs(wv).max()))
