@@ -41,7 +41,7 @@
 // Where it stands (MI355X, B = 256; tools/bench_split6.py, tools/split6_layers.py, tools/power_modes.sh, profiles/r06_notes.md): rms error
 // 0.33 of the production hybrid fp32 kernel's; stand-alone 1.16-1.23x (16x16, 256 -> 256) and 1.09-1.18x (32x32, 128 -> 128) its speed over
 // 20-launch bursts, 1.12x / 1.08x sustained; planned in as precision mode 2 (GDDIM_PRECISION=split6).  End to end the mode is a wash
-// (136.5-139.7 images/s against 137.6-141.1 in fp32 mode): the modes that keep the bf16 matrix core busy run at a 12-14 % lower shader clock.
+// (136.5-140.6 images/s against 137.6-141.1 in fp32 mode, 0.98-1.01 box by box): the modes that keep the bf16 matrix core busy run at a 12-14 % lower shader clock.
 #include <cstdio>
 #include <cstdlib>
 

@@ -143,7 +143,7 @@ int gd_engine_weight_bytes(gd_engine *e, long long out4[4]);
  *   2  "split6" (round 6): mode 0 with the 3x3 stride-1 convolutions of the levels whose images are multiples of 16 x 16 pixels through
  *      the two-dimensional Winograd transform F(2x2,3x3) whose component GEMMs run in the EXACT three-piece bf16 split (six bf16 MFMAs per
  *      fp32 product, every dropped term <= 2^-24 of the product, fp32 accumulation): rms error 0.33 of mode 0's hybrid Winograd kernel
- *      against float64; per launch 1.07-1.23x its speed stand-alone, end to end 0.98-1.00 of mode 0's (the modes that keep the bf16
+ *      against float64; per launch 1.07-1.23x its speed stand-alone, end to end 0.98-1.01 of mode 0's (the modes that keep the bf16
  *      matrix core busy run at a 12-14 % lower shader clock: profiles/r06_notes.md).  Bias, per-image bias row, residual, scale, the fused GroupNorm
  *      statistics and -- on 16x16 images -- the GroupNorm (+ swish) itself in its epilogue.
  * Also selectable with GDDIM_PRECISION=bf16x3 / split6 at engine creation.  The reference has one arithmetic only (XLA fp32);
