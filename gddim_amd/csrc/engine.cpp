@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -19,6 +20,14 @@
 namespace gd {
 
 static thread_local std::string g_err;
+// Everything that is not pure queueing -- engine creation and destruction, parameter upload, weight transforms, schedules, precision
+// switches (hipMalloc / synchronous copies / hipDeviceSynchronize) and every stream capture -- runs under ONE process-wide lock: with
+// one issuing thread per device (gddim_amd/devices.py) a capture on one thread was invalidated by such a call on another ("operation
+// failed due to a previous error during capture": tests/test_gpu_devices.py, round 6).  A sampler call takes the lock on entry and
+// gives it back before it replays its graphs (hipGraphLaunch of a 21 350-node graph is 185 ms of host time: the part that must overlap
+// across devices); a warm call holds it for microseconds.
+static std::recursive_mutex g_cold;
+#define GD_COLD std::lock_guard<std::recursive_mutex> gd_cold_guard(g_cold)
 
 void set_error(const char *fmt, ...) {
     char buf[2048];
@@ -681,6 +690,7 @@ int gd_device_count(void) {
 
 // ---- engine ----
 int gd_engine_create(const gd_model_desc *desc, int device, gd_engine **out) {
+    GD_COLD;
     GD_CHECK(desc && out, "null argument");
     gd_engine *e = new gd_engine();
     e->opts = options_reload();  // an engine is built under the environment of its creation and keeps THAT table for life (options.h)
@@ -743,6 +753,7 @@ int gd_engine_create(const gd_model_desc *desc, int device, gd_engine **out) {
 }
 
 int gd_engine_destroy(gd_engine *e) {
+    GD_COLD;
     OptScope scope(e ? e->opts : nullptr);
     if (!e) return 0;
     if (!e->plan_only) {
@@ -947,6 +958,7 @@ static int build_split6_weights(gd_engine *e) {
 }
 
 int gd_engine_set_precision(gd_engine *e, int mode) {
+    GD_COLD;
     OptScope scope(e ? e->opts : nullptr);
     GD_CHECK(e, "null engine");
     GD_CHECK(mode == 0 || mode == 1 || mode == 2, "unknown precision mode %d (0 = fp32, 1 = bf16x3, 2 = split6)", mode);
@@ -966,6 +978,7 @@ int gd_engine_set_precision(gd_engine *e, int mode) {
 }
 
 int gd_engine_params_ready(gd_engine *e) {
+    GD_COLD;
     OptScope scope(e ? e->opts : nullptr);
     GD_CHECK(e, "null engine");
     std::string missing;
@@ -1062,6 +1075,7 @@ static int upload(float **dst, const float *src, size_t n) {
 
 int gd_engine_set_schedule_cld(gd_engine *e, int num_step, int n_slots, const float *ts_host, const float *coef_host,
                                int denoise, float t_denoise, const float *dn_F, const float *dn_GG, const float *dn_RinvT) {
+    GD_COLD;
     OptScope scope(e ? e->opts : nullptr);
     GD_CHECK(e && !e->plan_only, "engine has no GPU");
     GD_CHECK(num_step >= 0 && n_slots >= 2 && ts_host && coef_host, "bad schedule");
@@ -1103,6 +1117,7 @@ int gd_engine_set_schedule_cld(gd_engine *e, int num_step, int n_slots, const fl
 }
 
 int gd_engine_set_noise_cld(gd_engine *e, const float *pre_lin, const float *pre_noise, const float *post_noise) {
+    GD_COLD;
     OptScope scope(e ? e->opts : nullptr);
     GD_CHECK(e && !e->plan_only, "engine has no GPU");
     GD_CHECK(e->sched_kind == 1, "install the CLD schedule first (gd_engine_set_schedule_cld)");
@@ -1151,6 +1166,7 @@ int gd_randn_pairs(float *out_dev, long long n_pairs, unsigned long long seed, u
 
 int gd_engine_set_transforms_cld(gd_engine *e, const float *pre, const float *eps_lin, const float *u_lin, const float *dn_u_lin,
                                  const float *post) {
+    GD_COLD;
     OptScope scope(e ? e->opts : nullptr);
     GD_CHECK(e && !e->plan_only, "engine has no GPU");
     GD_CHECK(e->sched_kind == 1, "install the CLD schedule first (gd_engine_set_schedule_cld)");
@@ -1232,6 +1248,7 @@ int gd_sample_cld(gd_engine *e, int batch, const float *u_in_dev, float *x_out_d
                   int use_graph, void *stream) {
     OptScope scope(e ? e->opts : nullptr);
     DeviceScope dscope(e);
+    std::unique_lock<std::recursive_mutex> cold(g_cold);  // table rebuilds and captures under the lock; released before the replay
     GD_TRY(check_compute(e, batch));
     GD_CHECK(e->sched_kind == 1, "no CLD schedule installed (gd_engine_set_schedule_cld)");
     GD_CHECK(u_in_dev && x_out_dev && v_out_dev, "null device pointer");
@@ -1312,6 +1329,7 @@ int gd_sample_cld(gd_engine *e, int batch, const float *u_in_dev, float *x_out_d
             int r2 = capture_end(l.s, &l.g->loop);
             if (r || r2) return 1;
         }
+        cold.unlock();
         GD_HIP(hipGraphLaunch(l.g->loop, l.s));
         GD_TRY(launch_copy_floats(e->xout_stage, x_out_dev, (long long)n_out, l.s));
         GD_TRY(launch_copy_floats(e->vout_stage, v_out_dev, (long long)n_out, l.s));
@@ -1335,11 +1353,13 @@ int gd_sample_cld(gd_engine *e, int batch, const float *u_in_dev, float *x_out_d
                 if (r || r2) return 1;
             }
         }
+        cold.unlock();
         for (int k = 0; k < e->num_step; ++k)
             for (int i = 0; i < nl; ++i) GD_HIP(hipGraphLaunch(L[i].g->step, L[i].s));
         if (e->denoise)
             for (int i = 0; i < nl; ++i) GD_HIP(hipGraphLaunch(L[i].g->fin, L[i].s));
     } else {
+        cold.unlock();
         for (int k = 0; k < e->num_step; ++k)
             for (int i = 0; i < nl; ++i) GD_TRY(step_body(L[i]));
         if (e->denoise)
@@ -1358,6 +1378,7 @@ int gd_sample_cld(gd_engine *e, int batch, const float *u_in_dev, float *x_out_d
 
 int gd_engine_set_schedule_blur(gd_engine *e, int nfe, const float *ts_host, const float *mean_coef_host,
                                 const float *std_coef_host) {
+    GD_COLD;
     OptScope scope(e ? e->opts : nullptr);
     GD_CHECK(e && !e->plan_only, "engine has no GPU");
     GD_CHECK(nfe >= 1 && ts_host && mean_coef_host && std_coef_host, "bad schedule");
@@ -1376,6 +1397,7 @@ int gd_engine_set_schedule_blur(gd_engine *e, int nfe, const float *ts_host, con
 }
 
 int gd_engine_set_schedule_blur_deis(gd_engine *e, int nfe, int n_slots, const float *ts_host, const float *coef_host) {
+    GD_COLD;
     OptScope scope(e ? e->opts : nullptr);
     GD_CHECK(e && !e->plan_only, "engine has no GPU");
     GD_CHECK(nfe >= 1 && n_slots >= 2 && ts_host && coef_host, "bad schedule");
@@ -1402,6 +1424,7 @@ int gd_engine_set_schedule_blur_deis(gd_engine *e, int nfe, int n_slots, const f
 }
 
 int gd_engine_set_model2eps_blur(gd_engine *e, const float *rows_host) {
+    GD_COLD;
     OptScope scope(e ? e->opts : nullptr);
     GD_CHECK(e && !e->plan_only, "engine has no GPU");
     GD_CHECK(e->sched_kind == 2 || e->sched_kind == 3, "install a blur schedule first (gd_engine_set_schedule_blur[_deis])");
@@ -1418,6 +1441,7 @@ int gd_sample_blur(gd_engine *e, int batch, const float *y_in_dev, float *x_out_
                    void *stream) {
     OptScope scope(e ? e->opts : nullptr);
     DeviceScope dscope(e);
+    std::unique_lock<std::recursive_mutex> cold(g_cold);  // (as in gd_sample_cld)
     GD_TRY(check_compute(e, batch));
     GD_CHECK(e->sched_kind == 2 || e->sched_kind == 3, "no blur schedule installed (gd_engine_set_schedule_blur[_deis])");
     GD_TRY(ensure_temb_table(e));
@@ -1493,6 +1517,7 @@ int gd_sample_blur(gd_engine *e, int batch, const float *y_in_dev, float *x_out_
             int r2 = capture_end(l.s, &l.g->loop);
             if (r || r2) return 1;
         }
+        cold.unlock();
         GD_HIP(hipGraphLaunch(l.g->loop, l.s));
         GD_TRY(launch_copy_floats(e->xout_stage, x_out_dev, (long long)n, l.s));
         GD_HIP(hipEventRecord(e->ev_out[0], l.s));
@@ -1509,9 +1534,11 @@ int gd_sample_blur(gd_engine *e, int batch, const float *y_in_dev, float *x_out_
                 if (r || r2) return 1;
             }
         }
+        cold.unlock();
         for (int k = 0; k < e->num_step; ++k)
             for (int i = 0; i < nl; ++i) GD_HIP(hipGraphLaunch(L[i].g->step, L[i].s));
     } else {
+        cold.unlock();
         for (int k = 0; k < e->num_step; ++k)
             for (int i = 0; i < nl; ++i) GD_TRY(step_body(L[i]));
     }

@@ -244,6 +244,48 @@ def pmap_sampler(sampler, prng, pstate, batch_size, u, sde, data_shape, n_out, *
                  for d in range(n_dev)]
     else:
         parts = shard_input(u, devices)
-    outs = [sampler(seeds[d], pstate, batch_size, parts[d], slot=d, **kw) for d in range(n_dev)]
+    if n_dev > 1 and os.environ.get("GDDIM_DEVICE_THREADS", "1").strip() not in ("0", "off", "no", "false"):
+        outs = _issue_threaded(sampler, seeds, pstate, batch_size, parts, devices, kw)
+    else:
+        outs = [sampler(seeds[d], pstate, batch_size, parts[d], slot=d, **kw) for d in range(n_dev)]
     sharded = tuple(ShardedDeviceArray([o[i] for o in outs]) for i in range(n_out))
     return sharded + tuple(outs[0][n_out:])
+
+
+_ISSUE_POOLS = {}
+
+
+def _issue_threaded(sampler, seeds, pstate, batch_size, parts, devices, kw):
+    """One issuing thread per device.  A sampler call is queued work only, but queueing is not free: hipGraphLaunch of the whole-call
+    graph (21 350 kernel nodes at NFE 50) takes 185 ms of host time at B = 256 (358 ms at B = 512; tools/devices_overhead.py), and a
+    second launch from the SAME thread waited for the first graph on the one-GPU box -- issued back to back from one thread, device d
+    would start d x 185 ms late at best.  The native calls release the GIL (ctypes), every C entry point sets its thread's HIP device
+    (DeviceScope), captures are thread-local (hipStreamCaptureModeThreadLocal), engines share nothing.  Each thread works on the stream
+    the CALLER had current on its device, so ordering against the caller's earlier and later work is what the serial form gives.
+    GDDIM_DEVICE_THREADS=0: the serial form (bit-identical results: tests/test_gpu_devices.py)."""
+    import concurrent.futures
+    import torch
+    n_dev = len(devices)
+    pool = _ISSUE_POOLS.get(n_dev)
+    if pool is None:
+        pool = _ISSUE_POOLS[n_dev] = concurrent.futures.ThreadPoolExecutor(max_workers=n_dev, thread_name_prefix="gddim-dev")
+    on_gpu = torch.cuda.is_available()
+    streams = [torch.cuda.current_stream(devices[d]) if on_gpu else None for d in range(n_dev)]
+
+    def one(d):
+        if not on_gpu:
+            return sampler(seeds[d], pstate, batch_size, parts[d], slot=d, **kw)
+        with torch.cuda.device(devices[d]), torch.cuda.stream(streams[d]):
+            return sampler(seeds[d], pstate, batch_size, parts[d], slot=d, **kw)
+
+    futs = [pool.submit(one, d) for d in range(n_dev)]
+    outs, first_error = [], None
+    for f in futs:  # wait for every device before raising: no thread keeps issuing into a call that already failed
+        try:
+            outs.append(f.result())
+        except BaseException as exc:  # noqa: BLE001 -- re-raised below
+            outs.append(None)
+            first_error = first_error or exc
+    if first_error is not None:
+        raise first_error
+    return outs

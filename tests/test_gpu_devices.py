@@ -221,3 +221,53 @@ def test_time_embedding_table_follows_schedule_and_weights(native_lib):
     assert torch.equal(e1, e2)
     model.close()
     fresh.close()
+
+
+def test_psampler_threaded_issue_equals_serial_issue(native_lib, monkeypatch):
+    """One issuing thread per device (the default for n_dev > 1: hipGraphLaunch of the whole-call graph costs the host 185 ms at B = 256,
+    and issued from one thread device d would start d launches late) against the calls back to back from the calling thread
+    (GDDIM_DEVICE_THREADS=0): bit-identical shards, first call (engine creation, weight upload, graph capture in the threads) and replay,
+    CLD and blur, the input produced on a non-default stream of the caller."""
+    from gddim_amd import devices
+    from gddim_amd.cld import sampling
+    from gddim_amd.datasets import get_data_inverse_scaler
+    cfg = tiny_config("cld", nf=16, num_res_blocks=1, image_size=16, ch_mult=(1, 2, 2), attn=(8,))
+    cfg.sampling.method, cfg.sampling.nfe, cfg.sampling.deis_order, cfg.sampling.noise_removal = 'deis', 6, 2, True
+    monkeypatch.setenv("GDDIM_LOCAL_DEVICES", "0,0,0")
+    res = {}
+    side = torch.cuda.Stream(device=0)
+    for threads in ("1", "0"):
+        monkeypatch.setenv("GDDIM_DEVICE_THREADS", threads)
+        params, sde, model, state = _cld(cfg)
+        pfn = sampling.get_sampling_fn(cfg, sde, model, None, get_data_inverse_scaler(cfg))
+        with torch.cuda.stream(side):  # the caller's stream: the threads must order their work on it
+            u = torch.as_tensor(_noise(3, 4, 16), device="cuda:0") * 1.0
+            first = pfn([5, 6, 7], state, 4, u)
+            again = pfn([5, 6, 7], state, 4, u)
+            got = [t.clone() for t in first[0].shards + first[1].shards + again[0].shards + again[1].shards]
+        side.synchronize()
+        assert len(model._engines) == 3 and devices.local_device_count() == 3
+        res[threads] = got
+        model.close()
+    assert all(torch.isfinite(t).all() for t in res["1"])
+    assert all(torch.equal(a, b) for a, b in zip(res["1"], res["0"]))
+    assert all(torch.equal(a, b) for a, b in zip(res["1"][:6], res["1"][6:]))  # replay = first call
+    assert not torch.equal(res["1"][0], res["1"][1])
+
+
+def test_psampler_threaded_issue_surfaces_a_device_error(native_lib, monkeypatch):
+    """An error in one device's call reaches the caller after every thread has finished (no thread keeps issuing into a failed call)."""
+    from gddim_amd import devices
+    monkeypatch.setenv("GDDIM_LOCAL_DEVICES", "0,0")
+    monkeypatch.setenv("GDDIM_DEVICE_THREADS", "1")
+    seen = []
+
+    def sampler(seed, state, B, u, slot=0):
+        seen.append(slot)
+        if slot == 1:
+            raise RuntimeError("device 1 failed")
+        return (torch.zeros(2, device="cuda:0"), torch.zeros(2, device="cuda:0"), 3)
+
+    with pytest.raises(RuntimeError, match="device 1 failed"):
+        devices.pmap_sampler(sampler, [1, 2], None, 2, torch.zeros((2, 2, 4, 4, 3, 2), device="cuda:0"), None, (4, 4, 3, 2), 2)
+    assert sorted(seen) == [0, 1]
