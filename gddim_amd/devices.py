@@ -3,9 +3,10 @@
 In the reference ONE process drives every local accelerator: `prng` is a stack of `jax.local_device_count()` keys, `u` is
 `(n_dev, B, H, W, C[, 2])`, the result is a sharded array of shape `(n_dev, B, H, W, C)` whose shards stay on their devices
 until the caller's `np.clip(samples_org_x * 255., 0, 255)` pulls them to the host (cld_jax/run_lib.py:711-725).  Here the same
-thing is `n_dev` native engines, one per local GPU, driven from the calling thread: a sampler call is ONE asynchronous
-`hipGraphLaunch` per engine (the whole-call graph), issued back to back, so the GPUs run concurrently
-while the host thread has already returned.
+thing is `n_dev` native engines, one per local GPU: a sampler call is ONE asynchronous `hipGraphLaunch` per engine (the whole-call
+graph), each issued by its own short-lived task on a per-device thread (`_issue_threaded`: the launch of a
+21 350-node graph costs the host 185-360 ms, so one thread issuing them back to back would start device d that much late per
+device before it), so the GPUs run concurrently while the caller has already returned.
 
   local_devices()        the HIP device indices this process drives
   local_device_count()   jax.local_device_count()
